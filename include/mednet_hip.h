@@ -1,0 +1,144 @@
+/* mednet_hip.h -- C ABI of libmednet_hip.so: the MI355X (gfx950) 3D U-Net training hot path.
+ *
+ * The reference (tobiashepp/torch-mednet) has no FFI of its own: its hot path is torch.nn modules calling
+ * ATen.  Each entry point below therefore names the reference call site whose ATen op it replaces
+ * (paths relative to the reference root).  The Python host (mednet_hip/_lib.py, ctypes) is the only caller.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator); nothing is allocated,
+ *     freed or synchronised inside; launches go on `stream` (a hipStream_t passed as void*).
+ *   - activations are NDHWC ("channels_last_3d") unless a layout argument says otherwise; dtype arguments are
+ *     MEDNET_F32 / MEDNET_BF16; parameters and their gradients are always fp32 in PyTorch layout.
+ *   - return value: MEDNET_OK or a negative MEDNET_E_*; mednet_last_error() gives the text.  The Python shim
+ *     raises RuntimeError, matching the reference's assert/exception convention (components.py:30-31,56,65;
+ *     loss.py:28,66).
+ *   - workspace: *_ws_bytes() gives the scratch size a call needs; the caller passes a buffer at least that big.
+ *     Workspaces hold deterministic per-workgroup partials (no float atomics anywhere => bitwise reproducible).
+ */
+#ifndef MEDNET_HIP_H
+#define MEDNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mednet_stream; /* hipStream_t */
+
+enum { MEDNET_F32 = 0, MEDNET_BF16 = 1 };
+enum { MEDNET_NDHWC = 0, MEDNET_NCDHW = 1 };
+enum { MEDNET_ACT_NONE = 0, MEDNET_ACT_RELU = 1, MEDNET_ACT_LEAKY = 2, MEDNET_ACT_ELU = 3 };
+enum { MEDNET_POOL_MAX = 0, MEDNET_POOL_AVG = 1 };
+enum { MEDNET_ALGO_AUTO = 0, MEDNET_ALGO_DIRECT = 1, MEDNET_ALGO_MFMA = 2 };
+enum { MEDNET_REG_L2 = 0, MEDNET_REG_L1 = 1 };
+enum {
+  MEDNET_OK = 0, MEDNET_E_SHAPE = -1, MEDNET_E_DTYPE = -2, MEDNET_E_WORKSPACE = -3, MEDNET_E_HIP = -4,
+  MEDNET_E_UNSUPPORTED = -5
+};
+#define MEDNET_NO_IGNORE INT32_MIN
+
+int mednet_abi_version(void);
+const char* mednet_last_error(void);
+/* 1 if a gfx950 device is visible to this process, 0 otherwise (never throws). */
+int mednet_device_ok(void);
+
+/* ---- nn.Conv3d(k=3,p=1 | k=1,p=0, stride 1)  components.py:8-9,44 ; model.py:77,179 ------------------------ */
+/* Weight packing: PyTorch (Cout,Cin,k,k,k) [or ConvTranspose3d's (Cin,Cout,k,k,k) when transposed_src=1] ->
+ * opaque buffer holding the tap-major layouts the forward, data-gradient and MFMA kernels read. */
+size_t mednet_conv3d_pack_bytes(int cin, int cout, int ksize);
+int mednet_conv3d_pack(const float* w, void* packed, int cin, int cout, int ksize, int transposed_src,
+                       mednet_stream stream);
+/* y[n,z,y,x,co] = bias[co] + sum_{tap,ci} x[n,z+dz-1,y+dy-1,x+dx-1,ci] * W[co,ci,tap].
+ * dgrad=1 runs the data gradient with the same kernel: pass x := dy, cin := Cout, cout := Cin of the layer. */
+int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void* y, int n, int d, int h, int w,
+                      int cin, int cout, int ksize, int x_dtype, int x_layout, int y_dtype, int y_layout,
+                      int dgrad, int algo, mednet_stream stream);
+size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
+/* dw[co,ci,tap] = sum_{n,v} dy[n,v,co] * x[n,v+tap,ci]; dbias[co] = sum dy (nullable). */
+int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
+                        int cin, int cout, int ksize, int x_dtype, int x_layout, int dy_dtype, int dy_layout,
+                        int algo, void* ws, size_t ws_bytes, mednet_stream stream);
+
+/* ---- nn.ConvTranspose3d(k=3,s=2,p=1,output_padding=1,bias) + `x += encoder_features`  components.py:259-264,283-284 */
+/* (n,d,h,w) are the INPUT dims; output is (2d,2h,2w).  `skip` (nullable, y's dtype/shape) is added in the epilogue. */
+int mednet_convt3d_fwd(const void* x, const void* packed, const float* bias, const void* skip, void* y, int n,
+                       int d, int h, int w, int cin, int cout, int x_dtype, int y_dtype, mednet_stream stream);
+int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx, int n, int d, int h, int w, int cin,
+                         int cout, int dy_dtype, int dx_dtype, mednet_stream stream);
+size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
+                         int cin, int cout, int x_dtype, int dy_dtype, void* ws, size_t ws_bytes,
+                         mednet_stream stream);
+
+/* ---- nn.GroupNorm(G,C,eps) fused with the following activation and the residual add
+ *      components.py:57 (GroupNorm), :36-40 (ReLU/LeakyReLU(0.1)/ELU), :177-178 (out += residual; non_linearity) */
+size_t mednet_gn_ws_bytes(int n, int c, size_t spatial);
+/* stats[n][g] = {mean, rstd}; coef[n][c] = {gamma*rstd, beta - mean*gamma*rstd} (both outputs, fp32). */
+int mednet_gn_stats(const void* x, const float* gamma, const float* beta, float* stats, float* coef, int n,
+                    size_t spatial, int c, int groups, float eps, int dtype, void* ws, size_t ws_bytes,
+                    mednet_stream stream);
+/* z = act(coef0*x + coef1 [+ residual]) */
+int mednet_gn_act_fwd(const void* x, const float* coef, const void* residual, void* z, int n, size_t spatial,
+                      int c, int act, int x_dtype, int z_dtype, mednet_stream stream);
+/* du = (dz [+ dz2]) * act'(z);  dgamma/dbeta;  dx = GroupNorm backward of du;  dres (nullable) := du. */
+int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x, const void* z, const float* stats,
+                      const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, int n,
+                      size_t spatial, int c, int groups, int act, int dtype, void* ws, size_t ws_bytes,
+                      mednet_stream stream);
+/* stand-alone activation (orders such as 'cr', 'crg'); in-place allowed (x == z). */
+int mednet_act_fwd(const void* x, void* z, size_t count, int act, int dtype, mednet_stream stream);
+int mednet_act_bwd(const void* dz, const void* z, void* dx, size_t count, int act, int dtype,
+                   mednet_stream stream);
+/* out = a + b (gradient joins the graph needs: residual + skip fan-in). */
+int mednet_add(const void* a, const void* b, void* out, size_t count, int dtype, mednet_stream stream);
+
+/* ---- nn.MaxPool3d(2) / nn.AvgPool3d(2)  components.py:208-212 ----------------------------------------------- */
+int mednet_pool2_fwd(const void* x, void* y, int n, int d, int h, int w, int c, int mode, int dtype,
+                     mednet_stream stream);
+/* dx has the INPUT shape; ties route to the first maximum in (z,y,x) scan order like ATen. */
+int mednet_pool2_bwd(const void* dy, const void* x, void* dx, int n, int d, int h, int w, int c, int mode,
+                     int dtype, mednet_stream stream);
+
+/* ---- F.interpolate(nearest, size=enc) + torch.cat((enc, x), 1)  components.py:277-280 (UNet3D decoder) ------- */
+int mednet_upcat_fwd(const void* enc, const void* x, void* out, int n, int d, int h, int w, int c_enc, int xd,
+                     int xh, int xw, int c_x, int dtype, mednet_stream stream);
+int mednet_upcat_bwd(const void* dout, void* denc, void* dx, int n, int d, int h, int w, int c_enc, int xd, int xh,
+                     int xw, int c_x, int dtype, mednet_stream stream);
+
+/* ---- losses.  logits are fp32 with element strides (stride_n, stride_c) and unit voxel stride (NCDHW or a
+ *      channel slice of it); labels are int64 N x spatial ------------------------------------------------------ */
+size_t mednet_loss_ws_bytes(int n, int c, size_t spatial);
+/* DiceLoss  loss.py:91-130 (+ :24-48, :58-88): softmax|sigmoid -> one-hot -> per-channel 2*w*I/clamp(D,eps) ->
+ * mean(1-dice).  saved[c] = {I_c, D_c} for the backward; dice_out (nullable) gets the per-channel dice. */
+int mednet_dice_fwd(const float* logits, const int64_t* labels, const float* weight, float* loss, float* saved,
+                    float* dice_out, int n, int c, size_t spatial, int64_t stride_n, int64_t stride_c, float eps,
+                    int sigmoid, int ignore_index, void* ws, size_t ws_bytes, mednet_stream stream);
+/* dlogits is contiguous N x C x spatial; scaled by *dloss (device scalar). */
+int mednet_dice_bwd(const float* logits, const int64_t* labels, const float* weight, const float* saved,
+                    const float* dloss, float* dlogits, int n, int c, size_t spatial, int64_t stride_n,
+                    int64_t stride_c, float eps, int sigmoid, int ignore_index, mednet_stream stream);
+/* nn.CrossEntropyLoss(weight)  segmentation.py:49: sum w_y * -log softmax_y / sum w_y.  saved[0] = sum w_y. */
+int mednet_ce_fwd(const float* logits, const int64_t* labels, const float* weight, float* loss, float* saved,
+                  int n, int c, size_t spatial, int64_t stride_n, int64_t stride_c, int ignore_index, void* ws,
+                  size_t ws_bytes, mednet_stream stream);
+int mednet_ce_bwd(const float* logits, const int64_t* labels, const float* weight, const float* saved,
+                  const float* dloss, float* dlogits, int n, int c, size_t spatial, int64_t stride_n,
+                  int64_t stride_c, int ignore_index, mednet_stream stream);
+/* LandmarkNet.loss regression term  landmarks.py:129-132: sum_c w_c * mean_{n,v} f(out[:,c]-hm[:,c]),
+ * f = square (L2) | abs (L1).  target is fp32 or uint8 (tgt_u8=1), contiguous N x C x spatial. */
+int mednet_heatmap_loss_fwd(const float* out, const void* target, const float* cweight, float* loss, int n, int c,
+                            size_t spatial, int64_t stride_n, int64_t stride_c, int kind, int tgt_u8, void* ws,
+                            size_t ws_bytes, mednet_stream stream);
+int mednet_heatmap_loss_bwd(const float* out, const void* target, const float* cweight, const float* dloss,
+                            float* dout, int n, int c, size_t spatial, int64_t stride_n, int64_t stride_c, int kind,
+                            int tgt_u8, mednet_stream stream);
+
+/* ---- torch.optim.Adam(lr) step  segmentation.py:119-120 (betas .9/.999, eps 1e-8, wd 0), flat fp32 buffers --- */
+int mednet_adam_step(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, float grad_scale,
+                     mednet_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,167 @@
+// C-ABI entry points for the convolution family + error plumbing.  See include/mednet_hip.h.
+#include <stdarg.h>
+#include <string.h>
+#include "common.h"
+#include "conv.h"
+
+namespace mednet {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MEDNET_E_HIP, "%s: %s", what, hipGetErrorString(e));
+  return MEDNET_OK;
+}
+
+}  // namespace mednet
+
+using namespace mednet;
+
+extern "C" int mednet_abi_version(void) { return 1; }
+extern "C" const char* mednet_last_error(void) { return g_err; }
+extern "C" int mednet_device_ok(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 0;
+  return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+// ---- packed weight buffer ---------------------------------------------------------------------------------------
+extern "C" size_t mednet_conv3d_pack_bytes(int cin, int cout, int ksize) { return pack_layout(cin, cout, ksize).total; }
+
+extern "C" int mednet_conv3d_pack(const float* w, void* packed, int cin, int cout, int ksize, int transposed_src,
+                                  mednet_stream stream) {
+  MEDNET_REQUIRE(ksize == 3 || ksize == 1, MEDNET_E_UNSUPPORTED, "conv3d_pack: kernel size %d (supported: 1, 3)", ksize);
+  MEDNET_REQUIRE(cin > 0 && cout > 0, MEDNET_E_SHAPE, "conv3d_pack: bad channels %d -> %d", cin, cout);
+  const PackLayout L = pack_layout(cin, cout, ksize);
+  char* base = (char*)packed;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch_pack_f32(w, (float*)(base + L.f32_fwd), (float*)(base + L.f32_bwd), cin, cout, L.taps, transposed_src, s);
+  if (rc) return rc;
+  if (L.mfma_bytes) rc = launch_pack_mfma(w, base + L.mfma_fwd, base + L.mfma_bwd, cin, cout, L.taps, transposed_src, s);
+  return rc;
+}
+
+static int conv_common_checks(const char* who, int n, int d, int h, int w, int cin, int cout, int ksize, int dt1, int dt2) {
+  MEDNET_REQUIRE(dtype_ok(dt1) && dtype_ok(dt2), MEDNET_E_DTYPE, "%s: bad dtype", who);
+  MEDNET_REQUIRE(ksize == 3 || ksize == 1, MEDNET_E_UNSUPPORTED, "%s: kernel size %d (supported: 1, 3)", who, ksize);
+  MEDNET_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, MEDNET_E_SHAPE,
+                 "%s: bad shape n=%d d=%d h=%d w=%d cin=%d cout=%d", who, n, d, h, w, cin, cout);
+  return MEDNET_OK;
+}
+
+extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void* y, int n, int d, int h,
+                                 int w, int cin, int cout, int ksize, int x_dtype, int x_layout, int y_dtype,
+                                 int y_layout, int dgrad, int algo, mednet_stream stream) {
+  int rc = conv_common_checks("conv3d_fwd", n, d, h, w, cin, cout, ksize, x_dtype, y_dtype);
+  if (rc) return rc;
+  // the pack was built for the layer's (Cin,Cout); a dgrad call swaps the roles
+  const PackLayout L = dgrad ? pack_layout(cout, cin, ksize) : pack_layout(cin, cout, ksize);
+  const char* base = (const char*)packed;
+  hipStream_t s = (hipStream_t)stream;
+  const bool mfma_ok = conv_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, x_layout, y_layout, bias != nullptr);
+  if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
+    return fail(MEDNET_E_UNSUPPORTED, "conv3d_fwd: MFMA path does not take cin=%d cout=%d k=%d dtypes %d->%d", cin, cout,
+                ksize, x_dtype, y_dtype);
+  if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
+    return launch_conv_mfma(x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), y, n, d, h, w, cin, cout, x_dtype, y_dtype, s);
+  ConvGeom g;
+  g.n = n; g.od = d; g.oh = h; g.ow = w; g.id = d; g.ih = h; g.iw = w;
+  g.k = cin; g.m = cout; g.ks = ksize;
+  g.in_planar = x_layout == MEDNET_NCDHW; g.out_planar = y_layout == MEDNET_NCDHW;
+  return launch_direct<MAP_CONV>(x, (const float*)(base + (dgrad ? L.f32_bwd : L.f32_fwd)), bias, nullptr, y, g, x_dtype,
+                                 y_dtype, s);
+}
+
+extern "C" size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize) {
+  const size_t a = wgrad_direct_ws_bytes((size_t)n * d * h * w, cout, cin, ksize);
+  const size_t b = wgrad_mfma_ws_bytes(n, d, h, w, cin, cout, ksize);
+  return (a > b ? a : b) + 256;
+}
+
+extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
+                                   int cin, int cout, int ksize, int x_dtype, int x_layout, int dy_dtype, int dy_layout,
+                                   int algo, void* ws, size_t ws_bytes, mednet_stream stream) {
+  int rc = conv_common_checks("conv3d_wgrad", n, d, h, w, cin, cout, ksize, x_dtype, dy_dtype);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (dbias) {
+    rc = launch_channel_sum(dy, dbias, n, (size_t)d * h * w, cout, dy_layout == MEDNET_NCDHW, dy_dtype, s);
+    if (rc) return rc;
+  }
+  const bool mfma_ok = wgrad_mfma_supported(cin, cout, ksize, x_dtype, dy_dtype, x_layout, dy_layout);
+  if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
+    return fail(MEDNET_E_UNSUPPORTED, "conv3d_wgrad: MFMA path does not take cin=%d cout=%d k=%d", cin, cout, ksize);
+  if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
+    return launch_wgrad_mfma(x, dy, dw, n, d, h, w, cin, cout, x_dtype, ws, ws_bytes, s);
+  WgradGeom g;
+  g.n = n; g.ad = d; g.ah = h; g.aw = w; g.bd = d; g.bh = h; g.bw = w;
+  g.ka = cout; g.kb = cin; g.ks = ksize; g.stride2 = 0;
+  g.a_planar = dy_layout == MEDNET_NCDHW; g.b_planar = x_layout == MEDNET_NCDHW;
+  g.chunk = 0;
+  return launch_wgrad_direct(dy, x, dw, g, dy_dtype, x_dtype, ws, ws_bytes, s);
+}
+
+// ---- ConvTranspose3d(k3,s2,p1,op1) ------------------------------------------------------------------------------------
+extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float* bias, const void* skip, void* y, int n,
+                                  int d, int h, int w, int cin, int cout, int x_dtype, int y_dtype,
+                                  mednet_stream stream) {
+  int rc = conv_common_checks("convt3d_fwd", n, d, h, w, cin, cout, 3, x_dtype, y_dtype);
+  if (rc) return rc;
+  const PackLayout L = pack_layout(cin, cout, 3);
+  ConvGeom g;
+  g.n = n; g.od = 2 * d; g.oh = 2 * h; g.ow = 2 * w; g.id = d; g.ih = h; g.iw = w;
+  g.k = cin; g.m = cout; g.ks = 3; g.in_planar = 0; g.out_planar = 0;
+  return launch_direct<MAP_CT_FWD>(x, (const float*)((const char*)packed + L.f32_fwd), bias, skip, y, g, x_dtype, y_dtype,
+                                   (hipStream_t)stream);
+}
+
+extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx, int n, int d, int h, int w, int cin,
+                                    int cout, int dy_dtype, int dx_dtype, mednet_stream stream) {
+  int rc = conv_common_checks("convt3d_dgrad", n, d, h, w, cin, cout, 3, dy_dtype, dx_dtype);
+  if (rc) return rc;
+  const PackLayout L = pack_layout(cin, cout, 3);
+  ConvGeom g;
+  g.n = n; g.od = d; g.oh = h; g.ow = w; g.id = 2 * d; g.ih = 2 * h; g.iw = 2 * w;
+  g.k = cout; g.m = cin; g.ks = 3; g.in_planar = 0; g.out_planar = 0;
+  return launch_direct<MAP_CT_DG>(dy, (const float*)((const char*)packed + L.f32_bwd), nullptr, nullptr, dx, g, dy_dtype,
+                                  dx_dtype, (hipStream_t)stream);
+}
+
+extern "C" size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  return wgrad_direct_ws_bytes((size_t)n * d * h * w, cin, cout, 3) + 256;
+}
+
+extern "C" int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
+                                    int cin, int cout, int x_dtype, int dy_dtype, void* ws, size_t ws_bytes,
+                                    mednet_stream stream) {
+  int rc = conv_common_checks("convt3d_wgrad", n, d, h, w, cin, cout, 3, x_dtype, dy_dtype);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (dbias) {
+    rc = launch_channel_sum(dy, dbias, n, (size_t)8 * d * h * w, cout, 0, dy_dtype, s);
+    if (rc) return rc;
+  }
+  WgradGeom g;
+  g.n = n; g.ad = d; g.ah = h; g.aw = w; g.bd = 2 * d; g.bh = 2 * h; g.bw = 2 * w;
+  g.ka = cin; g.kb = cout; g.ks = 3; g.stride2 = 1; g.a_planar = 0; g.b_planar = 0; g.chunk = 0;
+  return launch_wgrad_direct(x, dy, dw, g, x_dtype, dy_dtype, ws, ws_bytes, s);
+}

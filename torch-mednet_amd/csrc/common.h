@@ -1,0 +1,120 @@
+// Shared device/host helpers for libmednet_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mednet_hip.h"
+
+namespace mednet {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ---- error plumbing (host) -------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+#define MEDNET_REQUIRE(cond, code, ...)        \
+  do {                                         \
+    if (!(cond)) return fail(code, __VA_ARGS__); \
+  } while (0)
+
+inline bool dtype_ok(int dt) { return dt == MEDNET_F32 || dt == MEDNET_BF16; }
+inline size_t dtype_size(int dt) { return dt == MEDNET_BF16 ? 2 : 4; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- scalar load/store with conversion ---------------------------------------------------------------------
+__device__ __forceinline__ float ld(const float* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float ld(const bf16* p, size_t i) { return (float)p[i]; }
+__device__ __forceinline__ float ld(const uint8_t* p, size_t i) { return (float)p[i]; }
+__device__ __forceinline__ void st(float* p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void st(bf16* p, size_t i, float v) { p[i] = (bf16)v; }
+
+// ---- 8-wide vector load/store (caller guarantees 8-element alignment) ----------------------------------------
+struct F8 {
+  float v[8];
+};
+__device__ __forceinline__ F8 ld8(const float* p, size_t i) {
+  F8 r;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p + i);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(p + i + 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    r.v[k] = a[k];
+    r.v[k + 4] = b[k];
+  }
+  return r;
+}
+__device__ __forceinline__ F8 ld8(const bf16* p, size_t i) {
+  F8 r;
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(p + i);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r.v[k] = (float)a[k];
+  return r;
+}
+__device__ __forceinline__ void st8(float* p, size_t i, const F8& r) {
+  f32x4 a, b;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = r.v[k];
+    b[k] = r.v[k + 4];
+  }
+  *reinterpret_cast<f32x4*>(p + i) = a;
+  *reinterpret_cast<f32x4*>(p + i + 4) = b;
+}
+__device__ __forceinline__ void st8(bf16* p, size_t i, const F8& r) {
+  bf16x8 a;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = (bf16)r.v[k];
+  *reinterpret_cast<bf16x8*>(p + i) = a;
+}
+
+// ---- activations: components.py:36-40 (ReLU, LeakyReLU(0.1), ELU(alpha=1)), all "in-place" in the reference,
+//      so the backward is written in terms of the OUTPUT z (ATen elu_backward(is_result=true)) ---------------
+__device__ __forceinline__ float act_apply(float u, int act) {
+  switch (act) {
+    case MEDNET_ACT_RELU: return u > 0.f ? u : 0.f;
+    case MEDNET_ACT_LEAKY: return u > 0.f ? u : 0.1f * u;
+    case MEDNET_ACT_ELU: return u > 0.f ? u : expm1f(u);
+    default: return u;
+  }
+}
+__device__ __forceinline__ float act_grad_from_out(float z, int act) {
+  switch (act) {
+    case MEDNET_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case MEDNET_ACT_LEAKY: return z > 0.f ? 1.f : 0.1f;
+    case MEDNET_ACT_ELU: return z > 0.f ? 1.f : z + 1.f;
+    default: return 1.f;
+  }
+}
+
+// ---- reductions: wave64 shuffles, then LDS across the waves of a workgroup ----------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// Sum over a workgroup of NW waves; result valid in every thread. `scratch` holds >= NW floats.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += scratch[i];
+  return t;
+}
+
+}  // namespace mednet

@@ -1,0 +1,55 @@
+// Internal declarations shared by the convolution translation units.
+#pragma once
+#include "common.h"
+
+namespace mednet {
+
+enum { MAP_CONV = 0, MAP_CT_FWD = 1, MAP_CT_DG = 2 };
+
+struct ConvGeom {
+  int n, od, oh, ow;  // output dims
+  int id, ih, iw;     // input dims
+  int k, m;           // input channels, output channels
+  int ks;             // 3 or 1
+  int in_planar, out_planar;
+};
+
+struct WgradGeom {
+  int n, ad, ah, aw;  // dims of A's grid (the loop grid)
+  int bd, bh, bw;     // dims of B's grid
+  int ka, kb, ks, stride2;
+  int a_planar, b_planar;
+  size_t chunk;  // voxels per chunk (filled by the launcher)
+};
+
+// Byte offsets of the sections of a packed weight buffer (mednet_conv3d_pack).
+struct PackLayout {
+  int taps;
+  size_t f32_fwd, f32_bwd;    // float [T][Cin][Cout], float [T][Cout][Cin] (taps mirrored for Conv3d sources)
+  size_t mfma_fwd, mfma_bwd;  // bf16 fragment-ordered images for the MFMA kernels (0 bytes when not applicable)
+  size_t mfma_bytes;          // size of ONE mfma section
+  size_t total;
+};
+PackLayout pack_layout(int cin, int cout, int ksize);
+
+template <int MAP>
+int launch_direct(const void* x, const float* P, const float* bias, const void* skip, void* y, const ConvGeom& g,
+                  int x_dtype, int y_dtype, hipStream_t s);
+size_t wgrad_direct_ws_bytes(size_t nvox, int ka, int kb, int ks);
+int launch_wgrad_direct(const void* A, const void* B, float* dw, WgradGeom g, int a_dtype, int b_dtype, void* ws,
+                        size_t ws_bytes, hipStream_t s);
+int launch_channel_sum(const void* x, float* out, int n, size_t spatial, int c, int planar, int dtype, hipStream_t s);
+int launch_pack_f32(const float* w, float* Pf, float* Pb, int cin, int cout, int T, int transposed_src, hipStream_t s);
+
+// MFMA (bf16 matrix-core) kernels, conv_mfma.hip
+bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int x_layout, int y_layout, bool bias);
+int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, int d, int h, int w, int cin, int cout,
+                     int x_dtype, int y_dtype, hipStream_t s);
+int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, int cin, int cout, int T, int transposed_src,
+                     hipStream_t s);
+bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtype, int x_layout, int dy_layout);
+size_t wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
+int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, int dtype,
+                      void* ws, size_t ws_bytes, hipStream_t s);
+
+}  // namespace mednet

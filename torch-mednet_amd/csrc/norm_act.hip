@@ -1,0 +1,737 @@
+// GroupNorm (+activation, +residual), stand-alone activations, 2x2x2 pooling, nearest-upsample+concat.
+// All HBM-bound, channels-last: a lane reads 8 consecutive channels (16 B bf16 / 32 B fp32) of one voxel, a wave reads
+// 64 such vectors back to back, i.e. fully coalesced 1-2 KiB per wave-instruction.  Reductions use wave64 shuffles,
+// then LDS across the 4 waves of a workgroup, then a fixed-order fp64 combine of per-workgroup partials (no atomics:
+// results are bitwise reproducible).
+// Reference call sites: components.py:57 (GroupNorm), :36-40 (activations), :177-178 (residual add + activation),
+// :208-212 (pooling), :277-280 (interpolate + cat).
+#include "common.h"
+
+namespace mednet {
+
+// "column persistent" thread layout over a channels-last tensor: a thread keeps the same VEC channels for its
+// whole life, so per-channel coefficients live in registers and per-channel sums need no atomics.
+template <int VEC>
+struct Cols {
+  int cols, rows, col, row;
+  bool active;
+  __device__ __forceinline__ Cols(int c) {
+    cols = c / VEC;
+    rows = 256 / cols;
+    active = (int)threadIdx.x < rows * cols;
+    col = threadIdx.x % cols;
+    row = threadIdx.x / cols;
+  }
+};
+
+template <typename T, int VEC>
+struct VecIO;
+template <typename T>
+struct VecIO<T, 8> {
+  static __device__ __forceinline__ F8 load(const T* p, size_t i) { return ld8(p, i); }
+  static __device__ __forceinline__ void store(T* p, size_t i, const F8& v) { st8(p, i, v); }
+};
+template <typename T>
+struct VecIO<T, 1> {
+  static __device__ __forceinline__ F8 load(const T* p, size_t i) {
+    F8 r;
+    r.v[0] = ld(p, i);
+    return r;
+  }
+  static __device__ __forceinline__ void store(T* p, size_t i, const F8& v) { st(p, i, v.v[0]); }
+};
+
+static inline void chunk_plan(size_t spatial, int c, int vec, size_t& chunk_vox, unsigned& chunks) {
+  const int cols = c / vec;
+  const int rows = 256 / cols;
+  size_t cv = (spatial + 1023) / 1024;
+  if (cv < (size_t)rows * 8) cv = (size_t)rows * 8;
+  cv = (cv + rows - 1) / rows * rows;
+  chunk_vox = cv;
+  chunks = (unsigned)((spatial + cv - 1) / cv);
+}
+
+// Sum, across the workgroup, the per-thread values of threads that share a column. vals[k] (k < NV*VEC) per thread.
+// Result for (col, j) lands in out[col*NV*VEC + j] written by the threads of row 0.
+template <int NVAL>
+__device__ __forceinline__ void column_reduce(const float* vals, int cols, int rows, int col, int row, bool active,
+                                              float* lds, float* out) {
+  // lds: [256][NVAL]
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k) lds[(row * cols + col) * NVAL + k] = vals[k];
+  }
+  __syncthreads();
+  if (active && row == 0) {
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k) {
+      float s = 0.f;
+      for (int r = 0; r < rows; ++r) s += lds[(r * cols + col) * NVAL + k];
+      out[col * NVAL + k] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- GN statistics
+// partial[n][chunk][c][2] = {sum x, sum x^2}
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
+                                                         size_t spatial, int c, size_t chunk_vox) {
+  __shared__ float lds[256 * 2 * VEC];
+  const Cols<VEC> L(c);
+  const int n = blockIdx.y;
+  const size_t v0 = (size_t)blockIdx.x * chunk_vox;
+  const size_t v1 = v0 + chunk_vox < spatial ? v0 + chunk_vox : spatial;
+  float acc[2 * VEC];
+#pragma unroll
+  for (int k = 0; k < 2 * VEC; ++k) acc[k] = 0.f;
+  if (L.active) {
+    const T* base = x + (size_t)n * spatial * c + (size_t)L.col * VEC;
+    for (size_t v = v0 + L.row; v < v1; v += L.rows) {
+      const F8 xv = VecIO<T, VEC>::load(base, v * c);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        acc[2 * k] += xv.v[k];
+        acc[2 * k + 1] = fmaf(xv.v[k], xv.v[k], acc[2 * k + 1]);
+      }
+    }
+  }
+  float* out = partial + ((size_t)n * gridDim.x + blockIdx.x) * c * 2;
+  column_reduce<2 * VEC>(acc, L.cols, L.rows, L.col, L.row, L.active, lds, out);
+}
+
+// one wave per (n, g): fp64 combine -> mean, rstd; then the per-channel affine the apply kernel uses.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ stats,
+                                                         float* __restrict__ coef, int c, int groups, int chunks,
+                                                         double count, float eps) {
+  const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cg = c / groups;
+  double s = 0.0, q = 0.0;
+  const int items = chunks * cg;
+  for (int i = threadIdx.x; i < items; i += 64) {
+    const int ch = i / cg, cc = g * cg + i % cg;
+    const float* p = partial + (((size_t)n * chunks + ch) * c + cc) * 2;
+    s += (double)p[0];
+    q += (double)p[1];
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) {
+    stats[((size_t)n * groups + g) * 2] = (float)mean;
+    stats[((size_t)n * groups + g) * 2 + 1] = rstd;
+  }
+  for (int i = threadIdx.x; i < cg; i += 64) {
+    const int cc = g * cg + i;
+    const float ga = gamma ? gamma[cc] : 1.f, be = beta ? beta[cc] : 0.f;
+    const float a = ga * rstd;
+    coef[((size_t)n * c + cc) * 2] = a;
+    coef[((size_t)n * c + cc) * 2 + 1] = be - (float)mean * a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- GN apply (+act, +residual)
+template <typename TX, typename TZ, int VEC>
+__global__ __launch_bounds__(256) void gn_act_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ coef,
+                                                         const TZ* __restrict__ res, TZ* __restrict__ z,
+                                                         size_t spatial, int c, int act, size_t chunk_vox) {
+  const Cols<VEC> L(c);
+  if (!L.active) return;
+  const int n = blockIdx.y;
+  const size_t v0 = (size_t)blockIdx.x * chunk_vox;
+  const size_t v1 = v0 + chunk_vox < spatial ? v0 + chunk_vox : spatial;
+  float a[VEC], b[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    a[k] = coef[((size_t)n * c + L.col * VEC + k) * 2];
+    b[k] = coef[((size_t)n * c + L.col * VEC + k) * 2 + 1];
+  }
+  const size_t off = (size_t)n * spatial * c + (size_t)L.col * VEC;
+  for (size_t v = v0 + L.row; v < v1; v += L.rows) {
+    const size_t i = off + v * c;
+    F8 xv = VecIO<TX, VEC>::load(x, i);
+    F8 rv;
+    if (res) rv = VecIO<TZ, VEC>::load(res, i);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float u = fmaf(a[k], xv.v[k], b[k]);
+      if (res) u += rv.v[k];
+      xv.v[k] = act_apply(u, act);
+    }
+    VecIO<TZ, VEC>::store(z, i, xv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- GN backward
+// pass 1: partial[n][chunk][c][2] = {sum du, sum du * xhat},  du = (dz + dz2) * act'(z)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict__ dz, const T* __restrict__ dz2,
+                                                             const T* __restrict__ x, const T* __restrict__ z,
+                                                             const float* __restrict__ stats,
+                                                             float* __restrict__ partial, size_t spatial, int c,
+                                                             int groups, int act, size_t chunk_vox) {
+  __shared__ float lds[256 * 2 * VEC];
+  const Cols<VEC> L(c);
+  const int n = blockIdx.y;
+  const size_t v0 = (size_t)blockIdx.x * chunk_vox;
+  const size_t v1 = v0 + chunk_vox < spatial ? v0 + chunk_vox : spatial;
+  float acc[2 * VEC];
+#pragma unroll
+  for (int k = 0; k < 2 * VEC; ++k) acc[k] = 0.f;
+  if (L.active) {
+    const int cg = c / groups;
+    float mean[VEC], rstd[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int g = (L.col * VEC + k) / cg;
+      mean[k] = stats[((size_t)n * groups + g) * 2];
+      rstd[k] = stats[((size_t)n * groups + g) * 2 + 1];
+    }
+    const size_t off = (size_t)n * spatial * c + (size_t)L.col * VEC;
+    for (size_t v = v0 + L.row; v < v1; v += L.rows) {
+      const size_t i = off + v * c;
+      const F8 g1 = VecIO<T, VEC>::load(dz, i);
+      F8 g2, zv;
+      if (dz2) g2 = VecIO<T, VEC>::load(dz2, i);
+      if (act != MEDNET_ACT_NONE) zv = VecIO<T, VEC>::load(z, i);
+      const F8 xv = VecIO<T, VEC>::load(x, i);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        float du = g1.v[k] + (dz2 ? g2.v[k] : 0.f);
+        if (act != MEDNET_ACT_NONE) du *= act_grad_from_out(zv.v[k], act);
+        const float xh = (xv.v[k] - mean[k]) * rstd[k];
+        acc[2 * k] += du;
+        acc[2 * k + 1] = fmaf(du, xh, acc[2 * k + 1]);
+      }
+    }
+  }
+  float* out = partial + ((size_t)n * gridDim.x + blockIdx.x) * c * 2;
+  column_reduce<2 * VEC>(acc, L.cols, L.rows, L.col, L.row, L.active, lds, out);
+}
+
+// pass 2a: per (n,g): S1 = sum_c gamma_c * sum du_c, S2 = sum_c gamma_c * sum(du*xhat)_c  ->
+//   dx = k1_c * du + k2_g * x + k3_g,  k1 = rstd*gamma_c, k2 = -rstd^2*S2/M, k3 = (rstd^2*S2*mean - rstd*S1)/M
+// csum[n][c][2] keeps the per-(n,c) totals for pass 2b.
+__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float* __restrict__ partial,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma,
+                                                             float* __restrict__ bcoef, float* __restrict__ csum, int c,
+                                                             int groups, int chunks, double count) {
+  const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cg = c / groups;
+  double s1 = 0.0, s2 = 0.0;
+  // lanes own channels (cg may exceed 64: loop)
+  for (int i = threadIdx.x; i < cg; i += 64) {
+    const int cc = g * cg + i;
+    double a = 0.0, b = 0.0;
+    for (int ch = 0; ch < chunks; ++ch) {
+      const float* p = partial + (((size_t)n * chunks + ch) * c + cc) * 2;
+      a += (double)p[0];
+      b += (double)p[1];
+    }
+    csum[((size_t)n * c + cc) * 2] = (float)a;
+    csum[((size_t)n * c + cc) * 2 + 1] = (float)b;
+    const double ga = gamma ? (double)gamma[cc] : 1.0;
+    s1 += ga * a;
+    s2 += ga * b;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const double mean = stats[((size_t)n * groups + g) * 2], rstd = stats[((size_t)n * groups + g) * 2 + 1];
+  const float k2 = (float)(-rstd * rstd * s2 / count);
+  const float k3 = (float)((rstd * rstd * s2 * mean - rstd * s1) / count);
+  for (int i = threadIdx.x; i < cg; i += 64) {
+    const int cc = g * cg + i;
+    float* o = bcoef + ((size_t)n * c + cc) * 3;
+    o[0] = (float)rstd * (gamma ? gamma[cc] : 1.f);
+    o[1] = k2;
+    o[2] = k3;
+  }
+}
+// pass 2b: dgamma_c = sum_n sum(du*xhat), dbeta_c = sum_n sum du
+__global__ __launch_bounds__(256) void gn_bwd_params_kernel(const float* __restrict__ csum, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int n, int c) {
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc >= c) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < n; ++i) {
+    a += (double)csum[((size_t)i * c + cc) * 2];
+    b += (double)csum[((size_t)i * c + cc) * 2 + 1];
+  }
+  if (dbeta) dbeta[cc] = (float)a;
+  if (dgamma) dgamma[cc] = (float)b;
+}
+// pass 3: apply
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ dz2,
+                                                           const T* __restrict__ x, const T* __restrict__ z,
+                                                           const float* __restrict__ bcoef, T* __restrict__ dx,
+                                                           T* __restrict__ dres, size_t spatial, int c, int act,
+                                                           size_t chunk_vox) {
+  const Cols<VEC> L(c);
+  if (!L.active) return;
+  const int n = blockIdx.y;
+  const size_t v0 = (size_t)blockIdx.x * chunk_vox;
+  const size_t v1 = v0 + chunk_vox < spatial ? v0 + chunk_vox : spatial;
+  float k1[VEC], k2[VEC], k3[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const float* o = bcoef + ((size_t)n * c + L.col * VEC + k) * 3;
+    k1[k] = o[0];
+    k2[k] = o[1];
+    k3[k] = o[2];
+  }
+  const size_t off = (size_t)n * spatial * c + (size_t)L.col * VEC;
+  for (size_t v = v0 + L.row; v < v1; v += L.rows) {
+    const size_t i = off + v * c;
+    const F8 g1 = VecIO<T, VEC>::load(dz, i);
+    F8 g2, zv;
+    if (dz2) g2 = VecIO<T, VEC>::load(dz2, i);
+    if (act != MEDNET_ACT_NONE) zv = VecIO<T, VEC>::load(z, i);
+    const F8 xv = VecIO<T, VEC>::load(x, i);
+    F8 o, du8;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float du = g1.v[k] + (dz2 ? g2.v[k] : 0.f);
+      if (act != MEDNET_ACT_NONE) du *= act_grad_from_out(zv.v[k], act);
+      du8.v[k] = du;
+      o.v[k] = fmaf(k1[k], du, fmaf(k2[k], xv.v[k], k3[k]));
+    }
+    VecIO<T, VEC>::store(dx, i, o);
+    if (dres) VecIO<T, VEC>::store(dres, i, du8);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- flat elementwise
+template <typename T>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ z, size_t count, int act) {
+  const size_t stride = (size_t)gridDim.x * 256 * 8;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8; i < count; i += stride) {
+    if (i + 8 <= count) {
+      F8 v = ld8(x, i);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v.v[k] = act_apply(v.v[k], act);
+      st8(z, i, v);
+    } else {
+      for (size_t j = i; j < count; ++j) st(z, j, act_apply(ld(x, j), act));
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                                      T* __restrict__ dx, size_t count, int act) {
+  const size_t stride = (size_t)gridDim.x * 256 * 8;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8; i < count; i += stride) {
+    if (i + 8 <= count) {
+      F8 g = ld8(dz, i);
+      const F8 zv = ld8(z, i);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g.v[k] *= act_grad_from_out(zv.v[k], act);
+      st8(dx, i, g);
+    } else {
+      for (size_t j = i; j < count; ++j) st(dx, j, ld(dz, j) * act_grad_from_out(ld(z, j), act));
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o,
+                                                  size_t count) {
+  const size_t stride = (size_t)gridDim.x * 256 * 8;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8; i < count; i += stride) {
+    if (i + 8 <= count) {
+      F8 u = ld8(a, i);
+      const F8 w = ld8(b, i);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u.v[k] += w.v[k];
+      st8(o, i, u);
+    } else {
+      for (size_t j = i; j < count; ++j) st(o, j, ld(a, j) + ld(b, j));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- 2x2x2 pooling
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void pool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int d, int h,
+                                                        int w, int c, int mode) {
+  const int od = d / 2, oh = h / 2, ow = w / 2, cv = c / VEC;
+  const size_t total = (size_t)n * od * oh * ow * cv;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cc = (int)(i % cv);
+  size_t v = i / cv;
+  const int ox = (int)(v % ow);
+  v /= ow;
+  const int oy = (int)(v % oh);
+  v /= oh;
+  const int oz = (int)(v % od);
+  const int nn = (int)(v / od);
+  F8 best;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) best.v[k] = mode == MEDNET_POOL_MAX ? -INFINITY : 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int iz = 2 * oz + (t >> 2), iy = 2 * oy + ((t >> 1) & 1), ix = 2 * ox + (t & 1);
+    const size_t src = ((((size_t)nn * d + iz) * h + iy) * w + ix) * c + (size_t)cc * VEC;
+    const F8 xv = VecIO<T, VEC>::load(x, src);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      if (mode == MEDNET_POOL_MAX) best.v[k] = (xv.v[k] > best.v[k] || xv.v[k] != xv.v[k]) ? xv.v[k] : best.v[k];
+      else best.v[k] += xv.v[k];
+    }
+  }
+  if (mode == MEDNET_POOL_AVG) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) best.v[k] *= 0.125f;
+  }
+  VecIO<T, VEC>::store(y, i * VEC, best);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void pool2_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                        T* __restrict__ dx, int n, int d, int h, int w, int c, int mode) {
+  const int od = d / 2, oh = h / 2, ow = w / 2, cv = c / VEC;
+  const size_t total = (size_t)n * od * oh * ow * cv;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cc = (int)(i % cv);
+  size_t v = i / cv;
+  const int ox = (int)(v % ow);
+  v /= ow;
+  const int oy = (int)(v % oh);
+  v /= oh;
+  const int oz = (int)(v % od);
+  const int nn = (int)(v / od);
+  const F8 g = VecIO<T, VEC>::load(dy, i * VEC);
+  int arg[VEC];
+  if (mode == MEDNET_POOL_MAX) {
+    float best[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      best[k] = -INFINITY;
+      arg[k] = 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int iz = 2 * oz + (t >> 2), iy = 2 * oy + ((t >> 1) & 1), ix = 2 * ox + (t & 1);
+      const size_t src = ((((size_t)nn * d + iz) * h + iy) * w + ix) * c + (size_t)cc * VEC;
+      const F8 xv = VecIO<T, VEC>::load(x, src);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if (xv.v[k] > best[k] || xv.v[k] != xv.v[k]) {  // first maximum in scan order, NaN propagates (ATen)
+          best[k] = xv.v[k];
+          arg[k] = t;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int iz = 2 * oz + (t >> 2), iy = 2 * oy + ((t >> 1) & 1), ix = 2 * ox + (t & 1);
+    const size_t dst = ((((size_t)nn * d + iz) * h + iy) * w + ix) * c + (size_t)cc * VEC;
+    F8 o;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+      o.v[k] = mode == MEDNET_POOL_MAX ? (arg[k] == t ? g.v[k] : 0.f) : 0.125f * g.v[k];
+    VecIO<T, VEC>::store(dx, dst, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- upsample + concat
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
+  const float scale = (float)in / (float)out;  // ATen: compute_scales_value when only `size` is given
+  const int s = (int)floorf((float)dst * scale);
+  return s < in - 1 ? s : in - 1;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ enc, const T* __restrict__ x,
+                                                        T* __restrict__ out, int n, int d, int h, int w, int ce, int xd,
+                                                        int xh, int xw, int cx) {
+  const int ct = ce + cx;
+  const size_t total = (size_t)n * d * h * w * ct;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cc = (int)(i % ct);
+  size_t v = i / ct;
+  if (cc < ce) {
+    out[i] = enc[v * ce + cc];
+    return;
+  }
+  const int ox = (int)(v % w);
+  size_t r = v / w;
+  const int oy = (int)(r % h);
+  r /= h;
+  const int oz = (int)(r % d);
+  const int nn = (int)(r / d);
+  const int sz = nearest_src(oz, xd, d), sy = nearest_src(oy, xh, h), sx = nearest_src(ox, xw, w);
+  out[i] = x[((((size_t)nn * xd + sz) * xh + sy) * xw + sx) * cx + (cc - ce)];
+}
+// denc = dout[..., :ce]; dx[src] = sum over the destination voxels that map to src
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_bwd_enc_kernel(const T* __restrict__ dout, T* __restrict__ denc,
+                                                            size_t nvox, int ce, int ct) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvox * ce) return;
+  const size_t v = i / ce;
+  const int cc = (int)(i % ce);
+  denc[i] = dout[v * ct + cc];
+}
+__device__ __forceinline__ void dst_range(int src, int in, int out, int& lo, int& hi) {
+  // all dst with nearest_src(dst) == src form a contiguous run; find it by scanning a small window
+  int guess = (int)((double)src * out / in);
+  lo = guess - 2 < 0 ? 0 : guess - 2;
+  while (lo < out && nearest_src(lo, in, out) < src) ++lo;
+  hi = lo;
+  while (hi < out && nearest_src(hi, in, out) == src) ++hi;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_bwd_x_kernel(const T* __restrict__ dout, T* __restrict__ dx, int n, int d,
+                                                          int h, int w, int ce, int xd, int xh, int xw, int cx) {
+  const int ct = ce + cx;
+  const size_t total = (size_t)n * xd * xh * xw * cx;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cc = (int)(i % cx);
+  size_t v = i / cx;
+  const int sx = (int)(v % xw);
+  v /= xw;
+  const int sy = (int)(v % xh);
+  v /= xh;
+  const int sz = (int)(v % xd);
+  const int nn = (int)(v / xd);
+  int z0, z1, y0, y1, x0, x1;
+  dst_range(sz, xd, d, z0, z1);
+  dst_range(sy, xh, h, y0, y1);
+  dst_range(sx, xw, w, x0, x1);
+  float s = 0.f;
+  for (int oz = z0; oz < z1; ++oz)
+    for (int oy = y0; oy < y1; ++oy)
+      for (int ox = x0; ox < x1; ++ox)
+        s += ld(dout, ((((size_t)nn * d + oz) * h + oy) * w + ox) * ct + ce + cc);
+  st(dx, i, s);
+}
+
+// ---------------------------------------------------------------------------------------------- Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, size_t count, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                   float gscale) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+    float gr = g[i] * gscale;
+    if (wd != 0.f) gr = fmaf(wd, p[i], gr);
+    const float mi = b1 * m[i] + (1.f - b1) * gr;
+    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace mednet
+
+// =================================================================================================== C ABI
+using namespace mednet;
+
+static inline unsigned flat_grid(size_t count, size_t per_block) {
+  size_t b = (count + per_block - 1) / per_block;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+static inline int pick_vec(int c) { return (c % 8 == 0 && c / 8 <= 256) ? 8 : 1; }
+
+extern "C" size_t mednet_gn_ws_bytes(int n, int c, size_t spatial) {
+  (void)spatial;
+  // partial[n][<=1024 chunks][c][2] + bcoef[n][c][3] + csum[n][c][2]
+  return ((size_t)n * 1024 * c * 2 + (size_t)n * c * 5 + 64) * sizeof(float);
+}
+
+extern "C" int mednet_gn_stats(const void* x, const float* gamma, const float* beta, float* stats, float* coef,
+                               int n, size_t spatial, int c, int groups, float eps, int dtype, void* ws,
+                               size_t ws_bytes, mednet_stream stream) {
+  MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "gn_stats: bad dtype %d", dtype);
+  MEDNET_REQUIRE(n > 0 && c > 0 && groups > 0 && c % groups == 0 && spatial > 0, MEDNET_E_SHAPE,
+                 "gn_stats: bad shape n=%d c=%d groups=%d", n, c, groups);
+  const int vec = pick_vec(c);
+  MEDNET_REQUIRE(c / vec <= 256, MEDNET_E_UNSUPPORTED, "gn_stats: C=%d unsupported (need C%%8==0 or C<=256)", c);
+  MEDNET_REQUIRE(ws_bytes >= mednet_gn_ws_bytes(n, c, spatial), MEDNET_E_WORKSPACE, "gn_stats: workspace too small");
+  size_t cv;
+  unsigned chunks;
+  chunk_plan(spatial, c, vec, cv, chunks);
+  float* partial = (float*)ws;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(chunks, n);
+#define GO(T, V) hipLaunchKernelGGL((gn_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, partial, spatial, c, cv)
+  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+#undef GO
+  int rc = check_launch("gn_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n * groups), dim3(64), 0, s, partial, gamma, beta, stats, coef, c, groups,
+                     (int)chunks, (double)spatial * (c / groups), eps);
+  return check_launch("gn_finalize");
+}
+
+extern "C" int mednet_gn_act_fwd(const void* x, const float* coef, const void* residual, void* z, int n,
+                                 size_t spatial, int c, int act, int x_dtype, int z_dtype, mednet_stream stream) {
+  MEDNET_REQUIRE(dtype_ok(x_dtype) && dtype_ok(z_dtype), MEDNET_E_DTYPE, "gn_act_fwd: bad dtype");
+  MEDNET_REQUIRE(x_dtype == z_dtype, MEDNET_E_UNSUPPORTED, "gn_act_fwd: x and z must share a dtype");
+  const int vec = pick_vec(c);
+  MEDNET_REQUIRE(c / vec <= 256, MEDNET_E_UNSUPPORTED, "gn_act_fwd: C=%d unsupported", c);
+  size_t cv;
+  unsigned chunks;
+  chunk_plan(spatial, c, vec, cv, chunks);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(chunks, n);
+#define GO(T, V) hipLaunchKernelGGL((gn_act_fwd_kernel<T, T, V>), grid, dim3(256), 0, s, (const T*)x, coef, (const T*)residual, (T*)z, spatial, c, act, cv)
+  if (x_dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+#undef GO
+  return check_launch("gn_act_fwd");
+}
+
+extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x, const void* z, const float* stats,
+                                 const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, int n,
+                                 size_t spatial, int c, int groups, int act, int dtype, void* ws, size_t ws_bytes,
+                                 mednet_stream stream) {
+  MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "gn_act_bwd: bad dtype");
+  MEDNET_REQUIRE(c % groups == 0, MEDNET_E_SHAPE, "gn_act_bwd: C %% groups != 0");
+  MEDNET_REQUIRE(act == MEDNET_ACT_NONE || z != nullptr, MEDNET_E_SHAPE, "gn_act_bwd: z required for act'");
+  const int vec = pick_vec(c);
+  MEDNET_REQUIRE(c / vec <= 256, MEDNET_E_UNSUPPORTED, "gn_act_bwd: C=%d unsupported", c);
+  MEDNET_REQUIRE(ws_bytes >= mednet_gn_ws_bytes(n, c, spatial), MEDNET_E_WORKSPACE, "gn_act_bwd: workspace too small");
+  size_t cv;
+  unsigned chunks;
+  chunk_plan(spatial, c, vec, cv, chunks);
+  float* partial = (float*)ws;
+  float* bcoef = partial + (size_t)n * 1024 * c * 2;
+  float* csum = bcoef + (size_t)n * c * 3;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(chunks, n);
+#define GO(T, V) hipLaunchKernelGGL((gn_bwd_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, stats, partial, spatial, c, groups, act, cv)
+  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+#undef GO
+  int rc = check_launch("gn_bwd_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(64), 0, s, partial, stats, gamma, bcoef, csum, c,
+                     groups, (int)chunks, (double)spatial * (c / groups));
+  rc = check_launch("gn_bwd_finalize");
+  if (rc) return rc;
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((c + 255) / 256), dim3(256), 0, s, csum, dgamma, dbeta, n, c);
+    rc = check_launch("gn_bwd_params");
+    if (rc) return rc;
+  }
+#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv)
+  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+#undef GO
+  return check_launch("gn_bwd_apply");
+}
+
+extern "C" int mednet_act_fwd(const void* x, void* z, size_t count, int act, int dtype, mednet_stream stream) {
+  MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "act_fwd: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned g = flat_grid(count, 2048);
+  if (dtype == MEDNET_F32) hipLaunchKernelGGL(act_fwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, (float*)z, count, act);
+  else hipLaunchKernelGGL(act_fwd_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)x, (bf16*)z, count, act);
+  return check_launch("act_fwd");
+}
+extern "C" int mednet_act_bwd(const void* dz, const void* z, void* dx, size_t count, int act, int dtype,
+                              mednet_stream stream) {
+  MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "act_bwd: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned g = flat_grid(count, 2048);
+  if (dtype == MEDNET_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)dz, (const float*)z, (float*)dx, count, act);
+  else hipLaunchKernelGGL(act_bwd_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)dz, (const bf16*)z, (bf16*)dx, count, act);
+  return check_launch("act_bwd");
+}
+extern "C" int mednet_add(const void* a, const void* b, void* out, size_t count, int dtype, mednet_stream stream) {
+  MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "add: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned g = flat_grid(count, 2048);
+  if (dtype == MEDNET_F32) hipLaunchKernelGGL(add_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)out, count);
+  else hipLaunchKernelGGL(add_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, (bf16*)out, count);
+  return check_launch("add");
+}
+
+extern "C" int mednet_pool2_fwd(const void* x, void* y, int n, int d, int h, int w, int c, int mode, int dtype,
+                                mednet_stream stream) {
+  MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "pool2_fwd: bad dtype");
+  MEDNET_REQUIRE(d >= 2 && h >= 2 && w >= 2, MEDNET_E_SHAPE, "pool2_fwd: dims must be >= 2");
+  const int vec = c % 8 == 0 ? 8 : 1;
+  const size_t total = (size_t)n * (d / 2) * (h / 2) * (w / 2) * (c / vec);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((total + 255) / 256));
+#define GO(T, V) hipLaunchKernelGGL((pool2_fwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, (T*)y, n, d, h, w, c, mode)
+  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+#undef GO
+  return check_launch("pool2_fwd");
+}
+extern "C" int mednet_pool2_bwd(const void* dy, const void* x, void* dx, int n, int d, int h, int w, int c, int mode,
+                                int dtype, mednet_stream stream) {
+  MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "pool2_bwd: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  if ((d | h | w) & 1) {  // odd tails are never pooled: their gradient is zero
+    if (hipMemsetAsync(dx, 0, (size_t)n * d * h * w * c * dtype_size(dtype), s) != hipSuccess)
+      return fail(MEDNET_E_HIP, "pool2_bwd: memset failed");
+  }
+  const int vec = c % 8 == 0 ? 8 : 1;
+  const size_t total = (size_t)n * (d / 2) * (h / 2) * (w / 2) * (c / vec);
+  const dim3 grid((unsigned)((total + 255) / 256));
+#define GO(T, V) hipLaunchKernelGGL((pool2_bwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, (T*)dx, n, d, h, w, c, mode)
+  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+#undef GO
+  return check_launch("pool2_bwd");
+}
+
+extern "C" int mednet_upcat_fwd(const void* enc, const void* x, void* out, int n, int d, int h, int w, int c_enc,
+                                int xd, int xh, int xw, int c_x, int dtype, mednet_stream stream) {
+  MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "upcat_fwd: bad dtype");
+  const size_t total = (size_t)n * d * h * w * (c_enc + c_x);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == MEDNET_F32) hipLaunchKernelGGL(upcat_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)enc, (const float*)x, (float*)out, n, d, h, w, c_enc, xd, xh, xw, c_x);
+  else hipLaunchKernelGGL(upcat_fwd_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)enc, (const bf16*)x, (bf16*)out, n, d, h, w, c_enc, xd, xh, xw, c_x);
+  return check_launch("upcat_fwd");
+}
+extern "C" int mednet_upcat_bwd(const void* dout, void* denc, void* dx, int n, int d, int h, int w, int c_enc, int xd,
+                                int xh, int xw, int c_x, int dtype, mednet_stream stream) {
+  MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "upcat_bwd: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t nvox = (size_t)n * d * h * w;
+  const int ct = c_enc + c_x;
+  const dim3 g1((unsigned)((nvox * c_enc + 255) / 256));
+  const size_t tx = (size_t)n * xd * xh * xw * c_x;
+  const dim3 g2((unsigned)((tx + 255) / 256));
+  if (dtype == MEDNET_F32) {
+    hipLaunchKernelGGL(upcat_bwd_enc_kernel<float>, g1, dim3(256), 0, s, (const float*)dout, (float*)denc, nvox, c_enc, ct);
+    hipLaunchKernelGGL(upcat_bwd_x_kernel<float>, g2, dim3(256), 0, s, (const float*)dout, (float*)dx, n, d, h, w, c_enc, xd, xh, xw, c_x);
+  } else {
+    hipLaunchKernelGGL(upcat_bwd_enc_kernel<bf16>, g1, dim3(256), 0, s, (const bf16*)dout, (bf16*)denc, nvox, c_enc, ct);
+    hipLaunchKernelGGL(upcat_bwd_x_kernel<bf16>, g2, dim3(256), 0, s, (const bf16*)dout, (bf16*)dx, n, d, h, w, c_enc, xd, xh, xw, c_x);
+  }
+  return check_launch("upcat_bwd");
+}
+
+extern "C" int mednet_adam_step(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                mednet_stream stream) {
+  MEDNET_REQUIRE(step >= 1, MEDNET_E_SHAPE, "adam_step: step must be >= 1");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(count, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, count, lr,
+                     beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+  return check_launch("adam_step");
+}

@@ -1,0 +1,485 @@
+"""torch.autograd.Function wrappers around the C ABI: one per fused device op of the U-Net path.
+
+Every forward/backward here is a handful of libmednet_hip launches on torch's current HIP stream; PyTorch only
+provides memory (caching allocator), the stream and the autograd graph.  Internal activations are channels-last
+(`torch.channels_last_3d`: logical N,C,D,H,W, physical N,D,H,W,C) so the MFMA kernels read 16-byte channel
+fragments; the network input (C=1) and the logits (written planar by the 1x1x1 head) are plain NCDHW.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from . import config
+
+CL = torch.channels_last_3d
+
+
+def to_cl(x: torch.Tensor) -> torch.Tensor:
+    """Physical NDHWC. No-op for tensors produced by this package."""
+    return x.contiguous(memory_format=CL)
+
+
+def empty_cl(n, c, d, h, w, dtype, device):
+    return torch.empty((n, c, d, h, w), dtype=dtype, device=device, memory_format=CL)
+
+
+def _storage_dtype(x: torch.Tensor) -> torch.dtype:
+    return config.act_dtype()
+
+
+def _as_act(x: torch.Tensor) -> torch.Tensor:
+    """Inputs that are neither fp32 nor bf16 (e.g. fp16/fp64 user tensors) are brought to the activation dtype."""
+    if x.dtype in (torch.float32, torch.bfloat16):
+        return x
+    return x.to(config.act_dtype())
+
+
+# ------------------------------------------------------------------------------------------------- weights
+def pack_conv_weight(weight: torch.Tensor, ksize: int, transposed: bool) -> torch.Tensor:
+    """PyTorch-layout fp32 weight -> opaque packed buffer read by the forward / data-gradient kernels."""
+    L.require_gpu(weight, "pack_conv_weight")
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    nbytes = L.lib().mednet_conv3d_pack_bytes(cin, cout, ksize)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    L.check(L.lib().mednet_conv3d_pack(w.data_ptr(), buf.data_ptr(), cin, cout, ksize, int(transposed), L.stream()),
+            "conv3d_pack")
+    return buf
+
+
+# ------------------------------------------------------------------------------------------------- Conv3d
+class Conv3dFn(Function):
+    """nn.Conv3d(k in {1,3}, stride 1, padding k//2)  -- components.py:8-9,44; model.py:77,179."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, packed, ksize, out_planar, out_dtype):
+        L.require_gpu(x, "conv3d")
+        x = _as_act(x)
+        n, cin, d, h, w = x.shape
+        cout = weight.shape[0]
+        # Cin == 1: NCDHW and NDHWC coincide, so the network input is consumed as it arrives.
+        xin = x.contiguous() if cin == 1 else to_cl(x)
+        if out_planar:
+            y = torch.empty((n, cout, d, h, w), dtype=out_dtype, device=x.device)
+        else:
+            y = empty_cl(n, cout, d, h, w, out_dtype, x.device)
+        L.check(L.lib().mednet_conv3d_fwd(xin.data_ptr(), packed.data_ptr(), L.ptr(bias), y.data_ptr(), n, d, h, w, cin,
+                                          cout, ksize, L.dt(xin), L.NDHWC, L.dt(y), L.NCDHW if out_planar else L.NDHWC,
+                                          0, config.conv_algo(), L.stream()), "conv3d_fwd")
+        ctx.save_for_backward(xin, packed)
+        ctx.meta = (ksize, out_planar, cin, cout, bias is not None, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xin, packed = ctx.saved_tensors
+        ksize, out_planar, cin, cout, has_bias, x_dtype = ctx.meta
+        n, _, d, h, w = xin.shape
+        dy = dy.contiguous() if out_planar else to_cl(dy)
+        lib = L.lib()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_cl(n, cin, d, h, w, x_dtype, dy.device)
+            L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin,
+                                          ksize, L.dt(dy), L.NCDHW if out_planar else L.NDHWC, L.dt(dx), L.NDHWC, 1,
+                                          config.conv_algo(), L.stream()), "conv3d_dgrad")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((cout, cin, ksize, ksize, ksize), dtype=torch.float32, device=dy.device)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = torch.empty((cout,), dtype=torch.float32, device=dy.device)
+            nbytes = lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, ksize)
+            ws = L.workspace(nbytes, dy.device)
+            L.check(lib.mednet_conv3d_wgrad(xin.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), n, d, h, w, cin,
+                                            cout, ksize, L.dt(xin), L.NDHWC, L.dt(dy),
+                                            L.NCDHW if out_planar else L.NDHWC, config.conv_algo(), ws.data_ptr(),
+                                            ws.numel(), L.stream()), "conv3d_wgrad")
+        return dx, dw, db, None, None, None, None
+
+
+def conv3d(x, weight, bias, packed, ksize, out_planar=False, out_dtype=None):
+    return Conv3dFn.apply(x, weight, bias, packed, ksize, out_planar, out_dtype or config.act_dtype())
+
+
+# ------------------------------------------------------------------------------------------------- ConvTranspose3d (+ skip add)
+class ConvT3dFn(Function):
+    """nn.ConvTranspose3d(k=3,s=2,p=1,output_padding=1) with the decoder's `x += encoder_features` fused into the
+    epilogue  -- components.py:259-264,283-284."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, skip, packed):
+        L.require_gpu(x, "conv_transpose3d")
+        x = to_cl(_as_act(x))
+        n, cin, d, h, w = x.shape
+        cout = weight.shape[1]
+        y = empty_cl(n, cout, 2 * d, 2 * h, 2 * w, config.act_dtype(), x.device)
+        sk = None
+        if skip is not None:
+            if tuple(skip.shape) != tuple(y.shape):
+                raise RuntimeError(f"conv_transpose3d: skip shape {tuple(skip.shape)} != output {tuple(y.shape)}")
+            sk = to_cl(skip.to(y.dtype))
+        L.check(L.lib().mednet_convt3d_fwd(x.data_ptr(), packed.data_ptr(), L.ptr(bias), L.ptr(sk), y.data_ptr(), n, d, h,
+                                           w, cin, cout, L.dt(x), L.dt(y), L.stream()), "convt3d_fwd")
+        ctx.save_for_backward(x, packed)
+        ctx.meta = (cin, cout, bias is not None, skip is not None, None if skip is None else skip.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, packed = ctx.saved_tensors
+        cin, cout, has_bias, has_skip, skip_dtype = ctx.meta
+        n, _, d, h, w = x.shape
+        dy = to_cl(dy)
+        lib = L.lib()
+        dx = dw = db = dskip = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_cl(n, cin, d, h, w, x.dtype, dy.device)
+            L.check(lib.mednet_convt3d_dgrad(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), n, d, h, w, cin, cout,
+                                             L.dt(dy), L.dt(dx), L.stream()), "convt3d_dgrad")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((cin, cout, 3, 3, 3), dtype=torch.float32, device=dy.device)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = torch.empty((cout,), dtype=torch.float32, device=dy.device)
+            ws = L.workspace(lib.mednet_convt3d_wgrad_ws_bytes(n, d, h, w, cin, cout), dy.device)
+            L.check(lib.mednet_convt3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), n, d, h, w, cin, cout,
+                                             L.dt(x), L.dt(dy), ws.data_ptr(), ws.numel(), L.stream()), "convt3d_wgrad")
+        if has_skip and ctx.needs_input_grad[3]:
+            dskip = dy if dy.dtype == skip_dtype else dy.to(skip_dtype)
+        return dx, dw, db, dskip, None
+
+
+def conv_transpose3d(x, weight, bias, skip, packed):
+    return ConvT3dFn.apply(x, weight, bias, skip, packed)
+
+
+# ------------------------------------------------------------------------------------------------- GroupNorm (+act, +residual)
+class GroupNormActFn(Function):
+    """z = act(GroupNorm(x) [+ residual])  -- components.py:57, :36-40, :177-178."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, groups, eps, act):
+        L.require_gpu(x, "group_norm_act")
+        x = to_cl(_as_act(x))
+        n, c, d, h, w = x.shape
+        if c % groups:
+            raise RuntimeError(f"group_norm: C={c} not divisible by num_groups={groups}")
+        spatial = d * h * w
+        lib = L.lib()
+        stats = torch.empty((n, groups, 2), dtype=torch.float32, device=x.device)
+        coef = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+        ws = L.workspace(lib.mednet_gn_ws_bytes(n, c, spatial), x.device)
+        L.check(lib.mednet_gn_stats(x.data_ptr(), L.ptr(gamma), L.ptr(beta), stats.data_ptr(), coef.data_ptr(), n,
+                                    spatial, c, groups, eps, L.dt(x), ws.data_ptr(), ws.numel(), L.stream()), "gn_stats")
+        res = None
+        if residual is not None:
+            res = to_cl(residual.to(x.dtype))
+        z = torch.empty_like(x, memory_format=CL)
+        L.check(lib.mednet_gn_act_fwd(x.data_ptr(), coef.data_ptr(), L.ptr(res), z.data_ptr(), n, spatial, c, act,
+                                      L.dt(x), L.dt(z), L.stream()), "gn_act_fwd")
+        ctx.save_for_backward(x, z if act != L.ACT_NONE else None, stats, gamma)
+        ctx.meta = (groups, act, residual is not None, gamma is not None, beta is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, z, stats, gamma = ctx.saved_tensors
+        groups, act, has_res, has_gamma, has_beta = ctx.meta
+        n, c, d, h, w = x.shape
+        spatial = d * h * w
+        dz = to_cl(dz.to(x.dtype))
+        lib = L.lib()
+        dx = torch.empty_like(x, memory_format=CL)
+        dres = torch.empty_like(x, memory_format=CL) if has_res else None
+        dgamma = torch.empty((c,), dtype=torch.float32, device=x.device) if has_gamma else None
+        dbeta = torch.empty((c,), dtype=torch.float32, device=x.device) if has_beta else None
+        ws = L.workspace(lib.mednet_gn_ws_bytes(n, c, spatial), x.device)
+        L.check(lib.mednet_gn_act_bwd(dz.data_ptr(), None, x.data_ptr(), L.ptr(z), stats.data_ptr(), L.ptr(gamma),
+                                      dx.data_ptr(), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), n, spatial, c, groups, act,
+                                      L.dt(x), ws.data_ptr(), ws.numel(), L.stream()), "gn_act_bwd")
+        return dx, dgamma, dbeta, dres, None, None, None
+
+
+def group_norm_act(x, gamma, beta, groups, eps=1e-5, act=L.ACT_NONE, residual=None):
+    return GroupNormActFn.apply(x, gamma, beta, residual, groups, eps, act)
+
+
+# ------------------------------------------------------------------------------------------------- stand-alone activation
+class ActFn(Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        L.require_gpu(x, "activation")
+        x = _as_act(x)
+        xc = x if (x.is_contiguous() or x.is_contiguous(memory_format=CL)) else x.contiguous()
+        z = torch.empty_like(xc)  # preserves the memory format
+        L.check(L.lib().mednet_act_fwd(xc.data_ptr(), z.data_ptr(), xc.numel(), act, L.dt(xc), L.stream()), "act_fwd")
+        ctx.save_for_backward(z)
+        ctx.act = act
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (z,) = ctx.saved_tensors
+        if z.dim() == 5 and z.is_contiguous(memory_format=CL) and not z.is_contiguous():
+            dz = to_cl(dz)
+        else:
+            dz = dz.contiguous()
+        dz = dz.to(z.dtype)
+        dx = torch.empty_like(z)
+        L.check(L.lib().mednet_act_bwd(dz.data_ptr(), z.data_ptr(), dx.data_ptr(), z.numel(), ctx.act, L.dt(z),
+                                       L.stream()), "act_bwd")
+        return dx, None
+
+
+def activation(x, act):
+    return ActFn.apply(x, act)
+
+
+class AddFn(Function):
+    """out = a + b for two same-shape activations (only used when a residual join cannot be folded into a GroupNorm)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        L.require_gpu(a, "add")
+        a = to_cl(_as_act(a))
+        b = to_cl(b.to(a.dtype))
+        out = torch.empty_like(a, memory_format=CL)
+        L.check(L.lib().mednet_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), L.dt(a), L.stream()), "add")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+# ------------------------------------------------------------------------------------------------- pooling
+class Pool2Fn(Function):
+    """nn.MaxPool3d(2) / nn.AvgPool3d(2)  -- components.py:208-212."""
+
+    @staticmethod
+    def forward(ctx, x, mode):
+        L.require_gpu(x, "pool3d")
+        x = to_cl(_as_act(x))
+        n, c, d, h, w = x.shape
+        y = empty_cl(n, c, d // 2, h // 2, w // 2, x.dtype, x.device)
+        L.check(L.lib().mednet_pool2_fwd(x.data_ptr(), y.data_ptr(), n, d, h, w, c, mode, L.dt(x), L.stream()), "pool2_fwd")
+        ctx.save_for_backward(x)
+        ctx.mode = mode
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, c, d, h, w = x.shape
+        dy = to_cl(dy.to(x.dtype))
+        dx = torch.empty_like(x, memory_format=CL)
+        L.check(L.lib().mednet_pool2_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), n, d, h, w, c, ctx.mode, L.dt(x),
+                                         L.stream()), "pool2_bwd")
+        return dx, None
+
+
+def pool2(x, mode=L.POOL_MAX):
+    return Pool2Fn.apply(x, mode)
+
+
+# ------------------------------------------------------------------------------------------------- nearest upsample + concat
+class UpCatFn(Function):
+    """F.interpolate(x, size=enc.shape[2:], mode='nearest') ; torch.cat((enc, x), 1)  -- components.py:277-280."""
+
+    @staticmethod
+    def forward(ctx, enc, x):
+        L.require_gpu(x, "upsample_concat")
+        enc = to_cl(_as_act(enc))
+        x = to_cl(_as_act(x)).to(enc.dtype)
+        n, ce, d, h, w = enc.shape
+        _, cx, xd, xh, xw = x.shape
+        out = empty_cl(n, ce + cx, d, h, w, enc.dtype, enc.device)
+        L.check(L.lib().mednet_upcat_fwd(enc.data_ptr(), x.data_ptr(), out.data_ptr(), n, d, h, w, ce, xd, xh, xw, cx,
+                                         L.dt(enc), L.stream()), "upcat_fwd")
+        ctx.dims = (n, ce, d, h, w, cx, xd, xh, xw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, ce, d, h, w, cx, xd, xh, xw = ctx.dims
+        dout = to_cl(dout)
+        denc = empty_cl(n, ce, d, h, w, dout.dtype, dout.device)
+        dx = empty_cl(n, cx, xd, xh, xw, dout.dtype, dout.device)
+        L.check(L.lib().mednet_upcat_bwd(dout.data_ptr(), denc.data_ptr(), dx.data_ptr(), n, d, h, w, ce, xd, xh, xw, cx,
+                                         L.dt(dout), L.stream()), "upcat_bwd")
+        return denc, dx
+
+
+def upsample_concat(enc, x):
+    return UpCatFn.apply(enc, x)
+
+
+# ------------------------------------------------------------------------------------------------- losses
+def _planar_logits(logits: torch.Tensor):
+    """fp32 logits whose (D,H,W) block is dense: returns (tensor, stride_n, stride_c)."""
+    t = logits if logits.dtype == torch.float32 else logits.float()
+    sp = t.shape[2:]
+    dense = []
+    acc = 1
+    for s in reversed(sp):
+        dense.insert(0, acc)
+        acc *= s
+    if tuple(t.stride()[2:]) != tuple(dense):
+        t = t.contiguous()
+    return t, t.stride(0), t.stride(1)
+
+
+def _labels_i64(labels: torch.Tensor, shape):
+    if labels.dtype != torch.int64:
+        labels = labels.long()
+    if tuple(labels.shape) != tuple(shape):
+        raise AssertionError("'input' and 'target' must have the same shape")
+    return labels.contiguous()
+
+
+class DiceLossFn(Function):
+    """DiceLoss.forward  -- loss.py:114-130 (softmax|sigmoid, one-hot, per-channel dice over the WHOLE batch)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, weight, eps, sigmoid, ignore_index):
+        L.require_gpu(logits, "dice_loss")
+        lg, sn, sc = _planar_logits(logits)
+        n, c = lg.shape[:2]
+        spatial = lg[0, 0].numel()
+        lab = _labels_i64(labels, (n,) + tuple(lg.shape[2:]))
+        wt = None if weight is None else weight.to(device=lg.device, dtype=torch.float32).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=lg.device)
+        saved = torch.empty((c, 2), dtype=torch.float32, device=lg.device)
+        lib = L.lib()
+        ws = L.workspace(lib.mednet_loss_ws_bytes(n, c, spatial), lg.device)
+        ii = L.NO_IGNORE if ignore_index is None else int(ignore_index)
+        L.check(lib.mednet_dice_fwd(lg.data_ptr(), lab.data_ptr(), L.ptr(wt), loss.data_ptr(), saved.data_ptr(), None, n,
+                                    c, spatial, sn, sc, eps, int(sigmoid), ii, ws.data_ptr(), ws.numel(), L.stream()),
+                "dice_fwd")
+        ctx.save_for_backward(lg, lab, wt, saved)
+        ctx.meta = (eps, int(sigmoid), ii, sn, sc, logits.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lg, lab, wt, saved = ctx.saved_tensors
+        eps, sigmoid, ii, sn, sc, in_dtype = ctx.meta
+        n, c = lg.shape[:2]
+        spatial = lg[0, 0].numel()
+        dl = dloss.to(torch.float32).contiguous()
+        dlogits = torch.empty(lg.shape, dtype=torch.float32, device=lg.device)
+        L.check(L.lib().mednet_dice_bwd(lg.data_ptr(), lab.data_ptr(), L.ptr(wt), saved.data_ptr(), dl.data_ptr(),
+                                        dlogits.data_ptr(), n, c, spatial, sn, sc, eps, sigmoid, ii, L.stream()),
+                "dice_bwd")
+        return dlogits.to(in_dtype), None, None, None, None, None
+
+
+def dice_loss(logits, labels, weight=None, eps=1e-5, sigmoid=False, ignore_index=None):
+    return DiceLossFn.apply(logits, labels, weight, eps, sigmoid, ignore_index)
+
+
+def per_channel_dice(logits, labels, weight=None, eps=1e-5, sigmoid=False, ignore_index=None):
+    """dice_metric  -- loss.py:51-55 (no gradient)."""
+    L.require_gpu(logits, "dice_metric")
+    lg, sn, sc = _planar_logits(logits.detach())
+    n, c = lg.shape[:2]
+    spatial = lg[0, 0].numel()
+    lab = _labels_i64(labels, (n,) + tuple(lg.shape[2:]))
+    wt = None if weight is None else weight.to(device=lg.device, dtype=torch.float32).contiguous()
+    saved = torch.empty((c, 2), dtype=torch.float32, device=lg.device)
+    dice = torch.empty((c,), dtype=torch.float32, device=lg.device)
+    lib = L.lib()
+    ws = L.workspace(lib.mednet_loss_ws_bytes(n, c, spatial), lg.device)
+    ii = L.NO_IGNORE if ignore_index is None else int(ignore_index)
+    L.check(lib.mednet_dice_fwd(lg.data_ptr(), lab.data_ptr(), L.ptr(wt), None, saved.data_ptr(), dice.data_ptr(), n, c,
+                                spatial, sn, sc, eps, int(sigmoid), ii, ws.data_ptr(), ws.numel(), L.stream()), "dice_fwd")
+    return dice
+
+
+class CrossEntropyFn(Function):
+    """nn.CrossEntropyLoss(weight)(logits, labels), mean reduction  -- segmentation.py:49; landmarks.py:49."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, weight, ignore_index):
+        L.require_gpu(logits, "cross_entropy")
+        lg, sn, sc = _planar_logits(logits)
+        n, c = lg.shape[:2]
+        spatial = lg[0, 0].numel()
+        lab = _labels_i64(labels, (n,) + tuple(lg.shape[2:]))
+        wt = None if weight is None else weight.to(device=lg.device, dtype=torch.float32).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=lg.device)
+        saved = torch.empty((2,), dtype=torch.float32, device=lg.device)
+        lib = L.lib()
+        ws = L.workspace(lib.mednet_loss_ws_bytes(n, c, spatial), lg.device)
+        L.check(lib.mednet_ce_fwd(lg.data_ptr(), lab.data_ptr(), L.ptr(wt), loss.data_ptr(), saved.data_ptr(), n, c,
+                                  spatial, sn, sc, int(ignore_index), ws.data_ptr(), ws.numel(), L.stream()), "ce_fwd")
+        ctx.save_for_backward(lg, lab, wt, saved)
+        ctx.meta = (int(ignore_index), sn, sc, logits.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lg, lab, wt, saved = ctx.saved_tensors
+        ii, sn, sc, in_dtype = ctx.meta
+        n, c = lg.shape[:2]
+        spatial = lg[0, 0].numel()
+        dl = dloss.to(torch.float32).contiguous()
+        dlogits = torch.empty(lg.shape, dtype=torch.float32, device=lg.device)
+        L.check(L.lib().mednet_ce_bwd(lg.data_ptr(), lab.data_ptr(), L.ptr(wt), saved.data_ptr(), dl.data_ptr(),
+                                      dlogits.data_ptr(), n, c, spatial, sn, sc, ii, L.stream()), "ce_bwd")
+        return dlogits.to(in_dtype), None, None, None
+
+
+def cross_entropy(logits, labels, weight=None, ignore_index=-100):
+    return CrossEntropyFn.apply(logits, labels, weight, ignore_index)
+
+
+class HeatmapLossFn(Function):
+    """sum_c w_c * mean_{n,v} f(out[:,c] - hm[:,c])  -- landmarks.py:129-132 (f = square | abs)."""
+
+    @staticmethod
+    def forward(ctx, out, target, cweight, kind):
+        L.require_gpu(out, "heatmap_loss")
+        lg, sn, sc = _planar_logits(out)
+        n, c = lg.shape[:2]
+        spatial = lg[0, 0].numel()
+        if tuple(target.shape) != tuple(lg.shape):
+            raise RuntimeError(f"heatmap_loss: target shape {tuple(target.shape)} != output {tuple(lg.shape)}")
+        tgt = target if target.dtype in (torch.uint8, torch.float32) else target.float()
+        tgt = tgt.contiguous()
+        wt = None if cweight is None else torch.as_tensor(cweight, dtype=torch.float32, device=lg.device).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=lg.device)
+        lib = L.lib()
+        ws = L.workspace(lib.mednet_loss_ws_bytes(n, c, spatial), lg.device)
+        u8 = int(tgt.dtype == torch.uint8)
+        L.check(lib.mednet_heatmap_loss_fwd(lg.data_ptr(), tgt.data_ptr(), L.ptr(wt), loss.data_ptr(), n, c, spatial, sn,
+                                            sc, kind, u8, ws.data_ptr(), ws.numel(), L.stream()), "heatmap_loss_fwd")
+        ctx.save_for_backward(lg, tgt, wt)
+        ctx.meta = (kind, u8, sn, sc, out.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lg, tgt, wt = ctx.saved_tensors
+        kind, u8, sn, sc, in_dtype = ctx.meta
+        n, c = lg.shape[:2]
+        spatial = lg[0, 0].numel()
+        dl = dloss.to(torch.float32).contiguous()
+        dout = torch.empty(lg.shape, dtype=torch.float32, device=lg.device)
+        L.check(L.lib().mednet_heatmap_loss_bwd(lg.data_ptr(), tgt.data_ptr(), L.ptr(wt), dl.data_ptr(), dout.data_ptr(),
+                                                n, c, spatial, sn, sc, kind, u8, L.stream()), "heatmap_loss_bwd")
+        return dout.to(in_dtype), None, None, None
+
+
+def heatmap_loss(out, target, channel_weights=None, kind="L2"):
+    return HeatmapLossFn.apply(out, target, channel_weights, L.REG_L2 if kind == "L2" else L.REG_L1)
+
+
+# ------------------------------------------------------------------------------------------------- optimiser
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """In-place Adam on flat fp32 buffers (torch.optim.Adam defaults: segmentation.py:119-120)."""
+    L.require_gpu(p, "adam_step")
+    L.check(L.lib().mednet_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2,
+                                     eps, weight_decay, step, grad_scale, L.stream()), "adam_step")

@@ -1,0 +1,161 @@
+"""Building blocks of the 3D U-Nets with the reference's names, signatures, child-module names and parameter shapes
+(midasmednet/unet/components.py), executing on libmednet_hip.
+
+Fusions applied inside SingleConv / ExtResNetBlock / Decoder (the reference runs each as a separate ATen op):
+  conv -> [GroupNorm -> activation]           one GN-stats + one apply pass      (components.py:44,57,36-40)
+  GroupNorm(conv3) + residual -> activation   folded into that same apply pass   (components.py:175-178)
+  ConvTranspose3d + `x += encoder_features`   skip added in the conv epilogue    (components.py:283-284)
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import nn as hnn
+from .. import ops
+
+_ACT_MODULES = {"r": ("ReLU", hnn.ReLU, L.ACT_RELU), "l": ("LeakyReLU", hnn.LeakyReLU, L.ACT_LEAKY),
+                "e": ("ELU", hnn.ELU, L.ACT_ELU)}
+
+
+def conv3d(in_channels, out_channels, kernel_size, bias, padding=1):
+    return hnn.Conv3d(in_channels, out_channels, kernel_size, padding=padding, bias=bias)
+
+
+def create_conv(in_channels, out_channels, kernel_size, order, num_groups, padding=1):
+    """Order-string grammar of components.py:12-67: c conv, g groupnorm, b batchnorm, r/l/e activations."""
+    assert "c" in order, "Conv layer MUST be present"
+    assert order[0] not in "rle", "Non-linearity cannot be the first operation in the layer"
+    conv_pos = order.index("c")
+    modules = []
+    for i, ch in enumerate(order):
+        if ch in _ACT_MODULES:
+            name, cls, _ = _ACT_MODULES[ch]
+            modules.append((name, cls(inplace=True)))
+        elif ch == "c":
+            modules.append(("conv", conv3d(in_channels, out_channels, kernel_size,
+                                           bias=not ("g" in order or "b" in order), padding=padding)))
+        elif ch == "g":
+            nch = in_channels if i < conv_pos else out_channels
+            groups = 1 if nch < num_groups else num_groups
+            assert nch % groups == 0, (f"Expected number of channels in input to be divisible by num_groups. "
+                                       f"num_channels={nch}, num_groups={groups}")
+            modules.append(("groupnorm", hnn.GroupNorm(num_groups=groups, num_channels=nch)))
+        elif ch == "b":
+            # BatchNorm is reachable through the grammar but used by no caller of the reference; it stays a stock
+            # torch module (off the hot path, components.py:58-63).
+            modules.append(("batchnorm", nn.BatchNorm3d(in_channels if i < conv_pos else out_channels)))
+        else:
+            raise ValueError(f"Unsupported layer type '{ch}'. MUST be one of ['b', 'g', 'r', 'l', 'e', 'c']")
+    return modules
+
+
+class SingleConv(nn.Sequential):
+    def __init__(self, in_channels, out_channels, kernel_size=3, order="crg", num_groups=8, padding=1):
+        super().__init__()
+        for name, module in create_conv(in_channels, out_channels, kernel_size, order, num_groups, padding=padding):
+            self.add_module(name, module)
+
+    def forward(self, x, residual=None, final_act=L.ACT_NONE):
+        """`residual`/`final_act` let ExtResNetBlock fold `out += residual; act(out)` into the last GroupNorm."""
+        mods = list(self._modules.values())
+        i = 0
+        fused_res = False
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, hnn.GroupNorm):
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if isinstance(nxt, hnn._Act):
+                    x = m(x, act=nxt.code)
+                    i += 2
+                    continue
+                if nxt is None and residual is not None:
+                    x = m(x, act=final_act, residual=residual)
+                    fused_res = True
+                    i += 1
+                    continue
+                x = m(x)
+            elif isinstance(m, nn.BatchNorm3d):
+                x = m(x.float().contiguous()).to(memory_format=ops.CL)
+            else:
+                x = m(x)
+            i += 1
+        if residual is not None and not fused_res:
+            x = ops.activation(ops.AddFn.apply(x, residual), final_act)
+        return x
+
+
+class DoubleConv(nn.Sequential):
+    def __init__(self, in_channels, out_channels, encoder, kernel_size=3, order="crg", num_groups=8):
+        super().__init__()
+        if encoder:
+            c1_in, c1_out = in_channels, max(out_channels // 2, in_channels)
+            c2_in, c2_out = c1_out, out_channels
+        else:
+            c1_in, c1_out, c2_in, c2_out = in_channels, out_channels, out_channels, out_channels
+        self.add_module("SingleConv1", SingleConv(c1_in, c1_out, kernel_size, order, num_groups))
+        self.add_module("SingleConv2", SingleConv(c2_in, c2_out, kernel_size, order, num_groups))
+
+
+class ExtResNetBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, order="cge", num_groups=8, **kwargs):
+        super().__init__()
+        self.conv1 = SingleConv(in_channels, out_channels, kernel_size=kernel_size, order=order, num_groups=num_groups)
+        self.conv2 = SingleConv(out_channels, out_channels, kernel_size=kernel_size, order=order, num_groups=num_groups)
+        stripped = order.translate({ord(c): None for c in "rel"})
+        self.conv3 = SingleConv(out_channels, out_channels, kernel_size=kernel_size, order=stripped,
+                                num_groups=num_groups)
+        key = "l" if "l" in order else ("e" if "e" in order else "r")
+        self.non_linearity = _ACT_MODULES[key][1](inplace=True)
+
+    def forward(self, x):
+        residual = self.conv1(x)
+        out = self.conv2(residual)
+        return self.conv3(out, residual=residual, final_act=self.non_linearity.code)
+
+
+class Encoder(nn.Module):
+    def __init__(self, in_channels, out_channels, conv_kernel_size=3, apply_pooling=True, pool_kernel_size=(2, 2, 2),
+                 pool_type="max", basic_module=DoubleConv, conv_layer_order="crg", num_groups=8):
+        super().__init__()
+        assert pool_type in ["max", "avg"]
+        if apply_pooling:
+            self.pooling = (hnn.MaxPool3d if pool_type == "max" else hnn.AvgPool3d)(kernel_size=pool_kernel_size)
+        else:
+            self.pooling = None
+        self.basic_module = basic_module(in_channels, out_channels, encoder=True, kernel_size=conv_kernel_size,
+                                         order=conv_layer_order, num_groups=num_groups)
+
+    def forward(self, x):
+        if self.pooling is not None:
+            x = self.pooling(x)
+        return self.basic_module(x)
+
+
+class Decoder(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, scale_factor=(2, 2, 2), basic_module=DoubleConv,
+                 conv_layer_order="crg", num_groups=8):
+        super().__init__()
+        if basic_module == DoubleConv:
+            self.upsample = None  # nearest-neighbour interpolation + concatenation joining
+        else:
+            self.upsample = hnn.ConvTranspose3d(in_channels, out_channels, kernel_size=kernel_size, stride=scale_factor,
+                                                padding=1, output_padding=1)
+            in_channels = out_channels
+        self.basic_module = basic_module(in_channels, out_channels, encoder=False, kernel_size=kernel_size,
+                                         order=conv_layer_order, num_groups=num_groups)
+
+    def forward(self, encoder_features, x):
+        if self.upsample is None:
+            x = ops.upsample_concat(encoder_features, x)
+        else:
+            x = self.upsample(x, skip=encoder_features)
+        return self.basic_module(x)
+
+
+class FinalConv(nn.Sequential):
+    def __init__(self, in_channels, out_channels, kernel_size=3, order="crg", num_groups=8):
+        super().__init__()
+        self.add_module("SingleConv", SingleConv(in_channels, in_channels, kernel_size, order, num_groups))
+        self.add_module("final_conv", hnn.Conv3d(in_channels, out_channels, 1))

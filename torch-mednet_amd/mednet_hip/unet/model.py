@@ -1,0 +1,81 @@
+"""UNet3D / ResidualUNet3D with the constructor signatures, attributes and state_dict keys of
+midasmednet/unet/model.py, running on the MI355X kernels.
+
+Boundary: forward(x: N x Cin x D x H x W, fp32) -> logits N x out x D x H x W, fp32, NCDHW-contiguous.
+The 1x1x1 head writes the logits planar itself; everything between input and head is channels-last.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import nn as hnn
+from .. import ops
+from .components import Decoder, DoubleConv, Encoder, ExtResNetBlock, SingleConv  # noqa: F401  (re-exported like the reference)
+
+try:  # the reference derives from pl.LightningModule (model.py:11,113); keep that base when it is installed
+    import pytorch_lightning as _pl
+
+    _Base = _pl.LightningModule
+except Exception:  # pragma: no cover - pytorch_lightning is not part of this image
+    _Base = nn.Module
+
+
+def create_feature_maps(init_channel_number, number_of_fmaps):
+    return [init_channel_number * 2 ** k for k in range(number_of_fmaps)]
+
+
+class _Softmax1(nn.Module):
+    """nn.Softmax(dim=1) applied at test time only (model.py:107-108,211-212); off the training path."""
+
+    def forward(self, x):
+        return torch.softmax(x, dim=1)
+
+
+class _UNetCore(_Base):
+    def _assemble(self, in_channels, out_channels, f_maps, order, num_groups, block, default_levels):
+        if isinstance(f_maps, int):
+            f_maps = create_feature_maps(f_maps, number_of_fmaps=default_levels)
+        f_maps = list(f_maps)
+        concat = block is DoubleConv
+        self.encoders = nn.ModuleList(
+            Encoder(in_channels if i == 0 else f_maps[i - 1], f, apply_pooling=(i != 0), basic_module=block,
+                    conv_layer_order=order, num_groups=num_groups) for i, f in enumerate(f_maps))
+        rev = f_maps[::-1]
+        self.decoders = nn.ModuleList(
+            Decoder(rev[i] + rev[i + 1] if concat else rev[i], rev[i + 1], basic_module=block, conv_layer_order=order,
+                    num_groups=num_groups) for i in range(len(rev) - 1))
+        self.final_conv = hnn.Conv3d(f_maps[0], out_channels, 1, planar_output=True)
+
+    def forward(self, x):
+        skips = []
+        for enc in self.encoders:
+            x = enc(x)
+            skips.insert(0, x)
+        for dec, skip in zip(self.decoders, skips[1:]):
+            x = dec(skip, x)
+        x = self.final_conv(x)
+        if self.testing and self.final_activation is not None:
+            x = self.final_activation(x)
+        return x
+
+
+class UNet3D(_UNetCore):
+    def __init__(self, in_channels, out_channels, final_sigmoid, f_maps=64, layer_order="gcr", num_groups=8, **kwargs):
+        super().__init__()
+        self.testing = kwargs.get("testing", False)
+        self._assemble(in_channels, out_channels, f_maps, layer_order, num_groups, DoubleConv, default_levels=4)
+        self.final_activation = nn.Sigmoid() if final_sigmoid else _Softmax1()
+
+
+class ResidualUNet3D(_UNetCore):
+    def __init__(self, in_channels, out_channels, final_sigmoid, f_maps=32, conv_layer_order="cge", num_groups=8,
+                 skip_final_activation=False, **kwargs):
+        super().__init__()
+        self.testing = kwargs.get("testing", False)
+        self._assemble(in_channels, out_channels, f_maps, conv_layer_order, num_groups, ExtResNetBlock,
+                       default_levels=5)
+        if skip_final_activation:
+            self.final_activation = None
+        else:
+            self.final_activation = nn.Sigmoid() if final_sigmoid else _Softmax1()
