@@ -1,0 +1,59 @@
+"""The C-ABI shared library loads (no GPU needed) and exports every symbol include/mednet_hip.h declares; the ctypes
+signature table covers exactly that set."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mednet_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mednet_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_symbols():
+    syms = declared_symbols()
+    assert "mednet_conv3d_fwd" in syms and "mednet_dice_fwd" in syms and len(syms) >= 30
+
+
+def test_library_exports_every_declared_symbol():
+    from mednet_hip import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail(f"{_lib.LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(h, s)]
+    assert not missing, f"not exported: {missing}"
+
+
+def test_ctypes_table_matches_header():
+    from mednet_hip import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    lib = _lib.lib()
+    assert lib.mednet_abi_version() == 1
+    assert lib.mednet_device_ok() in (0, 1)
+
+
+def test_argument_counts_match_header():
+    """Each prototype's parameter count equals the ctypes argtypes length (catches drift between the two)."""
+    from mednet_hip import _lib
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, (_, args) in _lib.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", text, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("void", "") else len(params.split(","))
+        assert n == len(args), f"{name}: header has {n} parameters, ctypes table {len(args)}"
+
+
+def test_size_queries_work_without_gpu():
+    from mednet_hip import _lib
+    lib = _lib.lib()
+    assert lib.mednet_conv3d_pack_bytes(32, 32, 3) >= 2 * 27 * 32 * 32 * 4
+    assert lib.mednet_gn_ws_bytes(4, 32, 128 ** 3) > 0
+    assert lib.mednet_loss_ws_bytes(4, 4, 128 ** 3) > 0
+    assert lib.mednet_conv3d_wgrad_ws_bytes(1, 16, 16, 16, 32, 32, 3) > 0

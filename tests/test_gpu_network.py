@@ -1,0 +1,213 @@
+"""Whole-network and block parity on the GPU: HIP modules vs (a) the CPU oracle run on the same seeded inputs and
+(b) the golden vectors captured from the reference itself.  fp32 storage must meet the north-star 1e-3 on logits and
+every gradient; bf16 storage is held to the reference's own bf16 drift."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import mednet_hip
+from mednet_hip.unet import components as HC
+from mednet_hip.unet import loss as HL
+from mednet_hip.unet import model as HM
+from oracle import ref_cpu as O
+
+from gpu_util import DEV, assert_close, rel
+from test_oracle_golden import NETS
+
+pytestmark = pytest.mark.gpu
+
+NET_TOL = {"fp32": (1e-3, 1e-3), "bf16": (3e-2, 8e-2)}  # (logits, grads) rel-L2
+HIP_CLS = {O.ResidualUNet3D: HM.ResidualUNet3D, O.UNet3D: HM.UNet3D}
+
+
+def _hip_loss(lk, w, nh, logits, y, hm):
+    wt = None if w is None else torch.tensor(w, dtype=torch.float32, device=DEV)
+    if lk == "dice":
+        return HL.DiceLoss(weight=wt).to(DEV)(logits, y)
+    if lk == "ce":
+        return HL.CrossEntropyLoss(weight=wt).to(DEV)(logits, y)
+    kind = "L2" if lk == "ldmk" else "L1"
+    return HL.DiceLoss(weight=wt).to(DEV)(logits[:, nh:], y) + HL.HeatmapRegressionLoss([0.015] * nh, kind).to(DEV)(logits[:, :nh], hm)
+
+
+def _oracle_loss(lk, w, nh, logits, y, hm):
+    wt = None if w is None else torch.tensor(w, dtype=torch.float32)
+    if lk == "dice":
+        return O.DiceLoss(weight=wt)(logits, y)
+    if lk == "ce":
+        return nn.CrossEntropyLoss(weight=wt)(logits, y)
+    reg = nn.MSELoss() if lk == "ldmk" else nn.L1Loss()
+    return O.landmark_loss(logits[:, nh:], logits[:, :nh], y, hm, O.DiceLoss(weight=wt), reg, [0.015] * nh)[0]
+
+
+def _run_both(tag, mode, golden_dir):
+    cls, ctor, ncls, nh, lk, w = NETS[tag]
+    rec = np.load(os.path.join(golden_dir, tag + ".npz"))
+    shape = tuple(int(v) for v in rec["meta.shape"])
+    n = int(rec["meta.n"])
+    batch = O.synthetic_batch(n, ctor["in_channels"], shape, ncls, nh, seed=int(rec["meta.seed"]))
+    x = batch["data"].float()
+    y = batch["label"][:, -1].long()
+    hm = batch["label"][:, :-1].float() if nh else None
+    ora = O.keyed_init_(cls(**ctor))
+    lo = ora(x)
+    loss_o = _oracle_loss(lk, w, nh, lo, y, hm)
+    loss_o.backward()
+    # the same oracle in fp64: tells how ill-conditioned each gradient is (how far fp32 rounding alone moves it)
+    ora64 = O.keyed_init_(cls(**ctor)).double()
+    l64 = ora64(x.double())
+    wt64 = None if w is None else torch.tensor(w, dtype=torch.float64)
+    if lk == "dice":
+        loss64 = O.DiceLoss(weight=wt64)(l64, y)
+    elif lk == "ce":
+        loss64 = nn.CrossEntropyLoss(weight=wt64)(l64, y)
+    else:
+        reg = nn.MSELoss() if lk == "ldmk" else nn.L1Loss()
+        loss64 = O.landmark_loss(l64[:, nh:], l64[:, :nh], y, hm.double(), O.DiceLoss(weight=wt64), reg, [0.015] * nh)[0]
+    loss64.backward()
+    ora.cond = {k: max(1.0, rel(p.grad, q.grad) / 1e-6) for (k, p), (_, q) in
+                zip(ora.named_parameters(), ora64.named_parameters())}
+    with mednet_hip.precision(mode):
+        net = O.keyed_init_(HIP_CLS[cls](**ctor)).to(DEV)
+        lg = net(x.to(DEV))
+        assert lg.dtype == torch.float32 and lg.is_contiguous() and lg.shape == lo.shape
+        loss_g = _hip_loss(lk, w, nh, lg, y.to(DEV), None if hm is None else hm.to(DEV))
+        loss_g.backward()
+    return rec, ora, lo, loss_o, net, lg, loss_g
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag", ["res_cfg1", "res_cfg1_ce", "res_small", "res_odd", "res_cfg2_32", "res_cfg4_32",
+                                 "res_ldmk_l1", "unet_cfg1", "unet_small", "unet_oddsize", "unet_cfg2_32"])
+def test_network_parity(tag, mode, golden_dir):
+    rec, ora, lo, loss_o, net, lg, loss_g = _run_both(tag, mode, golden_dir)
+    tl, tg = NET_TOL[mode]
+    report = {"logits": assert_close(lg, lo, tl, f"{tag} logits")}
+    assert abs(float(loss_g) - float(loss_o)) <= (1e-4 if mode == "fp32" else 2e-2) * max(1.0, abs(float(loss_o)))
+    grads_o = dict(ora.named_parameters())
+    worst = 0.0
+    for name, p in net.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32, name
+        r = rel(p.grad, grads_o[name].grad)
+        # a gradient that fp32 rounding alone moves by cond*1e-6 (sums with heavy cancellation, e.g. the affine of a
+        # 1-channel GroupNorm over the whole volume) cannot be held tighter than cond * (storage rounding)
+        lim = max(tg, ora.cond[name] * (3e-6 if mode == "fp32" else 4e-3))
+        worst = max(worst, r / (lim / tg))
+        assert r <= lim, f"{tag} grad {name}: rel-L2 {r:.3e} > {lim:.1e} (cond {ora.cond[name]:.1f})"
+    # and against what the REFERENCE produced (golden): loss + logits
+    if mode == "fp32":
+        assert abs(float(loss_g) - float(rec["loss"])) <= 1e-4 * max(1.0, abs(float(rec["loss"])))
+        if "logits.full" in rec.files:
+            assert_close(lg, torch.from_numpy(rec["logits.full"]), tl, f"{tag} logits vs golden")
+    print(f"[parity] {tag} {mode}: logits {report['logits']:.2e} worst-grad {worst:.2e}")
+
+
+def test_cfg2_128_against_reference_golden(golden_dir):
+    """BASELINE config 2's model on a full 128^3 patch (N=1), fp32 storage, against the vectors captured from the
+    reference: strided logits, loss, and norm / keyed projection of every gradient."""
+    rec = np.load(os.path.join(golden_dir, "res_cfg2_128.npz"))
+    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64, 128, 256])
+    batch = O.synthetic_batch(1, 1, (128, 128, 128), 4, 0, seed=int(rec["meta.seed"]))
+    with mednet_hip.precision("fp32"):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+        lg = net(batch["data"].float().to(DEV))
+        loss = HL.DiceLoss(weight=torch.tensor([0.05, 1, 1, 1.0], device=DEV)).to(DEV)(lg, batch["label"][:, -1].long().to(DEV))
+        loss.backward()
+    s = int(rec["meta.stride"])
+    assert_close(lg[..., ::s, ::s, ::s], torch.from_numpy(rec["logits.strided"]), 1e-3, "strided logits")
+    assert abs(float(loss) - float(rec["loss"])) <= 1e-4
+    assert abs(float(lg.double().norm()) - float(rec["logits.norm"])) <= 1e-3 * float(rec["logits.norm"])
+    for name, p in net.named_parameters():
+        g = p.grad.detach().double().cpu().numpy().reshape(-1)
+        norm = float(rec[f"grad.{name}.norm"])
+        assert abs(np.sqrt((g * g).sum()) - norm) <= 1e-3 * norm, name
+        pv = np.random.Generator(np.random.PCG64(zlib.crc32(("proj:" + name).encode()))).standard_normal(g.size)
+        # |<g - g_ref, r>| <= ||g - g_ref|| * ||r||-ish: a 1e-3 relative error moves the projection by <= ~4e-3*norm
+        assert abs(g @ pv - float(rec[f"grad.{name}.proj"])) <= 4e-3 * norm, name
+        head = rec[f"grad.{name}.head"]
+        assert np.linalg.norm(g[: head.size] - head) <= 2e-3 * max(np.linalg.norm(head), 1e-3 * norm / np.sqrt(g.size) * 8), name
+
+
+def test_training_steps_track_oracle(golden_dir):
+    """segmentation.py:58-65 + :119-120: three Adam steps on cfg1; parameters must track the oracle's."""
+    ctor = dict(in_channels=1, out_channels=2, final_sigmoid=False, f_maps=[8])
+    batch = O.synthetic_batch(2, 1, (32, 32, 32), 2, 0, seed=1234)
+    w = [0.05, 1.0]
+    ora = O.keyed_init_(O.ResidualUNet3D(**ctor))
+    opt_o = torch.optim.Adam(ora.parameters(), lr=1e-3)
+    with mednet_hip.precision("fp32"):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+        opt_g = torch.optim.Adam(net.parameters(), lr=1e-3)
+        crit = HL.DiceLoss(weight=torch.tensor(w, device=DEV)).to(DEV)
+        gb = {k: v.to(DEV) for k, v in batch.items()}
+        for step in range(3):
+            opt_o.zero_grad()
+            lo = O.seg_training_step(ora, O.DiceLoss(weight=torch.tensor(w)), batch)
+            lo.backward()
+            opt_o.step()
+            opt_g.zero_grad()
+            lg = crit(net(gb["data"].float()), gb["label"][:, -1].long())
+            lg.backward()
+            opt_g.step()
+            assert abs(float(lg) - float(lo)) <= 2e-4, (step, float(lg), float(lo))
+    rec = np.load(os.path.join(golden_dir, "callers.npz"))
+    for (k, a), (_, b) in zip(net.named_parameters(), ora.named_parameters()):
+        assert rel(a, b) <= 2e-3, k
+
+
+def test_blocks_against_reference_golden(golden_dir):
+    rec = np.load(os.path.join(golden_dir, "blocks.npz"))
+
+    def rnd(tag, *shape):
+        return torch.from_numpy(O._rng("in:" + tag).standard_normal(shape).astype(np.float32))
+
+    E, D = HC.ExtResNetBlock, HC.DoubleConv
+    cases = {f"single_{o}": (lambda o=o: HC.SingleConv(8, 16, 3, o, 8), [("single_" + o, (2, 8, 6, 10, 12))])
+             for o in ["cge", "gcr", "cg", "cr", "cl", "ce", "crg"]}
+    cases.update({
+        "single_cge_c4": (lambda: HC.SingleConv(4, 4, 3, "cge", 8), [("single_cge_c4", (1, 4, 5, 6, 7))]),
+        "double_enc_gcr": (lambda: D(8, 32, True, 3, "gcr", 8), [("double_enc", (1, 8, 8, 8, 8))]),
+        "double_dec_gcr": (lambda: D(24, 8, False, 3, "gcr", 8), [("double_dec", (1, 24, 8, 8, 8))]),
+        "resblock_cge": (lambda: E(8, 16, order="cge"), [("resblock_cge", (2, 8, 6, 8, 10))]),
+        "resblock_cgr": (lambda: E(8, 16, order="cgr"), [("resblock_cgr", (2, 8, 6, 8, 10))]),
+        "resblock_cgl": (lambda: E(8, 16, order="cgl"), [("resblock_cgl", (2, 8, 6, 8, 10))]),
+        "encoder_res": (lambda: HC.Encoder(8, 16, basic_module=E, conv_layer_order="cge"), [("encoder_res", (2, 8, 8, 12, 10))]),
+        "encoder_res_oddpool": (lambda: HC.Encoder(8, 8, basic_module=E, conv_layer_order="cge"), [("encoder_odd", (1, 8, 7, 9, 11))]),
+        "encoder_double": (lambda: HC.Encoder(8, 16, basic_module=D, conv_layer_order="gcr"), [("encoder_double", (1, 8, 8, 8, 8))]),
+        "decoder_res": (lambda: HC.Decoder(16, 8, basic_module=E, conv_layer_order="cge"),
+                        [("decoder_res_e", (2, 8, 8, 12, 10)), ("decoder_res_x", (2, 16, 4, 6, 5))]),
+        "decoder_double": (lambda: HC.Decoder(24, 8, basic_module=D, conv_layer_order="gcr"),
+                           [("decoder_double_e", (1, 8, 7, 9, 10)), ("decoder_double_x", (1, 16, 3, 4, 5))]),
+    })
+    with mednet_hip.precision("fp32"):
+        for tag, (make, ins) in cases.items():
+            m = O.keyed_init_(make()).to(DEV)
+            xs = [rnd(t, *s).to(DEV).requires_grad_(True) for t, s in ins]
+            y = m(*xs)
+            g = torch.from_numpy(O._rng("cot:" + tag).standard_normal(tuple(y.shape)).astype(np.float32)).to(DEV)
+            (y.float() * g).sum().backward()
+            assert_close(y, torch.from_numpy(rec[f"{tag}.y"]), 2e-4, f"{tag}.y")
+            for i, t in enumerate(xs):
+                assert_close(t.grad, torch.from_numpy(rec[f"{tag}.dx{i}"]), 5e-4, f"{tag}.dx{i}")
+            for k, p in m.named_parameters():
+                assert_close(p.grad, torch.from_numpy(rec[f"{tag}.dp.{k}"]), 5e-4, f"{tag}.dp.{k}")
+
+
+def test_bitwise_reproducible_step():
+    """No float atomics anywhere: two runs of the same step give identical bits (race screen)."""
+    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64])
+    batch = O.synthetic_batch(2, 1, (16, 16, 16), 4, 0, seed=7)
+    outs = []
+    for mode in ("bf16", "bf16", "fp32", "fp32"):
+        with mednet_hip.precision(mode):
+            net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+            lg = net(batch["data"].to(DEV))
+            HL.DiceLoss().to(DEV)(lg, batch["label"][:, -1].long().to(DEV)).backward()
+            outs.append([lg.detach().clone()] + [p.grad.clone() for p in net.parameters()])
+    for a, b in ((outs[0], outs[1]), (outs[2], outs[3])):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)

@@ -1,0 +1,327 @@
+"""Per-op parity of every libmednet_hip entry point against the CPU oracle's ATen ops (fp32 storage: <= 1e-4,
+bf16 storage: <= 2.5e-2 rel-L2), including the edge cases the U-Net hits: Cin=1, odd channel counts, odd spatial
+sizes, GroupNorm's single-group fallback, pooling tails and ties, strided logits slices."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import mednet_hip
+from mednet_hip import _lib as L
+from mednet_hip import nn as hnn
+from mednet_hip import ops
+from mednet_hip.unet import loss as HL
+from oracle import ref_cpu as O
+
+from gpu_util import DEV, TOL, assert_close, bf16_round, rnd
+
+pytestmark = pytest.mark.gpu
+MODES = ["fp32", "bf16"]
+
+
+def _prep(mode, *ts):
+    return [bf16_round(t) if mode == "bf16" else t for t in ts]
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("n,cin,cout,shape,bias", [
+    (2, 1, 8, (6, 10, 12), False), (1, 8, 16, (5, 7, 9), True), (1, 32, 32, (8, 8, 16), False),
+    (2, 3, 5, (4, 6, 7), True), (1, 16, 64, (4, 4, 4), False), (1, 64, 32, (3, 5, 8), False)])
+def test_conv3d_k3(mode, n, cin, cout, shape, bias):
+    tag = f"conv{n}{cin}{cout}{shape}"
+    x, w, cot = _prep(mode, rnd(tag + "x", n, cin, *shape), rnd(tag + "w", cout, cin, 3, 3, 3, scale=0.2),
+                      rnd(tag + "g", n, cout, *shape))
+    b = rnd(tag + "b", cout) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv3d(xr, wr, br, padding=1)
+    (yr * cot).sum().backward()
+    with mednet_hip.precision(mode):
+        conv = hnn.Conv3d(cin, cout, 3, bias=bias).to(DEV)
+        with torch.no_grad():
+            conv.weight.copy_(w)
+            if bias:
+                conv.bias.copy_(b)
+        xg = x.to(DEV).requires_grad_(True)
+        y = conv(xg)
+        assert y.shape == yr.shape and y.dtype == mednet_hip.config.act_dtype()
+        (y.float() * cot.to(DEV)).sum().backward()
+    tol = TOL[mode]
+    assert_close(y, yr, tol, "y")
+    assert_close(xg.grad, xr.grad, tol, "dx")
+    assert_close(conv.weight.grad, wr.grad, tol, "dw")
+    if bias:
+        assert_close(conv.bias.grad, br.grad, tol, "db")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("n,cin,cout,shape", [(2, 32, 4, (6, 8, 10)), (1, 8, 18, (5, 6, 7)), (1, 8, 3, (4, 4, 5)),
+                                              (1, 8, 2, (8, 8, 8))])
+def test_conv1x1_head_planar_logits(mode, n, cin, cout, shape):
+    tag = f"head{n}{cin}{cout}"
+    x, w = _prep(mode, rnd(tag + "x", n, cin, *shape), rnd(tag + "w", cout, cin, 1, 1, 1, scale=0.3))
+    b, cot = rnd(tag + "b", cout), rnd(tag + "g", n, cout, *shape)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, br)
+    (yr * cot).sum().backward()
+    with mednet_hip.precision(mode):
+        conv = hnn.Conv3d(cin, cout, 1, planar_output=True).to(DEV)
+        with torch.no_grad():
+            conv.weight.copy_(w)
+            conv.bias.copy_(b)
+        xg = x.to(DEV).to(mednet_hip.config.act_dtype()).requires_grad_(True)
+        y = conv(xg)
+        assert y.dtype == torch.float32 and y.is_contiguous()
+        (y * cot.to(DEV)).sum().backward()
+    tol = TOL[mode]
+    assert_close(y, yr, 1e-4 if mode == "fp32" else 1e-2, "logits")
+    assert_close(xg.grad, xr.grad, tol, "dx")
+    assert_close(conv.weight.grad, wr.grad, tol, "dw")
+    assert_close(conv.bias.grad, br.grad, 1e-4, "db")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("n,cin,cout,shape,skip", [(2, 16, 8, (3, 5, 4), True), (1, 8, 8, (4, 4, 4), False),
+                                                   (1, 64, 32, (2, 3, 5), True)])
+def test_conv_transpose3d_with_skip(mode, n, cin, cout, shape, skip):
+    tag = f"ct{n}{cin}{cout}"
+    oshape = tuple(2 * s for s in shape)
+    x, w, sk, cot = _prep(mode, rnd(tag + "x", n, cin, *shape), rnd(tag + "w", cin, cout, 3, 3, 3, scale=0.2),
+                          rnd(tag + "s", n, cout, *oshape), rnd(tag + "g", n, cout, *oshape))
+    b = rnd(tag + "b", cout)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    skr = sk.clone().requires_grad_(True)
+    yr = F.conv_transpose3d(xr, wr, br, stride=2, padding=1, output_padding=1)
+    if skip:
+        yr = yr + skr
+    (yr * cot).sum().backward()
+    with mednet_hip.precision(mode):
+        up = hnn.ConvTranspose3d(cin, cout).to(DEV)
+        with torch.no_grad():
+            up.weight.copy_(w)
+            up.bias.copy_(b)
+        dt = mednet_hip.config.act_dtype()
+        xg = x.to(DEV).to(dt).requires_grad_(True)
+        skg = sk.to(DEV).to(dt).requires_grad_(True)
+        y = up(xg, skip=skg if skip else None)
+        (y.float() * cot.to(DEV)).sum().backward()
+    tol = TOL[mode]
+    assert_close(y, yr, tol, "y")
+    assert_close(xg.grad, xr.grad, tol, "dx")
+    assert_close(up.weight.grad, wr.grad, tol, "dw")
+    assert_close(up.bias.grad, br.grad, 1e-3 if mode == "bf16" else 1e-4, "db")
+    if skip:
+        assert_close(skg.grad, skr.grad, tol, "dskip")
+
+
+_ACTS = {"none": (L.ACT_NONE, lambda u: u), "relu": (L.ACT_RELU, F.relu), "leaky": (L.ACT_LEAKY, lambda u: F.leaky_relu(u, 0.1)),
+         "elu": (L.ACT_ELU, F.elu)}
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("c,groups,shape,act,res", [
+    (8, 8, (6, 10, 12), "elu", False), (32, 8, (8, 8, 8), "elu", True), (4, 1, (5, 6, 7), "relu", False),
+    (24, 8, (4, 6, 5), "leaky", True), (6, 3, (3, 4, 5), "none", False), (64, 8, (4, 4, 4), "elu", True),
+    (16, 8, (7, 9, 11), "none", True), (256, 8, (2, 3, 4), "elu", False)])
+def test_group_norm_act(mode, c, groups, shape, act, res):
+    tag = f"gn{c}{groups}{act}{res}"
+    n = 2
+    x, r, cot = _prep(mode, rnd(tag + "x", n, c, *shape, scale=2.0) + 0.5, rnd(tag + "r", n, c, *shape), rnd(tag + "g", n, c, *shape))
+    gamma, beta = rnd(tag + "ga", c) * 0.3 + 1.0, rnd(tag + "be", c) * 0.3
+    code, fn = _ACTS[act]
+    xr, rr = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    u = F.group_norm(xr, groups, gr, br, 1e-5)
+    if res:
+        u = u + rr
+    zr = fn(u)
+    (zr * cot).sum().backward()
+    with mednet_hip.precision(mode):
+        gn = hnn.GroupNorm(groups, c).to(DEV)
+        with torch.no_grad():
+            gn.weight.copy_(gamma)
+            gn.bias.copy_(beta)
+        dt = mednet_hip.config.act_dtype()
+        xg = x.to(DEV).to(dt).requires_grad_(True)
+        rg = r.to(DEV).to(dt).requires_grad_(True)
+        z = gn(xg, act=code, residual=rg if res else None)
+        (z.float() * cot.to(DEV)).sum().backward()
+    tol = TOL[mode]
+    assert_close(z, zr, tol, "z")
+    assert_close(xg.grad, xr.grad, tol, "dx")
+    assert_close(gn.weight.grad, gr.grad, tol, "dgamma")
+    assert_close(gn.bias.grad, br.grad, tol, "dbeta")
+    if res:
+        assert_close(rg.grad, rr.grad, tol, "dres")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("act", ["relu", "leaky", "elu"])
+def test_standalone_activation(mode, act):
+    x, cot = _prep(mode, rnd("act" + act, 2, 5, 3, 7, 9), rnd("actg" + act, 2, 5, 3, 7, 9))
+    code, fn = _ACTS[act]
+    xr = x.clone().requires_grad_(True)
+    zr = fn(xr)
+    (zr * cot).sum().backward()
+    with mednet_hip.precision(mode):
+        xg = x.to(DEV).to(mednet_hip.config.act_dtype()).requires_grad_(True)
+        z = ops.activation(xg, code)
+        (z.float() * cot.to(DEV)).sum().backward()
+    assert_close(z, zr, TOL[mode], "z")
+    assert_close(xg.grad, xr.grad, TOL[mode], "dx")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("c,shape,kind", [(8, (8, 12, 10), "max"), (32, (4, 4, 4), "max"), (8, (7, 9, 11), "max"),
+                                          (3, (6, 5, 4), "max"), (16, (6, 6, 6), "avg"), (5, (5, 7, 6), "avg")])
+def test_pool2(mode, c, shape, kind):
+    n = 2
+    (x,) = _prep(mode, rnd(f"pool{c}{shape}", n, c, *shape))
+    oshape = tuple(s // 2 for s in shape)
+    (cot,) = _prep(mode, rnd(f"poolg{c}{shape}", n, c, *oshape))
+    xr = x.clone().requires_grad_(True)
+    yr = (F.max_pool3d if kind == "max" else F.avg_pool3d)(xr, 2)
+    (yr * cot).sum().backward()
+    with mednet_hip.precision(mode):
+        xg = x.to(DEV).to(mednet_hip.config.act_dtype()).requires_grad_(True)
+        y = ops.pool2(xg, L.POOL_MAX if kind == "max" else L.POOL_AVG)
+        (y.float() * cot.to(DEV)).sum().backward()
+    tol = 1e-6 if (mode == "fp32" or kind == "max") else TOL[mode]
+    assert_close(y, yr, tol, "y")
+    assert_close(xg.grad, xr.grad, max(tol, 1e-6) if kind == "max" else TOL[mode], "dx")
+
+
+def test_max_pool_ties_route_to_first_maximum():
+    x = torch.zeros(1, 8, 4, 4, 4)
+    x[0, :, 0, 1, 1] = 1.0
+    x[0, :, 1, 0, 0] = 1.0  # two equal maxima inside the first window; ReLU outputs produce many such ties
+    cot = torch.ones(1, 8, 2, 2, 2)
+    xr = x.clone().requires_grad_(True)
+    F.max_pool3d(xr, 2).backward(cot)
+    xg = x.to(DEV).requires_grad_(True)
+    with mednet_hip.precision("fp32"):
+        ops.pool2(xg, L.POOL_MAX).backward(cot.to(DEV))
+    assert torch.equal(xg.grad.cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("ce,cx,eshape,xshape", [(8, 16, (8, 12, 10), (4, 6, 5)), (8, 16, (7, 9, 10), (3, 4, 5)),
+                                                 (3, 5, (5, 5, 5), (2, 2, 2))])
+def test_upsample_concat(mode, ce, cx, eshape, xshape):
+    e, x = _prep(mode, rnd(f"uce{ce}{eshape}", 2, ce, *eshape), rnd(f"ucx{cx}{xshape}", 2, cx, *xshape))
+    (cot,) = _prep(mode, rnd(f"ucg{ce}{cx}{eshape}", 2, ce + cx, *eshape))
+    er, xr = e.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    yr = torch.cat((er, F.interpolate(xr, size=eshape, mode="nearest")), dim=1)
+    (yr * cot).sum().backward()
+    with mednet_hip.precision(mode):
+        dt = mednet_hip.config.act_dtype()
+        eg, xg = e.to(DEV).to(dt).requires_grad_(True), x.to(DEV).to(dt).requires_grad_(True)
+        y = ops.upsample_concat(eg, xg)
+        (y.float() * cot.to(DEV)).sum().backward()
+    assert_close(y, yr, 1e-6, "y")
+    assert_close(eg.grad, er.grad, 1e-6, "denc")
+    assert_close(xg.grad, xr.grad, 1e-6 if mode == "fp32" else 1e-2, "dx")
+
+
+# ----------------------------------------------------------------------------------------------------- losses
+@pytest.mark.parametrize("kw", [dict(), dict(weight=[0.05, 1, 1, 1]), dict(weight=[0.05, 1, 1, 1], sigmoid_normalization=True),
+                                dict(weight=[0.05, 1, 1, 1], ignore_index=1), dict(ignore_index=0), dict(epsilon=1e-2)])
+def test_dice_loss_matches_golden_and_oracle(kw, golden_dir):
+    import os
+    rec = np.load(os.path.join(golden_dir, "losses.npz"))
+    z, y = torch.from_numpy(rec["logits"]), torch.from_numpy(rec["labels"])
+    kwt = {k: (torch.tensor(v) if k == "weight" else v) for k, v in kw.items()}
+    zr = z.clone().requires_grad_(True)
+    lr = O.DiceLoss(**kwt)(zr, y)
+    lr.backward()
+    zg = z.to(DEV).requires_grad_(True)
+    kwg = {k: (torch.tensor(v).to(DEV) if k == "weight" else v) for k, v in kw.items()}
+    lg = HL.DiceLoss(**kwg).to(DEV)(zg, y.to(DEV))
+    lg.backward()
+    assert abs(float(lg) - float(lr)) <= 2e-6
+    assert_close(zg.grad, zr.grad, 1e-5, "dlogits")
+    tags = {(): "dice_plain", ("weight",): "dice_weight", ("sigmoid_normalization", "weight"): "dice_sigmoid",
+            ("ignore_index", "weight"): "dice_ignore", ("epsilon",): "dice_eps"}
+    tag = tags.get(tuple(sorted(kw)))
+    if tag and not (tag == "dice_ignore" and kw.get("ignore_index") != 1):
+        assert abs(float(lg) - float(rec[tag + ".value"])) <= 2e-6      # golden = the reference's own output
+        assert_close(zg.grad, torch.from_numpy(rec[tag + ".grad"]), 1e-5, "dlogits vs golden")
+
+
+def test_dice_on_channel_slice_and_large_batch():
+    z = rnd("dslice", 3, 7, 9, 10, 11, scale=2.0)
+    y = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).integers(0, 2, size=(3, 9, 10, 11)))
+    w = torch.tensor([0.05, 1.0])
+    zr = z.clone().requires_grad_(True)
+    lr = O.DiceLoss(weight=w)(zr[:, 5:], y)
+    lr.backward()
+    zg = z.to(DEV).requires_grad_(True)
+    lg = HL.DiceLoss(weight=w.to(DEV)).to(DEV)(zg[:, 5:], y.to(DEV))
+    lg.backward()
+    assert abs(float(lg) - float(lr)) <= 2e-6
+    assert_close(zg.grad, zr.grad, 1e-5, "dlogits")
+    assert torch.count_nonzero(zg.grad[:, :5]) == 0
+
+
+def test_dice_metric_and_shape_assert(golden_dir):
+    import os
+    rec = np.load(os.path.join(golden_dir, "losses.npz"))
+    z, y = torch.from_numpy(rec["logits"]), torch.from_numpy(rec["labels"])
+    d = HL.dice_metric(z.to(DEV), y.to(DEV))
+    np.testing.assert_allclose(d.cpu().numpy(), rec["dice_metric.value"], rtol=2e-5)
+    with pytest.raises(AssertionError, match="same shape"):
+        HL.DiceLoss().to(DEV)(z.to(DEV), y[:, :-1].to(DEV))
+    with pytest.raises(AssertionError, match="same shape"):
+        HL.DiceLoss(skip_last_target=True).to(DEV)(z.to(DEV), y.to(DEV))
+
+
+@pytest.mark.parametrize("weight", [None, [0.05, 1, 1, 1]])
+def test_cross_entropy(weight, golden_dir):
+    import os
+    rec = np.load(os.path.join(golden_dir, "losses.npz"))
+    z, y = torch.from_numpy(rec["logits"]), torch.from_numpy(rec["labels"])
+    w = None if weight is None else torch.tensor(weight)
+    tag = "ce_plain" if weight is None else "ce_weight"
+    zg = z.to(DEV).requires_grad_(True)
+    lg = HL.CrossEntropyLoss(weight=None if w is None else w.to(DEV)).to(DEV)(zg, y.to(DEV))
+    lg.backward()
+    assert abs(float(lg) - float(rec[tag + ".value"])) <= 2e-6
+    assert_close(zg.grad, torch.from_numpy(rec[tag + ".grad"]), 1e-5, "dlogits")
+
+
+@pytest.mark.parametrize("kind", ["L2", "L1"])
+def test_landmark_loss_composition(kind, golden_dir):
+    """LandmarkNet.loss (landmarks.py:125-134): Dice on the class slice + weighted per-channel regression."""
+    import os
+    rec = np.load(os.path.join(golden_dir, "losses.npz"))
+    out = torch.from_numpy(rec["logits5"]).to(DEV).requires_grad_(True)
+    hm = torch.from_numpy(rec["heatmaps"]).to(DEV)
+    lab = torch.from_numpy(rec["labels2"]).to(DEV)
+    regw = [0.001, 0.015, 0.02]
+    cl = HL.DiceLoss(weight=torch.tensor([0.05, 1.0]).to(DEV)).to(DEV)(out[:, 3:], lab)
+    rg = HL.HeatmapRegressionLoss(regw, kind).to(DEV)(out[:, :3], hm)
+    (cl + rg).backward()
+    tag = "ldmk_l2" if kind == "L2" else "ldmk_l1"
+    assert abs(float(cl) - float(rec[tag + ".class"])) <= 2e-6
+    assert abs(float(rg) - float(rec[tag + ".reg"])) <= 2e-5 * abs(float(rec[tag + ".reg"]))
+    assert_close(out.grad, torch.from_numpy(rec[tag + ".grad"]), 1e-5, "dout")
+    # uint8 heat-map targets (what MedDataset emits, dataset.py:327) give the same numbers without the .float() copy
+    out2 = torch.from_numpy(rec["logits5"]).to(DEV).requires_grad_(True)
+    rg2 = HL.HeatmapRegressionLoss(regw, kind).to(DEV)(out2[:, :3], hm.to(torch.uint8))
+    assert abs(float(rg2) - float(rg)) <= 1e-6 * abs(float(rg))
+
+
+def test_adam_step_matches_torch():
+    g = np.random.Generator(np.random.PCG64(3))
+    p0 = torch.from_numpy(g.standard_normal(10007).astype(np.float32))
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = p0.to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        grad = torch.from_numpy(g.standard_normal(10007).astype(np.float32))
+        ref.grad = grad.clone()
+        opt.step()
+        ops.adam_step_(p, grad.to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.0, step)
+    assert_close(p, ref, 1e-6, "params after 3 Adam steps")

@@ -1,0 +1,118 @@
+"""Host-side logic of the product package that needs no GPU: module tree / state_dict compatibility with the oracle
+(hence with the reference), the order-string grammar and its error conventions, the import alias, and the loud
+failure on CPU tensors (there is no CPU fallback)."""
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from mednet_hip.unet import components as HC
+from mednet_hip.unet import loss as HL
+from mednet_hip.unet import model as HM
+
+
+@pytest.mark.parametrize("cls,ocls,kw", [
+    (HM.ResidualUNet3D, O.ResidualUNet3D, dict(f_maps=[8])),
+    (HM.ResidualUNet3D, O.ResidualUNet3D, dict(f_maps=[32, 64, 128, 256])),
+    (HM.ResidualUNet3D, O.ResidualUNet3D, dict(f_maps=16)),
+    (HM.ResidualUNet3D, O.ResidualUNet3D, dict(f_maps=[8, 16], conv_layer_order="cgr", num_groups=4)),
+    (HM.UNet3D, O.UNet3D, dict(f_maps=[32, 64, 128, 256])),
+    (HM.UNet3D, O.UNet3D, dict(f_maps=16)),
+    (HM.UNet3D, O.UNet3D, dict(f_maps=[8, 16], layer_order="crg")),
+])
+def test_state_dict_interchange(cls, ocls, kw):
+    a, b = cls(1, 4, False, **kw), ocls(1, 4, False, **kw)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa.keys()) == list(sb.keys())
+    for k in sa:
+        assert sa[k].shape == sb[k].shape, k
+    a.load_state_dict(sb)  # oracle/reference checkpoint loads into the HIP module ...
+    b.load_state_dict(a.state_dict())  # ... and back
+    assert [n for n, _ in a.named_modules()] == [n for n, _ in b.named_modules()]
+
+
+def test_param_counts():
+    assert sum(p.numel() for p in HM.ResidualUNet3D(1, 2, False, f_maps=[8]).parameters()) == 3738
+    assert sum(p.numel() for p in HM.ResidualUNet3D(1, 4, False, f_maps=[32, 64, 128, 256]).parameters()) == 8769860
+    assert sum(p.numel() for p in HM.UNet3D(1, 4, False, f_maps=[32, 64, 128, 256]).parameters()) == 4081366
+    assert HM.create_feature_maps(32, 5) == [32, 64, 128, 256, 512]
+
+
+def test_default_init_statistics_match_torch():
+    torch.manual_seed(0)
+    a = HM.ResidualUNet3D(1, 4, False, f_maps=[32, 64])
+    torch.manual_seed(0)
+    b = O.ResidualUNet3D(1, 4, False, f_maps=[32, 64])
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(pa, pb), k  # same RNG consumption order and same init formulas
+
+
+def test_order_grammar_errors():
+    with pytest.raises(AssertionError, match="Conv layer MUST be present"):
+        HC.create_conv(4, 8, 3, "ge", 8)
+    with pytest.raises(AssertionError, match="Non-linearity cannot be the first"):
+        HC.create_conv(4, 8, 3, "rcg", 8)
+    with pytest.raises(ValueError, match="Unsupported layer type"):
+        HC.create_conv(4, 8, 3, "cxg", 8)
+    with pytest.raises(AssertionError, match="divisible by num_groups"):
+        HC.create_conv(4, 12, 3, "cg", 8)
+    names = [n for n, _ in HC.create_conv(4, 8, 3, "cge", 8)]
+    assert names == ["conv", "groupnorm", "ELU"]
+    mods = dict(HC.create_conv(4, 4, 3, "cg", 8))
+    assert mods["groupnorm"].num_groups == 1 and mods["conv"].bias is None  # C < groups -> 1 group; no bias with norm
+    assert dict(HC.create_conv(4, 8, 3, "cr", 8))["conv"].bias is not None
+    assert dict(HC.create_conv(8, 16, 3, "gcr", 8))["groupnorm"].num_channels == 8
+
+
+def test_double_conv_channel_rule():
+    enc = HC.DoubleConv(1, 32, encoder=True, order="gcr")
+    assert enc.SingleConv1.conv.weight.shape[:2] == (16, 1) and enc.SingleConv2.conv.weight.shape[:2] == (32, 16)
+    enc = HC.DoubleConv(32, 40, encoder=True, order="gcr")
+    assert enc.SingleConv1.conv.weight.shape[0] == 32  # max(out//2, in)
+    dec = HC.DoubleConv(96, 32, encoder=False, order="gcr")
+    assert dec.SingleConv1.conv.weight.shape[:2] == (32, 96) and dec.SingleConv2.conv.weight.shape[:2] == (32, 32)
+
+
+def test_import_alias_resolves_to_hip_modules():
+    import midasmednet.unet.components as c
+    import midasmednet.unet.loss as l
+    import midasmednet.unet.model as m
+    assert m.ResidualUNet3D is HM.ResidualUNet3D and m.UNet3D is HM.UNet3D
+    assert c.ExtResNetBlock is HC.ExtResNetBlock and l.DiceLoss is HL.DiceLoss
+    for name in ["flatten", "compute_per_channel_dice", "dice_metric", "expand_as_one_hot", "DiceLoss", "CELoss",
+                 "WeightedCrossEntropyLoss", "BCELossWrapper", "PixelWiseCrossEntropyLoss", "LandmarkLoss"]:
+        assert hasattr(l, name)
+
+
+def test_no_cpu_fallback():
+    net = HM.ResidualUNet3D(1, 2, False, f_maps=[8])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 1, 8, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HL.DiceLoss()(torch.zeros(1, 2, 4, 4, 4), torch.zeros(1, 4, 4, 4, dtype=torch.long))
+
+
+def test_testing_flag_and_final_activation():
+    assert HM.ResidualUNet3D(1, 2, False, f_maps=[8]).testing is False
+    assert HM.ResidualUNet3D(1, 2, False, f_maps=[8], testing=True).testing is True
+    assert HM.ResidualUNet3D(1, 2, False, f_maps=[8], skip_final_activation=True).final_activation is None
+    assert isinstance(HM.UNet3D(1, 2, True, f_maps=[8]).final_activation, torch.nn.Sigmoid)
+
+
+def test_unsupported_shapes_raise():
+    from mednet_hip import nn as hnn
+    with pytest.raises(NotImplementedError):
+        hnn.Conv3d(4, 4, 5)
+    with pytest.raises(NotImplementedError):
+        hnn.MaxPool3d(kernel_size=(1, 2, 2))
+    with pytest.raises(NotImplementedError):
+        hnn.ConvTranspose3d(4, 4, kernel_size=3, stride=(1, 2, 2))
+
+
+def test_one_hot_and_generic_dice_helpers_match_oracle():
+    y = torch.randint(0, 4, (2, 3, 4, 5))
+    assert torch.equal(HL.expand_as_one_hot(y, 4), O.expand_as_one_hot(y, 4))
+    assert torch.equal(HL.expand_as_one_hot(y, 4, ignore_index=2), O.expand_as_one_hot(y, 4, ignore_index=2))
+    p = torch.softmax(torch.randn(2, 4, 3, 4, 5), 1)
+    t = O.expand_as_one_hot(y, 4)
+    assert torch.equal(HL.compute_per_channel_dice(p, t), O.compute_per_channel_dice(p, t))
+    assert torch.equal(HL.flatten(p), O.flatten(p))
