@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 128^3 patches/sec, training, 3D U-Net 32-base-ch (BASELINE.json), on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One step = SegmentationNet.training_step on one batch (segmentation.py:58-65): fwd + DiceLoss + bwd, one RCCL
+all-reduce of the flat gradient buffer, Adam -- BASELINE config 2 (ResidualUNet3D f_maps=[32,64,128,256], 4 classes,
+128^3 patches, batch 4 per GPU, bf16 storage / fp32 accumulate), weak scaling.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "torch-mednet_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, MI355X_MICROARCH.md
+F_MAPS = [32, 64, 128, 256]
+FLOP_PER_PATCH = 3447.9e9  # 6 x forward conv/convT MACs of ResidualUNet3D cfg2 at 128^3
+
+
+def cpu_baseline(steps: int):
+    """The oracle (plain torch.nn restatement of the reference) timed on this box's host cores: cfg2's model, N=1,
+    128^3, fp32, fwd + DiceLoss + bwd + Adam -- a bounded sample (1 warm-up + `steps` timed steps)."""
+    from oracle import ref_cpu as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = O.keyed_init_(O.ResidualUNet3D(1, 4, False, f_maps=F_MAPS))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = O.DiceLoss(weight=torch.tensor([0.05, 1.0, 1.0, 1.0]))
+    batch = O.synthetic_batch(1, 1, (128, 128, 128), 4, 0, seed=1234)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = O.seg_training_step(model, crit, batch)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    timed = sorted(times[1:])
+    med = timed[len(timed) // 2]
+    return {"value": round(1.0 / med, 5), "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": f"oracle ResidualUNet3D {F_MAPS} 4-class, one 128^3 patch (N=1), fp32, fwd+Dice+bwd+Adam, "
+                      f"1 warm-up + {steps} timed steps (median {med:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="patches per GPU per step (config 2: 4)")
+    ap.add_argument("--patch", type=int, default=128)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    import mednet_hip
+    from mednet_hip import _lib, ops
+    from mednet_hip.train import SegmentationStep
+    from mednet_hip.unet.model import ResidualUNet3D
+    from mednet_hip.synth import keyed_init_, synthetic_batch
+
+    assert _lib.lib().mednet_device_ok() == 1, "libmednet_hip.so sees no gfx950 device"
+    mednet_hip.set_precision(a.precision)
+    model = keyed_init_(ResidualUNet3D(1, 4, False, f_maps=F_MAPS)).to(dev)
+    step = SegmentationStep(model, loss_weight=[0.05, 1.0, 1.0, 1.0], lr=1e-3, world_size=world)
+    P = a.patch
+    batch = {k: v.to(dev) for k, v in synthetic_batch(a.batch, 1, (P, P, P), 4, 0, seed=1234 + rank).items()}
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = step(batch)
+    sync()
+    if not a.no_roofline:
+        # dominant kernel: the 3x3x3 conv at full resolution with f0 -> f0 channels (forward launches; the data
+        # gradient runs the same kernel).  HIP events on the launch stream (= torch's current stream).
+        ops.PROFILE.update(enabled=True, events=[],
+                           match=lambda k, ci, co, d, h, w: k == 3 and ci == F_MAPS[0] and co == F_MAPS[0] and d == P)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    ops.PROFILE["enabled"] = False
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        patches = a.batch * world * a.steps
+        out = {
+            "metric": "128^3 patches/sec training, 3D U-Net 32-base-ch", "value": round(patches / dt, 4),
+            "unit": "patches/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": f"ResidualUNet3D f_maps={F_MAPS} 4-class, {P}^3 patches, batch {a.batch}/GPU, "
+                                   f"fwd+DiceLoss+bwd+allreduce+Adam (BASELINE config {'2' if world == 1 else '3'})",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "loss": round(final_loss, 6)},
+        }
+        if P == 128 and a.precision == "bf16":
+            out["model_flops_utilization"] = round(patches / dt * FLOP_PER_PATCH / (world * MFMA_PEAK_TFLOPS["bf16"] * 1e12), 4)
+        if not a.no_roofline and ops.PROFILE["events"]:
+            ev = ops.PROFILE["events"]
+            ms = [e0.elapsed_time(e1) for e0, e1, _ in ev]
+            flops = ev[0][2]
+            avg = sum(ms) / len(ms)
+            peak = MFMA_PEAK_TFLOPS[a.precision]
+            ach = flops / (avg * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "conv3d 3x3x3 32->32 @128^3 (fwd launches)", "bound": "mfma",
+                               "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                               "traffic": None, "launches": len(ms), "avg_ms": round(avg, 4),
+                               "flop_per_launch": flops}
+        if a.cpu_steps > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

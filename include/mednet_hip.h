@@ -64,10 +64,10 @@ int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, 
 int mednet_convt3d_fwd(const void* x, const void* packed, const float* bias, const void* skip, void* y, int n,
                        int d, int h, int w, int cin, int cout, int x_dtype, int y_dtype, mednet_stream stream);
 int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx, int n, int d, int h, int w, int cin,
-                         int cout, int dy_dtype, int dx_dtype, mednet_stream stream);
+                         int cout, int dy_dtype, int dx_dtype, int algo, mednet_stream stream);
 size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
 int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
-                         int cin, int cout, int x_dtype, int dy_dtype, void* ws, size_t ws_bytes,
+                         int cin, int cout, int x_dtype, int dy_dtype, int algo, void* ws, size_t ws_bytes,
                          mednet_stream stream);
 
 /* ---- nn.GroupNorm(G,C,eps) fused with the following activation and the residual add

@@ -1,0 +1,62 @@
+"""The N>1 path on CPU: world_size-2 gloo.  Checks the trainer's flat-buffer exchange (train.FlatParams +
+train.allreduce_gradients) against the definition in SURVEY 8(e): every rank ends with the MEAN of the per-rank-batch
+gradients (Dice is reduced over the local batch first), and identical parameters after the update."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "torch-mednet_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle import ref_cpu as O
+    from mednet_hip.train import FlatParams, allreduce_gradients
+    model = O.keyed_init_(O.ResidualUNet3D(1, 2, False, f_maps=[8]))
+    flat = FlatParams(model)
+    # parameters now alias the flat buffer
+    assert all(p.data.data_ptr() >= flat.flat.data_ptr() for p in flat.params)
+    batch = O.synthetic_batch(2, 1, (16, 16, 16), 2, 0, seed=1234 + rank)  # per-rank patches (seed + rank)
+    loss = O.seg_training_step(model, O.DiceLoss(weight=torch.tensor([0.05, 1.0])), batch)
+    loss.backward()
+    for p in flat.params:  # the CPU oracle has no direct-gradient kernels: stage its grads into the flat buffer
+        p._mednet_grad.copy_(p.grad)
+    local = flat.grad.clone()
+    scale = allreduce_gradients(flat.grad, world)
+    torch.save({"local": local, "reduced": flat.grad * scale, "scale": scale}, os.path.join(out, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world2(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    assert r0["scale"] == 0.5
+    assert not torch.equal(r0["local"], r1["local"])  # different patches per rank
+    mean = 0.5 * (r0["local"] + r1["local"])
+    assert torch.allclose(r0["reduced"], mean, rtol=1e-6, atol=1e-9)
+    assert torch.equal(r0["reduced"], r1["reduced"])  # every rank applies the same update
+
+
+def test_synth_generators_match_oracle():
+    from oracle import ref_cpu as O
+    from mednet_hip import synth
+    a = O.synthetic_batch(2, 1, (8, 8, 8), 4, 3, seed=99)
+    b = synth.synthetic_batch(2, 1, (8, 8, 8), 4, 3, seed=99)
+    assert torch.equal(a["data"], b["data"]) and torch.equal(a["label"], b["label"])
+    m1 = O.keyed_init_(O.ResidualUNet3D(1, 4, False, f_maps=[8, 16]))
+    m2 = synth.keyed_init_(O.ResidualUNet3D(1, 4, False, f_maps=[8, 16]))
+    for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p, q), k

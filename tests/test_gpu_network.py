@@ -95,7 +95,7 @@ def test_network_parity(tag, mode, golden_dir):
         r = rel(p.grad, grads_o[name].grad)
         # a gradient that fp32 rounding alone moves by cond*1e-6 (sums with heavy cancellation, e.g. the affine of a
         # 1-channel GroupNorm over the whole volume) cannot be held tighter than cond * (storage rounding)
-        lim = max(tg, ora.cond[name] * (3e-6 if mode == "fp32" else 4e-3))
+        lim = max(tg, ora.cond[name] * 3e-6) if mode == "fp32" else tg * ora.cond[name]
         worst = max(worst, r / (lim / tg))
         assert r <= lim, f"{tag} grad {name}: rel-L2 {r:.3e} > {lim:.1e} (cond {ora.cond[name]:.1f})"
     # and against what the REFERENCE produced (golden): loss + logits
@@ -211,3 +211,35 @@ def test_bitwise_reproducible_step():
     for a, b in ((outs[0], outs[1]), (outs[2], outs[3])):
         for u, v in zip(a, b):
             assert torch.equal(u, v)
+
+
+def test_trainer_direct_gradients_and_fused_adam(golden_dir):
+    """train.SegmentationStep (flat buffers, kernels writing gradients in place, fused Adam) follows the same
+    trajectory as the oracle + torch.optim.Adam for three steps (segmentation.py:58-65,119-120)."""
+    from mednet_hip.train import SegmentationStep
+    ctor = dict(in_channels=1, out_channels=2, final_sigmoid=False, f_maps=[8])
+    batch = O.synthetic_batch(2, 1, (32, 32, 32), 2, 0, seed=1234)
+    w = [0.05, 1.0]
+    ora = O.keyed_init_(O.ResidualUNet3D(**ctor))
+    opt_o = torch.optim.Adam(ora.parameters(), lr=1e-3)
+    with mednet_hip.precision("fp32"):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+        step = SegmentationStep(net, loss_weight=w, lr=1e-3)
+        gb = {k: v.to(DEV) for k, v in batch.items()}
+        for i in range(3):
+            opt_o.zero_grad()
+            lo = O.seg_training_step(ora, O.DiceLoss(weight=torch.tensor(w)), batch)
+            lo.backward()
+            if i == 0:
+                first = {k: p.grad.clone() for k, p in ora.named_parameters()}
+            opt_o.step()
+            lg = step(gb)
+            if i == 0:
+                step.flat.grads_as_attr()
+                for k, p in net.named_parameters():
+                    assert_close(p.grad, first[k], 1e-3, f"direct grad {k}")
+            assert abs(float(lg) - float(lo)) <= 2e-4, (i, float(lg), float(lo))
+    for (k, a), (_, b) in zip(net.named_parameters(), ora.named_parameters()):
+        assert rel(a, b) <= 2e-3, k
+    rec = np.load(os.path.join(golden_dir, "callers.npz"))
+    assert abs(float(rec["seg.loss"]) - 0.77166152) < 1e-6  # the reference's own first-step loss on this batch

@@ -325,3 +325,80 @@ def test_adam_step_matches_torch():
         opt.step()
         ops.adam_step_(p, grad.to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.0, step)
     assert_close(p, ref, 1e-6, "params after 3 Adam steps")
+
+
+# ----------------------------------------------------------------------------------------------------- MFMA kernels
+def _conv_case(n, cin, cout, shape, tag):
+    x = bf16_round(rnd(tag + "x", n, cin, *shape))
+    w = bf16_round(rnd(tag + "w", cout, cin, 3, 3, 3, scale=0.08))
+    cot = bf16_round(rnd(tag + "g", n, cout, *shape))
+    return x, w, cot
+
+
+@pytest.mark.parametrize("n,cin,cout,shape", [
+    (1, 32, 32, (4, 8, 16)),      # exactly one brick
+    (2, 32, 32, (9, 11, 21)),     # ragged bricks in every dimension, two samples
+    (1, 64, 32, (8, 16, 16)),     # 4 K-chunks
+    (1, 32, 64, (6, 8, 32)),      # two output-channel blocks
+    (1, 128, 128, (5, 6, 7)),     # volume smaller than a brick
+    (1, 256, 256, (4, 4, 4)),
+    (2, 64, 64, (16, 16, 16)),
+])
+def test_conv3d_mfma_fwd_dgrad_wgrad(n, cin, cout, shape):
+    """The bf16 MFMA kernels (forced) against the fp32 oracle AND against the direct kernels on identical bf16 inputs
+    (weights pre-rounded to bf16, so the only differences are accumulation order and the bf16 rounding of outputs)."""
+    tag = f"mfma{n}{cin}{cout}{shape}"
+    x, w, cot = _conv_case(n, cin, cout, shape, tag)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, padding=1)
+    (yr * cot).sum().backward()
+    res = {}
+    for algo in ("mfma", "direct"):
+        mednet_hip.set_conv_algo(algo)
+        try:
+            with mednet_hip.precision("bf16"):
+                conv = hnn.Conv3d(cin, cout, 3, bias=False).to(DEV)
+                with torch.no_grad():
+                    conv.weight.copy_(w)
+                xg = x.to(DEV).bfloat16().requires_grad_(True)
+                y = conv(xg)
+                y.backward(cot.to(DEV).bfloat16())
+                res[algo] = (y.detach().float().cpu(), xg.grad.float().cpu(), conv.weight.grad.cpu())
+        finally:
+            mednet_hip.set_conv_algo("auto")
+    y, dx, dw = res["mfma"]
+    assert_close(y, yr, 6e-3, "y vs oracle")          # bf16 output rounding only (2^-9 relative per element)
+    assert_close(dx, xr.grad, 6e-3, "dx vs oracle")
+    assert_close(dw, wr.grad, 2e-4, "dw vs oracle")   # fp32 output, fp32 accumulation
+    yd, dxd, dwd = res["direct"]
+    assert_close(y, yd, 5e-3, "y vs direct kernel")
+    assert_close(dx, dxd, 5e-3, "dx vs direct kernel")
+    assert_close(dw, dwd, 2e-4, "dw vs direct kernel")
+
+
+@pytest.mark.parametrize("n,cin,cout,shape", [(1, 64, 32, (2, 4, 16)), (2, 64, 32, (3, 5, 9)), (1, 256, 128, (4, 4, 4)),
+                                              (1, 32, 32, (5, 9, 17))])
+def test_conv_transpose_mfma_dgrad_wgrad(n, cin, cout, shape):
+    tag = f"ctm{n}{cin}{cout}{shape}"
+    oshape = tuple(2 * s for s in shape)
+    x = bf16_round(rnd(tag + "x", n, cin, *shape))
+    w = bf16_round(rnd(tag + "w", cin, cout, 3, 3, 3, scale=0.08))
+    cot = bf16_round(rnd(tag + "g", n, cout, *oshape))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv_transpose3d(xr, wr, None, stride=2, padding=1, output_padding=1)
+    (yr * cot).sum().backward()
+    mednet_hip.set_conv_algo("mfma")
+    try:
+        with mednet_hip.precision("bf16"):
+            up = hnn.ConvTranspose3d(cin, cout).to(DEV)
+            with torch.no_grad():
+                up.weight.copy_(w)
+                up.bias.zero_()
+            xg = x.to(DEV).bfloat16().requires_grad_(True)
+            y = up(xg)
+            y.backward(cot.to(DEV).bfloat16())
+    finally:
+        mednet_hip.set_conv_algo("auto")
+    assert_close(y, yr, 6e-3, "y")
+    assert_close(xg.grad, xr.grad, 6e-3, "dx (MFMA stride-2 gather)")
+    assert_close(up.weight.grad, wr.grad, 2e-4, "dw (MFMA, transposing LDS reads)")

@@ -135,10 +135,15 @@ extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float
 }
 
 extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx, int n, int d, int h, int w, int cin,
-                                    int cout, int dy_dtype, int dx_dtype, mednet_stream stream) {
+                                    int cout, int dy_dtype, int dx_dtype, int algo, mednet_stream stream) {
   int rc = conv_common_checks("convt3d_dgrad", n, d, h, w, cin, cout, 3, dy_dtype, dx_dtype);
   if (rc) return rc;
   const PackLayout L = pack_layout(cin, cout, 3);
+  const bool mfma_ok = L.mfma_bytes && dy_dtype == MEDNET_BF16 && dx_dtype == MEDNET_BF16;
+  if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
+    return fail(MEDNET_E_UNSUPPORTED, "convt3d_dgrad: MFMA path does not take cin=%d cout=%d", cin, cout);
+  if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
+    return launch_convt_dgrad_mfma(dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cin, cout, (hipStream_t)stream);
   ConvGeom g;
   g.n = n; g.od = d; g.oh = h; g.ow = w; g.id = 2 * d; g.ih = 2 * h; g.iw = 2 * w;
   g.k = cout; g.m = cin; g.ks = 3; g.in_planar = 0; g.out_planar = 0;
@@ -147,11 +152,13 @@ extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx
 }
 
 extern "C" size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
-  return wgrad_direct_ws_bytes((size_t)n * d * h * w, cin, cout, 3) + 256;
+  const size_t a = wgrad_direct_ws_bytes((size_t)n * d * h * w, cin, cout, 3);
+  const size_t b = convt_wgrad_mfma_ws_bytes(n, d, h, w, cin, cout);
+  return (a > b ? a : b) + 256;
 }
 
 extern "C" int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
-                                    int cin, int cout, int x_dtype, int dy_dtype, void* ws, size_t ws_bytes,
+                                    int cin, int cout, int x_dtype, int dy_dtype, int algo, void* ws, size_t ws_bytes,
                                     mednet_stream stream) {
   int rc = conv_common_checks("convt3d_wgrad", n, d, h, w, cin, cout, 3, x_dtype, dy_dtype);
   if (rc) return rc;
@@ -160,6 +167,11 @@ extern "C" int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, fl
     rc = launch_channel_sum(dy, dbias, n, (size_t)8 * d * h * w, cout, 0, dy_dtype, s);
     if (rc) return rc;
   }
+  const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_BF16;
+  if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
+    return fail(MEDNET_E_UNSUPPORTED, "convt3d_wgrad: MFMA path does not take cin=%d cout=%d", cin, cout);
+  if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
+    return launch_convt_wgrad_mfma(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
   WgradGeom g;
   g.n = n; g.ad = d; g.ah = h; g.aw = w; g.bd = 2 * d; g.bh = 2 * h; g.bw = 2 * w;
   g.ka = cin; g.kb = cout; g.ks = 3; g.stride2 = 1; g.a_planar = 0; g.b_planar = 0; g.chunk = 0;

@@ -51,5 +51,10 @@ bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtyp
 size_t wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
 int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, int dtype,
                       void* ws, size_t ws_bytes, hipStream_t s);
+int launch_convt_dgrad_mfma(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin,
+                            int cout, hipStream_t s);
+size_t convt_wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+int launch_convt_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout,
+                            void* ws, size_t ws_bytes, hipStream_t s);
 
 }  // namespace mednet

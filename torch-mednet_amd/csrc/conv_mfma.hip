@@ -1,7 +1,231 @@
-// bf16 MFMA convolution kernels (placeholder translation unit: filled in by the MFMA milestone).
+// bf16 MFMA (matrix-core) kernels for the 3x3x3 convolutions of the U-Net: forward / data-gradient (one kernel, two
+// weight images) and weight-gradient.  gfx950 only: v_mfma_f32_32x32x16_bf16, ds_read_b128, ds_read_b64_tr_b16.
+//
+// ---- forward / data gradient: implicit GEMM, im2col-free ---------------------------------------------------------
+//   D[co][voxel] += sum_tap sum_ci W[tap][co][ci] * X[voxel + tap][ci]       (M = 32 output channels, N = 32 voxels)
+// A workgroup (4 waves) owns a TZ x TY x 16 brick of output voxels and one block of 32 output channels.  The K loop
+// walks the input channels 16 at a time (one MFMA k-step).  Per chunk the brick's input halo (6x10x18 voxels x 16 ch)
+// and the 27x32x16 weight slice are staged in LDS ONCE and reused by all 27 taps: every MFMA B operand is a single
+// conflict-free ds_read_b128 (8 channels of one voxel), every A operand one ds_read_b128 shared by 4 N-tiles.
+// Staging is software-pipelined through registers (global loads of chunk k+1 are in flight while chunk k is on the
+// matrix cores) and two workgroups share a CU (62 KB LDS each) so one brick's LDS fill overlaps the other's MFMAs.
+// LDS images are split by k-half:  in[h][voxel][8 ch],  w[tap][h][co][8 ch]  so that the 16 lanes a ds_read_b128
+// services together hit 16 distinct 16-byte slots; N-tile rows are rotated by the halo row pitch for the same reason.
+//
+// ---- weight gradient ----------------------------------------------------------------------------------------------
+//   R[tap][a][b] = sum_voxel A[voxel][a] * B[map(voxel, tap)][b]     (conv: A = dy, B = x;  convT: A = x, B = dy)
+// The contraction index is the voxel, which is the slow axis of both channels-last operands, so both MFMA operands
+// are read with the hardware transposing LDS read (ds_read_b64_tr_b16): no transposed copy is ever materialised.
+// A wave keeps 7 of the 27 taps (7 x 16 accumulator registers) and walks its workgroup's bricks; per-workgroup
+// partials are summed in a fixed order by a second kernel (deterministic, no atomics).
 #include "conv.h"
 
 namespace mednet {
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+// One MFMA operand (8 k-values) from two transposing LDS reads.  Each lane passes the address of 4 consecutive channels
+// of ONE voxel row; the hardware hands lane i of every 16-lane group channel i of 4 voxel rows (measured mapping:
+// tools/probes/tr_probe.hip).  The whole-vector form matters: extracting the four 16-bit results one by one made
+// hipcc (ROCm 7.2) broadcast element 0.
+__device__ __forceinline__ bf16x8 tr_operand(const char* base, int second_read_byte_offset) {
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + second_read_byte_offset));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ================================================================================================== geometry
+template <int STRIDE>
+struct FwdTile;
+template <>
+struct FwdTile<1> {  // conv forward / data gradient
+  static constexpr int TZ = 4, TY = 8, TX = 16;
+};
+template <>
+struct FwdTile<2> {  // ConvTranspose3d data gradient: in = 2*out - 1 + tap
+  static constexpr int TZ = 2, TY = 4, TX = 16;
+};
+
+// ================================================================================================== forward kernel
+struct FwdArgs {
+  const bf16* x;
+  const bf16* wpk;  // [cb][kc][27][2][32][8]
+  bf16* y;
+  int n, od, oh, ow;  // output grid
+  int id, ih, iw;     // input grid
+  int cin, cout;
+  int tiles_z, tiles_y, tiles_x, ntiles;  // per sample * n
+  int nkc, ncb;
+};
+
+template <int STRIDE>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
+  using G = FwdTile<STRIDE>;
+  constexpr int TZ = G::TZ, TY = G::TY, TX = G::TX;
+  constexpr int HZ = STRIDE * (TZ - 1) + 3, HY = STRIDE * (TY - 1) + 3, HX = STRIDE * (TX - 1) + 3;
+  constexpr int NV = HZ * HY * HX;
+  constexpr int NTW = TZ * TY * TX / 32 / 4;  // N-tiles per wave
+  constexpr int IN_ROUNDS = (2 * NV + 255) / 256;
+  constexpr int W_CHUNKS = 27 * 2 * 32;  // 16-byte pieces of one weight slice
+  constexpr int W_ROUNDS = (W_CHUNKS + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16x8* in_lds = reinterpret_cast<bf16x8*>(smem);                // [2][NV]
+  bf16x8* w_lds = reinterpret_cast<bf16x8*>(smem) + 2 * NV;        // [27][2][32]
+
+  // ---- which brick / channel block: all channel blocks of a brick run on the same XCD (ids 8 apart share an L2)
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int tile = (local / a.ncb) * 8 + xcd;
+  const int cb = local % a.ncb;
+  if (tile >= a.ntiles) return;
+  int tt = tile;
+  const int tx0 = (tt % a.tiles_x) * TX;
+  tt /= a.tiles_x;
+  const int ty0 = (tt % a.tiles_y) * TY;
+  tt /= a.tiles_y;
+  const int tz0 = (tt % a.tiles_z) * TZ;
+  const int n = tt / a.tiles_z;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- staging plan (independent of the K chunk): global element offset of each 16-byte piece, -1 = zero fill
+  long long goff[IN_ROUNDS];
+#pragma unroll
+  for (int it = 0; it < IN_ROUNDS; ++it) {
+    const int p = it * 256 + tid;
+    const int v = p >> 1, hh = p & 1;
+    long long off = -1;
+    if (v < NV) {
+      const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
+      const int gz = STRIDE * tz0 - 1 + hz, gy = STRIDE * ty0 - 1 + hy, gx = STRIDE * tx0 - 1 + hx;
+      if (gz >= 0 && gz < a.id && gy >= 0 && gy < a.ih && gx >= 0 && gx < a.iw)
+        off = ((((long long)n * a.id + gz) * a.ih + gy) * a.iw + gx) * a.cin + hh * 8;
+      else
+        off = -2;  // inside the tile image but outside the volume: zero padding
+    }
+    goff[it] = off;
+  }
+  const bf16* wsrc = a.wpk + (size_t)cb * a.nkc * (W_CHUNKS * 8);
+
+  bf16x8 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
+  auto prefetch = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) {
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (goff[it] >= 0) v = *reinterpret_cast<const bf16x8*>(a.x + goff[it] + kc * 16);
+      in_reg[it] = v;
+    }
+    const bf16* ws = wsrc + (size_t)kc * (W_CHUNKS * 8);
+#pragma unroll
+    for (int it = 0; it < W_ROUNDS; ++it) {
+      const int c = it * 256 + tid;
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (c < W_CHUNKS) v = *reinterpret_cast<const bf16x8*>(ws + (size_t)c * 8);
+      w_reg[it] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) {
+      const int p = it * 256 + tid;
+      if (goff[it] != -1) in_lds[(p & 1) * NV + (p >> 1)] = in_reg[it];
+    }
+#pragma unroll
+    for (int it = 0; it < W_ROUNDS; ++it) {
+      const int c = it * 256 + tid;
+      if (c < W_CHUNKS) w_lds[c] = w_reg[it];
+    }
+  };
+
+  // ---- this lane's voxel in each of the wave's N-tiles (2 rows x 16 voxels), row-rotated for conflict-free reads
+  int lbase[NTW];   // LDS voxel index of tap (0,0,0) for this lane
+  int ovox[NTW];    // output voxel linear index inside the sample, or -1
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int g = wv * NTW + t;
+    const int lz = g / (TY / 2), ly = (g % (TY / 2)) * 2 + (r >> 4);
+    const int i = r & 15;
+    const int lx = STRIDE == 1 ? ((i - (r >> 4) * HX) & 15) : i;
+    lbase[t] = ((STRIDE * lz) * HY + STRIDE * ly) * HX + STRIDE * lx + h * NV;
+    const int oz = tz0 + lz, oy = ty0 + ly, ox = tx0 + lx;
+    ovox[t] = (oz < a.od && oy < a.oh && ox < a.ow) ? ((oz * a.oh + oy) * a.ow + ox) : -1;
+  }
+
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  prefetch(0);
+  for (int kc = 0; kc < a.nkc; ++kc) {
+    __syncthreads();  // every wave is done reading the previous chunk's LDS image
+    commit();
+    __syncthreads();
+    if (kc + 1 < a.nkc) prefetch(kc + 1);  // in flight while the matrix cores work on chunk kc
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+      const int toff = (tz * HY + ty) * HX + tx;
+      const bf16x8 wa = w_lds[(tap * 2 + h) * 32 + r];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const bf16x8 xb = in_lds[lbase[t] + toff];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: D[row = co][col = voxel]; lane holds co = (i&3) + 8*(i>>2) + 4*h for its voxel (col = r)
+  const size_t ovol = (size_t)a.od * a.oh * a.ow;
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    if (ovox[t] < 0) continue;
+    bf16* yp = a.y + ((size_t)n * ovol + ovox[t]) * a.cout + cb * 32 + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[t][q * 4 + j];
+      *reinterpret_cast<bf16x4*>(yp + 8 * q) = o;
+    }
+  }
+}
+
+// ================================================================================================== weight packing
+// element e of section [cb][kc][tap][h][co][j]  <-  Weff[cb*32+co][kc*16+h*8+j][tap]
+// mode 0: conv fwd      Weff[m][k][t] = W[m][k][t]            (W: Cout,Cin,27)  M=Cout K=Cin
+// mode 1: conv dgrad    Weff[m][k][t] = W[k][m][26-t]                           M=Cin  K=Cout
+// mode 2: convT fwd     Weff[m][k][t] = Wt[k][m][t]           (Wt: Cin,Cout,27) M=Cout K=Cin
+// mode 3: convT dgrad   Weff[m][k][t] = Wt[m][k][t]                             M=Cin  K=Cout
+__global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict__ w, bf16* __restrict__ out, int M, int K,
+                                                        int mode) {
+  const size_t total = (size_t)M * K * 27;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  size_t q = e;
+  const int j = (int)(q % 8);
+  q /= 8;
+  const int co = (int)(q % 32);
+  q /= 32;
+  const int h = (int)(q % 2);
+  q /= 2;
+  const int tap = (int)(q % 27);
+  q /= 27;
+  const int nkc = K / 16;
+  const int kc = (int)(q % nkc);
+  const int cb = (int)(q / nkc);
+  const int m = cb * 32 + co, k = kc * 16 + h * 8 + j;
+  float v;
+  if (mode == 0) v = w[((size_t)m * K + k) * 27 + tap];
+  else if (mode == 1) v = w[((size_t)k * M + m) * 27 + (26 - tap)];
+  else if (mode == 2) v = w[((size_t)k * M + m) * 27 + tap];
+  else v = w[((size_t)m * K + k) * 27 + tap];
+  out[e] = (bf16)v;
+}
 
 PackLayout pack_layout(int cin, int cout, int ksize) {
   PackLayout L;
@@ -9,22 +233,285 @@ PackLayout pack_layout(int cin, int cout, int ksize) {
   const size_t f32 = align_up((size_t)L.taps * cin * cout * sizeof(float), 256);
   L.f32_fwd = 0;
   L.f32_bwd = f32;
-  L.mfma_bytes = 0;
+  const bool mfma = ksize == 3 && cin % 32 == 0 && cout % 32 == 0;
+  L.mfma_bytes = mfma ? align_up((size_t)27 * cin * cout * sizeof(bf16), 256) : 0;
   L.mfma_fwd = 2 * f32;
-  L.mfma_bwd = 2 * f32;
+  L.mfma_bwd = 2 * f32 + L.mfma_bytes;
   L.total = 2 * f32 + 2 * L.mfma_bytes + 256;
   return L;
 }
 
-bool conv_mfma_supported(int, int, int, int, int, int, int, bool) { return false; }
-int launch_conv_mfma(const void*, const void*, void*, int, int, int, int, int, int, int, int, hipStream_t) {
-  return fail(MEDNET_E_UNSUPPORTED, "conv_mfma: not built");
+int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, int cin, int cout, int T, int transposed_src,
+                     hipStream_t s) {
+  if (T != 27) return MEDNET_OK;
+  const size_t total = (size_t)cin * cout * 27;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  // forward image: M = cout, K = cin; backward (data-gradient) image: M = cin, K = cout
+  hipLaunchKernelGGL(pack_mfma_kernel, grid, dim3(256), 0, s, w, (bf16*)sec_fwd, cout, cin, transposed_src ? 2 : 0);
+  hipLaunchKernelGGL(pack_mfma_kernel, grid, dim3(256), 0, s, w, (bf16*)sec_bwd, cin, cout, transposed_src ? 3 : 1);
+  return check_launch("pack_mfma");
 }
-int launch_pack_mfma(const float*, void*, void*, int, int, int, int, hipStream_t) { return MEDNET_OK; }
-bool wgrad_mfma_supported(int, int, int, int, int, int, int) { return false; }
-size_t wgrad_mfma_ws_bytes(int, int, int, int, int, int, int) { return 0; }
-int launch_wgrad_mfma(const void*, const void*, float*, int, int, int, int, int, int, int, void*, size_t, hipStream_t) {
-  return fail(MEDNET_E_UNSUPPORTED, "wgrad_mfma: not built");
+
+bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int x_layout, int y_layout, bool bias) {
+  return ksize == 3 && cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && y_dtype == MEDNET_BF16 &&
+         x_layout == MEDNET_NDHWC && y_layout == MEDNET_NDHWC && !bias;
+}
+
+template <int STRIDE>
+static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, int oh, int ow, int id, int ih, int iw,
+                      int cin, int cout, hipStream_t s) {
+  using G = FwdTile<STRIDE>;
+  constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
+  constexpr size_t lds = ((size_t)2 * HZ * HY * HX + 27 * 2 * 32) * 16;
+  static_assert(lds <= 80 * 1024, "two workgroups must fit one CU");
+  FwdArgs a;
+  a.x = (const bf16*)x;
+  a.wpk = (const bf16*)sec;
+  a.y = (bf16*)y;
+  a.n = n; a.od = od; a.oh = oh; a.ow = ow; a.id = id; a.ih = ih; a.iw = iw;
+  a.cin = cin; a.cout = cout;
+  a.tiles_z = (od + G::TZ - 1) / G::TZ;
+  a.tiles_y = (oh + G::TY - 1) / G::TY;
+  a.tiles_x = (ow + G::TX - 1) / G::TX;
+  a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
+  a.nkc = cin / 16;
+  a.ncb = cout / 32;
+  const unsigned grid = (unsigned)((a.ntiles + 7) / 8) * 8 * a.ncb;
+  static bool attr_set[3] = {false, false, false};
+  if (!attr_set[STRIDE]) {
+    if (hipFuncSetAttribute((const void*)conv_mfma_kernel<STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return fail(MEDNET_E_HIP, "conv_mfma: cannot raise dynamic LDS to %zu", lds);
+    attr_set[STRIDE] = true;
+  }
+  hipLaunchKernelGGL((conv_mfma_kernel<STRIDE>), dim3(grid), dim3(256), lds, s, a);
+  return check_launch("conv_mfma");
+}
+
+int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, int d, int h, int w, int cin, int cout,
+                     int x_dtype, int y_dtype, hipStream_t s) {
+  (void)x_dtype;
+  (void)y_dtype;
+  return launch_fwd<1>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, s);
+}
+
+int launch_convt_dgrad_mfma(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin,
+                            int cout, hipStream_t s) {
+  // dx (d,h,w; Cin channels) <- dy (2d,2h,2w; Cout channels)
+  return launch_fwd<2>(dy, packed_section, dx, n, d, h, w, 2 * d, 2 * h, 2 * w, cout, cin, s);
+}
+
+// ================================================================================================== weight gradient
+template <int STRIDE>
+struct WgTile;
+template <>
+struct WgTile<1> {
+  static constexpr int TZ = 2, TY = 8, TX = 16;
+};
+template <>
+struct WgTile<2> {
+  static constexpr int TZ = 1, TY = 4, TX = 16;
+};
+
+struct WgArgs {
+  const bf16* A;  // loop grid tensor (ad,ah,aw; ka channels)
+  const bf16* B;  // shifted tensor   (bd,bh,bw; kb channels)
+  float* part;    // [wg][27][32][32]
+  int n, ad, ah, aw, bd, bh, bw, ka, kb;
+  int tiles_z, tiles_y, tiles_x, ntiles;
+  int nab, nbb, splits;
+};
+
+template <int STRIDE>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
+  using G = WgTile<STRIDE>;
+  constexpr int TZ = G::TZ, TY = G::TY, TX = G::TX;
+  constexpr int HZ = STRIDE * (TZ - 1) + 3, HY = STRIDE * (TY - 1) + 3, HX = STRIDE * (TX - 1) + 3;
+  constexpr int NA = TZ * TY * TX, NB = HZ * HY * HX;
+  constexpr int A_ROUNDS = (NA * 4 + 255) / 256, B_ROUNDS = (NB * 4 + 255) / 256;
+  constexpr int KSTEPS = NA / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* A_lds = reinterpret_cast<bf16*>(smem);            // [NA][32]
+  bf16* B_lds = reinterpret_cast<bf16*>(smem) + NA * 32;  // [NB][32]
+
+  const int pair = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
+  const int ab = pair / a.nbb, bb = pair % a.nbb;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, hk = lane >> 5;
+  // byte offset inside a 64-byte voxel row of the 4 channels this lane addresses in a transposing read
+  const int coloff = (16 * (g & 1) + 4 * p) * 2;
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  for (int tile = split; tile < a.ntiles; tile += a.splits) {
+    int tt = tile;
+    const int tx0 = (tt % a.tiles_x) * TX;
+    tt /= a.tiles_x;
+    const int ty0 = (tt % a.tiles_y) * TY;
+    tt /= a.tiles_y;
+    const int tz0 = (tt % a.tiles_z) * TZ;
+    const int n = tt / a.tiles_z;
+    __syncthreads();  // previous brick fully consumed
+    // ---- stage A brick (zero outside the volume) and B halo brick
+#pragma unroll
+    for (int it = 0; it < A_ROUNDS; ++it) {
+      const int c = it * 256 + tid;
+      if (c < NA * 4) {
+        const int v = c >> 2, part = c & 3;
+        const int lx = v % TX, ly = (v / TX) % TY, lz = v / (TX * TY);
+        const int gz = tz0 + lz, gy = ty0 + ly, gx = tx0 + lx;
+        bf16x8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (gz < a.ad && gy < a.ah && gx < a.aw)
+          val = *reinterpret_cast<const bf16x8*>(a.A + ((((size_t)n * a.ad + gz) * a.ah + gy) * a.aw + gx) * a.ka + ab * 32 + part * 8);
+        *reinterpret_cast<bf16x8*>(A_lds + v * 32 + part * 8) = val;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < B_ROUNDS; ++it) {
+      const int c = it * 256 + tid;
+      if (c < NB * 4) {
+        const int v = c >> 2, part = c & 3;
+        const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
+        const int gz = STRIDE * tz0 - 1 + hz, gy = STRIDE * ty0 - 1 + hy, gx = STRIDE * tx0 - 1 + hx;
+        bf16x8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (gz >= 0 && gz < a.bd && gy >= 0 && gy < a.bh && gx >= 0 && gx < a.bw)
+          val = *reinterpret_cast<const bf16x8*>(a.B + ((((size_t)n * a.bd + gz) * a.bh + gy) * a.bw + gx) * a.kb + bb * 32 + part * 8);
+        *reinterpret_cast<bf16x8*>(B_lds + v * 32 + part * 8) = val;
+      }
+    }
+    __syncthreads();
+    // ---- contraction over the brick's voxels, 16 x-consecutive voxels per MFMA k-step
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int lz = ks / TY, ly = ks % TY;
+      // A operand: rows = channels of A, k = voxel x = 8*hk + 4*rd + q
+      const int v0 = (lz * TY + ly) * TX + 8 * hk + q;
+      const bf16x8 fa = tr_operand(reinterpret_cast<const char*>(A_lds) + v0 * 64 + coloff, 4 * 64);
+      const int bv0 = ((STRIDE * lz) * HY + STRIDE * ly) * HX + STRIDE * (8 * hk + q);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int tap = wv + 4 * i;
+        if (tap < 27) {
+          const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+          const int bv = bv0 + (tz * HY + ty) * HX + tx;
+          const bf16x8 fb = tr_operand(reinterpret_cast<const char*>(B_lds) + bv * 64 + coloff, 4 * STRIDE * 64);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- partial[wg][tap][a][b]: row a = (j&3) + 8*(j>>2) + 4*hk, col b = lane & 31
+  float* out = a.part + (size_t)blockIdx.x * 27 * 1024;
+  const int col = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = wv + 4 * i;
+    if (tap < 27) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = (j & 3) + 8 * (j >> 2) + 4 * hk;
+        out[((size_t)tap * 32 + row) * 32 + col] = acc[i][j];
+      }
+    }
+  }
+}
+
+// dw[(a*KB + b)*27 + tap] = sum_split part[(pair*splits + split)][tap][a%32][b%32]
+__global__ __launch_bounds__(256) void wgrad_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                int ka, int kb, int nbb, int splits) {
+  const size_t total = (size_t)ka * kb * 27;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  // thread index enumerates [pair][tap][a32][b32] so reads are coalesced
+  const int b32 = (int)(e % 32), a32 = (int)((e / 32) % 32), tap = (int)((e / 1024) % 27);
+  const int pair = (int)(e / (1024 * 27));
+  const int ab = pair / nbb, bb = pair % nbb;
+  const float* src = part + ((size_t)pair * splits) * 27 * 1024 + (size_t)tap * 1024 + a32 * 32 + b32;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += src[(size_t)k * 27 * 1024];
+  dw[((size_t)(ab * 32 + a32) * kb + bb * 32 + b32) * 27 + tap] = s;
+}
+
+bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtype, int x_layout, int dy_layout) {
+  return ksize == 3 && cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_BF16 &&
+         x_layout == MEDNET_NDHWC && dy_layout == MEDNET_NDHWC;
+}
+
+template <int STRIDE>
+static void wgrad_plan(int n, int ad, int ah, int aw, int ka, int kb, WgArgs& a) {
+  using G = WgTile<STRIDE>;
+  a.tiles_z = (ad + G::TZ - 1) / G::TZ;
+  a.tiles_y = (ah + G::TY - 1) / G::TY;
+  a.tiles_x = (aw + G::TX - 1) / G::TX;
+  a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
+  a.nab = ka / 32;
+  a.nbb = kb / 32;
+  const int pairs = a.nab * a.nbb;
+  int splits = (1024 + pairs - 1) / pairs;
+  if (splits > a.ntiles) splits = a.ntiles;
+  if (splits < 1) splits = 1;
+  a.splits = splits;
+}
+
+size_t wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize) {
+  if (ksize != 3 || cin % 32 || cout % 32) return 0;
+  WgArgs a;
+  wgrad_plan<1>(n, d, h, w, cout, cin, a);
+  return (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+}
+
+template <int STRIDE>
+static int launch_wg(const void* A, const void* B, float* dw, int n, int ad, int ah, int aw, int bd, int bh, int bw,
+                     int ka, int kb, void* ws, size_t ws_bytes, hipStream_t s) {
+  using G = WgTile<STRIDE>;
+  constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
+  constexpr size_t lds = ((size_t)G::TZ * G::TY * G::TX + (size_t)HZ * HY * HX) * 64;
+  static_assert(lds <= 80 * 1024, "two workgroups must fit one CU");
+  WgArgs a;
+  a.A = (const bf16*)A;
+  a.B = (const bf16*)B;
+  a.part = (float*)ws;
+  a.n = n; a.ad = ad; a.ah = ah; a.aw = aw; a.bd = bd; a.bh = bh; a.bw = bw; a.ka = ka; a.kb = kb;
+  wgrad_plan<STRIDE>(n, ad, ah, aw, ka, kb, a);
+  const size_t need = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+  MEDNET_REQUIRE(ws_bytes >= need, MEDNET_E_WORKSPACE, "wgrad_mfma: workspace %zu < %zu", ws_bytes, need);
+  static bool attr_set[3] = {false, false, false};
+  if (!attr_set[STRIDE]) {
+    if (hipFuncSetAttribute((const void*)wgrad_mfma_kernel<STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return fail(MEDNET_E_HIP, "wgrad_mfma: cannot raise dynamic LDS to %zu", lds);
+    attr_set[STRIDE] = true;
+  }
+  hipLaunchKernelGGL((wgrad_mfma_kernel<STRIDE>), dim3(a.nab * a.nbb * a.splits), dim3(256), lds, s, a);
+  int rc = check_launch("wgrad_mfma");
+  if (rc) return rc;
+  const size_t total = (size_t)ka * kb * 27;
+  hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, ka, kb,
+                     a.nbb, a.splits);
+  return check_launch("wgrad_mfma_reduce");
+}
+
+int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, int dtype,
+                      void* ws, size_t ws_bytes, hipStream_t s) {
+  (void)dtype;
+  // conv: A = dy (Cout rows), B = x (Cin cols) shifted by tap - 1
+  return launch_wg<1>(dy, x, dw, n, d, h, w, d, h, w, cout, cin, ws, ws_bytes, s);
+}
+
+size_t convt_wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  if (cin % 32 || cout % 32) return 0;
+  WgArgs a;
+  wgrad_plan<2>(n, d, h, w, cin, cout, a);
+  return (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+}
+
+int launch_convt_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout,
+                            void* ws, size_t ws_bytes, hipStream_t s) {
+  // convT: A = x (Cin rows) on the (d,h,w) grid, B = dy (Cout cols) on the (2d,2h,2w) grid at 2v - 1 + tap
+  return launch_wg<2>(x, dy, dw, n, d, h, w, 2 * d, 2 * h, 2 * w, cin, cout, ws, ws_bytes, s);
 }
 
 }  // namespace mednet

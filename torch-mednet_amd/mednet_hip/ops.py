@@ -15,6 +15,19 @@ from . import config
 
 CL = torch.channels_last_3d
 
+# Optional profiling of the dominant kernel (bench.py): list of (start_event, end_event, flops) per matching launch
+PROFILE = {"enabled": False, "events": [], "match": None}
+
+
+def _grad_target(param, shape):
+    """Trainer hook (train.FlatParams): when a Parameter carries `_mednet_grad` (a contiguous fp32 view into the flat
+    gradient buffer) the kernels write the gradient there and autograd gets None -> no copy / accumulate kernels."""
+    tgt = getattr(param, "_mednet_grad", None)
+    if tgt is not None:
+        assert tuple(tgt.shape) == tuple(shape) and tgt.dtype == torch.float32 and tgt.is_contiguous()
+        return tgt, True
+    return torch.empty(shape, dtype=torch.float32, device=param.device), False
+
 
 def to_cl(x: torch.Tensor) -> torch.Tensor:
     """Physical NDHWC. No-op for tensors produced by this package."""
@@ -67,11 +80,19 @@ class Conv3dFn(Function):
             y = torch.empty((n, cout, d, h, w), dtype=out_dtype, device=x.device)
         else:
             y = empty_cl(n, cout, d, h, w, out_dtype, x.device)
+        prof = PROFILE["enabled"] and PROFILE["match"] is not None and PROFILE["match"](ksize, cin, cout, d, h, w)
+        if prof:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         L.check(L.lib().mednet_conv3d_fwd(xin.data_ptr(), packed.data_ptr(), L.ptr(bias), y.data_ptr(), n, d, h, w, cin,
                                           cout, ksize, L.dt(xin), L.NDHWC, L.dt(y), L.NCDHW if out_planar else L.NDHWC,
                                           0, config.conv_algo(), L.stream()), "conv3d_fwd")
+        if prof:
+            e1.record()
+            PROFILE["events"].append((e0, e1, 2.0 * n * d * h * w * cin * cout * ksize ** 3))
         ctx.save_for_backward(xin, packed)
         ctx.meta = (ksize, out_planar, cin, cout, bias is not None, x.dtype)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -87,17 +108,19 @@ class Conv3dFn(Function):
             L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin,
                                           ksize, L.dt(dy), L.NCDHW if out_planar else L.NDHWC, L.dt(dx), L.NDHWC, 1,
                                           config.conv_algo(), L.stream()), "conv3d_dgrad")
+        direct_w = direct_b = False
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((cout, cin, ksize, ksize, ksize), dtype=torch.float32, device=dy.device)
+            weight, bias = ctx.params
+            dw, direct_w = _grad_target(weight, (cout, cin, ksize, ksize, ksize))
             if has_bias and ctx.needs_input_grad[2]:
-                db = torch.empty((cout,), dtype=torch.float32, device=dy.device)
+                db, direct_b = _grad_target(bias, (cout,))
             nbytes = lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, ksize)
             ws = L.workspace(nbytes, dy.device)
             L.check(lib.mednet_conv3d_wgrad(xin.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), n, d, h, w, cin,
                                             cout, ksize, L.dt(xin), L.NDHWC, L.dt(dy),
                                             L.NCDHW if out_planar else L.NDHWC, config.conv_algo(), ws.data_ptr(),
                                             ws.numel(), L.stream()), "conv3d_wgrad")
-        return dx, dw, db, None, None, None, None
+        return dx, (None if direct_w else dw), (None if direct_b else db), None, None, None, None
 
 
 def conv3d(x, weight, bias, packed, ksize, out_planar=False, out_dtype=None):
@@ -125,6 +148,7 @@ class ConvT3dFn(Function):
                                            w, cin, cout, L.dt(x), L.dt(y), L.stream()), "convt3d_fwd")
         ctx.save_for_backward(x, packed)
         ctx.meta = (cin, cout, bias is not None, skip is not None, None if skip is None else skip.dtype)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -138,17 +162,20 @@ class ConvT3dFn(Function):
         if ctx.needs_input_grad[0]:
             dx = empty_cl(n, cin, d, h, w, x.dtype, dy.device)
             L.check(lib.mednet_convt3d_dgrad(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), n, d, h, w, cin, cout,
-                                             L.dt(dy), L.dt(dx), L.stream()), "convt3d_dgrad")
+                                             L.dt(dy), L.dt(dx), config.conv_algo(), L.stream()), "convt3d_dgrad")
+        direct_w = direct_b = False
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((cin, cout, 3, 3, 3), dtype=torch.float32, device=dy.device)
+            weight, bias = ctx.params
+            dw, direct_w = _grad_target(weight, (cin, cout, 3, 3, 3))
             if has_bias and ctx.needs_input_grad[2]:
-                db = torch.empty((cout,), dtype=torch.float32, device=dy.device)
+                db, direct_b = _grad_target(bias, (cout,))
             ws = L.workspace(lib.mednet_convt3d_wgrad_ws_bytes(n, d, h, w, cin, cout), dy.device)
             L.check(lib.mednet_convt3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), n, d, h, w, cin, cout,
-                                             L.dt(x), L.dt(dy), ws.data_ptr(), ws.numel(), L.stream()), "convt3d_wgrad")
+                                             L.dt(x), L.dt(dy), config.conv_algo(), ws.data_ptr(), ws.numel(), L.stream()),
+                    "convt3d_wgrad")
         if has_skip and ctx.needs_input_grad[3]:
             dskip = dy if dy.dtype == skip_dtype else dy.to(skip_dtype)
-        return dx, dw, db, dskip, None
+        return dx, (None if direct_w else dw), (None if direct_b else db), dskip, None
 
 
 def conv_transpose3d(x, weight, bias, skip, packed):
@@ -181,6 +208,7 @@ class GroupNormActFn(Function):
                                       L.dt(x), L.dt(z), L.stream()), "gn_act_fwd")
         ctx.save_for_backward(x, z if act != L.ACT_NONE else None, stats, gamma)
         ctx.meta = (groups, act, residual is not None, gamma is not None, beta is not None)
+        ctx.params = (gamma, beta)
         return z
 
     @staticmethod
@@ -193,13 +221,14 @@ class GroupNormActFn(Function):
         lib = L.lib()
         dx = torch.empty_like(x, memory_format=CL)
         dres = torch.empty_like(x, memory_format=CL) if has_res else None
-        dgamma = torch.empty((c,), dtype=torch.float32, device=x.device) if has_gamma else None
-        dbeta = torch.empty((c,), dtype=torch.float32, device=x.device) if has_beta else None
+        pg, pb = ctx.params
+        dgamma, direct_g = _grad_target(pg, (c,)) if has_gamma else (None, False)
+        dbeta, direct_b = _grad_target(pb, (c,)) if has_beta else (None, False)
         ws = L.workspace(lib.mednet_gn_ws_bytes(n, c, spatial), x.device)
         L.check(lib.mednet_gn_act_bwd(dz.data_ptr(), None, x.data_ptr(), L.ptr(z), stats.data_ptr(), L.ptr(gamma),
                                       dx.data_ptr(), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), n, spatial, c, groups, act,
                                       L.dt(x), ws.data_ptr(), ws.numel(), L.stream()), "gn_act_bwd")
-        return dx, dgamma, dbeta, dres, None, None, None
+        return dx, (None if direct_g else dgamma), (None if direct_b else dbeta), dres, None, None, None
 
 
 def group_norm_act(x, gamma, beta, groups, eps=1e-5, act=L.ACT_NONE, residual=None):

@@ -1,0 +1,129 @@
+"""Training-step harness for the hot path: the callers' step contract (segmentation.py:58-65, landmarks.py:66-83,
+configure_optimizers :119-120) plus what pytorch_lightning's Trainer(gpus=N) adds around it (train_seg.py:126): one
+gradient all-reduce per step over RCCL and the Adam update.
+
+MI355X-first layout: all parameters live in ONE flat fp32 buffer and all gradients in another.  Backward kernels
+write each parameter gradient straight into its slice (no autograd accumulate kernels), the data-parallel exchange
+is a single RCCL all-reduce of the flat gradient buffer (35 MB for config 3), its 1/world averaging is folded into the
+fused Adam kernel, and Adam is one launch over the flat buffers.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .unet import loss as HL
+
+
+class FlatParams:
+    """Re-homes a module's parameters into one flat fp32 buffer (+ a flat gradient buffer the kernels write into)."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        self.offsets = []
+        total = 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += (p.numel() + 63) // 64 * 64  # 256-byte aligned slices
+        self.total = total
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, off in zip(self.params, self.offsets):
+            view = self.flat[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p._mednet_grad = self.grad[off:off + p.numel()].view_as(p)
+
+    def grads_as_attr(self):
+        """Expose the flat slices as .grad (for inspection / torch optimizers)."""
+        for p in self.params:
+            p.grad = p._mednet_grad
+
+    def release(self):
+        for p in self.params:
+            if hasattr(p, "_mednet_grad"):
+                del p._mednet_grad
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr) semantics (betas .9/.999, eps 1e-8, weight_decay 0) as one kernel over FlatParams."""
+
+    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.flat, self.lr, self.betas, self.eps, self.wd = flat, lr, betas, eps, weight_decay
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.t = 0
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        ops.adam_step_(self.flat.flat, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
+                       self.wd, self.t, grad_scale)
+        self._bump()
+
+    def _bump(self):
+        # torch's version counter only moves on torch in-place ops; a no-op in-place op on the flat buffer does not
+        # reach the views' counters, so packed-weight caches are keyed on this step counter as well.
+        for p in self.flat.params:
+            p._mednet_step = self.t
+
+
+def allreduce_gradients(flat_grad: torch.Tensor, world_size: int):
+    """The data-parallel exchange: ONE all-reduce(sum) of the flat gradient buffer (RCCL over xGMI on GPUs; any
+    torch.distributed backend in tests).  Returns the scale the optimizer must apply (1/world) so that the update uses
+    the mean of the per-rank-batch gradients -- what PL's DDP does with the reference (Dice is reduced
+    over the LOCAL batch, then gradients are averaged)."""
+    if world_size > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    return 1.0 / world_size
+
+
+class SegmentationStep:
+    """One data-parallel training step of SegmentationNet (segmentation.py:58-65) on the MI355X path."""
+
+    def __init__(self, model, loss_weight=None, lr=1e-3, loss="DICE", world_size=1):
+        self.model = model
+        dev = next(model.parameters()).device
+        w = None if loss_weight is None else torch.tensor(loss_weight, dtype=torch.float32, device=dev)
+        self.loss = (HL.DiceLoss(weight=w) if loss == "DICE" else HL.CrossEntropyLoss(weight=w)).to(dev)
+        self.flat = FlatParams(model)
+        self.opt = FlatAdam(self.flat, lr=lr)
+        self.world = world_size
+
+    def __call__(self, batch):
+        inputs = batch["data"].float()
+        labels = batch["label"][:, -1, ...].long()
+        outputs = self.model(inputs)
+        loss = self.loss(outputs, labels)
+        loss.backward()
+        scale = allreduce_gradients(self.flat.grad, self.world)  # 1/world is applied inside the Adam kernel
+        self.opt.step(grad_scale=scale)
+        return loss.detach()
+
+
+class LandmarkStep:
+    """LandmarkNet.training_step (landmarks.py:66-83, loss :125-134) with the per-channel regression loop fused."""
+
+    def __init__(self, model, class_weight, regression_weight, regression="L2", lr=1e-3, world_size=1):
+        self.model = model
+        dev = next(model.parameters()).device
+        self.loss_class = HL.DiceLoss(weight=torch.tensor(class_weight, dtype=torch.float32, device=dev)).to(dev)
+        self.loss_reg = HL.HeatmapRegressionLoss(regression_weight, regression).to(dev)
+        self.flat = FlatParams(model)
+        self.opt = FlatAdam(self.flat, lr=lr)
+        self.world = world_size
+
+    def __call__(self, batch):
+        inputs = batch["data"].float()
+        heatmaps = batch["label"][:, :-1, ...]  # uint8 is consumed directly by the fused regression kernel
+        nh = heatmaps.shape[1]
+        labels = batch["label"][:, -1, ...].long()
+        outputs = self.model(inputs)
+        class_loss = self.loss_class(outputs[:, nh:, ...], labels)
+        regression_loss = self.loss_reg(outputs[:, :nh, ...], heatmaps)
+        loss = regression_loss + class_loss
+        loss.backward()
+        scale = allreduce_gradients(self.flat.grad, self.world)
+        self.opt.step(grad_scale=scale)
+        return loss.detach(), class_loss.detach(), regression_loss.detach()
