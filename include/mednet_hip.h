@@ -62,7 +62,8 @@ int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, 
 /* ---- nn.ConvTranspose3d(k=3,s=2,p=1,output_padding=1,bias) + `x += encoder_features`  components.py:259-264,283-284 */
 /* (n,d,h,w) are the INPUT dims; output is (2d,2h,2w).  `skip` (nullable, y's dtype/shape) is added in the epilogue. */
 int mednet_convt3d_fwd(const void* x, const void* packed, const float* bias, const void* skip, void* y, int n,
-                       int d, int h, int w, int cin, int cout, int x_dtype, int y_dtype, mednet_stream stream);
+                       int d, int h, int w, int cin, int cout, int x_dtype, int y_dtype, int algo,
+                       mednet_stream stream);
 int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx, int n, int d, int h, int w, int cin,
                          int cout, int dy_dtype, int dx_dtype, int algo, mednet_stream stream);
 size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);

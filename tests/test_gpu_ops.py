@@ -384,8 +384,10 @@ def test_conv_transpose_mfma_dgrad_wgrad(n, cin, cout, shape):
     x = bf16_round(rnd(tag + "x", n, cin, *shape))
     w = bf16_round(rnd(tag + "w", cin, cout, 3, 3, 3, scale=0.08))
     cot = bf16_round(rnd(tag + "g", n, cout, *oshape))
+    b = rnd(tag + "b", cout)
+    sk = bf16_round(rnd(tag + "s", n, cout, *oshape))
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-    yr = F.conv_transpose3d(xr, wr, None, stride=2, padding=1, output_padding=1)
+    yr = F.conv_transpose3d(xr, wr, b, stride=2, padding=1, output_padding=1) + sk
     (yr * cot).sum().backward()
     mednet_hip.set_conv_algo("mfma")
     try:
@@ -393,12 +395,12 @@ def test_conv_transpose_mfma_dgrad_wgrad(n, cin, cout, shape):
             up = hnn.ConvTranspose3d(cin, cout).to(DEV)
             with torch.no_grad():
                 up.weight.copy_(w)
-                up.bias.zero_()
+                up.bias.copy_(b)
             xg = x.to(DEV).bfloat16().requires_grad_(True)
-            y = up(xg)
+            y = up(xg, skip=sk.to(DEV).bfloat16())
             y.backward(cot.to(DEV).bfloat16())
     finally:
         mednet_hip.set_conv_algo("auto")
-    assert_close(y, yr, 6e-3, "y")
+    assert_close(y, yr, 6e-3, "y (MFMA, 8 parity classes, bias + skip epilogue)")
     assert_close(xg.grad, xr.grad, 6e-3, "dx (MFMA stride-2 gather)")
     assert_close(up.weight.grad, wr.grad, 2e-4, "dw (MFMA, transposing LDS reads)")

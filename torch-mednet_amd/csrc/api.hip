@@ -94,7 +94,13 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
 extern "C" size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize) {
   const size_t a = wgrad_direct_ws_bytes((size_t)n * d * h * w, cout, cin, ksize);
   const size_t b = wgrad_mfma_ws_bytes(n, d, h, w, cin, cout, ksize);
-  return (a > b ? a : b) + 256;
+  const size_t c1 = cin == 1 ? wgrad_c1_ws_bytes(n, d, h, w, cout) : 0;
+  const size_t c2 = ksize == 1 ? wgrad_1x1_ws_bytes(n, (size_t)d * h * w, cin, cout) : 0;
+  size_t m = a > b ? a : b;
+  if (c1 > m) m = c1;
+  if (c2 > m) m = c2;
+  // the bias-gradient partials live behind the weight-gradient partials
+  return align_up(m, 256) + channel_sum_ws_bytes(n, (size_t)d * h * w, cout) + 256;
 }
 
 extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
@@ -104,9 +110,17 @@ extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, flo
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (dbias) {
-    rc = launch_channel_sum(dy, dbias, n, (size_t)d * h * w, cout, dy_layout == MEDNET_NCDHW, dy_dtype, s);
+    const size_t need = channel_sum_ws_bytes(n, (size_t)d * h * w, cout);
+    MEDNET_REQUIRE(ws_bytes >= need, MEDNET_E_WORKSPACE, "conv3d_wgrad: workspace too small for the bias gradient");
+    rc = launch_channel_sum(dy, dbias, n, (size_t)d * h * w, cout, dy_layout == MEDNET_NCDHW, dy_dtype,
+                            (char*)ws + (ws_bytes - need) / 256 * 256, need, s);
     if (rc) return rc;
+    ws_bytes = (ws_bytes - need) / 256 * 256;
   }
+  if (algo != MEDNET_ALGO_DIRECT && wgrad_c1_supported(cin, cout, ksize, x_layout, dy_layout))
+    return launch_wgrad_c1(x, dy, dw, n, d, h, w, cout, x_dtype, dy_dtype, ws, ws_bytes, s);
+  if (algo != MEDNET_ALGO_DIRECT && wgrad_1x1_supported(cin, cout, ksize, x_layout, dy_layout, dy_dtype))
+    return launch_wgrad_1x1(x, dy, dw, n, (size_t)d * h * w, cin, cout, x_dtype, ws, ws_bytes, s);
   const bool mfma_ok = wgrad_mfma_supported(cin, cout, ksize, x_dtype, dy_dtype, x_layout, dy_layout);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_wgrad: MFMA path does not take cin=%d cout=%d k=%d", cin, cout, ksize);
@@ -122,11 +136,17 @@ extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, flo
 
 // ---- ConvTranspose3d(k3,s2,p1,op1) ------------------------------------------------------------------------------------
 extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float* bias, const void* skip, void* y, int n,
-                                  int d, int h, int w, int cin, int cout, int x_dtype, int y_dtype,
+                                  int d, int h, int w, int cin, int cout, int x_dtype, int y_dtype, int algo,
                                   mednet_stream stream) {
   int rc = conv_common_checks("convt3d_fwd", n, d, h, w, cin, cout, 3, x_dtype, y_dtype);
   if (rc) return rc;
   const PackLayout L = pack_layout(cin, cout, 3);
+  const bool mfma_ok = L.mfma_bytes && x_dtype == MEDNET_BF16 && y_dtype == MEDNET_BF16;
+  if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
+    return fail(MEDNET_E_UNSUPPORTED, "convt3d_fwd: MFMA path does not take cin=%d cout=%d", cin, cout);
+  if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
+    return launch_convt_fwd_mfma(x, (const char*)packed + L.mfma_fwd, bias, skip, y, n, d, h, w, cin, cout,
+                                 (hipStream_t)stream);
   ConvGeom g;
   g.n = n; g.od = 2 * d; g.oh = 2 * h; g.ow = 2 * w; g.id = d; g.ih = h; g.iw = w;
   g.k = cin; g.m = cout; g.ks = 3; g.in_planar = 0; g.out_planar = 0;
@@ -154,7 +174,7 @@ extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx
 extern "C" size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
   const size_t a = wgrad_direct_ws_bytes((size_t)n * d * h * w, cin, cout, 3);
   const size_t b = convt_wgrad_mfma_ws_bytes(n, d, h, w, cin, cout);
-  return (a > b ? a : b) + 256;
+  return align_up(a > b ? a : b, 256) + channel_sum_ws_bytes(n, (size_t)8 * d * h * w, cout) + 256;
 }
 
 extern "C" int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
@@ -164,8 +184,12 @@ extern "C" int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, fl
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (dbias) {
-    rc = launch_channel_sum(dy, dbias, n, (size_t)8 * d * h * w, cout, 0, dy_dtype, s);
+    const size_t need = channel_sum_ws_bytes(n, (size_t)8 * d * h * w, cout);
+    MEDNET_REQUIRE(ws_bytes >= need, MEDNET_E_WORKSPACE, "convt3d_wgrad: workspace too small for the bias gradient");
+    rc = launch_channel_sum(dy, dbias, n, (size_t)8 * d * h * w, cout, 0, dy_dtype,
+                            (char*)ws + (ws_bytes - need) / 256 * 256, need, s);
     if (rc) return rc;
+    ws_bytes = (ws_bytes - need) / 256 * 256;
   }
   const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_BF16;
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)

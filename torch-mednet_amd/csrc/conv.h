@@ -38,7 +38,17 @@ int launch_direct(const void* x, const float* P, const float* bias, const void* 
 size_t wgrad_direct_ws_bytes(size_t nvox, int ka, int kb, int ks);
 int launch_wgrad_direct(const void* A, const void* B, float* dw, WgradGeom g, int a_dtype, int b_dtype, void* ws,
                         size_t ws_bytes, hipStream_t s);
-int launch_channel_sum(const void* x, float* out, int n, size_t spatial, int c, int planar, int dtype, hipStream_t s);
+size_t channel_sum_ws_bytes(int n, size_t spatial, int c);
+int launch_channel_sum(const void* x, float* out, int n, size_t spatial, int c, int planar, int dtype, void* ws,
+                       size_t ws_bytes, hipStream_t s);
+bool wgrad_1x1_supported(int cin, int cout, int ksize, int x_layout, int dy_layout, int dy_dtype);
+size_t wgrad_1x1_ws_bytes(int n, size_t spatial, int cin, int cout);
+int launch_wgrad_1x1(const void* z, const void* dy, float* dw, int n, size_t spatial, int cin, int cout, int z_dtype,
+                     void* ws, size_t ws_bytes, hipStream_t s);
+bool wgrad_c1_supported(int cin, int cout, int ksize, int x_layout, int dy_layout);
+size_t wgrad_c1_ws_bytes(int n, int d, int h, int w, int cout);
+int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cout, int x_dtype,
+                    int dy_dtype, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_pack_f32(const float* w, float* Pf, float* Pb, int cin, int cout, int T, int transposed_src, hipStream_t s);
 
 // MFMA (bf16 matrix-core) kernels, conv_mfma.hip
@@ -51,6 +61,8 @@ bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtyp
 size_t wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
 int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, int dtype,
                       void* ws, size_t ws_bytes, hipStream_t s);
+int launch_convt_fwd_mfma(const void* x, const void* sec, const float* bias, const void* skip, void* y, int n, int d,
+                          int h, int w, int cin, int cout, hipStream_t s);
 int launch_convt_dgrad_mfma(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin,
                             int cout, hipStream_t s);
 size_t convt_wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout);

@@ -95,8 +95,24 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const TI* __restrict__
     }
   } else {
     const size_t o = v * g.m + m0;
+    if constexpr (COB % 8 == 0) {  // 16/32-byte vector stores: one instruction per 8 channels instead of 8
 #pragma unroll
-    for (int j = 0; j < COB; ++j) st(y, o + j, acc[j] + (skip ? ld(skip, o + j) : 0.f));
+      for (int j0 = 0; j0 < COB; j0 += 8) {
+        F8 ov;
+        if (skip) {
+          const F8 sk = ld8(skip, o + j0);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ov.v[j] = acc[j0 + j] + sk.v[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ov.v[j] = acc[j0 + j];
+        }
+        st8(y, o + j0, ov);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < COB; ++j) st(y, o + j, acc[j] + (skip ? ld(skip, o + j) : 0.f));
+    }
   }
 }
 
@@ -189,9 +205,16 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
                                                             size_t count, int chunks) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= count) return;
-  float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += part[(size_t)c * count + i];
-  out[i] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // independent chains keep 4 loads in flight; fixed order => reproducible
+  int c = 0;
+  for (; c + 4 <= chunks; c += 4) {
+    s0 += part[(size_t)c * count + i];
+    s1 += part[(size_t)(c + 1) * count + i];
+    s2 += part[(size_t)(c + 2) * count + i];
+    s3 += part[(size_t)(c + 3) * count + i];
+  }
+  for (; c < chunks; ++c) s0 += part[(size_t)c * count + i];
+  out[i] = (s0 + s1) + (s2 + s3);
 }
 
 static void wgrad_plan(size_t nvox, int ka, int kb, size_t& chunk, unsigned& chunks) {
@@ -242,29 +265,296 @@ int launch_wgrad_direct(const void* A, const void* B, float* dw, WgradGeom g, in
   return check_launch("wgrad_reduce");
 }
 
-// ---- per-channel sum over voxels (bias gradients) -----------------------------------------------------------
+// ---- per-channel sum over voxels (bias gradients): per-workgroup partials, then a fixed-order combine -------------
+constexpr int CS_ITEMS = 256 * 32;  // elements of one channel plane / voxels of a channels-last slab per workgroup
+// planar (NCDHW): grid (chunks, c, n); channels-last: grid (chunks, 1, n) with thread -> channel = tid % c
 template <typename T>
-__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int n,
-                                                          size_t spatial, int c, int planar) {
-  __shared__ float scratch[4];
-  const int ch = blockIdx.x;
-  float s = 0.f;
-  const size_t total = (size_t)n * spatial;
-  for (size_t i = threadIdx.x; i < total; i += 256) {
-    const size_t nn = i / spatial, sp = i - nn * spatial;
-    s += planar ? ld(x, (nn * c + ch) * spatial + sp) : ld(x, i * c + ch);
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const T* __restrict__ x, float* __restrict__ part,
+                                                                  size_t spatial, int c, int planar) {
+  __shared__ float scratch[256];
+  const int n = blockIdx.z;
+  if (planar) {
+    const int ch = blockIdx.y;
+    const T* p = x + ((size_t)n * c + ch) * spatial;
+    const size_t v0 = (size_t)blockIdx.x * CS_ITEMS;
+    const size_t v1 = v0 + CS_ITEMS < spatial ? v0 + CS_ITEMS : spatial;
+    float s = 0.f;
+    for (size_t v = v0 + threadIdx.x; v < v1; v += 256) s += ld(p, v);
+    s = block_sum<4>(s, scratch);
+    if (threadIdx.x == 0) part[((size_t)n * gridDim.x + blockIdx.x) * c + ch] = s;
+  } else if (c <= 256) {
+    // thread t owns channel t % c; rows = 256 / c voxel rows are active
+    const int rows = 256 / c, row = threadIdx.x / c, ch = threadIdx.x % c;
+    const bool active = row < rows;
+    const size_t per = CS_ITEMS / c;
+    const size_t b0 = (size_t)blockIdx.x * per;
+    const size_t b1 = b0 + per < spatial ? b0 + per : spatial;
+    float s = 0.f;
+    if (active)
+      for (size_t v = b0 + row; v < b1; v += rows) s += ld(x, ((size_t)n * spatial + v) * c + ch);
+    scratch[threadIdx.x] = active ? s : 0.f;
+    __syncthreads();
+    if ((int)threadIdx.x < c) {
+      float t = 0.f;
+      for (int r = 0; r < rows; ++r) t += scratch[r * c + threadIdx.x];
+      part[((size_t)n * gridDim.x + blockIdx.x) * c + threadIdx.x] = t;
+    }
+  } else {
+    // wide layers: a thread walks its channels (tid, tid + 256, ...) over the block's 32 voxels
+    const size_t per = CS_ITEMS / 256;
+    const size_t b0 = (size_t)blockIdx.x * per;
+    const size_t b1 = b0 + per < spatial ? b0 + per : spatial;
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+      float s = 0.f;
+      for (size_t v = b0; v < b1; ++v) s += ld(x, ((size_t)n * spatial + v) * c + ch);
+      part[((size_t)n * gridDim.x + blockIdx.x) * c + ch] = s;
+    }
   }
-  s = block_sum<4>(s, scratch);
-  if (threadIdx.x == 0) out[ch] = s;
+}
+// one wave per channel: fp64 combine over (n, chunks)
+__global__ __launch_bounds__(64) void channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                               int items, int c) {
+  const int ch = blockIdx.x;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < items; i += 64) s += (double)part[(size_t)i * c + ch];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[ch] = (float)s;
 }
 
-int launch_channel_sum(const void* x, float* out, int n, size_t spatial, int c, int planar, int dtype,
-                       hipStream_t s) {
+size_t channel_sum_ws_bytes(int n, size_t spatial, int c) {
+  const size_t chunks_planar = (spatial + CS_ITEMS - 1) / CS_ITEMS;
+  const size_t per = CS_ITEMS / (c < 256 ? c : 256);
+  const size_t chunks_cl = (spatial + per - 1) / per;
+  const size_t chunks = chunks_planar > chunks_cl ? chunks_planar : chunks_cl;
+  return (size_t)n * chunks * c * sizeof(float) + 256;
+}
+
+int launch_channel_sum(const void* x, float* out, int n, size_t spatial, int c, int planar, int dtype, void* ws,
+                       size_t ws_bytes, hipStream_t s) {
+  MEDNET_REQUIRE(ws_bytes >= channel_sum_ws_bytes(n, spatial, c), MEDNET_E_WORKSPACE, "channel_sum: workspace too small");
+  const size_t per = planar ? CS_ITEMS : CS_ITEMS / (c < 256 ? c : 256);
+  const unsigned chunks = (unsigned)((spatial + per - 1) / per);
+  const dim3 grid(chunks, planar ? c : 1, n);
+  float* part = (float*)ws;
   if (dtype == MEDNET_F32)
-    hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(c), dim3(256), 0, s, (const float*)x, out, n, spatial, c, planar);
+    hipLaunchKernelGGL(channel_sum_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x, part, spatial, c, planar);
   else
-    hipLaunchKernelGGL(channel_sum_kernel<bf16>, dim3(c), dim3(256), 0, s, (const bf16*)x, out, n, spatial, c, planar);
-  return check_launch("channel_sum");
+    hipLaunchKernelGGL(channel_sum_partial_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, part, spatial, c, planar);
+  int rc = check_launch("channel_sum_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(c), dim3(64), 0, s, part, out, (int)(n * chunks), c);
+  return check_launch("channel_sum_final");
+}
+
+// ---- first-layer weight gradient (Cin == 1): dw[co][tap] = sum_v dy[v][co] * x[v + tap - 1] -------------------------
+// The generic kernel would leave 15/16 of its threads idle here, and this layer sees the largest tensor of the net.
+// A workgroup walks 4x8x32-voxel bricks: the brick's x halo (6x10x34 floats) sits in LDS, thread (co, g) keeps the 27
+// taps of its output channel in registers and handles 4 consecutive voxels per step so that each LDS row read (6 floats)
+// feeds 12 FMAs; dy is read straight from HBM, 32 consecutive channels per half-wave (64 B bf16 rows, coalesced).
+constexpr int W1_TZ = 4, W1_TY = 8, W1_TX = 32;
+constexpr int W1_HZ = W1_TZ + 2, W1_HY = W1_TY + 2, W1_HX = W1_TX + 2, W1_HXP = W1_HX + 2;  // row pitch 36 floats
+
+template <typename TX_, typename TDY, int CO>
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(const TX_* __restrict__ x, const TDY* __restrict__ dy,
+                                                       float* __restrict__ part, int n, int d, int h, int w,
+                                                       int tiles_z, int tiles_y, int tiles_x, int ntiles) {
+  constexpr int G = 256 / CO;  // voxel groups per workgroup
+  __shared__ float xs[W1_HZ * W1_HY * W1_HXP];
+  __shared__ float red[256 * 27 / (CO >= 32 ? 1 : 1)];
+  const int co = threadIdx.x % CO, g = threadIdx.x / CO;
+  float acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int tt = tile;
+    const int x0 = (tt % tiles_x) * W1_TX;
+    tt /= tiles_x;
+    const int y0 = (tt % tiles_y) * W1_TY;
+    tt /= tiles_y;
+    const int z0 = (tt % tiles_z) * W1_TZ;
+    const int nn = tt / tiles_z;
+    __syncthreads();
+    for (int i = threadIdx.x; i < W1_HZ * W1_HY * W1_HX; i += 256) {
+      const int hx = i % W1_HX, hy = (i / W1_HX) % W1_HY, hz = i / (W1_HX * W1_HY);
+      const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      float v = 0.f;
+      if (gz >= 0 && gz < d && gy >= 0 && gy < h && gx >= 0 && gx < w) v = ld(x, (((size_t)nn * d + gz) * h + gy) * w + gx);
+      xs[(hz * W1_HY + hy) * W1_HXP + hx] = v;
+    }
+    __syncthreads();
+    // quads of 4 consecutive x voxels: 4*8*8 = 256 quads per brick
+    for (int qd = g; qd < W1_TZ * W1_TY * (W1_TX / 4); qd += G) {
+      const int qx = (qd % (W1_TX / 4)) * 4, qy = (qd / (W1_TX / 4)) % W1_TY, qz = qd / ((W1_TX / 4) * W1_TY);
+      const int gz = z0 + qz, gy = y0 + qy;
+      float dv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int gx = x0 + qx + k;
+        dv[k] = (gz < d && gy < h && gx < w) ? ld(dy, ((((size_t)nn * d + gz) * h + gy) * w + gx) * CO + co) : 0.f;
+      }
+#pragma unroll
+      for (int tz = 0; tz < 3; ++tz)
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+          const float* row = xs + ((qz + tz) * W1_HY + qy + ty) * W1_HXP + qx;
+          float r[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) r[k] = row[k];
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[(tz * 3 + ty) * 3 + tx] = fmaf(dv[k], r[k + tx], acc[(tz * 3 + ty) * 3 + tx]);
+        }
+    }
+  }
+  // sum the G voxel groups of each channel, then one partial per workgroup
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 27; ++t) red[(t * G + g) * CO + co] = acc[t];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 27 * CO; i += 256) {
+    const int t = i / CO, c2 = i % CO;
+    float s = 0.f;
+    for (int k = 0; k < G; ++k) s += red[(t * G + k) * CO + c2];
+    part[(size_t)blockIdx.x * (27 * CO) + (size_t)c2 * 27 + t] = s;
+  }
+}
+
+// ---- 1x1x1 head weight gradient: dw[m][k] = sum_v dy[m][v] (planar fp32 logits gradient) * z[v][k] (channels-last) ----
+// HBM-bound (one pass over z): a thread owns 8 input channels of a voxel column ("column persistent", like GroupNorm) and
+// an 8-row block of output channels; per-workgroup partials, fixed-order combine.
+template <typename TZ>
+__global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict__ dy, const TZ* __restrict__ z,
+                                                        float* __restrict__ part, size_t spatial, int k, int m,
+                                                        size_t chunk_vox) {
+  __shared__ float lds[256 * 8];
+  const int cols = k / 8, rows = 256 / cols;
+  const int col = threadIdx.x % cols, row = threadIdx.x / cols;
+  const bool active = (int)threadIdx.x < rows * cols;
+  const int n = blockIdx.z, m0 = blockIdx.y * 8;
+  const size_t v0 = (size_t)blockIdx.x * chunk_vox;
+  const size_t v1 = v0 + chunk_vox < spatial ? v0 + chunk_vox : spatial;
+  float acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+  if (active) {
+    const TZ* zb = z + (size_t)n * spatial * k + (size_t)col * 8;
+    for (size_t v = v0 + row; v < v1; v += rows) {
+      const F8 zv = ld8(zb, v * k);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = (m0 + i < m) ? dy[((size_t)n * m + m0 + i) * spatial + v] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(d, zv.v[j], acc[i][j]);
+      }
+    }
+  }
+  // reduce the `rows` threads that share a column, one output row at a time
+  float* out = part + (((size_t)n * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * 8 * k;
+  for (int i = 0; i < 8; ++i) {
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) lds[(row * cols + col) * 8 + j] = acc[i][j];
+    }
+    __syncthreads();
+    if (active && row == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += lds[(r * cols + col) * 8 + j];
+        out[(size_t)i * k + col * 8 + j] = s;
+      }
+    }
+  }
+}
+// dw[mm][kk] = sum over (n, chunk) of part[n][chunk][mb][i][kk]
+__global__ __launch_bounds__(64) void wgrad_1x1_final_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                             int items, int mblocks, int k, int m) {
+  const int mm = blockIdx.x / k, kk = blockIdx.x % k;
+  const int mb = mm / 8, i = mm % 8;
+  double s = 0.0;
+  for (int it = threadIdx.x; it < items; it += 64) s += (double)part[(((size_t)it * mblocks + mb) * 8 + i) * k + kk];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) dw[(size_t)mm * k + kk] = (float)s;
+}
+bool wgrad_1x1_supported(int cin, int cout, int ksize, int x_layout, int dy_layout, int dy_dtype) {
+  return ksize == 1 && cin % 8 == 0 && cin / 8 <= 256 && x_layout == MEDNET_NDHWC && dy_layout == MEDNET_NCDHW &&
+         dy_dtype == MEDNET_F32 && cout <= 4096;
+}
+static void wgrad_1x1_plan(size_t spatial, int k, size_t& chunk_vox, unsigned& chunks) {
+  const int rows = 256 / (k / 8);
+  size_t cv = (spatial + 511) / 512;
+  if (cv < (size_t)rows * 8) cv = (size_t)rows * 8;
+  cv = (cv + rows - 1) / rows * rows;
+  chunk_vox = cv;
+  chunks = (unsigned)((spatial + cv - 1) / cv);
+}
+size_t wgrad_1x1_ws_bytes(int n, size_t spatial, int cin, int cout) {
+  if (cin % 8 || cin / 8 > 256) return 0;
+  size_t cv;
+  unsigned chunks;
+  wgrad_1x1_plan(spatial, cin, cv, chunks);
+  return (size_t)n * chunks * ((cout + 7) / 8) * 8 * cin * sizeof(float);
+}
+int launch_wgrad_1x1(const void* z, const void* dy, float* dw, int n, size_t spatial, int cin, int cout, int z_dtype,
+                     void* ws, size_t ws_bytes, hipStream_t s) {
+  size_t cv;
+  unsigned chunks;
+  wgrad_1x1_plan(spatial, cin, cv, chunks);
+  const int mblocks = (cout + 7) / 8;
+  MEDNET_REQUIRE(ws_bytes >= wgrad_1x1_ws_bytes(n, spatial, cin, cout), MEDNET_E_WORKSPACE, "wgrad_1x1: workspace too small");
+  const dim3 grid(chunks, mblocks, n);
+  float* part = (float*)ws;
+  if (z_dtype == MEDNET_F32)
+    hipLaunchKernelGGL(wgrad_1x1_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)z, part, spatial, cin, cout, cv);
+  else
+    hipLaunchKernelGGL(wgrad_1x1_kernel<bf16>, grid, dim3(256), 0, s, (const float*)dy, (const bf16*)z, part, spatial, cin, cout, cv);
+  int rc = check_launch("wgrad_1x1");
+  if (rc) return rc;
+  hipLaunchKernelGGL(wgrad_1x1_final_kernel, dim3(cout * cin), dim3(64), 0, s, part, dw, (int)(n * chunks), mblocks, cin, cout);
+  return check_launch("wgrad_1x1_final");
+}
+
+bool wgrad_c1_supported(int cin, int cout, int ksize, int x_layout, int dy_layout) {
+  return cin == 1 && ksize == 3 && (cout == 8 || cout == 16 || cout == 32 || cout == 64) && dy_layout == MEDNET_NDHWC &&
+         (x_layout == MEDNET_NDHWC || x_layout == MEDNET_NCDHW);
+}
+static int wgrad_c1_blocks(int ntiles) { return ntiles < 1024 ? ntiles : 1024; }
+size_t wgrad_c1_ws_bytes(int n, int d, int h, int w, int cout) {
+  const int nt = n * ((d + W1_TZ - 1) / W1_TZ) * ((h + W1_TY - 1) / W1_TY) * ((w + W1_TX - 1) / W1_TX);
+  return (size_t)wgrad_c1_blocks(nt) * 27 * cout * sizeof(float);
+}
+int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cout, int x_dtype,
+                    int dy_dtype, void* ws, size_t ws_bytes, hipStream_t s) {
+  const int tz = (d + W1_TZ - 1) / W1_TZ, ty = (h + W1_TY - 1) / W1_TY, tx = (w + W1_TX - 1) / W1_TX;
+  const int nt = n * tz * ty * tx;
+  const int blocks = wgrad_c1_blocks(nt);
+  MEDNET_REQUIRE(ws_bytes >= (size_t)blocks * 27 * cout * sizeof(float), MEDNET_E_WORKSPACE, "wgrad_c1: workspace too small");
+  float* part = (float*)ws;
+#define W1_GO(TX__, TDY__, CO__)                                                                                       \
+  hipLaunchKernelGGL((wgrad_c1_kernel<TX__, TDY__, CO__>), dim3(blocks), dim3(256), 0, s, (const TX__*)x, (const TDY__*)dy, \
+                     part, n, d, h, w, tz, ty, tx, nt)
+#define W1_CO(TX__, TDY__)                         \
+  do {                                             \
+    if (cout == 8) W1_GO(TX__, TDY__, 8);          \
+    else if (cout == 16) W1_GO(TX__, TDY__, 16);   \
+    else if (cout == 32) W1_GO(TX__, TDY__, 32);   \
+    else W1_GO(TX__, TDY__, 64);                   \
+  } while (0)
+  if (x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32) W1_CO(float, float);
+  else if (x_dtype == MEDNET_F32 && dy_dtype == MEDNET_BF16) W1_CO(float, bf16);
+  else if (x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_BF16) W1_CO(bf16, bf16);
+  else W1_CO(bf16, float);
+#undef W1_CO
+#undef W1_GO
+  int rc = check_launch("wgrad_c1");
+  if (rc) return rc;
+  const size_t count = (size_t)27 * cout;
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part, dw, count, blocks);
+  return check_launch("wgrad_c1_reduce");
 }
 
 // ---- weight packing -------------------------------------------------------------------------------------------

@@ -195,6 +195,174 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   }
 }
 
+// ================================================================================================== ConvTranspose3d forward
+// out[2j + p] = bias + skip + sum_{taps k of parity class p} W[k] * x[j + delta_k]   (per dim: k=1 -> p=0,d=0; k=0 -> p=1,d=1;
+// k=2 -> p=1,d=0).  A workgroup owns a 2x4x16 brick of INPUT voxels (4x8x32 outputs); a wave owns one N-tile of 32 input
+// voxels and keeps all 8 output parity classes of it in registers (8 x 16 accumulators), so the staged input brick and
+// weight slice are used by all 27 taps exactly as in the forward convolution.  Bias and the decoder's skip tensor
+// (`x += encoder_features`, components.py:283-284) are added in the epilogue.
+struct CtArgs {
+  const bf16* x;
+  const bf16* wpk;
+  const float* bias;
+  const bf16* skip;
+  bf16* y;
+  int n, id, ih, iw;  // input grid (output is 2x)
+  int cin, cout;
+  int tiles_z, tiles_y, tiles_x, ntiles;
+  int nkc, ncb;
+};
+
+__global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
+  constexpr int TZ = 2, TY = 4, TX = 16;
+  constexpr int HZ = TZ + 1, HY = TY + 1, HX = TX + 1;
+  constexpr int NV = HZ * HY * HX;
+  constexpr int IN_ROUNDS = (2 * NV + 255) / 256;
+  constexpr int W_CHUNKS = 27 * 2 * 32;
+  constexpr int W_ROUNDS = (W_CHUNKS + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16x8* in_lds = reinterpret_cast<bf16x8*>(smem);
+  bf16x8* w_lds = reinterpret_cast<bf16x8*>(smem) + 2 * NV;
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int tile = (local / a.ncb) * 8 + xcd;
+  const int cb = local % a.ncb;
+  if (tile >= a.ntiles) return;
+  int tt = tile;
+  const int tx0 = (tt % a.tiles_x) * TX;
+  tt /= a.tiles_x;
+  const int ty0 = (tt % a.tiles_y) * TY;
+  tt /= a.tiles_y;
+  const int tz0 = (tt % a.tiles_z) * TZ;
+  const int n = tt / a.tiles_z;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  long long goff[IN_ROUNDS];
+#pragma unroll
+  for (int it = 0; it < IN_ROUNDS; ++it) {
+    const int p = it * 256 + tid;
+    const int v = p >> 1, hh = p & 1;
+    long long off = -1;
+    if (v < NV) {
+      const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
+      const int gz = tz0 + hz, gy = ty0 + hy, gx = tx0 + hx;
+      off = (gz < a.id && gy < a.ih && gx < a.iw)
+                ? ((((long long)n * a.id + gz) * a.ih + gy) * a.iw + gx) * a.cin + hh * 8
+                : -2;
+    }
+    goff[it] = off;
+  }
+  const bf16* wsrc = a.wpk + (size_t)cb * a.nkc * (W_CHUNKS * 8);
+  bf16x8 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
+  auto prefetch = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) {
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (goff[it] >= 0) v = *reinterpret_cast<const bf16x8*>(a.x + goff[it] + kc * 16);
+      in_reg[it] = v;
+    }
+    const bf16* ws = wsrc + (size_t)kc * (W_CHUNKS * 8);
+#pragma unroll
+    for (int it = 0; it < W_ROUNDS; ++it) {
+      const int c = it * 256 + tid;
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (c < W_CHUNKS) v = *reinterpret_cast<const bf16x8*>(ws + (size_t)c * 8);
+      w_reg[it] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) {
+      const int p = it * 256 + tid;
+      if (goff[it] != -1) in_lds[(p & 1) * NV + (p >> 1)] = in_reg[it];
+    }
+#pragma unroll
+    for (int it = 0; it < W_ROUNDS; ++it) {
+      const int c = it * 256 + tid;
+      if (c < W_CHUNKS) w_lds[c] = w_reg[it];
+    }
+  };
+
+  // the wave's N-tile: rows (lz, ly0 + yy), yy = r >> 4, rotated by the row pitch so the 16 lanes of a read group differ
+  const int lz = wv / (TY / 2), ly = (wv % (TY / 2)) * 2 + (r >> 4);
+  const int lx = ((r & 15) - (r >> 4) * HX) & 15;
+  const int lbase = (lz * HY + ly) * HX + lx + h * NV;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
+
+  prefetch(0);
+  for (int kc = 0; kc < a.nkc; ++kc) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (kc + 1 < a.nkc) prefetch(kc + 1);
+    bf16x8 xb[8];
+#pragma unroll
+    for (int dl = 0; dl < 8; ++dl) xb[dl] = in_lds[lbase + (((dl >> 2) & 1) * HY + ((dl >> 1) & 1)) * HX + (dl & 1)];
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+      const int pz = kz != 1, py = ky != 1, px = kx != 1;      // output parity of this tap
+      const int dz = kz == 0, dy = ky == 0, dx = kx == 0;      // input offset of this tap
+      const bf16x8 wa = w_lds[(tap * 2 + h) * 32 + r];
+      acc[pz * 4 + py * 2 + px] =
+          __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb[dz * 4 + dy * 2 + dx], acc[pz * 4 + py * 2 + px], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: + bias + skip, 8 parity classes
+  const int jz = tz0 + lz, jy = ty0 + ly, jx = tx0 + lx;
+  if (jz < a.id && jy < a.ih && jx < a.iw) {
+    const int od = 2 * a.id, oh = 2 * a.ih, ow = 2 * a.iw;
+    float bv[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[q * 4 + j] = a.bias ? a.bias[cb * 32 + 8 * q + 4 * h + j] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int oz = 2 * jz + (p >> 2), oy = 2 * jy + ((p >> 1) & 1), ox = 2 * jx + (p & 1);
+      const size_t o = ((((size_t)n * od + oz) * oh + oy) * ow + ox) * a.cout + cb * 32 + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bf16x4 sk = {0, 0, 0, 0};
+        if (a.skip) sk = *reinterpret_cast<const bf16x4*>(a.skip + o + 8 * q);
+        bf16x4 ov;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ov[j] = (bf16)(acc[p][q * 4 + j] + bv[q * 4 + j] + (float)sk[j]);
+        *reinterpret_cast<bf16x4*>(a.y + o + 8 * q) = ov;
+      }
+    }
+  }
+}
+
+int launch_convt_fwd_mfma(const void* x, const void* sec, const float* bias, const void* skip, void* y, int n, int d,
+                          int h, int w, int cin, int cout, hipStream_t s) {
+  constexpr size_t lds = ((size_t)2 * 3 * 5 * 17 + 27 * 2 * 32) * 16;
+  CtArgs a;
+  a.x = (const bf16*)x;
+  a.wpk = (const bf16*)sec;
+  a.bias = bias;
+  a.skip = (const bf16*)skip;
+  a.y = (bf16*)y;
+  a.n = n; a.id = d; a.ih = h; a.iw = w; a.cin = cin; a.cout = cout;
+  a.tiles_z = (d + 1) / 2;
+  a.tiles_y = (h + 3) / 4;
+  a.tiles_x = (w + 15) / 16;
+  a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
+  a.nkc = cin / 16;
+  a.ncb = cout / 32;
+  const unsigned grid = (unsigned)((a.ntiles + 7) / 8) * 8 * a.ncb;
+  hipLaunchKernelGGL(convt_fwd_mfma_kernel, dim3(grid), dim3(256), lds, s, a);
+  return check_launch("convt_fwd_mfma");
+}
+
 // ================================================================================================== weight packing
 // element e of section [cb][kc][tap][h][co][j]  <-  Weff[cb*32+co][kc*16+h*8+j][tap]
 // mode 0: conv fwd      Weff[m][k][t] = W[m][k][t]            (W: Cout,Cin,27)  M=Cout K=Cin
@@ -430,9 +598,16 @@ __global__ __launch_bounds__(256) void wgrad_mfma_reduce_kernel(const float* __r
   const int pair = (int)(e / (1024 * 27));
   const int ab = pair / nbb, bb = pair % nbb;
   const float* src = part + ((size_t)pair * splits) * 27 * 1024 + (size_t)tap * 1024 + a32 * 32 + b32;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += src[(size_t)k * 27 * 1024];
-  dw[((size_t)(ab * 32 + a32) * kb + bb * 32 + b32) * 27 + tap] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // 4 loads in flight; fixed order => bitwise reproducible
+  int k = 0;
+  for (; k + 4 <= splits; k += 4) {
+    s0 += src[(size_t)k * 27 * 1024];
+    s1 += src[(size_t)(k + 1) * 27 * 1024];
+    s2 += src[(size_t)(k + 2) * 27 * 1024];
+    s3 += src[(size_t)(k + 3) * 27 * 1024];
+  }
+  for (; k < splits; ++k) s0 += src[(size_t)k * 27 * 1024];
+  dw[((size_t)(ab * 32 + a32) * kb + bb * 32 + b32) * 27 + tap] = (s0 + s1) + (s2 + s3);
 }
 
 bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtype, int x_layout, int dy_layout) {
@@ -450,7 +625,7 @@ static void wgrad_plan(int n, int ad, int ah, int aw, int ka, int kb, WgArgs& a)
   a.nab = ka / 32;
   a.nbb = kb / 32;
   const int pairs = a.nab * a.nbb;
-  int splits = (1024 + pairs - 1) / pairs;
+  int splits = (512 + pairs - 1) / pairs;  // ~2 workgroups per CU resident: one wave of workgroups, 56 MB of partials
   if (splits > a.ntiles) splits = a.ntiles;
   if (splits < 1) splits = 1;
   a.splits = splits;

@@ -101,19 +101,36 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
   column_reduce<2 * VEC>(acc, L.cols, L.rows, L.col, L.row, L.active, lds, out);
 }
 
-// one wave per (n, g): fp64 combine -> mean, rstd; then the per-channel affine the apply kernel uses.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial,
+// stage 1 of every finalize: csum[n][c][2] = sum over chunks of partial[n][chunk][c][2]; one wave per (n, c), lanes stride
+// the chunks (fp64, fixed order).
+__global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ csum,
+                                                             int c, int chunks) {
+  const int n = blockIdx.x / c, cc = blockIdx.x % c;
+  double a = 0.0, b = 0.0;
+  for (int ch = threadIdx.x; ch < chunks; ch += 64) {
+    const float* p = partial + (((size_t)n * chunks + ch) * c + cc) * 2;
+    a += (double)p[0];
+    b += (double)p[1];
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (threadIdx.x == 0) {
+    csum[((size_t)n * c + cc) * 2] = (float)a;
+    csum[((size_t)n * c + cc) * 2 + 1] = (float)b;
+  }
+}
+
+// stage 2: one wave per (n, g): mean, rstd; then the per-channel affine the apply kernel uses.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ csum,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ stats,
-                                                         float* __restrict__ coef, int c, int groups, int chunks,
-                                                         double count, float eps) {
+                                                         float* __restrict__ coef, int c, int groups, double count,
+                                                         float eps) {
   const int n = blockIdx.x / groups, g = blockIdx.x % groups;
   const int cg = c / groups;
   double s = 0.0, q = 0.0;
-  const int items = chunks * cg;
-  for (int i = threadIdx.x; i < items; i += 64) {
-    const int ch = i / cg, cc = g * cg + i % cg;
-    const float* p = partial + (((size_t)n * chunks + ch) * c + cc) * 2;
+  for (int i = threadIdx.x; i < cg; i += 64) {
+    const float* p = csum + ((size_t)n * c + g * cg + i) * 2;
     s += (double)p[0];
     q += (double)p[1];
   }
@@ -217,29 +234,19 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict
 
 // pass 2a: per (n,g): S1 = sum_c gamma_c * sum du_c, S2 = sum_c gamma_c * sum(du*xhat)_c  ->
 //   dx = k1_c * du + k2_g * x + k3_g,  k1 = rstd*gamma_c, k2 = -rstd^2*S2/M, k3 = (rstd^2*S2*mean - rstd*S1)/M
-// csum[n][c][2] keeps the per-(n,c) totals for pass 2b.
-__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float* __restrict__ partial,
+// csum[n][c][2] (from reduce_partials_kernel) holds the per-(n,c) totals.
+__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float* __restrict__ csum,
                                                              const float* __restrict__ stats,
                                                              const float* __restrict__ gamma,
-                                                             float* __restrict__ bcoef, float* __restrict__ csum, int c,
-                                                             int groups, int chunks, double count) {
+                                                             float* __restrict__ bcoef, int c, int groups, double count) {
   const int n = blockIdx.x / groups, g = blockIdx.x % groups;
   const int cg = c / groups;
   double s1 = 0.0, s2 = 0.0;
-  // lanes own channels (cg may exceed 64: loop)
   for (int i = threadIdx.x; i < cg; i += 64) {
     const int cc = g * cg + i;
-    double a = 0.0, b = 0.0;
-    for (int ch = 0; ch < chunks; ++ch) {
-      const float* p = partial + (((size_t)n * chunks + ch) * c + cc) * 2;
-      a += (double)p[0];
-      b += (double)p[1];
-    }
-    csum[((size_t)n * c + cc) * 2] = (float)a;
-    csum[((size_t)n * c + cc) * 2 + 1] = (float)b;
     const double ga = gamma ? (double)gamma[cc] : 1.0;
-    s1 += ga * a;
-    s2 += ga * b;
+    s1 += ga * (double)csum[((size_t)n * c + cc) * 2];
+    s2 += ga * (double)csum[((size_t)n * c + cc) * 2 + 1];
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
@@ -575,8 +582,10 @@ extern "C" int mednet_gn_stats(const void* x, const float* gamma, const float* b
 #undef GO
   int rc = check_launch("gn_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n * groups), dim3(64), 0, s, partial, gamma, beta, stats, coef, c, groups,
-                     (int)chunks, (double)spatial * (c / groups), eps);
+  float* csum = partial + (size_t)n * 1024 * c * 2 + (size_t)n * c * 3;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n * c), dim3(64), 0, s, partial, csum, c, (int)chunks);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, gamma, beta, stats, coef, c, groups,
+                     (double)spatial * (c / groups), eps);
   return check_launch("gn_finalize");
 }
 
@@ -622,8 +631,9 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
 #undef GO
   int rc = check_launch("gn_bwd_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(64), 0, s, partial, stats, gamma, bcoef, csum, c,
-                     groups, (int)chunks, (double)spatial * (c / groups));
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n * c), dim3(64), 0, s, partial, csum, c, (int)chunks);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, stats, gamma, bcoef, c, groups,
+                     (double)spatial * (c / groups));
   rc = check_launch("gn_bwd_finalize");
   if (rc) return rc;
   if (dgamma || dbeta) {

@@ -34,7 +34,7 @@ SIGNATURES = {
     "mednet_conv3d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "mednet_conv3d_wgrad_ws_bytes": (_sz, [_i] * 7),
     "mednet_conv3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp, _sz, _vp]),
-    "mednet_convt3d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
+    "mednet_convt3d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "mednet_convt3d_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "mednet_convt3d_wgrad_ws_bytes": (_sz, [_i] * 6),
     "mednet_convt3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 9 + [_vp, _sz, _vp]),

@@ -145,7 +145,7 @@ class ConvT3dFn(Function):
                 raise RuntimeError(f"conv_transpose3d: skip shape {tuple(skip.shape)} != output {tuple(y.shape)}")
             sk = to_cl(skip.to(y.dtype))
         L.check(L.lib().mednet_convt3d_fwd(x.data_ptr(), packed.data_ptr(), L.ptr(bias), L.ptr(sk), y.data_ptr(), n, d, h,
-                                           w, cin, cout, L.dt(x), L.dt(y), L.stream()), "convt3d_fwd")
+                                           w, cin, cout, L.dt(x), L.dt(y), config.conv_algo(), L.stream()), "convt3d_fwd")
         ctx.save_for_backward(x, packed)
         ctx.meta = (cin, cout, bias is not None, skip is not None, None if skip is None else skip.dtype)
         ctx.params = (weight, bias)
