@@ -30,11 +30,37 @@ F_MAPS = [32, 64, 128, 256]
 FLOP_PER_PATCH = 3447.9e9  # 6 x forward conv/convT MACs of ResidualUNet3D cfg2 at 128^3
 
 
+def host_cores() -> int:
+    """Cores this process may actually use: affinity mask and cgroup CPU quota; a box that shows every core of a shared
+    host but grants a share (the 1-GPU boxes grant 16) would otherwise be oversubscribed 16x by the oracle."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // p))
+    except Exception:
+        pass
+    cap = int(os.environ.get("MEDNET_CPU_BASELINE_CORES", "16"))  # CPU share of a 1-GPU box
+    return min(n, cap)
+
+
 def cpu_baseline(steps: int):
     """The oracle (plain torch.nn restatement of the reference) timed on this box's host cores: cfg2's model, N=1,
     128^3, fp32, fwd + DiceLoss + bwd + Adam -- a bounded sample (1 warm-up + `steps` timed steps)."""
     from oracle import ref_cpu as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     model = O.keyed_init_(O.ResidualUNet3D(1, 4, False, f_maps=F_MAPS))
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
@@ -53,6 +79,18 @@ def cpu_baseline(steps: int):
     return {"value": round(1.0 / med, 5), "unit": "patches/s", "cores": cores, "kind": "port",
             "sample": f"oracle ResidualUNet3D {F_MAPS} 4-class, one 128^3 patch (N=1), fp32, fwd+Dice+bwd+Adam, "
                       f"1 warm-up + {steps} timed steps (median {med:.2f} s/step)"}
+
+
+def pmc_traffic(batch: int, patch: int):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with
+    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; FETCH_SIZE doubled as the gfx950 guide prescribes).  PMC cannot be
+    collected from inside the timed run, so this is the last profiled value for this exact launch shape, else null."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        grid = batch * (patch // 4) * (patch // 8) * (patch // 16) * 256  # threads of the 32->32 full-resolution launch
+        return d[f"mednet::conv_mfma_kernel<1> grid={grid}"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def main():
@@ -137,9 +175,9 @@ def main():
             avg = sum(ms) / len(ms)
             peak = MFMA_PEAK_TFLOPS[a.precision]
             ach = flops / (avg * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "conv3d 3x3x3 32->32 @128^3 (fwd launches)", "bound": "mfma",
+            out["roofline"] = {"kernel": "conv_mfma_kernel<1>: conv3d 3x3x3 32->32 @128^3 (fwd launches)", "bound": "mfma",
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": None, "launches": len(ms), "avg_ms": round(avg, 4),
+                               "traffic": pmc_traffic(a.batch, P), "launches": len(ms), "avg_ms": round(avg, 4),
                                "flop_per_launch": flops}
         if a.cpu_steps > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.cpu_steps)
