@@ -41,6 +41,8 @@ int mednet_abi_version(void);
 const char* mednet_last_error(void);
 /* 1 if a gfx950 device is visible to this process, 0 otherwise (never throws). */
 int mednet_device_ok(void);
+/* Kernel-variant knobs for in-process A/B measurements (e.g. "conv_pipe" 0|1); results never depend on them. */
+int mednet_set_option(const char* name, int value);
 
 /* ---- nn.Conv3d(k=3,p=1 | k=1,p=0, stride 1)  components.py:8-9,44 ; model.py:77,179 ------------------------ */
 /* Weight packing: PyTorch (Cout,Cin,k,k,k) [or ConvTranspose3d's (Cin,Cout,k,k,k) when transposed_src=1] ->

@@ -27,9 +27,33 @@ int check_launch(const char* what) {
   return MEDNET_OK;
 }
 
+struct Option {
+  char name[32];
+  int value;
+};
+static Option g_options[16];
+static int g_noptions = 0;
+int tuning_option(const char* name, int default_value) {
+  for (int i = 0; i < g_noptions; ++i)
+    if (strcmp(g_options[i].name, name) == 0) return g_options[i].value;
+  return default_value;
+}
+
 }  // namespace mednet
 
 using namespace mednet;
+
+extern "C" int mednet_set_option(const char* name, int value) {
+  for (int i = 0; i < g_noptions; ++i)
+    if (strcmp(g_options[i].name, name) == 0) {
+      g_options[i].value = value;
+      return MEDNET_OK;
+    }
+  MEDNET_REQUIRE(g_noptions < 16 && strlen(name) < 32, MEDNET_E_UNSUPPORTED, "set_option: table full or name too long");
+  strcpy(g_options[g_noptions].name, name);
+  g_options[g_noptions++].value = value;
+  return MEDNET_OK;
+}
 
 extern "C" int mednet_abi_version(void) { return 1; }
 extern "C" const char* mednet_last_error(void) { return g_err; }

@@ -17,6 +17,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 void set_error(const char* fmt, ...);
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
+// tuning knobs (mednet_set_option): experiments A/B kernel variants inside ONE process
+int tuning_option(const char* name, int default_value);
 
 #define MEDNET_REQUIRE(cond, code, ...)        \
   do {                                         \

@@ -58,7 +58,7 @@ struct FwdArgs {
   int nkc, ncb;
 };
 
-template <int STRIDE>
+template <int STRIDE, bool PIPE>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   using G = FwdTile<STRIDE>;
   constexpr int TZ = G::TZ, TY = G::TY, TX = G::TX;
@@ -109,27 +109,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   const bf16* wsrc = a.wpk + (size_t)cb * a.nkc * (W_CHUNKS * 8);
 
   bf16x8 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
+  // Branch-free: every lane always loads (padding / out-of-image lanes read a valid dummy address); what is invalid
+  // is replaced by zeros when the registers are committed to LDS, so the 16 loads issue back to back with no waits.
   auto prefetch = [&](int kc) {
 #pragma unroll
-    for (int it = 0; it < IN_ROUNDS; ++it) {
-      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (goff[it] >= 0) v = *reinterpret_cast<const bf16x8*>(a.x + goff[it] + kc * 16);
-      in_reg[it] = v;
-    }
+    for (int it = 0; it < IN_ROUNDS; ++it)
+      in_reg[it] = *reinterpret_cast<const bf16x8*>(a.x + (goff[it] >= 0 ? goff[it] : 0) + kc * 16);
     const bf16* ws = wsrc + (size_t)kc * (W_CHUNKS * 8);
 #pragma unroll
     for (int it = 0; it < W_ROUNDS; ++it) {
       const int c = it * 256 + tid;
-      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (c < W_CHUNKS) v = *reinterpret_cast<const bf16x8*>(ws + (size_t)c * 8);
-      w_reg[it] = v;
+      w_reg[it] = *reinterpret_cast<const bf16x8*>(ws + (size_t)(c < W_CHUNKS ? c : W_CHUNKS - 1) * 8);
     }
   };
   auto commit = [&]() {
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int it = 0; it < IN_ROUNDS; ++it) {
       const int p = it * 256 + tid;
-      if (goff[it] != -1) in_lds[(p & 1) * NV + (p >> 1)] = in_reg[it];
+      if (goff[it] != -1) in_lds[(p & 1) * NV + (p >> 1)] = goff[it] >= 0 ? in_reg[it] : zero;
     }
 #pragma unroll
     for (int it = 0; it < W_ROUNDS; ++it) {
@@ -164,17 +162,40 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     commit();
     __syncthreads();
     if (kc + 1 < a.nkc) prefetch(kc + 1);  // in flight while the matrix cores work on chunk kc
+    if constexpr (PIPE) {
+      // Software-pipelined over the 27 taps: the fragments of tap t+1 (1 weight + NTW input ds_read_b128) are in flight
+      // while tap t is on the matrix cores; sched_group_barrier pins that interleave (hipcc otherwise sinks each read
+      // to just in front of its MFMA and exposes the LDS latency 108 times per chunk).
+      bf16x8 wa[2], xb[2][NTW];
+      wa[0] = w_lds[h * 32 + r];
 #pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
-      constexpr int dummy = 0;
-      (void)dummy;
-      const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-      const int toff = (tz * HY + ty) * HX + tx;
-      const bf16x8 wa = w_lds[(tap * 2 + h) * 32 + r];
+      for (int t = 0; t < NTW; ++t) xb[0][t] = in_lds[lbase[t]];
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        const bf16x8 xb = in_lds[lbase[t] + toff];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[t], 0, 0, 0);
+      for (int tap = 0; tap < 27; ++tap) {
+        const int cur = tap & 1, nxt = cur ^ 1;
+        if (tap + 1 < 27) {
+          const int t1 = tap + 1;
+          const int toff = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3;
+          wa[nxt] = w_lds[(t1 * 2 + h) * 32 + r];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) xb[nxt][t] = in_lds[lbase[t] + toff];
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur], xb[cur][t], acc[t], 0, 0, 0);
+        if (tap + 1 < 27) __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);  // DS reads of tap+1 first ...
+        __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                         // ... then the MFMAs of tap
+      }
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        const int toff = ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
+        const bf16x8 wa = w_lds[(tap * 2 + h) * 32 + r];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          const bf16x8 xb = in_lds[lbase[t] + toff];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[t], 0, 0, 0);
+        }
       }
     }
   }
@@ -256,27 +277,25 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
   }
   const bf16* wsrc = a.wpk + (size_t)cb * a.nkc * (W_CHUNKS * 8);
   bf16x8 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
+  // Branch-free: every lane always loads (padding / out-of-image lanes read a valid dummy address); what is invalid
+  // is replaced by zeros when the registers are committed to LDS, so the 16 loads issue back to back with no waits.
   auto prefetch = [&](int kc) {
 #pragma unroll
-    for (int it = 0; it < IN_ROUNDS; ++it) {
-      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (goff[it] >= 0) v = *reinterpret_cast<const bf16x8*>(a.x + goff[it] + kc * 16);
-      in_reg[it] = v;
-    }
+    for (int it = 0; it < IN_ROUNDS; ++it)
+      in_reg[it] = *reinterpret_cast<const bf16x8*>(a.x + (goff[it] >= 0 ? goff[it] : 0) + kc * 16);
     const bf16* ws = wsrc + (size_t)kc * (W_CHUNKS * 8);
 #pragma unroll
     for (int it = 0; it < W_ROUNDS; ++it) {
       const int c = it * 256 + tid;
-      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (c < W_CHUNKS) v = *reinterpret_cast<const bf16x8*>(ws + (size_t)c * 8);
-      w_reg[it] = v;
+      w_reg[it] = *reinterpret_cast<const bf16x8*>(ws + (size_t)(c < W_CHUNKS ? c : W_CHUNKS - 1) * 8);
     }
   };
   auto commit = [&]() {
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int it = 0; it < IN_ROUNDS; ++it) {
       const int p = it * 256 + tid;
-      if (goff[it] != -1) in_lds[(p & 1) * NV + (p >> 1)] = in_reg[it];
+      if (goff[it] != -1) in_lds[(p & 1) * NV + (p >> 1)] = goff[it] >= 0 ? in_reg[it] : zero;
     }
 #pragma unroll
     for (int it = 0; it < W_ROUNDS; ++it) {
@@ -305,14 +324,18 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
     bf16x8 xb[8];
 #pragma unroll
     for (int dl = 0; dl < 8; ++dl) xb[dl] = in_lds[lbase + (((dl >> 2) & 1) * HY + ((dl >> 1) & 1)) * HX + (dl & 1)];
+    bf16x8 wa[2];
+    wa[0] = w_lds[h * 32 + r];
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
       const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
       const int pz = kz != 1, py = ky != 1, px = kx != 1;      // output parity of this tap
       const int dz = kz == 0, dy = ky == 0, dx = kx == 0;      // input offset of this tap
-      const bf16x8 wa = w_lds[(tap * 2 + h) * 32 + r];
-      acc[pz * 4 + py * 2 + px] =
-          __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb[dz * 4 + dy * 2 + dx], acc[pz * 4 + py * 2 + px], 0, 0, 0);
+      if (tap + 1 < 27) wa[(tap + 1) & 1] = w_lds[((tap + 1) * 2 + h) * 32 + r];  // next weight fragment in flight
+      acc[pz * 4 + py * 2 + px] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[tap & 1], xb[dz * 4 + dy * 2 + dx],
+                                                                          acc[pz * 4 + py * 2 + px], 0, 0, 0);
+      if (tap + 1 < 27) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
   }
 
@@ -447,12 +470,15 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   const unsigned grid = (unsigned)((a.ntiles + 7) / 8) * 8 * a.ncb;
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[STRIDE]) {
-    if (hipFuncSetAttribute((const void*)conv_mfma_kernel<STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv_mfma_kernel<STRIDE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv_mfma_kernel<STRIDE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(MEDNET_E_HIP, "conv_mfma: cannot raise dynamic LDS to %zu", lds);
     attr_set[STRIDE] = true;
   }
-  hipLaunchKernelGGL((conv_mfma_kernel<STRIDE>), dim3(grid), dim3(256), lds, s, a);
+  if (tuning_option("conv_pipe", 1))
+    hipLaunchKernelGGL((conv_mfma_kernel<STRIDE, true>), dim3(grid), dim3(256), lds, s, a);
+  else
+    hipLaunchKernelGGL((conv_mfma_kernel<STRIDE, false>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_mfma");
 }
 
@@ -525,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
     const int n = tt / a.tiles_z;
     __syncthreads();  // previous brick fully consumed
     // ---- stage A brick (zero outside the volume) and B halo brick
-#pragma unroll
+#pragma unroll 4
     for (int it = 0; it < A_ROUNDS; ++it) {
       const int c = it * 256 + tid;
       if (c < NA * 4) {
@@ -538,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
         *reinterpret_cast<bf16x8*>(A_lds + v * 32 + part * 8) = val;
       }
     }
-#pragma unroll
+#pragma unroll 4
     for (int it = 0; it < B_ROUNDS; ++it) {
       const int c = it * 256 + tid;
       if (c < NB * 4) {
@@ -552,23 +578,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
       }
     }
     __syncthreads();
-    // ---- contraction over the brick's voxels, 16 x-consecutive voxels per MFMA k-step
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      const int lz = ks / TY, ly = ks % TY;
-      // A operand: rows = channels of A, k = voxel x = 8*hk + 4*rd + q
-      const int v0 = (lz * TY + ly) * TX + 8 * hk + q;
-      const bf16x8 fa = tr_operand(reinterpret_cast<const char*>(A_lds) + v0 * 64 + coloff, 4 * 64);
-      const int bv0 = ((STRIDE * lz) * HY + STRIDE * ly) * HX + STRIDE * (8 * hk + q);
+    // ---- contraction over the brick's voxels, 16 x-consecutive voxels per MFMA k-step.  Two operand sets: the 16
+    // transposing reads of k-step s+1 are in flight while the 7 MFMAs of k-step s run (sched_group_barrier pins it).
+    // Wave 3 has only 6 taps: its 7th slot recomputes tap 26 and is discarded at write-out.
+    const char* Ab = reinterpret_cast<const char*>(A_lds) + coloff;
+    const char* Bb = reinterpret_cast<const char*>(B_lds) + coloff;
+    int toff[7];
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int tap = wv + 4 * i;
-        if (tap < 27) {
-          const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-          const int bv = bv0 + (tz * HY + ty) * HX + tx;
-          const bf16x8 fb = tr_operand(reinterpret_cast<const char*>(B_lds) + bv * 64 + coloff, 4 * STRIDE * 64);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
-        }
-      }
+    for (int i = 0; i < 7; ++i) {
+      const int tap = wv + 4 * i < 27 ? wv + 4 * i : 26;
+      toff[i] = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 64;
+    }
+    auto load_set = [&](int ks, bf16x8& fa, bf16x8 (&fb)[7]) {
+      fa = tr_operand(Ab + (ks * TX + 8 * hk + q) * 64, 4 * 64);
+      const char* brow = Bb + (((STRIDE * (ks / TY)) * HY + STRIDE * (ks % TY)) * HX + STRIDE * (8 * hk + q)) * 64;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) fb[i] = tr_operand(brow + toff[i], 4 * STRIDE * 64);
+    };
+    bf16x8 fa0, fa1, fb0[7], fb1[7];
+    load_set(0, fa0, fb0);
+    static_assert(KSTEPS % 2 == 0, "k-steps are consumed in pairs");
+    for (int ks = 0; ks < KSTEPS; ks += 2) {
+      load_set(ks + 1, fa1, fb1);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0[i], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+      load_set(ks + 2 < KSTEPS ? ks + 2 : ks, fa0, fb0);  // (the last pair re-reads a valid step; result unused)
+#pragma unroll
+      for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1[i], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
     }
   }
   // ---- partial[wg][tap][a][b]: row a = (j&3) + 8*(j>>2) + 4*hk, col b = lane & 31

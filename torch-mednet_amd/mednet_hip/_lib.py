@@ -29,6 +29,7 @@ SIGNATURES = {
     "mednet_abi_version": (_i, []),
     "mednet_last_error": (C.c_char_p, []),
     "mednet_device_ok": (_i, []),
+    "mednet_set_option": (_i, [C.c_char_p, _i]),
     "mednet_conv3d_pack_bytes": (_sz, [_i, _i, _i]),
     "mednet_conv3d_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mednet_conv3d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
