@@ -113,8 +113,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MEDNET_FORCE_DIST") == "1"  # the latter: 1-rank RCCL rehearsal
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     import mednet_hip
@@ -130,8 +134,12 @@ def main():
     P = a.patch
     batch = {k: v.to(dev) for k, v in synthetic_batch(a.batch, 1, (P, P, P), 4, 0, seed=1234 + rank).items()}
 
+    if use_dist and world == 1:
+        step.world = 1
+        step.force_allreduce = True
+
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -150,7 +158,7 @@ def main():
     dt = time.perf_counter() - t0
     ops.PROFILE["enabled"] = False
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     final_loss = float(loss)
@@ -182,7 +190,7 @@ def main():
         if a.cpu_steps > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.cpu_steps)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

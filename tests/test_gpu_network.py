@@ -268,3 +268,52 @@ def test_trainer_direct_gradients_and_fused_adam(golden_dir):
         assert rel(a, b) <= 2e-3, k
     rec = np.load(os.path.join(golden_dir, "callers.npz"))
     assert abs(float(rec["seg.loss"]) - 0.77166152) < 1e-6  # the reference's own first-step loss on this batch
+
+
+def test_landmark_step_matches_oracle():
+    """LandmarkNet.training_step + .loss (landmarks.py:66-83,125-134) through train.LandmarkStep: uint8 heat maps straight
+    from the batch dict, fused regression loss, Dice on the class slice, flat-buffer Adam."""
+    from mednet_hip.train import LandmarkStep
+    ctor = dict(in_channels=1, out_channels=5, final_sigmoid=False, f_maps=[8, 16])
+    batch = O.synthetic_batch(2, 1, (16, 16, 16), 2, 3, seed=4321)
+    regw = [0.015, 0.02, 0.001]
+    ora = O.keyed_init_(O.ResidualUNet3D(**ctor))
+    opt = torch.optim.Adam(ora.parameters(), lr=1e-3)
+    with mednet_hip.precision("fp32"):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+        step = LandmarkStep(net, class_weight=[0.05, 1.0], regression_weight=regw, regression="L2", lr=1e-3)
+        gb = {k: v.to(DEV) for k, v in batch.items()}
+        for i in range(2):
+            opt.zero_grad()
+            tot, cl, rg = O.ldmk_training_step(ora, O.DiceLoss(weight=torch.tensor([0.05, 1.0])), nn.MSELoss(), regw, batch)
+            tot.backward()
+            opt.step()
+            gt, gc, gr = step(gb)
+            assert abs(float(gc) - float(cl)) <= 2e-4, (i, float(gc), float(cl))
+            assert abs(float(gr) - float(rg)) <= 2e-4 * abs(float(rg)), (i, float(gr), float(rg))
+            assert abs(float(gt) - float(tot)) <= 2e-4 * abs(float(tot))
+    for (k, a), (_, b) in zip(net.named_parameters(), ora.named_parameters()):
+        assert rel(a, b) <= 2e-3, k
+
+
+def test_cfg5_shape_smoke_bf16():
+    """BASELINE config 5's topology (5 levels, 64 base channels -> 1024 at the bottom) at a reduced patch, bf16 storage:
+    exercises the >256-channel paths (GroupNorm columns, wide bias sums, 32x32 channel-block pairs up to 1024x1024)
+    against the oracle."""
+    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[64, 128, 256, 512, 1024])
+    batch = O.synthetic_batch(1, 1, (32, 32, 16), 4, 0, seed=1234)
+    ora = O.keyed_init_(O.ResidualUNet3D(**ctor))
+    lo = ora(batch["data"])
+    loss_o = O.DiceLoss(weight=torch.tensor([0.05, 1, 1, 1.0]))(lo, batch["label"][:, -1].long())
+    loss_o.backward()
+    with mednet_hip.precision("bf16"):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+        lg = net(batch["data"].to(DEV))
+        loss = HL.DiceLoss(weight=torch.tensor([0.05, 1, 1, 1.0], device=DEV)).to(DEV)(lg, batch["label"][:, -1].long().to(DEV))
+        loss.backward()
+    assert_close(lg, lo, 3e-2, "cfg5 logits")
+    num = den = 0.0
+    for p, q in zip(net.parameters(), ora.parameters()):
+        num += float((p.grad.cpu().double() - q.grad.double()).pow(2).sum())
+        den += float(q.grad.double().pow(2).sum())
+    assert (num / den) ** 0.5 <= 6e-2

@@ -44,14 +44,22 @@ def conv_case(cin, cout, s):
                                         ws.data_ptr(), ws.numel(), st), "wgrad")
 
     res = []
-    for rnd in range(3):  # interleaved rounds in ONE process (A/B rule)
-        for pipe in (0, 1):
-            lib.mednet_set_option(b"conv_pipe", pipe)
-            res.append((pipe, timeit(fwd)))
-    lib.mednet_set_option(b"conv_pipe", 1)
-    t0 = min(t for p, t in res if p == 0); t1 = min(t for p, t in res if p == 1)
+    variants = [int(v) for v in os.environ.get("KB_ABLATE", "0").split(",")]
+    for rnd in range(2):  # interleaved rounds in ONE process (A/B rule)
+        for pv in variants:
+            lib.mednet_set_option(b"conv_ablate", pv)
+            res.append((pv, timeit(fwd)))
+    lib.mednet_set_option(b"conv_ablate", 0)
     tw = timeit(wg)
-    print(f"conv {cin:3d}->{cout:3d} @{s:3d}^3 N={N}: fwd nopipe {t0*1e3:7.1f} us {flop/t0/1e9:7.1f} TF/s | pipe {t1*1e3:7.1f} us {flop/t1/1e9:7.1f} TF/s | wgrad {tw*1e3:7.1f} us {flop/tw/1e9:7.1f} TF/s", flush=True)
+    wres = {}
+    for rnd in range(2):
+        for av in (0, 1, 2):
+            lib.mednet_set_option(b"wgrad_ablate", av)
+            wres[av] = min(wres.get(av, 1e9), timeit(wg))
+    lib.mednet_set_option(b"wgrad_ablate", 0)
+    print("   wgrad ablate: " + " | ".join(f"{k}: {v*1e3:6.1f} us" for k, v in wres.items()))
+    txt = " | ".join(f"ablate={pv}: {min(t for p, t in res if p == pv)*1e3:6.1f} us {flop/min(t for p, t in res if p == pv)/1e9:6.1f} TF/s" for pv in variants)
+    print(f"conv {cin:3d}->{cout:3d} @{s:3d}^3 N={N}: fwd {txt} | wgrad {tw*1e3:7.1f} us {flop/tw/1e9:7.1f} TF/s", flush=True)
 
 
 def gn_case(c, s):

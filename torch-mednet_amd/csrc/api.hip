@@ -145,7 +145,8 @@ extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, flo
     return launch_wgrad_c1(x, dy, dw, n, d, h, w, cout, x_dtype, dy_dtype, ws, ws_bytes, s);
   if (algo != MEDNET_ALGO_DIRECT && wgrad_1x1_supported(cin, cout, ksize, x_layout, dy_layout, dy_dtype))
     return launch_wgrad_1x1(x, dy, dw, n, (size_t)d * h * w, cin, cout, x_dtype, ws, ws_bytes, s);
-  const bool mfma_ok = wgrad_mfma_supported(cin, cout, ksize, x_dtype, dy_dtype, x_layout, dy_layout);
+  const bool mfma_ok = wgrad_mfma_supported(cin, cout, ksize, x_dtype, dy_dtype, x_layout, dy_layout) &&
+                       wgrad_mfma_fits(n, d, h, w, cin > cout ? cin : cout, 1);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_wgrad: MFMA path does not take cin=%d cout=%d k=%d", cin, cout, ksize);
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
@@ -215,7 +216,8 @@ extern "C" int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, fl
     if (rc) return rc;
     ws_bytes = (ws_bytes - need) / 256 * 256;
   }
-  const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_BF16;
+  const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_BF16 &&
+                       wgrad_mfma_fits(n, d, h, w, cin > 8 * cout ? cin : 8 * cout, 1);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_wgrad: MFMA path does not take cin=%d cout=%d", cin, cout);
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)

@@ -81,7 +81,7 @@ __device__ __forceinline__ float act_apply(float u, int act) {
   switch (act) {
     case MEDNET_ACT_RELU: return u > 0.f ? u : 0.f;
     case MEDNET_ACT_LEAKY: return u > 0.f ? u : 0.1f * u;
-    case MEDNET_ACT_ELU: return u > 0.f ? u : expm1f(u);
+    case MEDNET_ACT_ELU: return u > 0.f ? u : __expf(u) - 1.f;  // ATen computes exp(x) - 1 too (not expm1)
     default: return u;
   }
 }
@@ -91,6 +91,45 @@ __device__ __forceinline__ float act_grad_from_out(float z, int act) {
     case MEDNET_ACT_LEAKY: return z > 0.f ? 1.f : 0.1f;
     case MEDNET_ACT_ELU: return z > 0.f ? 1.f : z + 1.f;
     default: return 1.f;
+  }
+}
+
+// N-wide forms: ONE (wave-uniform) switch per vector instead of one per element
+template <int N>
+__device__ __forceinline__ void act_apply_n(float* u, int act) {
+  switch (act) {
+    case MEDNET_ACT_RELU:
+#pragma unroll
+      for (int k = 0; k < N; ++k) u[k] = u[k] > 0.f ? u[k] : 0.f;
+      break;
+    case MEDNET_ACT_LEAKY:
+#pragma unroll
+      for (int k = 0; k < N; ++k) u[k] = u[k] > 0.f ? u[k] : 0.1f * u[k];
+      break;
+    case MEDNET_ACT_ELU:
+#pragma unroll
+      for (int k = 0; k < N; ++k) u[k] = u[k] > 0.f ? u[k] : __expf(u[k]) - 1.f;
+      break;
+    default: break;
+  }
+}
+// g[k] *= act'(.) expressed through the activation OUTPUT z
+template <int N>
+__device__ __forceinline__ void act_grad_n(float* g, const float* z, int act) {
+  switch (act) {
+    case MEDNET_ACT_RELU:
+#pragma unroll
+      for (int k = 0; k < N; ++k) g[k] = z[k] > 0.f ? g[k] : 0.f;
+      break;
+    case MEDNET_ACT_LEAKY:
+#pragma unroll
+      for (int k = 0; k < N; ++k) g[k] = z[k] > 0.f ? g[k] : 0.1f * g[k];
+      break;
+    case MEDNET_ACT_ELU:
+#pragma unroll
+      for (int k = 0; k < N; ++k) g[k] = z[k] > 0.f ? g[k] : g[k] * (z[k] + 1.f);
+      break;
+    default: break;
   }
 }
 

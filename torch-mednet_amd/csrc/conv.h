@@ -58,6 +58,7 @@ int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, 
 int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, int cin, int cout, int T, int transposed_src,
                      hipStream_t s);
 bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtype, int x_layout, int dy_layout);
+bool wgrad_mfma_fits(int n, int d, int h, int w, int cmax, int scale);
 size_t wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
 int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, int dtype,
                       void* ws, size_t ws_bytes, hipStream_t s);

@@ -56,6 +56,7 @@ struct FwdArgs {
   int cin, cout;
   int tiles_z, tiles_y, tiles_x, ntiles;  // per sample * n
   int nkc, ncb;
+  int ablate;  // timing-only experiments (mednet_set_option "conv_ablate"): 1 no re-prefetch, 2 no LDS commit, 4 no barriers, 8 no epilogue
 };
 
 template <int STRIDE, bool PIPE>
@@ -72,41 +73,60 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   bf16x8* in_lds = reinterpret_cast<bf16x8*>(smem);                // [2][NV]
   bf16x8* w_lds = reinterpret_cast<bf16x8*>(smem) + 2 * NV;        // [27][2][32]
 
-  // ---- which brick / channel block: all channel blocks of a brick run on the same XCD (ids 8 apart share an L2)
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, local = bid >> 3;
-  const int tile = (local / a.ncb) * 8 + xcd;
-  const int cb = local % a.ncb;
-  if (tile >= a.ntiles) return;
-  int tt = tile;
-  const int tx0 = (tt % a.tiles_x) * TX;
-  tt /= a.tiles_x;
-  const int ty0 = (tt % a.tiles_y) * TY;
-  tt /= a.tiles_y;
-  const int tz0 = (tt % a.tiles_z) * TZ;
-  const int n = tt / a.tiles_z;
-
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
 
-  // ---- staging plan (independent of the K chunk): global element offset of each 16-byte piece, -1 = zero fill
-  long long goff[IN_ROUNDS];
-#pragma unroll
-  for (int it = 0; it < IN_ROUNDS; ++it) {
-    const int p = it * 256 + tid;
-    const int v = p >> 1, hh = p & 1;
-    long long off = -1;
-    if (v < NV) {
-      const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
-      const int gz = STRIDE * tz0 - 1 + hz, gy = STRIDE * ty0 - 1 + hy, gx = STRIDE * tx0 - 1 + hx;
-      if (gz >= 0 && gz < a.id && gy >= 0 && gy < a.ih && gx >= 0 && gx < a.iw)
-        off = ((((long long)n * a.id + gz) * a.ih + gy) * a.iw + gx) * a.cin + hh * 8;
-      else
-        off = -2;  // inside the tile image but outside the volume: zero padding
+  // ---- work items: (brick, channel block).  All channel blocks of a brick run on the same XCD (ids 8 apart share an
+  // L2).  The workgroup is PERSISTENT: it walks items w = blockIdx.x, + gridDim.x, ... and treats (item, K-chunk) as one
+  // flat sequence of stages, so the global loads of the NEXT brick's first chunk are already in flight while the last
+  // chunk of the current brick is on the matrix cores (no per-brick load-latency bubble, no relaunch gap).
+  const int total = ((a.ntiles + 7) / 8) * 8 * a.ncb;
+  const int step = gridDim.x;
+  int tx0, ty0, tz0, n, cb;  // brick being STAGED (the prefetch target)
+  auto decode = [&](int w) -> bool {
+    const int xcd = w & 7, local = w >> 3;
+    const int tile = (local / a.ncb) * 8 + xcd;
+    cb = local % a.ncb;
+    if (tile >= a.ntiles) return false;
+    int tt = tile;
+    tx0 = (tt % a.tiles_x) * TX;
+    tt /= a.tiles_x;
+    ty0 = (tt % a.tiles_y) * TY;
+    tt /= a.tiles_y;
+    tz0 = (tt % a.tiles_z) * TZ;
+    n = tt / a.tiles_z;
+    return true;
+  };
+  auto next_item = [&](int w) -> int {  // first valid item at or after w (stride `step`), or -1
+    while (w < total) {
+      if (decode(w)) return w;
+      w += step;
     }
-    goff[it] = off;
-  }
-  const bf16* wsrc = a.wpk + (size_t)cb * a.nkc * (W_CHUNKS * 8);
+    return -1;
+  };
+
+  // ---- staging plan of the brick being staged: global element offset of each 16-byte piece
+  //      (-1: beyond the tile image, never written; -2: inside the image but outside the volume -> zero padding)
+  long long goff[IN_ROUNDS];
+  const bf16* wsrc = a.wpk;
+  auto plan = [&]() {
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) {
+      const int p = it * 256 + tid;
+      const int v = p >> 1, hh = p & 1;
+      long long off = -1;
+      if (v < NV) {
+        const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
+        const int gz = STRIDE * tz0 - 1 + hz, gy = STRIDE * ty0 - 1 + hy, gx = STRIDE * tx0 - 1 + hx;
+        if (gz >= 0 && gz < a.id && gy >= 0 && gy < a.ih && gx >= 0 && gx < a.iw)
+          off = ((((long long)n * a.id + gz) * a.ih + gy) * a.iw + gx) * a.cin + hh * 8;
+        else
+          off = -2;
+      }
+      goff[it] = off;
+    }
+    wsrc = a.wpk + (size_t)cb * a.nkc * (W_CHUNKS * 8);
+  };
 
   bf16x8 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
   // Branch-free: every lane always loads (padding / out-of-image lanes read a valid dummy address); what is invalid
@@ -136,83 +156,99 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     }
   };
 
-  // ---- this lane's voxel in each of the wave's N-tiles (2 rows x 16 voxels), row-rotated for conflict-free reads
-  int lbase[NTW];   // LDS voxel index of tap (0,0,0) for this lane
-  int ovox[NTW];    // output voxel linear index inside the sample, or -1
+  // ---- this lane's voxel in each of the wave's N-tiles (2 rows x 16 voxels), row-rotated for conflict-free reads;
+  //      brick-local, hence the same for every brick
+  int lbase[NTW], loz[NTW], loy[NTW], lox[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const int g = wv * NTW + t;
-    const int lz = g / (TY / 2), ly = (g % (TY / 2)) * 2 + (r >> 4);
+    loz[t] = g / (TY / 2);
+    loy[t] = (g % (TY / 2)) * 2 + (r >> 4);
     const int i = r & 15;
-    const int lx = STRIDE == 1 ? ((i - (r >> 4) * HX) & 15) : i;
-    lbase[t] = ((STRIDE * lz) * HY + STRIDE * ly) * HX + STRIDE * lx + h * NV;
-    const int oz = tz0 + lz, oy = ty0 + ly, ox = tx0 + lx;
-    ovox[t] = (oz < a.od && oy < a.oh && ox < a.ow) ? ((oz * a.oh + oy) * a.ow + ox) : -1;
+    lox[t] = STRIDE == 1 ? ((i - (r >> 4) * HX) & 15) : i;
+    lbase[t] = ((STRIDE * loz[t]) * HY + STRIDE * loy[t]) * HX + STRIDE * lox[t] + h * NV;
   }
 
-  f32x16 acc[NTW];
-#pragma unroll
-  for (int t = 0; t < NTW; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
+  int w = next_item(blockIdx.x);
+  if (w < 0) return;
+  plan();
   prefetch(0);
-  for (int kc = 0; kc < a.nkc; ++kc) {
-    __syncthreads();  // every wave is done reading the previous chunk's LDS image
-    commit();
-    __syncthreads();
-    if (kc + 1 < a.nkc) prefetch(kc + 1);  // in flight while the matrix cores work on chunk kc
-    if constexpr (PIPE) {
-      // Software-pipelined over the 27 taps: the fragments of tap t+1 (1 weight + NTW input ds_read_b128) are in flight
-      // while tap t is on the matrix cores; sched_group_barrier pins that interleave (hipcc otherwise sinks each read
-      // to just in front of its MFMA and exposes the LDS latency 108 times per chunk).
-      bf16x8 wa[2], xb[2][NTW];
-      wa[0] = w_lds[h * 32 + r];
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) xb[0][t] = in_lds[lbase[t]];
-#pragma unroll
-      for (int tap = 0; tap < 27; ++tap) {
-        const int cur = tap & 1, nxt = cur ^ 1;
-        if (tap + 1 < 27) {
-          const int t1 = tap + 1;
-          const int toff = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3;
-          wa[nxt] = w_lds[(t1 * 2 + h) * 32 + r];
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) xb[nxt][t] = in_lds[lbase[t] + toff];
-        }
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur], xb[cur][t], acc[t], 0, 0, 0);
-        if (tap + 1 < 27) __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);  // DS reads of tap+1 first ...
-        __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                         // ... then the MFMAs of tap
-      }
-    } else {
-#pragma unroll
-      for (int tap = 0; tap < 27; ++tap) {
-        const int toff = ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
-        const bf16x8 wa = w_lds[(tap * 2 + h) * 32 + r];
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-          const bf16x8 xb = in_lds[lbase[t] + toff];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[t], 0, 0, 0);
-        }
-      }
-    }
-  }
-
-  // ---- epilogue: D[row = co][col = voxel]; lane holds co = (i&3) + 8*(i>>2) + 4*h for its voxel (col = r)
   const size_t ovol = (size_t)a.od * a.oh * a.ow;
+  while (true) {
+    // origin / channel block of the brick whose chunks are about to be COMPUTED (decode() will move on to the next)
+    const int cz0 = tz0, cy0 = ty0, cx0 = tx0, cn = n, ccb = cb;
+    f32x16 acc[NTW];
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    if (ovox[t] < 0) continue;
-    bf16* yp = a.y + ((size_t)n * ovol + ovox[t]) * a.cout + cb * 32 + 4 * h;
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      bf16x4 o;
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    int wnext = -1;
+    for (int kc = 0; kc < a.nkc; ++kc) {
+      if (!(a.ablate & 4)) __syncthreads();  // every wave is done reading the previous stage's LDS image
+      if (!(a.ablate & 2)) commit();
+      if (!(a.ablate & 4)) __syncthreads();
+      if (kc + 1 < a.nkc) {
+        if (!(a.ablate & 1)) prefetch(kc + 1);  // in flight while the matrix cores work on chunk kc
+      } else {
+        wnext = next_item(w + step);
+        if (wnext >= 0) {
+          plan();
+          if (!(a.ablate & 1)) prefetch(0);  // the next brick's first chunk flies under this brick's last chunk + epilogue
+        }
+      }
+      if constexpr (PIPE) {
+        // Software-pipelined over the 27 taps: the fragments of tap t+1 (1 weight + NTW input ds_read_b128) are in
+        // flight while tap t is on the matrix cores; sched_group_barrier pins that interleave.
+        bf16x8 wa[2], xb[2][NTW];
+        wa[0] = w_lds[h * 32 + r];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[t][q * 4 + j];
-      *reinterpret_cast<bf16x4*>(yp + 8 * q) = o;
+        for (int t = 0; t < NTW; ++t) xb[0][t] = in_lds[lbase[t]];
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+          const int cur = tap & 1, nxt = cur ^ 1;
+          if (tap + 1 < 27) {
+            const int t1 = tap + 1;
+            const int toff = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3;
+            wa[nxt] = w_lds[(t1 * 2 + h) * 32 + r];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) xb[nxt][t] = in_lds[lbase[t] + toff];
+          }
+#pragma unroll
+          for (int t = 0; t < NTW; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur], xb[cur][t], acc[t], 0, 0, 0);
+          if (tap + 1 < 27) __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);  // DS reads of tap+1 first ...
+          __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                         // ... then the MFMAs of tap
+        }
+      } else {
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+          const int toff = ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
+          const bf16x8 wa = w_lds[(tap * 2 + h) * 32 + r];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            const bf16x8 xb = in_lds[lbase[t] + toff];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[t], 0, 0, 0);
+          }
+        }
+      }
     }
+    // ---- epilogue: D[row = co][col = voxel]; lane holds co = (i&3) + 8*(i>>2) + 4*h for its voxel (col = r)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int oz = cz0 + loz[t], oy = cy0 + loy[t], ox = cx0 + lox[t];
+      if (oz < a.od && oy < a.oh && ox < a.ow && !((a.ablate & 8) && acc[t][0] != 12345.f)) {
+        bf16* yp = a.y + ((size_t)cn * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.cout + ccb * 32 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[t][q * 4 + j];
+          *reinterpret_cast<bf16x4*>(yp + 8 * q) = o;
+        }
+      }
+    }
+    if (wnext < 0) break;
+    w = wnext;
   }
 }
 
@@ -467,7 +503,11 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
   a.nkc = cin / 16;
   a.ncb = cout / 32;
-  const unsigned grid = (unsigned)((a.ntiles + 7) / 8) * 8 * a.ncb;
+  a.ablate = tuning_option("conv_ablate", 0);
+  unsigned grid = (unsigned)((a.ntiles + 7) / 8) * 8 * a.ncb;
+  // persistent workgroups: 2 per CU resident (62 KB LDS each); the stride must keep an item's XCD (multiple of 8)
+  const unsigned resident = (unsigned)tuning_option("conv_persist", 0) * 512u;
+  if (resident && grid > resident) grid = resident;
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[STRIDE]) {
     if (hipFuncSetAttribute((const void*)conv_mfma_kernel<STRIDE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
@@ -514,6 +554,8 @@ struct WgArgs {
   int n, ad, ah, aw, bd, bh, bw, ka, kb;
   int tiles_z, tiles_y, tiles_x, ntiles;
   int nab, nbb, splits;
+  int ablate;  // timing-only experiments ("wgrad_ablate"): 1 stage only the first brick, 2 skip the MFMA loop
+  unsigned bytesA, bytesB;  // buffer-resource sizes (tensors < 4 GB)
 };
 
 template <int STRIDE>
@@ -654,6 +696,10 @@ bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtyp
   return ksize == 3 && cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_BF16 &&
          x_layout == MEDNET_NDHWC && dy_layout == MEDNET_NDHWC;
 }
+// the kernel addresses its operands through buffer resources with 32-bit byte offsets
+bool wgrad_mfma_fits(int n, int d, int h, int w, int cmax, int scale) {
+  return (double)n * d * h * w * scale * cmax * 2.0 < 4294960000.0;
+}
 
 template <int STRIDE>
 static void wgrad_plan(int n, int ad, int ah, int aw, int ka, int kb, WgArgs& a) {
@@ -691,6 +737,9 @@ static int launch_wg(const void* A, const void* B, float* dw, int n, int ad, int
   a.part = (float*)ws;
   a.n = n; a.ad = ad; a.ah = ah; a.aw = aw; a.bd = bd; a.bh = bh; a.bw = bw; a.ka = ka; a.kb = kb;
   wgrad_plan<STRIDE>(n, ad, ah, aw, ka, kb, a);
+  a.ablate = tuning_option("wgrad_ablate", 0);
+  a.bytesA = (unsigned)((size_t)n * ad * ah * aw * ka * 2);
+  a.bytesB = (unsigned)((size_t)n * bd * bh * bw * kb * 2);
   const size_t need = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
   MEDNET_REQUIRE(ws_bytes >= need, MEDNET_E_WORKSPACE, "wgrad_mfma: workspace %zu < %zu", ws_bytes, need);
   static bool attr_set[3] = {false, false, false};

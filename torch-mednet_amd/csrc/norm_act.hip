@@ -88,7 +88,20 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
   for (int k = 0; k < 2 * VEC; ++k) acc[k] = 0.f;
   if (L.active) {
     const T* base = x + (size_t)n * spatial * c + (size_t)L.col * VEC;
-    for (size_t v = v0 + L.row; v < v1; v += L.rows) {
+    size_t v = v0 + L.row;
+    for (; v + 3 * (size_t)L.rows < v1; v += 4 * (size_t)L.rows) {  // 4 independent 16-byte loads in flight per lane
+      F8 xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv[u] = VecIO<T, VEC>::load(base, (v + (size_t)u * L.rows) * c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          acc[2 * k] += xv[u].v[k];
+          acc[2 * k + 1] = fmaf(xv[u].v[k], xv[u].v[k], acc[2 * k + 1]);
+        }
+    }
+    for (; v < v1; v += L.rows) {
       const F8 xv = VecIO<T, VEC>::load(base, v * c);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
@@ -170,18 +183,35 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const TX* __restrict__ 
     b[k] = coef[((size_t)n * c + L.col * VEC + k) * 2 + 1];
   }
   const size_t off = (size_t)n * spatial * c + (size_t)L.col * VEC;
-  for (size_t v = v0 + L.row; v < v1; v += L.rows) {
-    const size_t i = off + v * c;
-    F8 xv = VecIO<TX, VEC>::load(x, i);
-    F8 rv;
-    if (res) rv = VecIO<TZ, VEC>::load(res, i);
+  auto one = [&](const F8& xin, const F8& rin, F8& out) {
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-      float u = fmaf(a[k], xv.v[k], b[k]);
-      if (res) u += rv.v[k];
-      xv.v[k] = act_apply(u, act);
+      out.v[k] = fmaf(a[k], xin.v[k], b[k]);
+      if (res) out.v[k] += rin.v[k];
     }
-    VecIO<TZ, VEC>::store(z, i, xv);
+    act_apply_n<VEC>(out.v, act);
+  };
+  size_t v = v0 + L.row;
+  for (; v + (size_t)L.rows < v1; v += 2 * (size_t)L.rows) {  // two voxels per trip: 2-4 loads in flight per lane
+    const size_t i0 = off + v * c, i1 = off + (v + L.rows) * c;
+    const F8 x0 = VecIO<TX, VEC>::load(x, i0), x1 = VecIO<TX, VEC>::load(x, i1);
+    F8 r0, r1, z0, z1;
+    if (res) {
+      r0 = VecIO<TZ, VEC>::load(res, i0);
+      r1 = VecIO<TZ, VEC>::load(res, i1);
+    }
+    one(x0, r0, z0);
+    one(x1, r1, z1);
+    VecIO<TZ, VEC>::store(z, i0, z0);
+    VecIO<TZ, VEC>::store(z, i1, z1);
+  }
+  for (; v < v1; v += L.rows) {
+    const size_t i = off + v * c;
+    const F8 xv = VecIO<TX, VEC>::load(x, i);
+    F8 rv, zv;
+    if (res) rv = VecIO<TZ, VEC>::load(res, i);
+    one(xv, rv, zv);
+    VecIO<TZ, VEC>::store(z, i, zv);
   }
 }
 
@@ -211,22 +241,30 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict
       rstd[k] = stats[((size_t)n * groups + g) * 2 + 1];
     }
     const size_t off = (size_t)n * spatial * c + (size_t)L.col * VEC;
-    for (size_t v = v0 + L.row; v < v1; v += L.rows) {
-      const size_t i = off + v * c;
-      const F8 g1 = VecIO<T, VEC>::load(dz, i);
+    auto one = [&](size_t i) {
+      F8 g1 = VecIO<T, VEC>::load(dz, i);
       F8 g2, zv;
       if (dz2) g2 = VecIO<T, VEC>::load(dz2, i);
       if (act != MEDNET_ACT_NONE) zv = VecIO<T, VEC>::load(z, i);
       const F8 xv = VecIO<T, VEC>::load(x, i);
+      if (dz2) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) g1.v[k] += g2.v[k];
+      }
+      act_grad_n<VEC>(g1.v, zv.v, act);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
-        float du = g1.v[k] + (dz2 ? g2.v[k] : 0.f);
-        if (act != MEDNET_ACT_NONE) du *= act_grad_from_out(zv.v[k], act);
         const float xh = (xv.v[k] - mean[k]) * rstd[k];
-        acc[2 * k] += du;
-        acc[2 * k + 1] = fmaf(du, xh, acc[2 * k + 1]);
+        acc[2 * k] += g1.v[k];
+        acc[2 * k + 1] = fmaf(g1.v[k], xh, acc[2 * k + 1]);
       }
+    };
+    size_t v = v0 + L.row;
+    for (; v + (size_t)L.rows < v1; v += 2 * (size_t)L.rows) {
+      one(off + v * c);
+      one(off + (v + L.rows) * c);
     }
+    for (; v < v1; v += L.rows) one(off + v * c);
   }
   float* out = partial + ((size_t)n * gridDim.x + blockIdx.x) * c * 2;
   column_reduce<2 * VEC>(acc, L.cols, L.rows, L.col, L.row, L.active, lds, out);
@@ -295,24 +333,29 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     k3[k] = o[2];
   }
   const size_t off = (size_t)n * spatial * c + (size_t)L.col * VEC;
-  for (size_t v = v0 + L.row; v < v1; v += L.rows) {
-    const size_t i = off + v * c;
-    const F8 g1 = VecIO<T, VEC>::load(dz, i);
+  auto one = [&](size_t i) {
+    F8 g1 = VecIO<T, VEC>::load(dz, i);
     F8 g2, zv;
     if (dz2) g2 = VecIO<T, VEC>::load(dz2, i);
     if (act != MEDNET_ACT_NONE) zv = VecIO<T, VEC>::load(z, i);
     const F8 xv = VecIO<T, VEC>::load(x, i);
-    F8 o, du8;
+    if (dz2) {
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      float du = g1.v[k] + (dz2 ? g2.v[k] : 0.f);
-      if (act != MEDNET_ACT_NONE) du *= act_grad_from_out(zv.v[k], act);
-      du8.v[k] = du;
-      o.v[k] = fmaf(k1[k], du, fmaf(k2[k], xv.v[k], k3[k]));
+      for (int k = 0; k < VEC; ++k) g1.v[k] += g2.v[k];
     }
+    act_grad_n<VEC>(g1.v, zv.v, act);
+    F8 o;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o.v[k] = fmaf(k1[k], g1.v[k], fmaf(k2[k], xv.v[k], k3[k]));
     VecIO<T, VEC>::store(dx, i, o);
-    if (dres) VecIO<T, VEC>::store(dres, i, du8);
+    if (dres) VecIO<T, VEC>::store(dres, i, g1);
+  };
+  size_t v = v0 + L.row;
+  for (; v + (size_t)L.rows < v1; v += 2 * (size_t)L.rows) {
+    one(off + v * c);
+    one(off + (v + L.rows) * c);
   }
+  for (; v < v1; v += L.rows) one(off + v * c);
 }
 
 // ---------------------------------------------------------------------------------------------- flat elementwise

@@ -69,12 +69,12 @@ class FlatAdam:
             p._mednet_step = self.t
 
 
-def allreduce_gradients(flat_grad: torch.Tensor, world_size: int):
+def allreduce_gradients(flat_grad: torch.Tensor, world_size: int, force: bool = False):
     """The data-parallel exchange: ONE all-reduce(sum) of the flat gradient buffer (RCCL over xGMI on GPUs; any
     torch.distributed backend in tests).  Returns the scale the optimizer must apply (1/world) so that the update uses
     the mean of the per-rank-batch gradients -- what PL's DDP does with the reference (Dice is reduced
     over the LOCAL batch, then gradients are averaged)."""
-    if world_size > 1:
+    if world_size > 1 or force:
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return 1.0 / world_size
 
@@ -97,7 +97,7 @@ class SegmentationStep:
         outputs = self.model(inputs)
         loss = self.loss(outputs, labels)
         loss.backward()
-        scale = allreduce_gradients(self.flat.grad, self.world)  # 1/world is applied inside the Adam kernel
+        scale = allreduce_gradients(self.flat.grad, self.world, getattr(self, "force_allreduce", False))  # 1/world folded into Adam
         self.opt.step(grad_scale=scale)
         return loss.detach()
 
