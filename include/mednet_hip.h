@@ -83,9 +83,11 @@ int mednet_gn_stats(const void* x, const float* gamma, const float* beta, float*
 /* z = act(coef0*x + coef1 [+ residual]) */
 int mednet_gn_act_fwd(const void* x, const float* coef, const void* residual, void* z, int n, size_t spatial,
                       int c, int act, int x_dtype, int z_dtype, mednet_stream stream);
-/* du = (dz [+ dz2]) * act'(z);  dgamma/dbeta;  dx = GroupNorm backward of du;  dres (nullable) := du. */
-int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x, const void* z, const float* stats,
-                      const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, int n,
+/* du = (dz [+ dz2]) * act';  dgamma/dbeta;  dx = GroupNorm backward of du;  dres (nullable) := du.
+ * act' comes from the activated output z when given (ATen's in-place semantics), else -- no residual branch -- it is
+ * recomputed from x and the forward coefficients `coef`, which saves reading z back (one tensor less per pass). */
+int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x, const void* z, const float* coef,
+                      const float* stats, const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, int n,
                       size_t spatial, int c, int groups, int act, int dtype, void* ws, size_t ws_bytes,
                       mednet_stream stream);
 /* stand-alone activation (orders such as 'cr', 'crg'); in-place allowed (x == z). */

@@ -133,6 +133,26 @@ __device__ __forceinline__ void act_grad_n(float* g, const float* z, int act) {
   }
 }
 
+// g[k] *= act'(u) from the pre-activation u (used when z is not read back: u is recomputed from the conv output)
+template <int N>
+__device__ __forceinline__ void act_grad_pre_n(float* g, const float* u, int act) {
+  switch (act) {
+    case MEDNET_ACT_RELU:
+#pragma unroll
+      for (int k = 0; k < N; ++k) g[k] = u[k] > 0.f ? g[k] : 0.f;
+      break;
+    case MEDNET_ACT_LEAKY:
+#pragma unroll
+      for (int k = 0; k < N; ++k) g[k] = u[k] > 0.f ? g[k] : 0.1f * g[k];
+      break;
+    case MEDNET_ACT_ELU:
+#pragma unroll
+      for (int k = 0; k < N; ++k) g[k] = u[k] > 0.f ? g[k] : g[k] * __expf(u[k]);
+      break;
+    default: break;
+  }
+}
+
 // ---- reductions: wave64 shuffles, then LDS across the waves of a workgroup ----------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const TX* __restrict__ 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict__ dz, const T* __restrict__ dz2,
                                                              const T* __restrict__ x, const T* __restrict__ z,
+                                                             const float* __restrict__ coef,
                                                              const float* __restrict__ stats,
                                                              float* __restrict__ partial, size_t spatial, int c,
                                                              int groups, int act, size_t chunk_vox) {
@@ -233,25 +234,33 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict
   for (int k = 0; k < 2 * VEC; ++k) acc[k] = 0.f;
   if (L.active) {
     const int cg = c / groups;
-    float mean[VEC], rstd[VEC];
+    float mean[VEC], rstd[VEC], ca[VEC], cb[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       const int g = (L.col * VEC + k) / cg;
       mean[k] = stats[((size_t)n * groups + g) * 2];
       rstd[k] = stats[((size_t)n * groups + g) * 2 + 1];
+      ca[k] = z ? 0.f : coef[((size_t)n * c + L.col * VEC + k) * 2];
+      cb[k] = z ? 0.f : coef[((size_t)n * c + L.col * VEC + k) * 2 + 1];
     }
     const size_t off = (size_t)n * spatial * c + (size_t)L.col * VEC;
     auto one = [&](size_t i) {
       F8 g1 = VecIO<T, VEC>::load(dz, i);
       F8 g2, zv;
       if (dz2) g2 = VecIO<T, VEC>::load(dz2, i);
-      if (act != MEDNET_ACT_NONE) zv = VecIO<T, VEC>::load(z, i);
+      if (act != MEDNET_ACT_NONE && z) zv = VecIO<T, VEC>::load(z, i);
       const F8 xv = VecIO<T, VEC>::load(x, i);
       if (dz2) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) g1.v[k] += g2.v[k];
       }
-      act_grad_n<VEC>(g1.v, zv.v, act);
+      if (z) {
+        act_grad_n<VEC>(g1.v, zv.v, act);
+      } else {  // the activated tensor is not read back: its pre-activation is one FMA away from the conv output
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) zv.v[k] = fmaf(ca[k], xv.v[k], cb[k]);
+        act_grad_pre_n<VEC>(g1.v, zv.v, act);
+      }
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         const float xh = (xv.v[k] - mean[k]) * rstd[k];
@@ -316,6 +325,7 @@ __global__ __launch_bounds__(256) void gn_bwd_params_kernel(const float* __restr
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ dz2,
                                                            const T* __restrict__ x, const T* __restrict__ z,
+                                                           const float* __restrict__ coef,
                                                            const float* __restrict__ bcoef, T* __restrict__ dx,
                                                            T* __restrict__ dres, size_t spatial, int c, int act,
                                                            size_t chunk_vox) {
@@ -324,26 +334,34 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
   const int n = blockIdx.y;
   const size_t v0 = (size_t)blockIdx.x * chunk_vox;
   const size_t v1 = v0 + chunk_vox < spatial ? v0 + chunk_vox : spatial;
-  float k1[VEC], k2[VEC], k3[VEC];
+  float k1[VEC], k2[VEC], k3[VEC], ca[VEC], cb[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
     const float* o = bcoef + ((size_t)n * c + L.col * VEC + k) * 3;
     k1[k] = o[0];
     k2[k] = o[1];
     k3[k] = o[2];
+    ca[k] = z ? 0.f : coef[((size_t)n * c + L.col * VEC + k) * 2];
+    cb[k] = z ? 0.f : coef[((size_t)n * c + L.col * VEC + k) * 2 + 1];
   }
   const size_t off = (size_t)n * spatial * c + (size_t)L.col * VEC;
   auto one = [&](size_t i) {
     F8 g1 = VecIO<T, VEC>::load(dz, i);
     F8 g2, zv;
     if (dz2) g2 = VecIO<T, VEC>::load(dz2, i);
-    if (act != MEDNET_ACT_NONE) zv = VecIO<T, VEC>::load(z, i);
+    if (act != MEDNET_ACT_NONE && z) zv = VecIO<T, VEC>::load(z, i);
     const F8 xv = VecIO<T, VEC>::load(x, i);
     if (dz2) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) g1.v[k] += g2.v[k];
     }
-    act_grad_n<VEC>(g1.v, zv.v, act);
+    if (z) {
+      act_grad_n<VEC>(g1.v, zv.v, act);
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) zv.v[k] = fmaf(ca[k], xv.v[k], cb[k]);
+      act_grad_pre_n<VEC>(g1.v, zv.v, act);
+    }
     F8 o;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) o.v[k] = fmaf(k1[k], g1.v[k], fmaf(k2[k], xv.v[k], k3[k]));
@@ -650,13 +668,15 @@ extern "C" int mednet_gn_act_fwd(const void* x, const float* coef, const void* r
   return check_launch("gn_act_fwd");
 }
 
-extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x, const void* z, const float* stats,
-                                 const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, int n,
+extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x, const void* z, const float* coef,
+                                 const float* stats, const float* gamma, void* dx, void* dres, float* dgamma,
+                                 float* dbeta, int n,
                                  size_t spatial, int c, int groups, int act, int dtype, void* ws, size_t ws_bytes,
                                  mednet_stream stream) {
   MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "gn_act_bwd: bad dtype");
   MEDNET_REQUIRE(c % groups == 0, MEDNET_E_SHAPE, "gn_act_bwd: C %% groups != 0");
-  MEDNET_REQUIRE(act == MEDNET_ACT_NONE || z != nullptr, MEDNET_E_SHAPE, "gn_act_bwd: z required for act'");
+  MEDNET_REQUIRE(act == MEDNET_ACT_NONE || z != nullptr || coef != nullptr, MEDNET_E_SHAPE,
+                 "gn_act_bwd: act' needs the activated output z or the forward coefficients");
   const int vec = pick_vec(c);
   MEDNET_REQUIRE(c / vec <= 256, MEDNET_E_UNSUPPORTED, "gn_act_bwd: C=%d unsupported", c);
   MEDNET_REQUIRE(ws_bytes >= mednet_gn_ws_bytes(n, c, spatial), MEDNET_E_WORKSPACE, "gn_act_bwd: workspace too small");
@@ -668,7 +688,7 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
   float* csum = bcoef + (size_t)n * c * 3;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(chunks, n);
-#define GO(T, V) hipLaunchKernelGGL((gn_bwd_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, stats, partial, spatial, c, groups, act, cv)
+#define GO(T, V) hipLaunchKernelGGL((gn_bwd_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, coef, stats, partial, spatial, c, groups, act, cv)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
   else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
 #undef GO
@@ -684,7 +704,7 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
     rc = check_launch("gn_bwd_params");
     if (rc) return rc;
   }
-#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv)
+#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
   else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
 #undef GO

@@ -42,7 +42,7 @@ SIGNATURES = {
     "mednet_gn_ws_bytes": (_sz, [_i, _i, _sz]),
     "mednet_gn_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _f, _i, _vp, _sz, _vp]),
     "mednet_gn_act_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _vp]),
-    "mednet_gn_act_bwd": (_i, [_vp] * 10 + [_i, _sz, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mednet_gn_act_bwd": (_i, [_vp] * 11 + [_i, _sz, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mednet_act_fwd": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
     "mednet_act_bwd": (_i, [_vp, _vp, _vp, _sz, _i, _i, _vp]),
     "mednet_add": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),

@@ -19,6 +19,53 @@ CL = torch.channels_last_3d
 PROFILE = {"enabled": False, "events": [], "match": None}
 
 
+# ---- weight gradients on a side stream (trainer mode only) ------------------------------------------------------------
+# In the backward pass the weight gradient of a layer is off the critical path (nothing needs dW before the all-reduce /
+# Adam), while the data gradient -> GroupNorm backward chain is HBM-bound.  When the trainer provides in-place gradient
+# targets, weight-gradient kernels are launched on a second HIP stream so the matrix-core work overlaps the bandwidth
+# work of the main stream.  train.py joins the streams before the gradient exchange.
+SIDE = {"enabled": False, "stream": None, "keepalive": []}
+
+
+def side_stream(device):
+    if SIDE["stream"] is None:
+        SIDE["stream"] = torch.cuda.Stream(device=device)
+    return SIDE["stream"]
+
+
+def join_side_stream():
+    if SIDE["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(SIDE["stream"])
+    SIDE["keepalive"].clear()
+
+
+class _OnSide:
+    """Context: run the enclosed launches on the side stream after everything queued so far on the main stream."""
+
+    def __init__(self, active, device, *tensors):
+        self.active, self.device, self.tensors = active, device, tensors
+
+    def __enter__(self):
+        if self.active:
+            main = torch.cuda.current_stream(self.device)
+            side = side_stream(self.device)
+            side.wait_stream(main)
+            for t in self.tensors:
+                if t is not None:
+                    t.record_stream(side)  # keep the allocator from recycling operands the side stream still reads
+                    # ... and keep autograd from accumulating INTO them: a gradient handed on to autograd (ConvTranspose's
+                    # skip gradient is `dy` itself) is summed in place with later arrivals when nobody else holds it
+                    SIDE["keepalive"].append(t)
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def _grad_target(param, shape):
     """Trainer hook (train.FlatParams): when a Parameter carries `_mednet_grad` (a contiguous fp32 view into the flat
     gradient buffer) the kernels write the gradient there and autograd gets None -> no copy / accumulate kernels."""
@@ -103,23 +150,25 @@ class Conv3dFn(Function):
         dy = dy.contiguous() if out_planar else to_cl(dy)
         lib = L.lib()
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = empty_cl(n, cin, d, h, w, x_dtype, dy.device)
-            L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin,
-                                          ksize, L.dt(dy), L.NCDHW if out_planar else L.NDHWC, L.dt(dx), L.NDHWC, 1,
-                                          config.conv_algo(), L.stream()), "conv3d_dgrad")
         direct_w = direct_b = False
         if ctx.needs_input_grad[1]:
             weight, bias = ctx.params
             dw, direct_w = _grad_target(weight, (cout, cin, ksize, ksize, ksize))
             if has_bias and ctx.needs_input_grad[2]:
                 db, direct_b = _grad_target(bias, (cout,))
-            nbytes = lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, ksize)
-            ws = L.workspace(nbytes, dy.device)
-            L.check(lib.mednet_conv3d_wgrad(xin.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), n, d, h, w, cin,
-                                            cout, ksize, L.dt(xin), L.NDHWC, L.dt(dy),
-                                            L.NCDHW if out_planar else L.NDHWC, config.conv_algo(), ws.data_ptr(),
-                                            ws.numel(), L.stream()), "conv3d_wgrad")
+            on_side = SIDE["enabled"] and direct_w and (db is None or direct_b)
+            with _OnSide(on_side, dy.device, xin, dy):
+                nbytes = lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, ksize)
+                ws = L.workspace(nbytes, dy.device)
+                L.check(lib.mednet_conv3d_wgrad(xin.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), n, d, h, w, cin,
+                                                cout, ksize, L.dt(xin), L.NDHWC, L.dt(dy),
+                                                L.NCDHW if out_planar else L.NDHWC, config.conv_algo(), ws.data_ptr(),
+                                                ws.numel(), L.stream()), "conv3d_wgrad")
+        if ctx.needs_input_grad[0]:
+            dx = empty_cl(n, cin, d, h, w, x_dtype, dy.device)
+            L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin,
+                                          ksize, L.dt(dy), L.NCDHW if out_planar else L.NDHWC, L.dt(dx), L.NDHWC, 1,
+                                          config.conv_algo(), L.stream()), "conv3d_dgrad")
         return dx, (None if direct_w else dw), (None if direct_b else db), None, None, None, None
 
 
@@ -159,20 +208,22 @@ class ConvT3dFn(Function):
         dy = to_cl(dy)
         lib = L.lib()
         dx = dw = db = dskip = None
-        if ctx.needs_input_grad[0]:
-            dx = empty_cl(n, cin, d, h, w, x.dtype, dy.device)
-            L.check(lib.mednet_convt3d_dgrad(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), n, d, h, w, cin, cout,
-                                             L.dt(dy), L.dt(dx), config.conv_algo(), L.stream()), "convt3d_dgrad")
         direct_w = direct_b = False
         if ctx.needs_input_grad[1]:
             weight, bias = ctx.params
             dw, direct_w = _grad_target(weight, (cin, cout, 3, 3, 3))
             if has_bias and ctx.needs_input_grad[2]:
                 db, direct_b = _grad_target(bias, (cout,))
-            ws = L.workspace(lib.mednet_convt3d_wgrad_ws_bytes(n, d, h, w, cin, cout), dy.device)
-            L.check(lib.mednet_convt3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), n, d, h, w, cin, cout,
-                                             L.dt(x), L.dt(dy), config.conv_algo(), ws.data_ptr(), ws.numel(), L.stream()),
-                    "convt3d_wgrad")
+            on_side = SIDE["enabled"] and direct_w and (db is None or direct_b)
+            with _OnSide(on_side, dy.device, x, dy):
+                ws = L.workspace(lib.mednet_convt3d_wgrad_ws_bytes(n, d, h, w, cin, cout), dy.device)
+                L.check(lib.mednet_convt3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), n, d, h, w, cin, cout,
+                                                 L.dt(x), L.dt(dy), config.conv_algo(), ws.data_ptr(), ws.numel(), L.stream()),
+                        "convt3d_wgrad")
+        if ctx.needs_input_grad[0]:
+            dx = empty_cl(n, cin, d, h, w, x.dtype, dy.device)
+            L.check(lib.mednet_convt3d_dgrad(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), n, d, h, w, cin, cout,
+                                             L.dt(dy), L.dt(dx), config.conv_algo(), L.stream()), "convt3d_dgrad")
         if has_skip and ctx.needs_input_grad[3]:
             dskip = dy if dy.dtype == skip_dtype else dy.to(skip_dtype)
         return dx, (None if direct_w else dw), (None if direct_b else db), dskip, None
@@ -206,14 +257,17 @@ class GroupNormActFn(Function):
         z = torch.empty_like(x, memory_format=CL)
         L.check(lib.mednet_gn_act_fwd(x.data_ptr(), coef.data_ptr(), L.ptr(res), z.data_ptr(), n, spatial, c, act,
                                       L.dt(x), L.dt(z), L.stream()), "gn_act_fwd")
-        ctx.save_for_backward(x, z if act != L.ACT_NONE else None, stats, gamma)
+        # the activated output is only read back when a residual entered the pre-activation; otherwise the backward
+        # recomputes act' from x and `coef` (one tensor less to read in each of its two passes)
+        keep_z = act != L.ACT_NONE and residual is not None
+        ctx.save_for_backward(x, z if keep_z else None, stats, gamma, coef)
         ctx.meta = (groups, act, residual is not None, gamma is not None, beta is not None)
         ctx.params = (gamma, beta)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, z, stats, gamma = ctx.saved_tensors
+        x, z, stats, gamma, coef = ctx.saved_tensors
         groups, act, has_res, has_gamma, has_beta = ctx.meta
         n, c, d, h, w = x.shape
         spatial = d * h * w
@@ -225,7 +279,7 @@ class GroupNormActFn(Function):
         dgamma, direct_g = _grad_target(pg, (c,)) if has_gamma else (None, False)
         dbeta, direct_b = _grad_target(pb, (c,)) if has_beta else (None, False)
         ws = L.workspace(lib.mednet_gn_ws_bytes(n, c, spatial), x.device)
-        L.check(lib.mednet_gn_act_bwd(dz.data_ptr(), None, x.data_ptr(), L.ptr(z), stats.data_ptr(), L.ptr(gamma),
+        L.check(lib.mednet_gn_act_bwd(dz.data_ptr(), None, x.data_ptr(), L.ptr(z), coef.data_ptr(), stats.data_ptr(), L.ptr(gamma),
                                       dx.data_ptr(), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), n, spatial, c, groups, act,
                                       L.dt(x), ws.data_ptr(), ws.numel(), L.stream()), "gn_act_bwd")
         return dx, (None if direct_g else dgamma), (None if direct_b else dbeta), dres, None, None, None

@@ -9,6 +9,8 @@ fused Adam kernel, and Adam is one launch over the flat buffers.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -69,6 +71,11 @@ class FlatAdam:
             p._mednet_step = self.t
 
 
+def finish_backward():
+    """Join the weight-gradient side stream (ops.SIDE) before anything reads the flat gradient buffer."""
+    ops.join_side_stream()
+
+
 def allreduce_gradients(flat_grad: torch.Tensor, world_size: int, force: bool = False):
     """The data-parallel exchange: ONE all-reduce(sum) of the flat gradient buffer (RCCL over xGMI on GPUs; any
     torch.distributed backend in tests).  Returns the scale the optimizer must apply (1/world) so that the update uses
@@ -90,6 +97,7 @@ class SegmentationStep:
         self.flat = FlatParams(model)
         self.opt = FlatAdam(self.flat, lr=lr)
         self.world = world_size
+        ops.SIDE["enabled"] = os.environ.get("MEDNET_SIDE_STREAM", "1") == "1"
 
     def __call__(self, batch):
         inputs = batch["data"].float()
@@ -97,6 +105,7 @@ class SegmentationStep:
         outputs = self.model(inputs)
         loss = self.loss(outputs, labels)
         loss.backward()
+        finish_backward()
         scale = allreduce_gradients(self.flat.grad, self.world, getattr(self, "force_allreduce", False))  # 1/world folded into Adam
         self.opt.step(grad_scale=scale)
         return loss.detach()
@@ -124,6 +133,7 @@ class LandmarkStep:
         regression_loss = self.loss_reg(outputs[:, :nh, ...], heatmaps)
         loss = regression_loss + class_loss
         loss.backward()
+        finish_backward()
         scale = allreduce_gradients(self.flat.grad, self.world)
         self.opt.step(grad_scale=scale)
         return loss.detach(), class_loss.detach(), regression_loss.detach()
