@@ -52,9 +52,14 @@ int mednet_conv3d_pack(const float* w, void* packed, int cin, int cout, int ksiz
                        mednet_stream stream);
 /* y[n,z,y,x,co] = bias[co] + sum_{tap,ci} x[n,z+dz-1,y+dy-1,x+dx-1,ci] * W[co,ci,tap].
  * dgrad=1 runs the data gradient with the same kernel: pass x := dy, cin := Cout, cout := Cin of the layer. */
+/* gn_partial (nullable): when the call takes the MFMA path the epilogue also writes the GroupNorm partial sums of the
+ * output, [n][chunks][cout][2] = {sum y, sum y^2} per brick, chunks = mednet_conv3d_fused_stats_chunks(...) (0 = this
+ * call cannot fuse them); mednet_gn_finalize turns them into statistics without another pass over y. */
+int mednet_conv3d_fused_stats_chunks(int d, int h, int w, int cin, int cout, int ksize, int x_dtype, int y_dtype,
+                                     int algo);
 int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void* y, int n, int d, int h, int w,
                       int cin, int cout, int ksize, int x_dtype, int x_layout, int y_dtype, int y_layout,
-                      int dgrad, int algo, mednet_stream stream);
+                      int dgrad, int algo, float* gn_partial, mednet_stream stream);
 size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
 /* dw[co,ci,tap] = sum_{n,v} dy[n,v,co] * x[n,v+tap,ci]; dbias[co] = sum dy (nullable). */
 int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
@@ -80,6 +85,11 @@ size_t mednet_gn_ws_bytes(int n, int c, size_t spatial);
 int mednet_gn_stats(const void* x, const float* gamma, const float* beta, float* stats, float* coef, int n,
                     size_t spatial, int c, int groups, float eps, int dtype, void* ws, size_t ws_bytes,
                     mednet_stream stream);
+/* the second half of mednet_gn_stats for partial sums produced elsewhere (fused conv epilogue):
+ * partial is [n][chunks][c][2]; ws needs n*c*2 floats. */
+int mednet_gn_finalize(const float* partial, int chunks, const float* gamma, const float* beta, float* stats,
+                       float* coef, int n, size_t spatial, int c, int groups, float eps, void* ws, size_t ws_bytes,
+                       mednet_stream stream);
 /* z = act(coef0*x + coef1 [+ residual]) */
 int mednet_gn_act_fwd(const void* x, const float* coef, const void* residual, void* z, int n, size_t spatial,
                       int c, int act, int x_dtype, int z_dtype, mednet_stream stream);

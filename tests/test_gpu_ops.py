@@ -404,3 +404,38 @@ def test_conv_transpose_mfma_dgrad_wgrad(n, cin, cout, shape):
     assert_close(y, yr, 6e-3, "y (MFMA, 8 parity classes, bias + skip epilogue)")
     assert_close(xg.grad, xr.grad, 6e-3, "dx (MFMA stride-2 gather)")
     assert_close(up.weight.grad, wr.grad, 2e-4, "dw (MFMA, transposing LDS reads)")
+
+
+@pytest.mark.parametrize("n,cout,shape", [(1, 32, (4, 8, 16)), (2, 32, (9, 11, 21)), (1, 64, (5, 6, 7))])
+def test_first_layer_mfma_keeps_fp32_input_precision(n, cout, shape):
+    """Cin=1 forward on the matrix cores (contraction over the 27 taps, x split into bf16 hi+lo): with bf16-representable
+    weights the only rounding left is the bf16 store of the output; x itself is NOT rounded to 8 bits."""
+    tag = f"c1{n}{cout}{shape}"
+    x = rnd(tag + "x", n, 1, *shape)                       # full fp32 input, not pre-rounded
+    w = bf16_round(rnd(tag + "w", cout, 1, 3, 3, 3, scale=0.2))
+    yr = F.conv3d(x, w, None, padding=1)
+    with mednet_hip.precision("bf16"):
+        conv = hnn.Conv3d(1, cout, 3, bias=False).to(DEV)
+        with torch.no_grad():
+            conv.weight.copy_(w)
+        y = conv(x.to(DEV))
+    assert y.dtype == torch.bfloat16
+    assert_close(y, yr, 3.0e-3, "y (bf16 store rounding only)")
+    assert_close(y, bf16_round(yr), 4e-4, "y vs correctly rounded reference")
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 4), (32, 18), (64, 2)])
+def test_head_dgrad_kernel(cin, cout):
+    x = bf16_round(rnd(f"hd{cin}{cout}x", 2, cin, 6, 8, 10))
+    w = rnd(f"hd{cin}{cout}w", cout, cin, 1, 1, 1, scale=0.3)
+    cot = rnd(f"hd{cin}{cout}g", 2, cout, 6, 8, 10)
+    xr = x.clone().requires_grad_(True)
+    (F.conv3d(xr, w) * cot).sum().backward()
+    with mednet_hip.precision("bf16"):
+        conv = hnn.Conv3d(cin, cout, 1, planar_output=True).to(DEV)
+        with torch.no_grad():
+            conv.weight.copy_(w)
+            conv.bias.zero_()
+        xg = x.to(DEV).bfloat16().requires_grad_(True)
+        (conv(xg) * cot.to(DEV)).sum().backward()
+    assert_close(xg.grad, xr.grad, 4e-3, "dz of the 1x1x1 head")

@@ -37,19 +37,17 @@ def conv_case(cin, cout, s):
     flop = 2.0 * N * s ** 3 * cin * cout * 27
 
     def fwd():
-        L.check(lib.mednet_conv3d_fwd(x.data_ptr(), pk.data_ptr(), None, y.data_ptr(), N, s, s, s, cin, cout, 3, 1, 0, 1, 0, 0, 2, st), "fwd")
+        L.check(lib.mednet_conv3d_fwd(x.data_ptr(), pk.data_ptr(), None, y.data_ptr(), N, s, s, s, cin, cout, 3, 1, 0, 1, 0, 0, 2, None, st), "fwd")
 
     def wg():
         L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, N, s, s, s, cin, cout, 3, 1, 0, 1, 0, 2,
                                         ws.data_ptr(), ws.numel(), st), "wgrad")
 
     res = []
-    variants = [int(v) for v in os.environ.get("KB_ABLATE", "0").split(",")]
-    for rnd in range(2):  # interleaved rounds in ONE process (A/B rule)
+    variants = [0]
+    for rnd in range(3):
         for pv in variants:
-            lib.mednet_set_option(b"conv_ablate", pv)
             res.append((pv, timeit(fwd)))
-    lib.mednet_set_option(b"conv_ablate", 0)
     tw = timeit(wg)
     wres = {}
     for rnd in range(2):
@@ -58,7 +56,7 @@ def conv_case(cin, cout, s):
             wres[av] = min(wres.get(av, 1e9), timeit(wg))
     lib.mednet_set_option(b"wgrad_ablate", 0)
     print("   wgrad ablate: " + " | ".join(f"{k}: {v*1e3:6.1f} us" for k, v in wres.items()))
-    txt = " | ".join(f"ablate={pv}: {min(t for p, t in res if p == pv)*1e3:6.1f} us {flop/min(t for p, t in res if p == pv)/1e9:6.1f} TF/s" for pv in variants)
+    txt = " | ".join(f" {min(t for p, t in res if p == pv)*1e3:6.1f} us {flop/min(t for p, t in res if p == pv)/1e9:6.1f} TF/s" for pv in variants)
     print(f"conv {cin:3d}->{cout:3d} @{s:3d}^3 N={N}: fwd {txt} | wgrad {tw*1e3:7.1f} us {flop/tw/1e9:7.1f} TF/s", flush=True)
 
 

@@ -92,21 +92,39 @@ static int conv_common_checks(const char* who, int n, int d, int h, int w, int c
   return MEDNET_OK;
 }
 
+extern "C" int mednet_conv3d_fused_stats_chunks(int d, int h, int w, int cin, int cout, int ksize, int x_dtype,
+                                                int y_dtype, int algo) {
+  if (algo == MEDNET_ALGO_DIRECT || !tuning_option("conv_fuse_stats", 1)) return 0;
+  if (!conv_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, MEDNET_NDHWC, false)) return 0;
+  return conv_mfma_stats_chunks(d, h, w);
+}
+
 extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void* y, int n, int d, int h,
                                  int w, int cin, int cout, int ksize, int x_dtype, int x_layout, int y_dtype,
-                                 int y_layout, int dgrad, int algo, mednet_stream stream) {
+                                 int y_layout, int dgrad, int algo, float* gn_partial, mednet_stream stream) {
   int rc = conv_common_checks("conv3d_fwd", n, d, h, w, cin, cout, ksize, x_dtype, y_dtype);
   if (rc) return rc;
   // the pack was built for the layer's (Cin,Cout); a dgrad call swaps the roles
   const PackLayout L = dgrad ? pack_layout(cout, cin, ksize) : pack_layout(cin, cout, ksize);
   const char* base = (const char*)packed;
   hipStream_t s = (hipStream_t)stream;
-  const bool mfma_ok = conv_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, x_layout, y_layout, bias != nullptr);
+  const bool mfma_ok = conv_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, x_layout, y_layout, bias != nullptr) &&
+                       conv_mfma_fits(n, d, h, w, cin);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_fwd: MFMA path does not take cin=%d cout=%d k=%d dtypes %d->%d", cin, cout,
                 ksize, x_dtype, y_dtype);
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
-    return launch_conv_mfma(x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), y, n, d, h, w, cin, cout, x_dtype, y_dtype, s);
+    return launch_conv_mfma(x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), y, n, d, h, w, cin, cout, x_dtype, y_dtype,
+                            gn_partial, s);
+  MEDNET_REQUIRE(gn_partial == nullptr, MEDNET_E_UNSUPPORTED,
+                 "conv3d_fwd: fused GroupNorm partials are only produced by the MFMA path (ask mednet_conv3d_fused_stats_chunks)");
+  // first layer (one input channel): contraction over the 27 taps on the matrix cores
+  if (!dgrad && algo != MEDNET_ALGO_DIRECT && x_layout == MEDNET_NDHWC &&
+      conv_c1_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, y_layout, bias != nullptr))
+    return launch_conv_c1_mfma(x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, s);
+  // data gradient of the 1x1x1 head: the packed backward image Pb[t=0][co][ci] is exactly W[m][k]
+  if (dgrad && !bias && algo != MEDNET_ALGO_DIRECT && head_dgrad_supported(cin, cout, ksize, x_dtype, x_layout, y_layout))
+    return launch_head_dgrad(x, (const float*)(base + L.f32_bwd), y, n, (size_t)d * h * w, cin, cout, y_dtype, s);
   ConvGeom g;
   g.n = n; g.od = d; g.oh = h; g.ow = w; g.id = d; g.ih = h; g.iw = w;
   g.k = cin; g.m = cout; g.ks = ksize;
@@ -184,7 +202,7 @@ extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx
   int rc = conv_common_checks("convt3d_dgrad", n, d, h, w, cin, cout, 3, dy_dtype, dx_dtype);
   if (rc) return rc;
   const PackLayout L = pack_layout(cin, cout, 3);
-  const bool mfma_ok = L.mfma_bytes && dy_dtype == MEDNET_BF16 && dx_dtype == MEDNET_BF16;
+  const bool mfma_ok = L.mfma_bytes && dy_dtype == MEDNET_BF16 && dx_dtype == MEDNET_BF16 && conv_mfma_fits(n, 2 * d, 2 * h, 2 * w, cout);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_dgrad: MFMA path does not take cin=%d cout=%d", cin, cout);
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)

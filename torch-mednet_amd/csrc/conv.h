@@ -41,6 +41,9 @@ int launch_wgrad_direct(const void* A, const void* B, float* dw, WgradGeom g, in
 size_t channel_sum_ws_bytes(int n, size_t spatial, int c);
 int launch_channel_sum(const void* x, float* out, int n, size_t spatial, int c, int planar, int dtype, void* ws,
                        size_t ws_bytes, hipStream_t s);
+bool head_dgrad_supported(int cin, int cout, int ksize, int x_dtype, int x_layout, int y_layout);
+int launch_head_dgrad(const void* dy, const float* Pb, void* dz, int n, size_t spatial, int m, int k, int out_dtype,
+                      hipStream_t s);
 bool wgrad_1x1_supported(int cin, int cout, int ksize, int x_layout, int dy_layout, int dy_dtype);
 size_t wgrad_1x1_ws_bytes(int n, size_t spatial, int cin, int cout);
 int launch_wgrad_1x1(const void* z, const void* dy, float* dw, int n, size_t spatial, int cin, int cout, int z_dtype,
@@ -52,9 +55,11 @@ int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int 
 int launch_pack_f32(const float* w, float* Pf, float* Pb, int cin, int cout, int T, int transposed_src, hipStream_t s);
 
 // MFMA (bf16 matrix-core) kernels, conv_mfma.hip
+bool conv_mfma_fits(int n, int d, int h, int w, int c);
 bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int x_layout, int y_layout, bool bias);
 int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, int d, int h, int w, int cin, int cout,
-                     int x_dtype, int y_dtype, hipStream_t s);
+                     int x_dtype, int y_dtype, float* gn_partial, hipStream_t s);
+int conv_mfma_stats_chunks(int d, int h, int w);
 int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, int cin, int cout, int T, int transposed_src,
                      hipStream_t s);
 bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtype, int x_layout, int dy_layout);
@@ -62,6 +67,8 @@ bool wgrad_mfma_fits(int n, int d, int h, int w, int cmax, int scale);
 size_t wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
 int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, int dtype,
                       void* ws, size_t ws_bytes, hipStream_t s);
+bool conv_c1_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int y_layout, bool bias);
+int launch_conv_c1_mfma(const void* x, const float* w_pt, void* y, int n, int d, int h, int w, int cout, hipStream_t s);
 int launch_convt_fwd_mfma(const void* x, const void* sec, const float* bias, const void* skip, void* y, int n, int d,
                           int h, int w, int cin, int cout, hipStream_t s);
 int launch_convt_dgrad_mfma(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin,

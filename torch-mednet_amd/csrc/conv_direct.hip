@@ -266,7 +266,7 @@ int launch_wgrad_direct(const void* A, const void* B, float* dw, WgradGeom g, in
 }
 
 // ---- per-channel sum over voxels (bias gradients): per-workgroup partials, then a fixed-order combine -------------
-constexpr int CS_ITEMS = 256 * 32;  // elements of one channel plane / voxels of a channels-last slab per workgroup
+constexpr int CS_ITEMS = 256 * 256;  // elements of one channel plane / of a channels-last slab per workgroup
 // planar (NCDHW): grid (chunks, c, n); channels-last: grid (chunks, 1, n) with thread -> channel = tid % c
 template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const T* __restrict__ x, float* __restrict__ part,
@@ -418,6 +418,65 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const TX_* __restrict__ x
     for (int k = 0; k < G; ++k) s += red[(t * G + k) * CO + c2];
     part[(size_t)blockIdx.x * (27 * CO) + (size_t)c2 * 27 + t] = s;
   }
+}
+
+// ---- 1x1x1 head data gradient: dz[v][k] = sum_m dy[m][v] * W[m][k]  (planar fp32 logits gradient -> channels-last) -----
+// HBM-bound (writes the full-resolution 32-channel tensor once): a lane owns 8 consecutive channels of one voxel, so a
+// wave stores 1 KB contiguous per instruction; the M x 8 weights of the lane's column live in registers.
+template <typename TO, int MMAX>
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ Pb /*[m][k]*/,
+                                                         TO* __restrict__ dz, size_t spatial, int k, int m, size_t chunk_vox) {
+  const int cols = k / 8, rows = 256 / cols;
+  const int col = threadIdx.x % cols, row = threadIdx.x / cols;
+  if ((int)threadIdx.x >= rows * cols) return;
+  const int n = blockIdx.y;
+  float w[MMAX][8];
+#pragma unroll
+  for (int i = 0; i < MMAX; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[i][j] = i < m ? Pb[(size_t)i * k + col * 8 + j] : 0.f;
+  const size_t v0 = (size_t)blockIdx.x * chunk_vox;
+  const size_t v1 = v0 + chunk_vox < spatial ? v0 + chunk_vox : spatial;
+  for (size_t v = v0 + row; v < v1; v += rows) {
+    F8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MMAX; ++i) {
+      if (i < m) {
+        const float d = dy[((size_t)n * m + i) * spatial + v];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = fmaf(d, w[i][j], o.v[j]);
+      }
+    }
+    st8(dz, ((size_t)n * spatial + v) * k + col * 8, o);
+  }
+}
+bool head_dgrad_supported(int cin /*dy channels = layer Cout*/, int cout /*dz channels = layer Cin*/, int ksize, int x_dtype,
+                          int x_layout, int y_layout) {
+  return ksize == 1 && x_dtype == MEDNET_F32 && x_layout == MEDNET_NCDHW && y_layout == MEDNET_NDHWC && cout % 8 == 0 &&
+         cout / 8 <= 256 && cin <= 32;
+}
+int launch_head_dgrad(const void* dy, const float* Pb, void* dz, int n, size_t spatial, int m, int k, int out_dtype,
+                      hipStream_t s) {
+  const int rows = 256 / (k / 8);
+  size_t cv = (spatial + 1023) / 1024;
+  if (cv < (size_t)rows * 8) cv = (size_t)rows * 8;
+  cv = (cv + rows - 1) / rows * rows;
+  const dim3 grid((unsigned)((spatial + cv - 1) / cv), n);
+#define HD_GO(TO_, MM_) hipLaunchKernelGGL((head_dgrad_kernel<TO_, MM_>), grid, dim3(256), 0, s, (const float*)dy, Pb, (TO_*)dz, spatial, k, m, cv)
+#define HD_M(TO_)                     \
+  do {                                \
+    if (m <= 4) HD_GO(TO_, 4);        \
+    else if (m <= 8) HD_GO(TO_, 8);   \
+    else if (m <= 16) HD_GO(TO_, 16); \
+    else HD_GO(TO_, 32);              \
+  } while (0)
+  if (out_dtype == MEDNET_F32) HD_M(float);
+  else HD_M(bf16);
+#undef HD_M
+#undef HD_GO
+  return check_launch("head_dgrad");
 }
 
 // ---- 1x1x1 head weight gradient: dw[m][k] = sum_v dy[m][v] (planar fp32 logits gradient) * z[v][k] (channels-last) ----

@@ -56,10 +56,11 @@ struct FwdArgs {
   int cin, cout;
   int tiles_z, tiles_y, tiles_x, ntiles;  // per sample * n
   int nkc, ncb;
-  int ablate;  // timing-only experiments (mednet_set_option "conv_ablate"): 1 no re-prefetch, 2 no LDS commit, 4 no barriers, 8 no epilogue
+  unsigned bytes_x;  // size of x for the buffer resource (tensors < 4 GB)
+  float* gn_partial;  // nullable: [n][bricks per sample][cout][2] = per-brick {sum y, sum y^2} of the STORED (rounded) outputs
 };
 
-template <int STRIDE, bool PIPE>
+template <int STRIDE>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   using G = FwdTile<STRIDE>;
   constexpr int TZ = G::TZ, TY = G::TY, TX = G::TX;
@@ -69,85 +70,64 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   constexpr int IN_ROUNDS = (2 * NV + 255) / 256;
   constexpr int W_CHUNKS = 27 * 2 * 32;  // 16-byte pieces of one weight slice
   constexpr int W_ROUNDS = (W_CHUNKS + 255) / 256;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16x8* in_lds = reinterpret_cast<bf16x8*>(smem);                // [2][NV]
-  bf16x8* w_lds = reinterpret_cast<bf16x8*>(smem) + 2 * NV;        // [27][2][32]
+  u32x4* in_lds = reinterpret_cast<u32x4*>(smem);                  // [2][NV] 16-byte pieces (8 bf16 channels)
+  u32x4* w_lds = reinterpret_cast<u32x4*>(smem) + 2 * NV;          // [27][2][32]
+  float* st_lds = reinterpret_cast<float*>(smem + ((size_t)2 * NV + W_CHUNKS) * 16);  // [4 waves][4][8][2]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
 
-  // ---- work items: (brick, channel block).  All channel blocks of a brick run on the same XCD (ids 8 apart share an
-  // L2).  The workgroup is PERSISTENT: it walks items w = blockIdx.x, + gridDim.x, ... and treats (item, K-chunk) as one
-  // flat sequence of stages, so the global loads of the NEXT brick's first chunk are already in flight while the last
-  // chunk of the current brick is on the matrix cores (no per-brick load-latency bubble, no relaunch gap).
-  const int total = ((a.ntiles + 7) / 8) * 8 * a.ncb;
-  const int step = gridDim.x;
-  int tx0, ty0, tz0, n, cb;  // brick being STAGED (the prefetch target)
-  auto decode = [&](int w) -> bool {
-    const int xcd = w & 7, local = w >> 3;
-    const int tile = (local / a.ncb) * 8 + xcd;
-    cb = local % a.ncb;
-    if (tile >= a.ntiles) return false;
-    int tt = tile;
-    tx0 = (tt % a.tiles_x) * TX;
-    tt /= a.tiles_x;
-    ty0 = (tt % a.tiles_y) * TY;
-    tt /= a.tiles_y;
-    tz0 = (tt % a.tiles_z) * TZ;
-    n = tt / a.tiles_z;
-    return true;
-  };
-  auto next_item = [&](int w) -> int {  // first valid item at or after w (stride `step`), or -1
-    while (w < total) {
-      if (decode(w)) return w;
-      w += step;
-    }
-    return -1;
-  };
+  // ---- work item: (brick, channel block).  All channel blocks of a brick run on the same XCD (ids 8 apart share an L2).
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int tile = (local / a.ncb) * 8 + xcd;
+  const int cb = local % a.ncb;
+  if (tile >= a.ntiles) return;
+  const int tiles_per_sample = a.tiles_x * a.tiles_y * a.tiles_z;
+  const int tis = tile % tiles_per_sample;
+  int tt = tile;
+  const int tx0 = (tt % a.tiles_x) * TX;
+  tt /= a.tiles_x;
+  const int ty0 = (tt % a.tiles_y) * TY;
+  tt /= a.tiles_y;
+  const int tz0 = (tt % a.tiles_z) * TZ;
+  const int n = tt / a.tiles_z;
 
-  // ---- staging plan of the brick being staged: global element offset of each 16-byte piece
-  //      (-1: beyond the tile image, never written; -2: inside the image but outside the volume -> zero padding)
-  long long goff[IN_ROUNDS];
-  const bf16* wsrc = a.wpk;
-  auto plan = [&]() {
+  // ---- staging plan (independent of the K chunk): 32-bit BYTE offset of each 16-byte piece for a buffer load whose
+  //      resource descriptor sits in SGPRs.  Pieces outside the volume get an offset beyond num_records: the hardware
+  //      range check returns zeros for them, so zero padding costs neither a branch nor a select.
+  const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.bytes_x, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  unsigned goff[IN_ROUNDS];
 #pragma unroll
-    for (int it = 0; it < IN_ROUNDS; ++it) {
-      const int p = it * 256 + tid;
-      const int v = p >> 1, hh = p & 1;
-      long long off = -1;
-      if (v < NV) {
-        const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
-        const int gz = STRIDE * tz0 - 1 + hz, gy = STRIDE * ty0 - 1 + hy, gx = STRIDE * tx0 - 1 + hx;
-        if (gz >= 0 && gz < a.id && gy >= 0 && gy < a.ih && gx >= 0 && gx < a.iw)
-          off = ((((long long)n * a.id + gz) * a.ih + gy) * a.iw + gx) * a.cin + hh * 8;
-        else
-          off = -2;
-      }
-      goff[it] = off;
-    }
-    wsrc = a.wpk + (size_t)cb * a.nkc * (W_CHUNKS * 8);
-  };
+  for (int it = 0; it < IN_ROUNDS; ++it) {
+    const int p = it * 256 + tid;
+    const int v = p >> 1, hh = p & 1;
+    const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
+    const int gz = STRIDE * tz0 - 1 + hz, gy = STRIDE * ty0 - 1 + hy, gx = STRIDE * tx0 - 1 + hx;
+    const bool in_vol = v < NV && gz >= 0 && gz < a.id && gy >= 0 && gy < a.ih && gx >= 0 && gx < a.iw;
+    goff[it] = in_vol ? (unsigned)((((n * a.id + gz) * a.ih + gy) * a.iw + gx) * a.cin + hh * 8) * 2u : OOB;
+  }
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)cb * a.nkc * W_CHUNKS;
 
-  bf16x8 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
-  // Branch-free: every lane always loads (padding / out-of-image lanes read a valid dummy address); what is invalid
-  // is replaced by zeros when the registers are committed to LDS, so the 16 loads issue back to back with no waits.
-  auto prefetch = [&](int kc) {
+  u32x4 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
+  auto prefetch = [&](int kc) {  // 16 loads issued back to back, nothing waits on them until commit()
 #pragma unroll
-    for (int it = 0; it < IN_ROUNDS; ++it)
-      in_reg[it] = *reinterpret_cast<const bf16x8*>(a.x + (goff[it] >= 0 ? goff[it] : 0) + kc * 16);
-    const bf16* ws = wsrc + (size_t)kc * (W_CHUNKS * 8);
+    for (int it = 0; it < IN_ROUNDS; ++it) in_reg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, goff[it], kc * 32, 0);
+    const u32x4* ws = wsrc + (size_t)kc * W_CHUNKS;
 #pragma unroll
     for (int it = 0; it < W_ROUNDS; ++it) {
       const int c = it * 256 + tid;
-      w_reg[it] = *reinterpret_cast<const bf16x8*>(ws + (size_t)(c < W_CHUNKS ? c : W_CHUNKS - 1) * 8);
+      w_reg[it] = ws[c < W_CHUNKS ? c : W_CHUNKS - 1];
     }
   };
   auto commit = [&]() {
-    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int it = 0; it < IN_ROUNDS; ++it) {
       const int p = it * 256 + tid;
-      if (goff[it] != -1) in_lds[(p & 1) * NV + (p >> 1)] = goff[it] >= 0 ? in_reg[it] : zero;
+      if (p < 2 * NV) in_lds[(p & 1) * NV + (p >> 1)] = in_reg[it];
     }
 #pragma unroll
     for (int it = 0; it < W_ROUNDS; ++it) {
@@ -156,99 +136,128 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     }
   };
 
-  // ---- this lane's voxel in each of the wave's N-tiles (2 rows x 16 voxels), row-rotated for conflict-free reads;
-  //      brick-local, hence the same for every brick
-  int lbase[NTW], loz[NTW], loy[NTW], lox[NTW];
+  // ---- this lane's voxel in each of the wave's N-tiles (2 rows x 16 voxels), row-rotated for conflict-free reads
+  auto tile_voxel = [&](int t, int& lz, int& ly, int& lx) {
+    const int g = wv * NTW + t;
+    lz = g / (TY / 2);
+    ly = (g % (TY / 2)) * 2 + (r >> 4);
+    const int i = r & 15;
+    lx = STRIDE == 1 ? ((i - (r >> 4) * HX) & 15) : i;
+  };
+  int lbase[NTW];  // LDS piece index of tap (0,0,0) for this lane
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
-    const int g = wv * NTW + t;
-    loz[t] = g / (TY / 2);
-    loy[t] = (g % (TY / 2)) * 2 + (r >> 4);
-    const int i = r & 15;
-    lox[t] = STRIDE == 1 ? ((i - (r >> 4) * HX) & 15) : i;
-    lbase[t] = ((STRIDE * loz[t]) * HY + STRIDE * loy[t]) * HX + STRIDE * lox[t] + h * NV;
+    int lz, ly, lx;
+    tile_voxel(t, lz, ly, lx);
+    lbase[t] = ((STRIDE * lz) * HY + STRIDE * ly) * HX + STRIDE * lx + h * NV;
   }
 
-  int w = next_item(blockIdx.x);
-  if (w < 0) return;
-  plan();
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
   prefetch(0);
+  for (int kc = 0; kc < a.nkc; ++kc) {
+    __syncthreads();  // every wave is done reading the previous chunk's LDS image
+    commit();
+    __syncthreads();
+    if (kc + 1 < a.nkc) prefetch(kc + 1);  // in flight while the matrix cores work on chunk kc
+    // Software-pipelined over the 27 taps: the fragments of tap t+1 (1 weight + NTW input ds_read_b128) are in flight
+    // while tap t is on the matrix cores; sched_group_barrier pins that interleave (hipcc otherwise sinks each read to
+    // just in front of its MFMA and exposes the LDS latency 108 times per chunk).
+    bf16x8 wa[2], xb[2][NTW];
+    wa[0] = __builtin_bit_cast(bf16x8, w_lds[h * 32 + r]);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) xb[0][t] = __builtin_bit_cast(bf16x8, in_lds[lbase[t]]);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int cur = tap & 1, nxt = cur ^ 1;
+      if (tap + 1 < 27) {
+        const int t1 = tap + 1;
+        const int toff = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3;
+        wa[nxt] = __builtin_bit_cast(bf16x8, w_lds[(t1 * 2 + h) * 32 + r]);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) xb[nxt][t] = __builtin_bit_cast(bf16x8, in_lds[lbase[t] + toff]);
+      }
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur], xb[cur][t], acc[t], 0, 0, 0);
+      if (tap + 1 < 27) __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);  // DS reads of tap+1 first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                         // ... then the MFMAs of tap
+    }
+  }
+
+  // ---- epilogue through LDS.  D[row = co][col = voxel]: the accumulator layout gives every lane four 8-byte pieces of
+  // its voxel's 64-byte channel row, so a direct store instruction would touch 32 rows with 8 bytes each.  Instead the
+  // brick's output is assembled in LDS (8-byte chunks XOR-swizzled by voxel so both the ds_write_b64 and the ds_read_b128
+  // are conflict-free) and written out as whole rows: 4 lanes per voxel, 16 voxels = 1 KB contiguous per wave instruction
+  // when Cout = 32.  The GroupNorm partial sums come from the same LDS image (8 channels per lane).
+  bf16* out_lds = reinterpret_cast<bf16*>(smem);  // [TZ*TY*TX voxels][32 co], reuses the input image
+  __syncthreads();                                // every wave is done with the MFMA reads of the last chunk
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    int lz, ly, lx;
+    tile_voxel(t, lz, ly, lx);
+    const int vl = (lz * TY + ly) * TX + lx;
+    const int sw = (vl >> 1) & 7;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[t][q * 4 + j];  // co = 8q + 4h + j
+      *reinterpret_cast<bf16x4*>(out_lds + vl * 32 + ((2 * q + h) ^ sw) * 4) = o;
+    }
+  }
+  __syncthreads();
+  float gs[8], gq[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) gs[k] = gq[k] = 0.f;
+  const int pj = tid & 3;
   const size_t ovol = (size_t)a.od * a.oh * a.ow;
-  while (true) {
-    // origin / channel block of the brick whose chunks are about to be COMPUTED (decode() will move on to the next)
-    const int cz0 = tz0, cy0 = ty0, cx0 = tx0, cn = n, ccb = cb;
-    f32x16 acc[NTW];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t)
+  for (int it = 0; it < (TZ * TY * TX * 4) / 256; ++it) {
+    const int vl = it * 64 + (tid >> 2);
+    const int sw = (vl >> 1) & 7;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(out_lds + vl * 32 + (pj ^ (sw >> 1)) * 8);
+    if (sw & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
+    const int oz = tz0 + vl / (TY * TX), oy = ty0 + (vl / TX) % TY, ox = tx0 + vl % TX;
+    if (oz < a.od && oy < a.oh && ox < a.ow) {
+      *reinterpret_cast<bf16x8*>(a.y + ((size_t)n * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.cout + cb * 32 + pj * 8) = v;
+      if (a.gn_partial) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    int wnext = -1;
-    for (int kc = 0; kc < a.nkc; ++kc) {
-      if (!(a.ablate & 4)) __syncthreads();  // every wave is done reading the previous stage's LDS image
-      if (!(a.ablate & 2)) commit();
-      if (!(a.ablate & 4)) __syncthreads();
-      if (kc + 1 < a.nkc) {
-        if (!(a.ablate & 1)) prefetch(kc + 1);  // in flight while the matrix cores work on chunk kc
-      } else {
-        wnext = next_item(w + step);
-        if (wnext >= 0) {
-          plan();
-          if (!(a.ablate & 1)) prefetch(0);  // the next brick's first chunk flies under this brick's last chunk + epilogue
-        }
-      }
-      if constexpr (PIPE) {
-        // Software-pipelined over the 27 taps: the fragments of tap t+1 (1 weight + NTW input ds_read_b128) are in
-        // flight while tap t is on the matrix cores; sched_group_barrier pins that interleave.
-        bf16x8 wa[2], xb[2][NTW];
-        wa[0] = w_lds[h * 32 + r];
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) xb[0][t] = in_lds[lbase[t]];
-#pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
-          const int cur = tap & 1, nxt = cur ^ 1;
-          if (tap + 1 < 27) {
-            const int t1 = tap + 1;
-            const int toff = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3;
-            wa[nxt] = w_lds[(t1 * 2 + h) * 32 + r];
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) xb[nxt][t] = in_lds[lbase[t] + toff];
-          }
-#pragma unroll
-          for (int t = 0; t < NTW; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur], xb[cur][t], acc[t], 0, 0, 0);
-          if (tap + 1 < 27) __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);  // DS reads of tap+1 first ...
-          __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                         // ... then the MFMAs of tap
-        }
-      } else {
-#pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
-          const int toff = ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
-          const bf16x8 wa = w_lds[(tap * 2 + h) * 32 + r];
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) {
-            const bf16x8 xb = in_lds[lbase[t] + toff];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[t], 0, 0, 0);
-          }
+        for (int k = 0; k < 8; ++k) {
+          const float f = (float)v[k];  // statistics of what is stored, exactly like the stand-alone pass
+          gs[k] += f;
+          gq[k] = fmaf(f, f, gq[k]);
         }
       }
     }
-    // ---- epilogue: D[row = co][col = voxel]; lane holds co = (i&3) + 8*(i>>2) + 4*h for its voxel (col = r)
+  }
+  if (a.gn_partial) {
+    // GroupNorm statistics fused into the producer (components.py:57 follows every conv of the 'c g .' orders)
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int oz = cz0 + loz[t], oy = cy0 + loy[t], ox = cx0 + lox[t];
-      if (oz < a.od && oy < a.oh && ox < a.ow && !((a.ablate & 8) && acc[t][0] != 12345.f)) {
-        bf16* yp = a.y + ((size_t)cn * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.cout + ccb * 32 + 4 * h;
+    for (int m = 4; m < 64; m <<= 1)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          bf16x4 o;
+      for (int k = 0; k < 8; ++k) {
+        gs[k] += __shfl_xor(gs[k], m, 64);
+        gq[k] += __shfl_xor(gq[k], m, 64);
+      }
+    if (lane < 4) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[t][q * 4 + j];
-          *reinterpret_cast<bf16x4*>(yp + 8 * q) = o;
-        }
+      for (int k = 0; k < 8; ++k) {
+        st_lds[((wv * 4 + pj) * 8 + k) * 2] = gs[k];
+        st_lds[((wv * 4 + pj) * 8 + k) * 2 + 1] = gq[k];
       }
     }
-    if (wnext < 0) break;
-    w = wnext;
+    __syncthreads();
+    if (tid < 64) {
+      const int co = tid >> 1, which = tid & 1;
+      float tot = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tot += st_lds[((k * 4 + (co >> 3)) * 8 + (co & 7)) * 2 + which];
+      a.gn_partial[(((size_t)n * tiles_per_sample + tis) * a.cout + cb * 32 + co) * 2 + which] = tot;
+    }
   }
 }
 
@@ -422,6 +431,112 @@ int launch_convt_fwd_mfma(const void* x, const void* sec, const float* bias, con
   return check_launch("convt_fwd_mfma");
 }
 
+// ================================================================================================== first layer (Cin = 1)
+// y[vox][co] = sum_tap W[co][tap] * x[vox + tap - 1]: with one input channel the contraction index is the TAP (27, padded
+// to 32 = two MFMA k-steps).  The B operand (k = tap, n = voxel) is gathered from an fp32 halo brick of x in LDS -- 8
+// scalar LDS reads per fragment -- and split into bf16 hi + lo parts (x = hi + lo to ~2^-17), so the network input keeps
+// fp32-level precision at 4 MFMAs per 32 voxels; the weights (32 x 32 bf16) live in registers for the kernel's lifetime.
+// The kernel is bound by writing its output (32 channels per input voxel); the VALU formulation it replaces was 4x slower.
+struct C1Args {
+  const float* x;    // N x D x H x W (one channel)
+  const float* w;    // packed forward image Pf[tap][co] (fp32)
+  bf16* y;           // NDHWC
+  int n, d, h, w_, cout;
+  int tiles_z, tiles_y, tiles_x, ntiles, ncb;
+};
+
+__global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
+  constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, NV = HZ * HY * HX, NTW = 4;
+  __shared__ float xs[NV];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tile = blockIdx.x / a.ncb, cb = blockIdx.x % a.ncb;
+  int tt = tile;
+  const int tx0 = (tt % a.tiles_x) * TX;
+  tt /= a.tiles_x;
+  const int ty0 = (tt % a.tiles_y) * TY;
+  tt /= a.tiles_y;
+  const int tz0 = (tt % a.tiles_z) * TZ;
+  const int n = tt / a.tiles_z;
+  // weights: A operand, lane (co = r, h) holds taps 8h..8h+7 (k-step 0) and 16+8h..16+8h+7 (k-step 1); taps >= 27 are 0
+  bf16x8 wa[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tap = ks * 16 + 8 * h + j;
+      wa[ks][j] = (bf16)(tap < 27 ? a.w[(size_t)tap * a.cout + cb * 32 + r] : 0.f);
+    }
+  // LDS offsets of this lane's 8 taps per k-step
+  int toff[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tap = ks * 16 + 8 * h + j;
+      toff[ks][j] = tap < 27 ? ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3 : 0;
+    }
+  for (int i = tid; i < NV; i += 256) {
+    const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
+    const int gz = tz0 - 1 + hz, gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+    xs[i] = (gz >= 0 && gz < a.d && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_)
+                ? a.x[(((size_t)n * a.d + gz) * a.h + gy) * a.w_ + gx]
+                : 0.f;
+  }
+  __syncthreads();
+  const size_t vol = (size_t)a.d * a.h * a.w_;
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int g = wv * NTW + t;
+    const int lz = g / (TY / 2), ly = (g % (TY / 2)) * 2 + (r >> 4), lx = r & 15;
+    const int base = (lz * HY + ly) * HX + lx;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = xs[base + toff[ks][j]];
+        hi[j] = (bf16)v;
+        lo[j] = (bf16)(v - (float)hi[j]);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], hi, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], lo, acc, 0, 0, 0);
+    }
+    const int oz = tz0 + lz, oy = ty0 + ly, ox = tx0 + lx;
+    if (oz < a.d && oy < a.h && ox < a.w_) {
+      bf16* yp = a.y + ((size_t)n * vol + ((size_t)oz * a.h + oy) * a.w_ + ox) * a.cout + cb * 32 + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[q * 4 + j];
+        *reinterpret_cast<bf16x4*>(yp + 8 * q) = o;
+      }
+    }
+  }
+}
+
+bool conv_c1_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int y_layout, bool bias) {
+  return cin == 1 && ksize == 3 && cout % 32 == 0 && x_dtype == MEDNET_F32 && y_dtype == MEDNET_BF16 &&
+         y_layout == MEDNET_NDHWC && !bias;
+}
+int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d, int h, int w, int cout, hipStream_t s) {
+  C1Args a;
+  a.x = (const float*)x;
+  a.w = w_pf;
+  a.y = (bf16*)y;
+  a.n = n; a.d = d; a.h = h; a.w_ = w; a.cout = cout;
+  a.tiles_z = (d + 3) / 4;
+  a.tiles_y = (h + 7) / 8;
+  a.tiles_x = (w + 15) / 16;
+  a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
+  a.ncb = cout / 32;
+  hipLaunchKernelGGL(conv_c1_mfma_kernel, dim3((unsigned)a.ntiles * a.ncb), dim3(256), 0, s, a);
+  return check_launch("conv_c1_mfma");
+}
+
 // ================================================================================================== weight packing
 // element e of section [cb][kc][tap][h][co][j]  <-  Weff[cb*32+co][kc*16+h*8+j][tap]
 // mode 0: conv fwd      Weff[m][k][t] = W[m][k][t]            (W: Cout,Cin,27)  M=Cout K=Cin
@@ -479,6 +594,8 @@ int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, int cin, int 
   return check_launch("pack_mfma");
 }
 
+// the kernels address the activation tensor through a buffer resource with 32-bit byte offsets
+bool conv_mfma_fits(int n, int d, int h, int w, int c) { return (double)n * d * h * w * c * 2.0 < 4294960000.0; }
 bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int x_layout, int y_layout, bool bias) {
   return ksize == 3 && cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && y_dtype == MEDNET_BF16 &&
          x_layout == MEDNET_NDHWC && y_layout == MEDNET_NDHWC && !bias;
@@ -486,12 +603,13 @@ bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype,
 
 template <int STRIDE>
 static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, int oh, int ow, int id, int ih, int iw,
-                      int cin, int cout, hipStream_t s) {
+                      int cin, int cout, float* gn_partial, hipStream_t s) {
   using G = FwdTile<STRIDE>;
   constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
-  constexpr size_t lds = ((size_t)2 * HZ * HY * HX + 27 * 2 * 32) * 16;
+  constexpr size_t lds = ((size_t)2 * HZ * HY * HX + 27 * 2 * 32) * 16 + 1024;  // + GroupNorm partial scratch
   static_assert(lds <= 80 * 1024, "two workgroups must fit one CU");
   FwdArgs a;
+  a.gn_partial = gn_partial;
   a.x = (const bf16*)x;
   a.wpk = (const bf16*)sec;
   a.y = (bf16*)y;
@@ -503,36 +621,33 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
   a.nkc = cin / 16;
   a.ncb = cout / 32;
-  a.ablate = tuning_option("conv_ablate", 0);
-  unsigned grid = (unsigned)((a.ntiles + 7) / 8) * 8 * a.ncb;
-  // persistent workgroups: 2 per CU resident (62 KB LDS each); the stride must keep an item's XCD (multiple of 8)
-  const unsigned resident = (unsigned)tuning_option("conv_persist", 0) * 512u;
-  if (resident && grid > resident) grid = resident;
+  a.bytes_x = (unsigned)((size_t)n * id * ih * iw * cin * 2);
+  const unsigned grid = (unsigned)((a.ntiles + 7) / 8) * 8 * a.ncb;
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[STRIDE]) {
-    if (hipFuncSetAttribute((const void*)conv_mfma_kernel<STRIDE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv_mfma_kernel<STRIDE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv_mfma_kernel<STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(MEDNET_E_HIP, "conv_mfma: cannot raise dynamic LDS to %zu", lds);
     attr_set[STRIDE] = true;
   }
-  if (tuning_option("conv_pipe", 1))
-    hipLaunchKernelGGL((conv_mfma_kernel<STRIDE, true>), dim3(grid), dim3(256), lds, s, a);
-  else
-    hipLaunchKernelGGL((conv_mfma_kernel<STRIDE, false>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<STRIDE>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_mfma");
 }
 
 int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, int d, int h, int w, int cin, int cout,
-                     int x_dtype, int y_dtype, hipStream_t s) {
+                     int x_dtype, int y_dtype, float* gn_partial, hipStream_t s) {
   (void)x_dtype;
   (void)y_dtype;
-  return launch_fwd<1>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, s);
+  return launch_fwd<1>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, gn_partial, s);
+}
+int conv_mfma_stats_chunks(int d, int h, int w) {
+  using G = FwdTile<1>;
+  return ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
 }
 
 int launch_convt_dgrad_mfma(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin,
                             int cout, hipStream_t s) {
   // dx (d,h,w; Cin channels) <- dy (2d,2h,2w; Cout channels)
-  return launch_fwd<2>(dy, packed_section, dx, n, d, h, w, 2 * d, 2 * h, 2 * w, cout, cin, s);
+  return launch_fwd<2>(dy, packed_section, dx, n, d, h, w, 2 * d, 2 * h, 2 * w, cout, cin, nullptr, s);
 }
 
 // ================================================================================================== weight gradient

@@ -650,6 +650,19 @@ extern "C" int mednet_gn_stats(const void* x, const float* gamma, const float* b
   return check_launch("gn_finalize");
 }
 
+extern "C" int mednet_gn_finalize(const float* partial, int chunks, const float* gamma, const float* beta, float* stats,
+                                  float* coef, int n, size_t spatial, int c, int groups, float eps, void* ws,
+                                  size_t ws_bytes, mednet_stream stream) {
+  MEDNET_REQUIRE(n > 0 && c > 0 && groups > 0 && c % groups == 0 && chunks > 0, MEDNET_E_SHAPE, "gn_finalize: bad shape");
+  MEDNET_REQUIRE(ws_bytes >= (size_t)n * c * 2 * sizeof(float), MEDNET_E_WORKSPACE, "gn_finalize: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* csum = (float*)ws;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n * c), dim3(64), 0, s, partial, csum, c, chunks);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, gamma, beta, stats, coef, c, groups,
+                     (double)spatial * (c / groups), eps);
+  return check_launch("gn_finalize");
+}
+
 extern "C" int mednet_gn_act_fwd(const void* x, const float* coef, const void* residual, void* z, int n,
                                  size_t spatial, int c, int act, int x_dtype, int z_dtype, mednet_stream stream) {
   MEDNET_REQUIRE(dtype_ok(x_dtype) && dtype_ok(z_dtype), MEDNET_E_DTYPE, "gn_act_fwd: bad dtype");

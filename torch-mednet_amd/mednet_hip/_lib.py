@@ -32,7 +32,9 @@ SIGNATURES = {
     "mednet_set_option": (_i, [C.c_char_p, _i]),
     "mednet_conv3d_pack_bytes": (_sz, [_i, _i, _i]),
     "mednet_conv3d_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "mednet_conv3d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp]),
+    "mednet_conv3d_fused_stats_chunks": (_i, [_i] * 9),
+    "mednet_conv3d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp]),
+    "mednet_gn_finalize": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _f, _vp, _sz, _vp]),
     "mednet_conv3d_wgrad_ws_bytes": (_sz, [_i] * 7),
     "mednet_conv3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp, _sz, _vp]),
     "mednet_convt3d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
@@ -76,6 +78,10 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
+        for item in os.environ.get("MEDNET_OPTIONS", "").split(","):  # e.g. "conv_fuse_stats=0,conv_persist=1" (A/B knobs)
+            if "=" in item:
+                k, v = item.split("=", 1)
+                h.mednet_set_option(k.strip().encode(), int(v))
         _lib = h
     return _lib
 

@@ -56,6 +56,10 @@ class Conv3d(nn.Module, _PackedWeightMixin):
         out_dtype = torch.float32 if self.planar_output else config.act_dtype()
         return ops.conv3d(x, self.weight, self.bias, self._packed(), self.kernel_size[0], self.planar_output, out_dtype)
 
+    def forward_with_stats(self, x):
+        """(y, GroupNorm partial sums of y or None) -- used when a GroupNorm follows (SingleConv fuses the two)."""
+        return ops.conv3d_with_stats(x, self.weight, self.bias, self._packed(), self.kernel_size[0])
+
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, bias={self.bias is not None}"
 
@@ -103,8 +107,8 @@ class GroupNorm(nn.Module):
             self.register_parameter("weight", None)
             self.register_parameter("bias", None)
 
-    def forward(self, x, act=L.ACT_NONE, residual=None):
-        return ops.group_norm_act(x, self.weight, self.bias, self.num_groups, self.eps, act, residual)
+    def forward(self, x, act=L.ACT_NONE, residual=None, partial=None):
+        return ops.group_norm_act(x, self.weight, self.bias, self.num_groups, self.eps, act, residual, partial)
 
     def extra_repr(self):
         return f"{self.num_groups}, {self.num_channels}, eps={self.eps}"

@@ -116,7 +116,7 @@ class Conv3dFn(Function):
     """nn.Conv3d(k in {1,3}, stride 1, padding k//2)  -- components.py:8-9,44; model.py:77,179."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, ksize, out_planar, out_dtype):
+    def forward(ctx, x, weight, bias, packed, ksize, out_planar, out_dtype, want_stats=False):
         L.require_gpu(x, "conv3d")
         x = _as_act(x)
         n, cin, d, h, w = x.shape
@@ -131,19 +131,30 @@ class Conv3dFn(Function):
         if prof:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        # GroupNorm partial sums from the conv epilogue (when the MFMA kernel takes this call): saves a pass over y
+        partial = None
+        if want_stats and bias is None and not out_planar:
+            chunks = L.lib().mednet_conv3d_fused_stats_chunks(d, h, w, cin, cout, ksize, L.dt(xin), L.dt(y), config.conv_algo())
+            if chunks > 0:
+                partial = torch.empty((n, chunks, cout, 2), dtype=torch.float32, device=x.device)
         L.check(L.lib().mednet_conv3d_fwd(xin.data_ptr(), packed.data_ptr(), L.ptr(bias), y.data_ptr(), n, d, h, w, cin,
                                           cout, ksize, L.dt(xin), L.NDHWC, L.dt(y), L.NCDHW if out_planar else L.NDHWC,
-                                          0, config.conv_algo(), L.stream()), "conv3d_fwd")
+                                          0, config.conv_algo(), L.ptr(partial), L.stream()), "conv3d_fwd")
         if prof:
             e1.record()
             PROFILE["events"].append((e0, e1, 2.0 * n * d * h * w * cin * cout * ksize ** 3))
         ctx.save_for_backward(xin, packed)
         ctx.meta = (ksize, out_planar, cin, cout, bias is not None, x.dtype)
         ctx.params = (weight, bias)
-        return y
+        if not want_stats:
+            return y
+        if partial is None:
+            partial = torch.empty(0, device=x.device)  # "no fused statistics"
+        ctx.mark_non_differentiable(partial)
+        return y, partial
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpartial=None):
         xin, packed = ctx.saved_tensors
         ksize, out_planar, cin, cout, has_bias, x_dtype = ctx.meta
         n, _, d, h, w = xin.shape
@@ -168,12 +179,18 @@ class Conv3dFn(Function):
             dx = empty_cl(n, cin, d, h, w, x_dtype, dy.device)
             L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin,
                                           ksize, L.dt(dy), L.NCDHW if out_planar else L.NDHWC, L.dt(dx), L.NDHWC, 1,
-                                          config.conv_algo(), L.stream()), "conv3d_dgrad")
-        return dx, (None if direct_w else dw), (None if direct_b else db), None, None, None, None
+                                          config.conv_algo(), None, L.stream()), "conv3d_dgrad")
+        return dx, (None if direct_w else dw), (None if direct_b else db), None, None, None, None, None
 
 
 def conv3d(x, weight, bias, packed, ksize, out_planar=False, out_dtype=None):
     return Conv3dFn.apply(x, weight, bias, packed, ksize, out_planar, out_dtype or config.act_dtype())
+
+
+def conv3d_with_stats(x, weight, bias, packed, ksize):
+    """conv + (when the kernel can) the GroupNorm partial sums of its output; returns (y, partial-or-None)."""
+    y, partial = Conv3dFn.apply(x, weight, bias, packed, ksize, False, config.act_dtype(), True)
+    return y, (partial if partial.numel() else None)
 
 
 # ------------------------------------------------------------------------------------------------- ConvTranspose3d (+ skip add)
@@ -238,7 +255,7 @@ class GroupNormActFn(Function):
     """z = act(GroupNorm(x) [+ residual])  -- components.py:57, :36-40, :177-178."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, groups, eps, act):
+    def forward(ctx, x, gamma, beta, residual, groups, eps, act, partial=None):
         L.require_gpu(x, "group_norm_act")
         x = to_cl(_as_act(x))
         n, c, d, h, w = x.shape
@@ -249,8 +266,13 @@ class GroupNormActFn(Function):
         stats = torch.empty((n, groups, 2), dtype=torch.float32, device=x.device)
         coef = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
         ws = L.workspace(lib.mednet_gn_ws_bytes(n, c, spatial), x.device)
-        L.check(lib.mednet_gn_stats(x.data_ptr(), L.ptr(gamma), L.ptr(beta), stats.data_ptr(), coef.data_ptr(), n,
-                                    spatial, c, groups, eps, L.dt(x), ws.data_ptr(), ws.numel(), L.stream()), "gn_stats")
+        if partial is not None:  # partial sums came out of the producing conv's epilogue
+            L.check(lib.mednet_gn_finalize(partial.data_ptr(), partial.shape[1], L.ptr(gamma), L.ptr(beta), stats.data_ptr(),
+                                           coef.data_ptr(), n, spatial, c, groups, eps, ws.data_ptr(), ws.numel(),
+                                           L.stream()), "gn_finalize")
+        else:
+            L.check(lib.mednet_gn_stats(x.data_ptr(), L.ptr(gamma), L.ptr(beta), stats.data_ptr(), coef.data_ptr(), n,
+                                        spatial, c, groups, eps, L.dt(x), ws.data_ptr(), ws.numel(), L.stream()), "gn_stats")
         res = None
         if residual is not None:
             res = to_cl(residual.to(x.dtype))
@@ -282,11 +304,11 @@ class GroupNormActFn(Function):
         L.check(lib.mednet_gn_act_bwd(dz.data_ptr(), None, x.data_ptr(), L.ptr(z), coef.data_ptr(), stats.data_ptr(), L.ptr(gamma),
                                       dx.data_ptr(), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), n, spatial, c, groups, act,
                                       L.dt(x), ws.data_ptr(), ws.numel(), L.stream()), "gn_act_bwd")
-        return dx, (None if direct_g else dgamma), (None if direct_b else dbeta), dres, None, None, None
+        return dx, (None if direct_g else dgamma), (None if direct_b else dbeta), dres, None, None, None, None
 
 
-def group_norm_act(x, gamma, beta, groups, eps=1e-5, act=L.ACT_NONE, residual=None):
-    return GroupNormActFn.apply(x, gamma, beta, residual, groups, eps, act)
+def group_norm_act(x, gamma, beta, groups, eps=1e-5, act=L.ACT_NONE, residual=None, partial=None):
+    return GroupNormActFn.apply(x, gamma, beta, residual, groups, eps, act, partial)
 
 
 # ------------------------------------------------------------------------------------------------- stand-alone activation

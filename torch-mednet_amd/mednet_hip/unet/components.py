@@ -62,20 +62,27 @@ class SingleConv(nn.Sequential):
         mods = list(self._modules.values())
         i = 0
         fused_res = False
+        partial = None  # GroupNorm partial sums of the tensor in `x`, when the conv that produced it supplied them
         while i < len(mods):
             m = mods[i]
             if isinstance(m, hnn.GroupNorm):
                 nxt = mods[i + 1] if i + 1 < len(mods) else None
                 if isinstance(nxt, hnn._Act):
-                    x = m(x, act=nxt.code)
+                    x = m(x, act=nxt.code, partial=partial)
                     i += 2
-                    continue
-                if nxt is None and residual is not None:
-                    x = m(x, act=final_act, residual=residual)
+                elif nxt is None and residual is not None:
+                    x = m(x, act=final_act, residual=residual, partial=partial)
                     fused_res = True
                     i += 1
-                    continue
-                x = m(x)
+                else:
+                    x = m(x, partial=partial)
+                    i += 1
+                partial = None
+                continue
+            partial = None
+            if isinstance(m, hnn.Conv3d) and i + 1 < len(mods) and isinstance(mods[i + 1], hnn.GroupNorm) \
+                    and m.bias is None and x.is_cuda:
+                x, partial = m.forward_with_stats(x)
             elif isinstance(m, nn.BatchNorm3d):
                 x = m(x.float().contiguous()).to(memory_format=ops.CL)
             else:
