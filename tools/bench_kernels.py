@@ -50,12 +50,12 @@ def conv_case(cin, cout, s):
             res.append((pv, timeit(fwd)))
     tw = timeit(wg)
     wres = {}
-    for rnd in range(2):
-        for av in (0, 1, 2):
-            lib.mednet_set_option(b"wgrad_ablate", av)
+    for rnd in range(3):
+        for av in (0, 1):
+            lib.mednet_set_option(b"wgrad_v2", av)
             wres[av] = min(wres.get(av, 1e9), timeit(wg))
-    lib.mednet_set_option(b"wgrad_ablate", 0)
-    print("   wgrad ablate: " + " | ".join(f"{k}: {v*1e3:6.1f} us" for k, v in wres.items()))
+    lib.mednet_set_option(b"wgrad_v2", 1)
+    print("   wgrad v1/v2: " + " | ".join(f"v{k+1}: {v*1e3:6.1f} us {flop/v/1e9:6.1f} TF/s" for k, v in wres.items()))
     txt = " | ".join(f" {min(t for p, t in res if p == pv)*1e3:6.1f} us {flop/min(t for p, t in res if p == pv)/1e9:6.1f} TF/s" for pv in variants)
     print(f"conv {cin:3d}->{cout:3d} @{s:3d}^3 N={N}: fwd {txt} | wgrad {tw*1e3:7.1f} us {flop/tw/1e9:7.1f} TF/s", flush=True)
 

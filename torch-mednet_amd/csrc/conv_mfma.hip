@@ -784,6 +784,144 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
   }
 }
 
+// ---- weight gradient, second generation (stride 1): 8 waves, one workgroup per CU, 4x8x16 bricks ---------------------
+// Measured on the first kernel: its time is the per-brick staging (2.8x halo at 2x8x16, no overlap inside the
+// workgroup), not the MFMAs.  Here the brick is twice as deep (halo 2.1x, half the fixed cost per MFMA), the 32 k-steps
+// of a brick are split between two groups of 4 waves (each wave still owns 7 taps = 112 accumulator registers; the two
+// groups' partial sums are separate slabs for the reduce kernel), and with 512 threads the next brick fits in 13 staging
+// registers per lane, fetched with buffer loads (hardware zero padding) while the current brick is on the matrix cores.
+struct Wg2Args {
+  const bf16* A;
+  const bf16* B;
+  float* part;  // [wg][2 k-groups][27][32][32]
+  int n, d, h, w, ka, kb;
+  int tiles_z, tiles_y, tiles_x, ntiles;
+  int nab, nbb, splits;
+  unsigned bytesA, bytesB;
+};
+
+__global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
+  constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+  constexpr int NA = TZ * TY * TX, NB = HZ * HY * HX;
+  constexpr int A_ROUNDS = NA * 4 / 512, B_ROUNDS = (NB * 4 + 511) / 512;
+  constexpr int KSTEPS = NA / 16;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* A_lds = reinterpret_cast<bf16*>(smem);
+  bf16* B_lds = reinterpret_cast<bf16*>(smem) + NA * 32;
+
+  const int pair = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
+  const int ab = pair / a.nbb, bb = pair % a.nbb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
+  const int kgrp = wvu >> 2, tw = wvu & 3;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, hk = lane >> 5;
+  const int coloff = (16 * (g & 1) + 4 * p) * 2;
+
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, a.bytesA, 0x00020000);
+  const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, a.bytesB, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  u32x4 regA[A_ROUNDS], regB[B_ROUNDS];
+  auto fetch = [&](int tile) {
+    int tt = tile;
+    const int tx0 = (tt % a.tiles_x) * TX;
+    tt /= a.tiles_x;
+    const int ty0 = (tt % a.tiles_y) * TY;
+    tt /= a.tiles_y;
+    const int tz0 = (tt % a.tiles_z) * TZ;
+    const int n = tt / a.tiles_z;
+#pragma unroll
+    for (int it = 0; it < A_ROUNDS; ++it) {
+      const int c = it * 512 + tid;
+      const int v = c >> 2, part = c & 3;
+      const int gz = tz0 + v / (TX * TY), gy = ty0 + (v / TX) % TY, gx = tx0 + v % TX;
+      const bool in_vol = gz < a.d && gy < a.h && gx < a.w;
+      const unsigned off = in_vol ? (unsigned)((((n * a.d + gz) * a.h + gy) * a.w + gx) * a.ka + ab * 32 + part * 8) * 2u : OOB;
+      regA[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < B_ROUNDS; ++it) {
+      const int c = it * 512 + tid;
+      const int v = c >> 2, part = c & 3;
+      const int gz = tz0 - 1 + v / (HX * HY), gy = ty0 - 1 + (v / HX) % HY, gx = tx0 - 1 + v % HX;
+      const bool in_vol = c < NB * 4 && gz >= 0 && gz < a.d && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+      const unsigned off = in_vol ? (unsigned)((((n * a.d + gz) * a.h + gy) * a.w + gx) * a.kb + bb * 32 + part * 8) * 2u : OOB;
+      regB[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, 0, 0);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_ROUNDS; ++it) *reinterpret_cast<u32x4*>(A_lds + (it * 512 + tid) * 8) = regA[it];
+#pragma unroll
+    for (int it = 0; it < B_ROUNDS; ++it) {
+      const int c = it * 512 + tid;
+      if (c < NB * 4) *reinterpret_cast<u32x4*>(B_lds + c * 8) = regB[it];
+    }
+  };
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  const char* Ab = reinterpret_cast<const char*>(A_lds) + coloff;
+  const char* Bb = reinterpret_cast<const char*>(B_lds) + coloff;
+  int toff[7];  // tap offsets live in SGPRs; the wave with 6 taps recomputes tap 26 in its 7th slot (discarded)
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = tw + 4 * i < 27 ? tw + 4 * i : 26;
+    toff[i] = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 64;
+  }
+
+  int tile = split;
+  if (tile < a.ntiles) fetch(tile);
+  for (; tile < a.ntiles; tile += a.splits) {
+    __syncthreads();  // previous brick fully consumed
+    commit();
+    __syncthreads();
+    if (tile + a.splits < a.ntiles) fetch(tile + a.splits);  // flies while this brick is on the matrix cores
+    for (int k2 = 0; k2 < KSTEPS / 2; ++k2) {
+      const int ks = 2 * k2 + kgrp;  // the two wave groups interleave the brick's k-steps
+      const bf16x8 fa = tr_operand(Ab + (ks * TX + 8 * hk + q) * 64, 4 * 64);
+      const char* brow = Bb + (((ks / TY) * HY + ks % TY) * HX + 8 * hk + q) * 64;
+      bf16x8 fb[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) fb[i] = tr_operand(brow + toff[i], 4 * 64);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[i], acc[i], 0, 0, 0);
+    }
+  }
+  float* out = a.part + ((size_t)blockIdx.x * 2 + kgrp) * 27 * 1024;
+  const int col = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = tw + 4 * i;
+    if (tap < 27) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) out[((size_t)tap * 32 + (j & 3) + 8 * (j >> 2) + 4 * hk) * 32 + col] = acc[i][j];
+    }
+  }
+}
+
+static void wgrad2_plan(int n, int d, int h, int w, int ka, int kb, Wg2Args& a) {
+  a.tiles_z = (d + 3) / 4;
+  a.tiles_y = (h + 7) / 8;
+  a.tiles_x = (w + 15) / 16;
+  a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
+  a.nab = ka / 32;
+  a.nbb = kb / 32;
+  const int pairs = a.nab * a.nbb;
+  int splits = (256 + pairs - 1) / pairs;  // one workgroup per CU
+  if (splits > a.ntiles) splits = a.ntiles;
+  if (splits < 1) splits = 1;
+  a.splits = splits;
+}
+static size_t wgrad2_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  Wg2Args a;
+  wgrad2_plan(n, d, h, w, cout, cin, a);
+  return (size_t)a.nab * a.nbb * a.splits * 2 * 27 * 1024 * sizeof(float);
+}
+
 // dw[(a*KB + b)*27 + tap] = sum_split part[(pair*splits + split)][tap][a%32][b%32]
 __global__ __launch_bounds__(256) void wgrad_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                 int ka, int kb, int nbb, int splits) {
@@ -836,7 +974,9 @@ size_t wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ks
   if (ksize != 3 || cin % 32 || cout % 32) return 0;
   WgArgs a;
   wgrad_plan<1>(n, d, h, w, cout, cin, a);
-  return (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+  const size_t v1 = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+  const size_t v2 = wgrad2_ws_bytes(n, d, h, w, cin, cout);
+  return v1 > v2 ? v1 : v2;
 }
 
 template <int STRIDE>
@@ -877,7 +1017,32 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
                       void* ws, size_t ws_bytes, hipStream_t s) {
   (void)dtype;
   // conv: A = dy (Cout rows), B = x (Cin cols) shifted by tap - 1
-  return launch_wg<1>(dy, x, dw, n, d, h, w, d, h, w, cout, cin, ws, ws_bytes, s);
+  if (!tuning_option("wgrad_v2", 1)) return launch_wg<1>(dy, x, dw, n, d, h, w, d, h, w, cout, cin, ws, ws_bytes, s);
+  constexpr size_t lds = ((size_t)4 * 8 * 16 + 6 * 10 * 18) * 64;
+  Wg2Args a;
+  a.A = (const bf16*)dy;
+  a.B = (const bf16*)x;
+  a.part = (float*)ws;
+  a.n = n; a.d = d; a.h = h; a.w = w; a.ka = cout; a.kb = cin;
+  wgrad2_plan(n, d, h, w, cout, cin, a);
+  a.bytesA = (unsigned)((size_t)n * d * h * w * cout * 2);
+  a.bytesB = (unsigned)((size_t)n * d * h * w * cin * 2);
+  const size_t need = (size_t)a.nab * a.nbb * a.splits * 2 * 27 * 1024 * sizeof(float);
+  MEDNET_REQUIRE(ws_bytes >= need, MEDNET_E_WORKSPACE, "wgrad_mfma2: workspace %zu < %zu", ws_bytes, need);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wgrad_mfma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(MEDNET_E_HIP, "wgrad_mfma2: cannot raise dynamic LDS to %zu", lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_mfma2_kernel, dim3(a.nab * a.nbb * a.splits), dim3(512), lds, s, a);
+  int rc = check_launch("wgrad_mfma2");
+  if (rc) return rc;
+  const size_t total = (size_t)cout * cin * 27;
+  // the reduce kernel sees the two k-groups of a workgroup as two consecutive splits
+  hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, cout, cin,
+                     a.nbb, a.splits * 2);
+  return check_launch("wgrad_mfma_reduce");
 }
 
 size_t convt_wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout) {

@@ -1,0 +1,144 @@
+"""ExtResNetBlock as ONE autograd node (midasmednet/unet/components.py:136-180).
+
+    z1 = act(GN1(conv1(x)));  z2 = act(GN2(conv2(z1)));  out = act(GN3(conv3(z2)) + z1)
+
+Hand-written backward over the C ABI instead of 9 chained autograd nodes: the post-activation tensor z1 has two consumers
+(conv2 and the residual add), so autograd would materialise both gradients and sum them with an ATen kernel (3 full-size
+tensor passes per block).  Here GroupNorm-1's backward reads the two gradient streams directly (`dz2` operand of
+mednet_gn_act_bwd), the weight gradients go to the side stream exactly as in the per-op path, and nothing but
+libmednet_hip kernels runs between the block's input and output.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+import os
+
+from . import _lib as L
+from . import config, ops
+
+ENABLED = os.environ.get("MEDNET_BLOCK_NODE", "1") == "1"
+WGRAD_FIRST = os.environ.get("MEDNET_WGRAD_FIRST", "1") == "1"  # A/B knob: launch order of the two gradients
+
+
+def _conv_fwd(x, packed, cout, want_stats):
+    n, cin, d, h, w = x.shape
+    lib = L.lib()
+    y = ops.empty_cl(n, cout, d, h, w, config.act_dtype(), x.device)
+    partial = None
+    if want_stats:
+        chunks = lib.mednet_conv3d_fused_stats_chunks(d, h, w, cin, cout, 3, L.dt(x), L.dt(y), config.conv_algo())
+        if chunks > 0:
+            partial = torch.empty((n, chunks, cout, 2), dtype=torch.float32, device=x.device)
+    L.check(lib.mednet_conv3d_fwd(x.data_ptr(), packed.data_ptr(), None, y.data_ptr(), n, d, h, w, cin, cout, 3, L.dt(x),
+                                  L.NDHWC, L.dt(y), L.NDHWC, 0, config.conv_algo(), L.ptr(partial), L.stream()), "conv3d_fwd")
+    return y, partial
+
+
+def _gn_fwd(y, partial, gamma, beta, groups, eps, act, residual):
+    n, c, d, h, w = y.shape
+    spatial = d * h * w
+    lib = L.lib()
+    stats = torch.empty((n, groups, 2), dtype=torch.float32, device=y.device)
+    coef = torch.empty((n, c, 2), dtype=torch.float32, device=y.device)
+    ws = L.workspace(lib.mednet_gn_ws_bytes(n, c, spatial), y.device)
+    if partial is not None:
+        L.check(lib.mednet_gn_finalize(partial.data_ptr(), partial.shape[1], gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(),
+                                       coef.data_ptr(), n, spatial, c, groups, eps, ws.data_ptr(), ws.numel(), L.stream()),
+                "gn_finalize")
+    else:
+        L.check(lib.mednet_gn_stats(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), coef.data_ptr(), n,
+                                    spatial, c, groups, eps, L.dt(y), ws.data_ptr(), ws.numel(), L.stream()), "gn_stats")
+    z = torch.empty_like(y, memory_format=ops.CL)
+    L.check(lib.mednet_gn_act_fwd(y.data_ptr(), coef.data_ptr(), L.ptr(residual), z.data_ptr(), n, spatial, c, act, L.dt(y),
+                                  L.dt(z), L.stream()), "gn_act_fwd")
+    return z, stats, coef
+
+
+def _gn_bwd(dz, dz2, y, z, coef, stats, gamma_p, beta_p, groups, act, want_dres):
+    """Returns (dy, dres, dgamma, dbeta, direct flags)."""
+    n, c, d, h, w = y.shape
+    spatial = d * h * w
+    lib = L.lib()
+    dy = torch.empty_like(y, memory_format=ops.CL)
+    dres = torch.empty_like(y, memory_format=ops.CL) if want_dres else None
+    dgamma, dg_direct = ops._grad_target(gamma_p, (c,))
+    dbeta, db_direct = ops._grad_target(beta_p, (c,))
+    ws = L.workspace(lib.mednet_gn_ws_bytes(n, c, spatial), y.device)
+    L.check(lib.mednet_gn_act_bwd(dz.data_ptr(), L.ptr(dz2), y.data_ptr(), L.ptr(z), coef.data_ptr(), stats.data_ptr(),
+                                  gamma_p.data_ptr(), dy.data_ptr(), L.ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n,
+                                  spatial, c, groups, act, L.dt(y), ws.data_ptr(), ws.numel(), L.stream()), "gn_act_bwd")
+    return dy, dres, (None if dg_direct else dgamma), (None if db_direct else dbeta)
+
+
+def _conv_bwd(x, dy, packed, weight_p, need_dx):
+    """Weight gradient (side stream in trainer mode) + data gradient.  Returns (dx, dw-or-None)."""
+    n, cin, d, h, w = x.shape
+    cout = dy.shape[1]
+    lib = L.lib()
+    # data gradient first (critical path), THEN the weight gradient on the side stream: queued behind the data gradient it
+    # overlaps the next GroupNorm backward (HBM-bound) instead of fighting the data gradient for the matrix cores
+    dx = None
+
+    def dgrad():
+        nonlocal dx
+        if need_dx:
+            dx = ops.empty_cl(n, cin, d, h, w, x.dtype if x.dtype in (torch.float32, torch.bfloat16) else config.act_dtype(), dy.device)
+            L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin, 3,
+                                          L.dt(dy), L.NDHWC, L.dt(dx), L.NDHWC, 1, config.conv_algo(), None, L.stream()),
+                    "conv3d_dgrad")
+
+    if not WGRAD_FIRST:
+        dgrad()
+    dw, direct = ops._grad_target(weight_p, (cout, cin, 3, 3, 3))
+    with ops._OnSide(ops.SIDE["enabled"] and direct, dy.device, x, dy):
+        ws = L.workspace(lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, 3), dy.device)
+        L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, n, d, h, w, cin, cout, 3, L.dt(x),
+                                        L.NDHWC, L.dt(dy), L.NDHWC, config.conv_algo(), ws.data_ptr(), ws.numel(), L.stream()),
+                "conv3d_wgrad")
+    if WGRAD_FIRST:
+        dgrad()
+    return dx, (None if direct else dw)
+
+
+class ResBlockFn(Function):
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, pk1, pk2, pk3, groups, eps, act):
+        L.require_gpu(x, "ExtResNetBlock")
+        x = ops._as_act(x)
+        xin = x.contiguous() if x.shape[1] == 1 else ops.to_cl(x)  # Cin == 1: NCDHW and NDHWC coincide
+        cout = w1.shape[0]
+        y1, p1 = _conv_fwd(xin, pk1, cout, True)
+        z1, s1, c1 = _gn_fwd(y1, p1, g1, b1, groups, eps, act, None)
+        y2, p2 = _conv_fwd(z1, pk2, cout, True)
+        z2, s2, c2 = _gn_fwd(y2, p2, g2, b2, groups, eps, act, None)
+        y3, p3 = _conv_fwd(z2, pk3, cout, True)
+        out, s3, c3 = _gn_fwd(y3, p3, g3, b3, groups, eps, act, z1)
+        ctx.save_for_backward(xin, y1, z1, y2, z2, y3, out, s1, c1, s2, c2, s3, c3, pk1, pk2, pk3)
+        ctx.params = (w1, g1, b1, w2, g2, b2, w3, g3, b3)
+        ctx.meta = (groups, act)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xin, y1, z1, y2, z2, y3, out, s1, c1, s2, c2, s3, c3, pk1, pk2, pk3 = ctx.saved_tensors
+        w1, g1, b1, w2, g2, b2, w3, g3, b3 = ctx.params
+        groups, act = ctx.meta
+        dout = ops.to_cl(dout.to(out.dtype))
+        # GN3 + residual + activation: act' from the block output; dres = gradient of the residual branch (into z1)
+        dy3, dres, dg3, db3 = _gn_bwd(dout, None, y3, out, c3, s3, g3, b3, groups, act, True)
+        dz2, dw3 = _conv_bwd(z2, dy3, pk3, w3, True)
+        dy2, _, dg2, db2 = _gn_bwd(dz2, None, y2, None, c2, s2, g2, b2, groups, act, False)
+        dz1, dw2 = _conv_bwd(z1, dy2, pk2, w2, True)
+        # z1 feeds conv2 AND the residual add: both gradient streams are summed inside GroupNorm-1's backward
+        dy1, _, dg1, db1 = _gn_bwd(dz1, dres, y1, None, c1, s1, g1, b1, groups, act, False)
+        dx, dw1 = _conv_bwd(xin, dy1, pk1, w1, ctx.needs_input_grad[0])
+        return (dx, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + (None,) * 6
+
+
+def res_block(x, convs, norms, groups, eps, act):
+    """convs / norms: the three mednet_hip.nn.Conv3d / GroupNorm modules of the block."""
+    (k1, k2, k3), (n1, n2, n3) = convs, norms
+    return ResBlockFn.apply(x, k1.weight, n1.weight, n1.bias, k2.weight, n2.weight, n2.bias, k3.weight, n3.weight, n3.bias,
+                            k1._packed(), k2._packed(), k3._packed(), groups, eps, act)

@@ -161,6 +161,11 @@ class Conv3dFn(Function):
         dy = dy.contiguous() if out_planar else to_cl(dy)
         lib = L.lib()
         dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_cl(n, cin, d, h, w, x_dtype, dy.device)
+            L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin,
+                                          ksize, L.dt(dy), L.NCDHW if out_planar else L.NDHWC, L.dt(dx), L.NDHWC, 1,
+                                          config.conv_algo(), None, L.stream()), "conv3d_dgrad")
         direct_w = direct_b = False
         if ctx.needs_input_grad[1]:
             weight, bias = ctx.params
@@ -175,11 +180,6 @@ class Conv3dFn(Function):
                                                 cout, ksize, L.dt(xin), L.NDHWC, L.dt(dy),
                                                 L.NCDHW if out_planar else L.NDHWC, config.conv_algo(), ws.data_ptr(),
                                                 ws.numel(), L.stream()), "conv3d_wgrad")
-        if ctx.needs_input_grad[0]:
-            dx = empty_cl(n, cin, d, h, w, x_dtype, dy.device)
-            L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin,
-                                          ksize, L.dt(dy), L.NCDHW if out_planar else L.NDHWC, L.dt(dx), L.NDHWC, 1,
-                                          config.conv_algo(), None, L.stream()), "conv3d_dgrad")
         return dx, (None if direct_w else dw), (None if direct_b else db), None, None, None, None, None
 
 
@@ -225,6 +225,10 @@ class ConvT3dFn(Function):
         dy = to_cl(dy)
         lib = L.lib()
         dx = dw = db = dskip = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_cl(n, cin, d, h, w, x.dtype, dy.device)
+            L.check(lib.mednet_convt3d_dgrad(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), n, d, h, w, cin, cout,
+                                             L.dt(dy), L.dt(dx), config.conv_algo(), L.stream()), "convt3d_dgrad")
         direct_w = direct_b = False
         if ctx.needs_input_grad[1]:
             weight, bias = ctx.params
@@ -237,10 +241,6 @@ class ConvT3dFn(Function):
                 L.check(lib.mednet_convt3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), n, d, h, w, cin, cout,
                                                  L.dt(x), L.dt(dy), config.conv_algo(), ws.data_ptr(), ws.numel(), L.stream()),
                         "convt3d_wgrad")
-        if ctx.needs_input_grad[0]:
-            dx = empty_cl(n, cin, d, h, w, x.dtype, dy.device)
-            L.check(lib.mednet_convt3d_dgrad(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), n, d, h, w, cin, cout,
-                                             L.dt(dy), L.dt(dx), config.conv_algo(), L.stream()), "convt3d_dgrad")
         if has_skip and ctx.needs_input_grad[3]:
             dskip = dy if dy.dtype == skip_dtype else dy.to(skip_dtype)
         return dx, (None if direct_w else dw), (None if direct_b else db), dskip, None

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from .. import block
 from .. import nn as hnn
 from .. import ops
 
@@ -116,7 +117,29 @@ class ExtResNetBlock(nn.Module):
         key = "l" if "l" in order else ("e" if "e" in order else "r")
         self.non_linearity = _ACT_MODULES[key][1](inplace=True)
 
+    def _plain(self):
+        """(convs, norms) when the block is 3 x [3^3 conv without bias -> GroupNorm (-> activation)] with one group count:
+        the shape every caller of the reference builds ('cge' and friends) and the one the single-node path takes."""
+        convs, norms = [], []
+        for sc, want_act in ((self.conv1, True), (self.conv2, True), (self.conv3, False)):
+            mods = list(sc._modules.values())
+            if len(mods) != (3 if want_act else 2) or not isinstance(mods[0], hnn.Conv3d) or not isinstance(mods[1], hnn.GroupNorm):
+                return None
+            if want_act and (not isinstance(mods[2], hnn._Act) or mods[2].code != self.non_linearity.code):
+                return None
+            if mods[0].bias is not None or mods[0].kernel_size[0] != 3 or not mods[1].affine:
+                return None
+            convs.append(mods[0])
+            norms.append(mods[1])
+        if len({m.num_groups for m in norms}) != 1 or len({m.eps for m in norms}) != 1:
+            return None
+        return convs, norms
+
     def forward(self, x):
+        plain = self._plain() if (x.is_cuda and block.ENABLED) else None
+        if plain is not None:
+            convs, norms = plain
+            return block.res_block(x, convs, norms, norms[0].num_groups, norms[0].eps, self.non_linearity.code)
         residual = self.conv1(x)
         out = self.conv2(residual)
         return self.conv3(out, residual=residual, final_act=self.non_linearity.code)
