@@ -282,6 +282,31 @@ __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const T* __res
     for (size_t v = v0 + threadIdx.x; v < v1; v += 256) s += ld(p, v);
     s = block_sum<4>(s, scratch);
     if (threadIdx.x == 0) part[((size_t)n * gridDim.x + blockIdx.x) * c + ch] = s;
+  } else if (c % 8 == 0 && c <= 2048) {
+    // a lane owns 8 consecutive channels (one 16-byte load per voxel); rows = 256 / (c/8) voxel rows per trip
+    const int cols = c / 8, rows = 256 / cols, row = threadIdx.x / cols, col = threadIdx.x % cols;
+    const bool active = row < rows;
+    const size_t per = CS_ITEMS / c;
+    const size_t b0 = (size_t)blockIdx.x * per;
+    const size_t b1 = b0 + per < spatial ? b0 + per : spatial;
+    float s8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s8[k] = 0.f;
+    if (active)
+      for (size_t v = b0 + row; v < b1; v += rows) {
+        const F8 xv = ld8(x, ((size_t)n * spatial + v) * c + (size_t)col * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s8[k] += xv.v[k];
+      }
+    __shared__ float red[256 * 8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = active ? s8[k] : 0.f;
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+      float t = 0.f;
+      for (int r = 0; r < rows; ++r) t += red[(r * cols + ch / 8) * 8 + ch % 8];
+      part[((size_t)n * gridDim.x + blockIdx.x) * c + ch] = t;
+    }
   } else if (c <= 256) {
     // thread t owns channel t % c; rows = 256 / c voxel rows are active
     const int rows = 256 / c, row = threadIdx.x / c, ch = threadIdx.x % c;
@@ -323,7 +348,7 @@ __global__ __launch_bounds__(64) void channel_sum_final_kernel(const float* __re
 
 size_t channel_sum_ws_bytes(int n, size_t spatial, int c) {
   const size_t chunks_planar = (spatial + CS_ITEMS - 1) / CS_ITEMS;
-  const size_t per = CS_ITEMS / (c < 256 ? c : 256);
+  const size_t per = (c % 8 == 0 && c <= 2048) ? CS_ITEMS / c : CS_ITEMS / (c < 256 ? c : 256);
   const size_t chunks_cl = (spatial + per - 1) / per;
   const size_t chunks = chunks_planar > chunks_cl ? chunks_planar : chunks_cl;
   return (size_t)n * chunks * c * sizeof(float) + 256;
@@ -332,7 +357,7 @@ size_t channel_sum_ws_bytes(int n, size_t spatial, int c) {
 int launch_channel_sum(const void* x, float* out, int n, size_t spatial, int c, int planar, int dtype, void* ws,
                        size_t ws_bytes, hipStream_t s) {
   MEDNET_REQUIRE(ws_bytes >= channel_sum_ws_bytes(n, spatial, c), MEDNET_E_WORKSPACE, "channel_sum: workspace too small");
-  const size_t per = planar ? CS_ITEMS : CS_ITEMS / (c < 256 ? c : 256);
+  const size_t per = planar ? CS_ITEMS : ((c % 8 == 0 && c <= 2048) ? CS_ITEMS / c : CS_ITEMS / (c < 256 ? c : 256));
   const unsigned chunks = (unsigned)((spatial + per - 1) / per);
   const dim3 grid(chunks, planar ? c : 1, n);
   float* part = (float*)ws;

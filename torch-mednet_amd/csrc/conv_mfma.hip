@@ -543,8 +543,11 @@ int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d,
 // mode 1: conv dgrad    Weff[m][k][t] = W[k][m][26-t]                           M=Cin  K=Cout
 // mode 2: convT fwd     Weff[m][k][t] = Wt[k][m][t]           (Wt: Cin,Cout,27) M=Cout K=Cin
 // mode 3: convT dgrad   Weff[m][k][t] = Wt[m][k][t]                             M=Cin  K=Cout
-__global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict__ w, bf16* __restrict__ out, int M, int K,
-                                                        int mode) {
+__global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict__ w, bf16* __restrict__ out0,
+                                                        bf16* __restrict__ out1, int M0, int K0, int mode0, int mode1) {
+  // blockIdx.y = 0: forward image (M0 x K0), 1: data-gradient image (K0 x M0): one launch for both
+  const int M = blockIdx.y ? K0 : M0, K = blockIdx.y ? M0 : K0, mode = blockIdx.y ? mode1 : mode0;
+  bf16* out = blockIdx.y ? out1 : out0;
   const size_t total = (size_t)M * K * 27;
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
@@ -587,10 +590,10 @@ int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, int cin, int 
                      hipStream_t s) {
   if (T != 27) return MEDNET_OK;
   const size_t total = (size_t)cin * cout * 27;
-  const dim3 grid((unsigned)((total + 255) / 256));
+  const dim3 grid((unsigned)((total + 255) / 256), 2);
   // forward image: M = cout, K = cin; backward (data-gradient) image: M = cin, K = cout
-  hipLaunchKernelGGL(pack_mfma_kernel, grid, dim3(256), 0, s, w, (bf16*)sec_fwd, cout, cin, transposed_src ? 2 : 0);
-  hipLaunchKernelGGL(pack_mfma_kernel, grid, dim3(256), 0, s, w, (bf16*)sec_bwd, cin, cout, transposed_src ? 3 : 1);
+  hipLaunchKernelGGL(pack_mfma_kernel, grid, dim3(256), 0, s, w, (bf16*)sec_fwd, (bf16*)sec_bwd, cout, cin,
+                     transposed_src ? 2 : 0, transposed_src ? 3 : 1);
   return check_launch("pack_mfma");
 }
 

@@ -133,22 +133,35 @@ __global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __rest
   }
 }
 
-// stage 2: one wave per (n, g): mean, rstd; then the per-channel affine the apply kernel uses.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ csum,
-                                                         const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float* __restrict__ stats,
-                                                         float* __restrict__ coef, int c, int groups, double count,
-                                                         float eps) {
+// one 256-thread workgroup per (n, g): its 4 waves split the group's channels, each wave sums a channel's per-chunk
+// partials (fp64, fixed order); then mean, rstd and the per-channel affine the apply kernel uses.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ stats,
+                                                          float* __restrict__ coef, int c, int groups, int chunks,
+                                                          double count, float eps) {
+  __shared__ double sh[2][4];
   const int n = blockIdx.x / groups, g = blockIdx.x % groups;
-  const int cg = c / groups;
+  const int cg = c / groups, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double s = 0.0, q = 0.0;
-  for (int i = threadIdx.x; i < cg; i += 64) {
-    const float* p = csum + ((size_t)n * c + g * cg + i) * 2;
-    s += (double)p[0];
-    q += (double)p[1];
+  for (int i = wv; i < cg; i += 4) {
+    const int cc = g * cg + i;
+    double a = 0.0, b = 0.0;
+    for (int ch = lane; ch < chunks; ch += 64) {
+      const float* p = partial + (((size_t)n * chunks + ch) * c + cc) * 2;
+      a += (double)p[0];
+      b += (double)p[1];
+    }
+    s += wave_sum(a);
+    q += wave_sum(b);
   }
-  s = wave_sum(s);
-  q = wave_sum(q);
+  if (lane == 0) {
+    sh[0][wv] = s;
+    sh[1][wv] = q;
+  }
+  __syncthreads();
+  s = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+  q = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
   const double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     stats[((size_t)n * groups + g) * 2] = (float)mean;
     stats[((size_t)n * groups + g) * 2 + 1] = rstd;
   }
-  for (int i = threadIdx.x; i < cg; i += 64) {
+  for (int i = threadIdx.x; i < cg; i += 256) {
     const int cc = g * cg + i;
     const float ga = gamma ? gamma[cc] : 1.f, be = beta ? beta[cc] : 0.f;
     const float a = ga * rstd;
@@ -643,10 +656,8 @@ extern "C" int mednet_gn_stats(const void* x, const float* gamma, const float* b
 #undef GO
   int rc = check_launch("gn_partial");
   if (rc) return rc;
-  float* csum = partial + (size_t)n * 1024 * c * 2 + (size_t)n * c * 3;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n * c), dim3(64), 0, s, partial, csum, c, (int)chunks);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, gamma, beta, stats, coef, c, groups,
-                     (double)spatial * (c / groups), eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n * groups), dim3(256), 0, s, partial, gamma, beta, stats, coef, c, groups,
+                     (int)chunks, (double)spatial * (c / groups), eps);
   return check_launch("gn_finalize");
 }
 
@@ -654,11 +665,10 @@ extern "C" int mednet_gn_finalize(const float* partial, int chunks, const float*
                                   float* coef, int n, size_t spatial, int c, int groups, float eps, void* ws,
                                   size_t ws_bytes, mednet_stream stream) {
   MEDNET_REQUIRE(n > 0 && c > 0 && groups > 0 && c % groups == 0 && chunks > 0, MEDNET_E_SHAPE, "gn_finalize: bad shape");
-  MEDNET_REQUIRE(ws_bytes >= (size_t)n * c * 2 * sizeof(float), MEDNET_E_WORKSPACE, "gn_finalize: workspace too small");
+  (void)ws;
+  (void)ws_bytes;
   hipStream_t s = (hipStream_t)stream;
-  float* csum = (float*)ws;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n * c), dim3(64), 0, s, partial, csum, c, chunks);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, gamma, beta, stats, coef, c, groups,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n * groups), dim3(256), 0, s, partial, gamma, beta, stats, coef, c, groups, chunks,
                      (double)spatial * (c / groups), eps);
   return check_launch("gn_finalize");
 }
