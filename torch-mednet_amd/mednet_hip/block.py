@@ -31,8 +31,9 @@ def _conv_fwd(x, packed, cout, want_stats):
         chunks = lib.mednet_conv3d_fused_stats_chunks(d, h, w, cin, cout, 3, L.dt(x), L.dt(y), config.conv_algo())
         if chunks > 0:
             partial = torch.empty((n, chunks, cout, 2), dtype=torch.float32, device=x.device)
-    L.check(lib.mednet_conv3d_fwd(x.data_ptr(), packed.data_ptr(), None, y.data_ptr(), n, d, h, w, cin, cout, 3, L.dt(x),
-                                  L.NDHWC, L.dt(y), L.NDHWC, 0, config.conv_algo(), L.ptr(partial), L.stream()), "conv3d_fwd")
+    with ops.profiled_conv(3, cin, cout, n, d, h, w):
+        L.check(lib.mednet_conv3d_fwd(x.data_ptr(), packed.data_ptr(), None, y.data_ptr(), n, d, h, w, cin, cout, 3, L.dt(x),
+                                      L.NDHWC, L.dt(y), L.NDHWC, 0, config.conv_algo(), L.ptr(partial), L.stream()), "conv3d_fwd")
     return y, partial
 
 

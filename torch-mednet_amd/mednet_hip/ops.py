@@ -66,6 +66,26 @@ class _OnSide:
         return False
 
 
+class profiled_conv:
+    """bench.py's live timing of the dominant kernel: HIP events on the launch stream around matching conv launches."""
+
+    def __init__(self, ksize, cin, cout, n, d, h, w):
+        self.on = PROFILE["enabled"] and PROFILE["match"] is not None and PROFILE["match"](ksize, cin, cout, d, h, w)
+        self.flops = 2.0 * n * d * h * w * cin * cout * ksize ** 3
+
+    def __enter__(self):
+        if self.on:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            PROFILE["events"].append((self.e0, self.e1, self.flops))
+        return False
+
+
 def _grad_target(param, shape):
     """Trainer hook (train.FlatParams): when a Parameter carries `_mednet_grad` (a contiguous fp32 view into the flat
     gradient buffer) the kernels write the gradient there and autograd gets None -> no copy / accumulate kernels."""
@@ -127,22 +147,16 @@ class Conv3dFn(Function):
             y = torch.empty((n, cout, d, h, w), dtype=out_dtype, device=x.device)
         else:
             y = empty_cl(n, cout, d, h, w, out_dtype, x.device)
-        prof = PROFILE["enabled"] and PROFILE["match"] is not None and PROFILE["match"](ksize, cin, cout, d, h, w)
-        if prof:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         # GroupNorm partial sums from the conv epilogue (when the MFMA kernel takes this call): saves a pass over y
         partial = None
         if want_stats and bias is None and not out_planar:
             chunks = L.lib().mednet_conv3d_fused_stats_chunks(d, h, w, cin, cout, ksize, L.dt(xin), L.dt(y), config.conv_algo())
             if chunks > 0:
                 partial = torch.empty((n, chunks, cout, 2), dtype=torch.float32, device=x.device)
-        L.check(L.lib().mednet_conv3d_fwd(xin.data_ptr(), packed.data_ptr(), L.ptr(bias), y.data_ptr(), n, d, h, w, cin,
-                                          cout, ksize, L.dt(xin), L.NDHWC, L.dt(y), L.NCDHW if out_planar else L.NDHWC,
-                                          0, config.conv_algo(), L.ptr(partial), L.stream()), "conv3d_fwd")
-        if prof:
-            e1.record()
-            PROFILE["events"].append((e0, e1, 2.0 * n * d * h * w * cin * cout * ksize ** 3))
+        with profiled_conv(ksize, cin, cout, n, d, h, w):
+            L.check(L.lib().mednet_conv3d_fwd(xin.data_ptr(), packed.data_ptr(), L.ptr(bias), y.data_ptr(), n, d, h, w, cin,
+                                              cout, ksize, L.dt(xin), L.NDHWC, L.dt(y), L.NCDHW if out_planar else L.NDHWC,
+                                              0, config.conv_algo(), L.ptr(partial), L.stream()), "conv3d_fwd")
         ctx.save_for_backward(xin, packed)
         ctx.meta = (ksize, out_planar, cin, cout, bias is not None, x.dtype)
         ctx.params = (weight, bias)
