@@ -343,6 +343,10 @@ def _conv_case(n, cin, cout, shape, tag):
     (1, 128, 128, (5, 6, 7)),     # volume smaller than a brick
     (1, 256, 256, (4, 4, 4)),
     (2, 64, 64, (16, 16, 16)),
+    (2, 16, 32, (9, 11, 21)),     # 16-channel sides (UNet3D's first DoubleConv): one k-step / half a channel block
+    (1, 32, 16, (8, 8, 16)),
+    (1, 16, 16, (5, 9, 17)),
+    (1, 48, 80, (4, 8, 16)),      # any multiple of 16: the last channel block is half full
 ])
 def test_conv3d_mfma_fwd_dgrad_wgrad(n, cin, cout, shape):
     """The bf16 MFMA kernels (forced) against the fp32 oracle AND against the direct kernels on identical bf16 inputs

@@ -184,7 +184,7 @@ extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float
   int rc = conv_common_checks("convt3d_fwd", n, d, h, w, cin, cout, 3, x_dtype, y_dtype);
   if (rc) return rc;
   const PackLayout L = pack_layout(cin, cout, 3);
-  const bool mfma_ok = L.mfma_bytes && x_dtype == MEDNET_BF16 && y_dtype == MEDNET_BF16;
+  const bool mfma_ok = L.mfma_bytes && cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && y_dtype == MEDNET_BF16;
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_fwd: MFMA path does not take cin=%d cout=%d", cin, cout);
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
@@ -202,7 +202,8 @@ extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx
   int rc = conv_common_checks("convt3d_dgrad", n, d, h, w, cin, cout, 3, dy_dtype, dx_dtype);
   if (rc) return rc;
   const PackLayout L = pack_layout(cin, cout, 3);
-  const bool mfma_ok = L.mfma_bytes && dy_dtype == MEDNET_BF16 && dx_dtype == MEDNET_BF16 && conv_mfma_fits(n, 2 * d, 2 * h, 2 * w, cout);
+  const bool mfma_ok = L.mfma_bytes && cin % 32 == 0 && cout % 32 == 0 && dy_dtype == MEDNET_BF16 && dx_dtype == MEDNET_BF16 &&
+                       conv_mfma_fits(n, 2 * d, 2 * h, 2 * w, cout);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_dgrad: MFMA path does not take cin=%d cout=%d", cin, cout);
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)

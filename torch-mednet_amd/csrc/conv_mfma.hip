@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     bf16x8 v = *reinterpret_cast<const bf16x8*>(out_lds + vl * 32 + (pj ^ (sw >> 1)) * 8);
     if (sw & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
     const int oz = tz0 + vl / (TY * TX), oy = ty0 + (vl / TX) % TY, ox = tx0 + vl % TX;
-    if (oz < a.od && oy < a.oh && ox < a.ow) {
+    if (oz < a.od && oy < a.oh && ox < a.ow && cb * 32 + pj * 8 < a.cout) {  // (a 16-channel layer fills half a block)
       *reinterpret_cast<bf16x8*>(a.y + ((size_t)n * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.cout + cb * 32 + pj * 8) = v;
       if (a.gn_partial) {
 #pragma unroll
@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       float tot = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) tot += st_lds[((k * 4 + (co >> 3)) * 8 + (co & 7)) * 2 + which];
-      a.gn_partial[(((size_t)n * tiles_per_sample + tis) * a.cout + cb * 32 + co) * 2 + which] = tot;
+      if (cb * 32 + co < a.cout)
+        a.gn_partial[(((size_t)n * tiles_per_sample + tis) * a.cout + cb * 32 + co) * 2 + which] = tot;
     }
   }
 }
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict_
   // blockIdx.y = 0: forward image (M0 x K0), 1: data-gradient image (K0 x M0): one launch for both
   const int M = blockIdx.y ? K0 : M0, K = blockIdx.y ? M0 : K0, mode = blockIdx.y ? mode1 : mode0;
   bf16* out = blockIdx.y ? out1 : out0;
-  const size_t total = (size_t)M * K * 27;
+  const size_t total = (size_t)((M + 31) / 32 * 32) * K * 27;  // rows beyond M (a 16-channel side) are zero padding
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   size_t q = e;
@@ -565,7 +566,8 @@ __global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict_
   const int cb = (int)(q / nkc);
   const int m = cb * 32 + co, k = kc * 16 + h * 8 + j;
   float v;
-  if (mode == 0) v = w[((size_t)m * K + k) * 27 + tap];
+  if (m >= M) v = 0.f;
+  else if (mode == 0) v = w[((size_t)m * K + k) * 27 + tap];
   else if (mode == 1) v = w[((size_t)k * M + m) * 27 + (26 - tap)];
   else if (mode == 2) v = w[((size_t)k * M + m) * 27 + tap];
   else v = w[((size_t)m * K + k) * 27 + tap];
@@ -578,18 +580,22 @@ PackLayout pack_layout(int cin, int cout, int ksize) {
   const size_t f32 = align_up((size_t)L.taps * cin * cout * sizeof(float), 256);
   L.f32_fwd = 0;
   L.f32_bwd = f32;
-  const bool mfma = ksize == 3 && cin % 32 == 0 && cout % 32 == 0;
-  L.mfma_bytes = mfma ? align_up((size_t)27 * cin * cout * sizeof(bf16), 256) : 0;
+  // the contraction side of an image needs a multiple of 16 (one MFMA k-step), its M side is padded to 32 rows
+  const bool mfma = ksize == 3 && cin % 16 == 0 && cout % 16 == 0;
+  const size_t fwd_bytes = mfma ? align_up((size_t)27 * ((cout + 31) / 32 * 32) * cin * sizeof(bf16), 256) : 0;
+  const size_t bwd_bytes = mfma ? align_up((size_t)27 * ((cin + 31) / 32 * 32) * cout * sizeof(bf16), 256) : 0;
+  L.mfma_bytes = fwd_bytes > bwd_bytes ? fwd_bytes : bwd_bytes;
   L.mfma_fwd = 2 * f32;
-  L.mfma_bwd = 2 * f32 + L.mfma_bytes;
-  L.total = 2 * f32 + 2 * L.mfma_bytes + 256;
+  L.mfma_bwd = 2 * f32 + fwd_bytes;
+  L.total = 2 * f32 + fwd_bytes + bwd_bytes + 256;
   return L;
 }
 
 int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, int cin, int cout, int T, int transposed_src,
                      hipStream_t s) {
   if (T != 27) return MEDNET_OK;
-  const size_t total = (size_t)cin * cout * 27;
+  const int cmax = cin > cout ? cin : cout, cmin = cin > cout ? cout : cin;
+  const size_t total = (size_t)((cmax + 31) / 32 * 32) * ((cmin + 31) / 32 * 32) * 27;  // covers both padded images
   const dim3 grid((unsigned)((total + 255) / 256), 2);
   // forward image: M = cout, K = cin; backward (data-gradient) image: M = cin, K = cout
   hipLaunchKernelGGL(pack_mfma_kernel, grid, dim3(256), 0, s, w, (bf16*)sec_fwd, (bf16*)sec_bwd, cout, cin,
@@ -600,7 +606,7 @@ int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, int cin, int 
 // the kernels address the activation tensor through a buffer resource with 32-bit byte offsets
 bool conv_mfma_fits(int n, int d, int h, int w, int c) { return (double)n * d * h * w * c * 2.0 < 4294960000.0; }
 bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int x_layout, int y_layout, bool bias) {
-  return ksize == 3 && cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && y_dtype == MEDNET_BF16 &&
+  return ksize == 3 && cin % 16 == 0 && cout % 16 == 0 && x_dtype == MEDNET_BF16 && y_dtype == MEDNET_BF16 &&
          x_layout == MEDNET_NDHWC && y_layout == MEDNET_NDHWC && !bias;
 }
 
@@ -623,7 +629,7 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   a.tiles_x = (ow + G::TX - 1) / G::TX;
   a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
   a.nkc = cin / 16;
-  a.ncb = cout / 32;
+  a.ncb = (cout + 31) / 32;
   a.bytes_x = (unsigned)((size_t)n * id * ih * iw * cin * 2);
   const unsigned grid = (unsigned)((a.ntiles + 7) / 8) * 8 * a.ncb;
   static bool attr_set[3] = {false, false, false};
@@ -838,7 +844,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
       const int c = it * 512 + tid;
       const int v = c >> 2, part = c & 3;
       const int gz = tz0 + v / (TX * TY), gy = ty0 + (v / TX) % TY, gx = tx0 + v % TX;
-      const bool in_vol = gz < a.d && gy < a.h && gx < a.w;
+      const bool in_vol = gz < a.d && gy < a.h && gx < a.w && ab * 32 + part * 8 < a.ka;
       const unsigned off = in_vol ? (unsigned)((((n * a.d + gz) * a.h + gy) * a.w + gx) * a.ka + ab * 32 + part * 8) * 2u : OOB;
       regA[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0);
     }
@@ -847,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
       const int c = it * 512 + tid;
       const int v = c >> 2, part = c & 3;
       const int gz = tz0 - 1 + v / (HX * HY), gy = ty0 - 1 + (v / HX) % HY, gx = tx0 - 1 + v % HX;
-      const bool in_vol = c < NB * 4 && gz >= 0 && gz < a.d && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+      const bool in_vol = c < NB * 4 && gz >= 0 && gz < a.d && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w && bb * 32 + part * 8 < a.kb;
       const unsigned off = in_vol ? (unsigned)((((n * a.d + gz) * a.h + gy) * a.w + gx) * a.kb + bb * 32 + part * 8) * 2u : OOB;
       regB[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, 0, 0);
     }
@@ -911,8 +917,8 @@ static void wgrad2_plan(int n, int d, int h, int w, int ka, int kb, Wg2Args& a) 
   a.tiles_y = (h + 7) / 8;
   a.tiles_x = (w + 15) / 16;
   a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
-  a.nab = ka / 32;
-  a.nbb = kb / 32;
+  a.nab = (ka + 31) / 32;  // a 16-channel operand is zero-padded to a 32-wide block by the buffer loads
+  a.nbb = (kb + 31) / 32;
   const int pairs = a.nab * a.nbb;
   int splits = (256 + pairs - 1) / pairs;  // one workgroup per CU
   if (splits > a.ntiles) splits = a.ntiles;
@@ -928,7 +934,7 @@ static size_t wgrad2_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
 // dw[(a*KB + b)*27 + tap] = sum_split part[(pair*splits + split)][tap][a%32][b%32]
 __global__ __launch_bounds__(256) void wgrad_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                 int ka, int kb, int nbb, int splits) {
-  const size_t total = (size_t)ka * kb * 27;
+  const size_t total = (size_t)((ka + 31) / 32) * nbb * 1024 * 27;
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   // thread index enumerates [pair][tap][a32][b32] so reads are coalesced
@@ -945,11 +951,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_reduce_kernel(const float* __r
     s3 += src[(size_t)(k + 3) * 27 * 1024];
   }
   for (; k < splits; ++k) s0 += src[(size_t)k * 27 * 1024];
-  dw[((size_t)(ab * 32 + a32) * kb + bb * 32 + b32) * 27 + tap] = (s0 + s1) + (s2 + s3);
+  if (ab * 32 + a32 < ka && bb * 32 + b32 < kb) dw[((size_t)(ab * 32 + a32) * kb + bb * 32 + b32) * 27 + tap] = (s0 + s1) + (s2 + s3);
 }
 
 bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtype, int x_layout, int dy_layout) {
-  return ksize == 3 && cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_BF16 &&
+  return ksize == 3 && cin % 16 == 0 && cout % 16 == 0 && x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_BF16 &&
          x_layout == MEDNET_NDHWC && dy_layout == MEDNET_NDHWC;
 }
 // the kernel addresses its operands through buffer resources with 32-bit byte offsets
@@ -974,10 +980,13 @@ static void wgrad_plan(int n, int ad, int ah, int aw, int ka, int kb, WgArgs& a)
 }
 
 size_t wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize) {
-  if (ksize != 3 || cin % 32 || cout % 32) return 0;
-  WgArgs a;
-  wgrad_plan<1>(n, d, h, w, cout, cin, a);
-  const size_t v1 = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+  if (ksize != 3 || cin % 16 || cout % 16) return 0;
+  size_t v1 = 0;
+  if (cin % 32 == 0 && cout % 32 == 0) {  // the first-generation kernel (option wgrad_v2=0) has no channel padding
+    WgArgs a;
+    wgrad_plan<1>(n, d, h, w, cout, cin, a);
+    v1 = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+  }
   const size_t v2 = wgrad2_ws_bytes(n, d, h, w, cin, cout);
   return v1 > v2 ? v1 : v2;
 }
@@ -1010,7 +1019,7 @@ static int launch_wg(const void* A, const void* B, float* dw, int n, int ad, int
   hipLaunchKernelGGL((wgrad_mfma_kernel<STRIDE>), dim3(a.nab * a.nbb * a.splits), dim3(256), lds, s, a);
   int rc = check_launch("wgrad_mfma");
   if (rc) return rc;
-  const size_t total = (size_t)ka * kb * 27;
+  const size_t total = (size_t)a.nab * a.nbb * 1024 * 27;
   hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, ka, kb,
                      a.nbb, a.splits);
   return check_launch("wgrad_mfma_reduce");
@@ -1020,7 +1029,8 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
                       void* ws, size_t ws_bytes, hipStream_t s) {
   (void)dtype;
   // conv: A = dy (Cout rows), B = x (Cin cols) shifted by tap - 1
-  if (!tuning_option("wgrad_v2", 1)) return launch_wg<1>(dy, x, dw, n, d, h, w, d, h, w, cout, cin, ws, ws_bytes, s);
+  if (!tuning_option("wgrad_v2", 1) && cin % 32 == 0 && cout % 32 == 0)
+    return launch_wg<1>(dy, x, dw, n, d, h, w, d, h, w, cout, cin, ws, ws_bytes, s);
   constexpr size_t lds = ((size_t)4 * 8 * 16 + 6 * 10 * 18) * 64;
   Wg2Args a;
   a.A = (const bf16*)dy;
@@ -1041,7 +1051,7 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
   hipLaunchKernelGGL(wgrad_mfma2_kernel, dim3(a.nab * a.nbb * a.splits), dim3(512), lds, s, a);
   int rc = check_launch("wgrad_mfma2");
   if (rc) return rc;
-  const size_t total = (size_t)cout * cin * 27;
+  const size_t total = (size_t)a.nab * a.nbb * 1024 * 27;
   // the reduce kernel sees the two k-groups of a workgroup as two consecutive splits
   hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, cout, cin,
                      a.nbb, a.splits * 2);
