@@ -530,18 +530,19 @@ __device__ __forceinline__ int nearest_src(int dst, int in, int out) {
   const int s = (int)floorf((float)dst * scale);
   return s < in - 1 ? s : in - 1;
 }
-template <typename T>
+// VEC channels per thread (8 when both channel counts allow 16-byte pieces): a piece never straddles the concat seam.
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ enc, const T* __restrict__ x,
                                                         T* __restrict__ out, int n, int d, int h, int w, int ce, int xd,
                                                         int xh, int xw, int cx) {
-  const int ct = ce + cx;
-  const size_t total = (size_t)n * d * h * w * ct;
+  const int ct = ce + cx, pv = ct / VEC;
+  const size_t total = (size_t)n * d * h * w * pv;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int cc = (int)(i % ct);
-  size_t v = i / ct;
+  const int cc = (int)(i % pv) * VEC;
+  size_t v = i / pv;
   if (cc < ce) {
-    out[i] = enc[v * ce + cc];
+    VecIO<T, VEC>::store(out, v * ct + cc, VecIO<T, VEC>::load(enc, v * ce + cc));
     return;
   }
   const int ox = (int)(v % w);
@@ -551,17 +552,19 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ en
   const int oz = (int)(r % d);
   const int nn = (int)(r / d);
   const int sz = nearest_src(oz, xd, d), sy = nearest_src(oy, xh, h), sx = nearest_src(ox, xw, w);
-  out[i] = x[((((size_t)nn * xd + sz) * xh + sy) * xw + sx) * cx + (cc - ce)];
+  VecIO<T, VEC>::store(out, v * ct + cc,
+                       VecIO<T, VEC>::load(x, ((((size_t)nn * xd + sz) * xh + sy) * xw + sx) * cx + (cc - ce)));
 }
 // denc = dout[..., :ce]; dx[src] = sum over the destination voxels that map to src
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void upcat_bwd_enc_kernel(const T* __restrict__ dout, T* __restrict__ denc,
                                                             size_t nvox, int ce, int ct) {
+  const int pv = ce / VEC;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nvox * ce) return;
-  const size_t v = i / ce;
-  const int cc = (int)(i % ce);
-  denc[i] = dout[v * ct + cc];
+  if (i >= nvox * pv) return;
+  const size_t v = i / pv;
+  const int cc = (int)(i % pv) * VEC;
+  VecIO<T, VEC>::store(denc, v * ce + cc, VecIO<T, VEC>::load(dout, v * ct + cc));
 }
 __device__ __forceinline__ void dst_range(int src, int in, int out, int& lo, int& hi) {
   // all dst with nearest_src(dst) == src form a contiguous run; find it by scanning a small window
@@ -571,15 +574,16 @@ __device__ __forceinline__ void dst_range(int src, int in, int out, int& lo, int
   hi = lo;
   while (hi < out && nearest_src(hi, in, out) == src) ++hi;
 }
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void upcat_bwd_x_kernel(const T* __restrict__ dout, T* __restrict__ dx, int n, int d,
                                                           int h, int w, int ce, int xd, int xh, int xw, int cx) {
-  const int ct = ce + cx;
-  const size_t total = (size_t)n * xd * xh * xw * cx;
+  const int ct = ce + cx, pv = cx / VEC;
+  const size_t total = (size_t)n * xd * xh * xw * pv;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int cc = (int)(i % cx);
-  size_t v = i / cx;
+  const int cc = (int)(i % pv) * VEC;
+  size_t v = i / pv;
+  const size_t dst = v * cx + cc;
   const int sx = (int)(v % xw);
   v /= xw;
   const int sy = (int)(v % xh);
@@ -590,12 +594,17 @@ __global__ __launch_bounds__(256) void upcat_bwd_x_kernel(const T* __restrict__ 
   dst_range(sz, xd, d, z0, z1);
   dst_range(sy, xh, h, y0, y1);
   dst_range(sx, xw, w, x0, x1);
-  float s = 0.f;
+  F8 s;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) s.v[k] = 0.f;
   for (int oz = z0; oz < z1; ++oz)
     for (int oy = y0; oy < y1; ++oy)
-      for (int ox = x0; ox < x1; ++ox)
-        s += ld(dout, ((((size_t)nn * d + oz) * h + oy) * w + ox) * ct + ce + cc);
-  st(dx, i, s);
+      for (int ox = x0; ox < x1; ++ox) {
+        const F8 g = VecIO<T, VEC>::load(dout, ((((size_t)nn * d + oz) * h + oy) * w + ox) * ct + ce + cc);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) s.v[k] += g.v[k];
+      }
+  VecIO<T, VEC>::store(dx, dst, s);
 }
 
 // ---------------------------------------------------------------------------------------------- Adam
@@ -795,11 +804,14 @@ extern "C" int mednet_pool2_bwd(const void* dy, const void* x, void* dx, int n, 
 extern "C" int mednet_upcat_fwd(const void* enc, const void* x, void* out, int n, int d, int h, int w, int c_enc,
                                 int xd, int xh, int xw, int c_x, int dtype, mednet_stream stream) {
   MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "upcat_fwd: bad dtype");
-  const size_t total = (size_t)n * d * h * w * (c_enc + c_x);
+  const int vec = (c_enc % 8 == 0 && c_x % 8 == 0) ? 8 : 1;
+  const size_t total = (size_t)n * d * h * w * ((c_enc + c_x) / vec);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)((total + 255) / 256));
-  if (dtype == MEDNET_F32) hipLaunchKernelGGL(upcat_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)enc, (const float*)x, (float*)out, n, d, h, w, c_enc, xd, xh, xw, c_x);
-  else hipLaunchKernelGGL(upcat_fwd_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)enc, (const bf16*)x, (bf16*)out, n, d, h, w, c_enc, xd, xh, xw, c_x);
+#define GO(T, V) hipLaunchKernelGGL((upcat_fwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)enc, (const T*)x, (T*)out, n, d, h, w, c_enc, xd, xh, xw, c_x)
+  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+#undef GO
   return check_launch("upcat_fwd");
 }
 extern "C" int mednet_upcat_bwd(const void* dout, void* denc, void* dx, int n, int d, int h, int w, int c_enc, int xd,
@@ -808,16 +820,19 @@ extern "C" int mednet_upcat_bwd(const void* dout, void* denc, void* dx, int n, i
   hipStream_t s = (hipStream_t)stream;
   const size_t nvox = (size_t)n * d * h * w;
   const int ct = c_enc + c_x;
-  const dim3 g1((unsigned)((nvox * c_enc + 255) / 256));
-  const size_t tx = (size_t)n * xd * xh * xw * c_x;
+  const int vec = (c_enc % 8 == 0 && c_x % 8 == 0) ? 8 : 1;
+  const dim3 g1((unsigned)((nvox * (c_enc / vec) + 255) / 256));
+  const size_t tx = (size_t)n * xd * xh * xw * (c_x / vec);
   const dim3 g2((unsigned)((tx + 255) / 256));
-  if (dtype == MEDNET_F32) {
-    hipLaunchKernelGGL(upcat_bwd_enc_kernel<float>, g1, dim3(256), 0, s, (const float*)dout, (float*)denc, nvox, c_enc, ct);
-    hipLaunchKernelGGL(upcat_bwd_x_kernel<float>, g2, dim3(256), 0, s, (const float*)dout, (float*)dx, n, d, h, w, c_enc, xd, xh, xw, c_x);
-  } else {
-    hipLaunchKernelGGL(upcat_bwd_enc_kernel<bf16>, g1, dim3(256), 0, s, (const bf16*)dout, (bf16*)denc, nvox, c_enc, ct);
-    hipLaunchKernelGGL(upcat_bwd_x_kernel<bf16>, g2, dim3(256), 0, s, (const bf16*)dout, (bf16*)dx, n, d, h, w, c_enc, xd, xh, xw, c_x);
-  }
+#define GO(T, V)                                                                                                        \
+  do {                                                                                                                  \
+    hipLaunchKernelGGL((upcat_bwd_enc_kernel<T, V>), g1, dim3(256), 0, s, (const T*)dout, (T*)denc, nvox, c_enc, ct);   \
+    hipLaunchKernelGGL((upcat_bwd_x_kernel<T, V>), g2, dim3(256), 0, s, (const T*)dout, (T*)dx, n, d, h, w, c_enc, xd,  \
+                       xh, xw, c_x);                                                                                    \
+  } while (0)
+  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+#undef GO
   return check_launch("upcat_bwd");
 }
 
