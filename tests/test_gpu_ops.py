@@ -410,6 +410,42 @@ def test_conv_transpose_mfma_dgrad_wgrad(n, cin, cout, shape):
     assert_close(up.weight.grad, wr.grad, 2e-4, "dw (MFMA, transposing LDS reads)")
 
 
+def test_conv3d_mfma_batch_larger_than_4GB():
+    """A batch whose activation tensor exceeds 4 GB (34 x 128^3 x 32 ch bf16 = 4.6 GB): the MFMA kernels address one
+    SAMPLE per buffer resource, so the last sample must come out bit-identical to the same sample run alone, and the
+    weight gradient of the whole batch must equal the sum of the two half-batch gradients."""
+    n, c, e = 34, 32, 128
+    g = torch.Generator(device=DEV).manual_seed(7)
+    mednet_hip.set_conv_algo("mfma")
+    try:
+        with mednet_hip.precision("bf16"):
+            conv = hnn.Conv3d(c, c, 3, bias=False).to(DEV)
+            x = torch.randn(n, c, e, e, e, device=DEV, dtype=torch.bfloat16, generator=g).contiguous(memory_format=torch.channels_last_3d)
+            cot = torch.randn(n, c, e, e, e, device=DEV, dtype=torch.bfloat16, generator=g).contiguous(memory_format=torch.channels_last_3d)
+            assert x.numel() * 2 > 2 ** 32
+
+            def run(xs, cs):
+                conv.weight.grad = None
+                xs = xs.detach().requires_grad_(True)
+                y = conv(xs)
+                y.backward(cs)
+                torch.cuda.synchronize()
+                return y.detach(), xs.grad, conv.weight.grad.clone()
+
+            y, dx, dw = run(x, cot)
+            y1, dx1, _ = run(x[n - 1:], cot[n - 1:])
+            assert torch.equal(y[n - 1:], y1) and torch.equal(dx[n - 1:], dx1)
+            y0, dx0, _ = run(x[:1], cot[:1])
+            assert torch.equal(y[:1], y0) and torch.equal(dx[:1], dx0)
+            del y, dx, y0, y1, dx0, dx1
+            h = n // 2
+            _, _, dwa = run(x[:h], cot[:h])
+            _, _, dwb = run(x[h:], cot[h:])
+            assert_close(dw, dwa + dwb, 1e-5, "dw of the 4.6 GB batch vs the sum of its halves")
+    finally:
+        mednet_hip.set_conv_algo("auto")
+
+
 @pytest.mark.parametrize("n,cout,shape", [(1, 32, (4, 8, 16)), (2, 32, (9, 11, 21)), (1, 64, (5, 6, 7))])
 def test_first_layer_mfma_keeps_fp32_input_precision(n, cout, shape):
     """Cin=1 forward on the matrix cores (contraction over the 27 taps, x split into bf16 hi+lo): with bf16-representable

@@ -56,7 +56,7 @@ struct FwdArgs {
   int cin, cout;
   int tiles_z, tiles_y, tiles_x, ntiles;  // per sample * n
   int nkc, ncb;
-  unsigned bytes_x;  // size of x for the buffer resource (tensors < 4 GB)
+  unsigned bytes_x;  // size of ONE SAMPLE of x for the buffer resource (< 4 GB)
   float* gn_partial;  // nullable: [n][bricks per sample][cout][2] = per-brick {sum y, sum y^2} of the STORED (rounded) outputs
 };
 
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   // ---- staging plan (independent of the K chunk): 32-bit BYTE offset of each 16-byte piece for a buffer load whose
   //      resource descriptor sits in SGPRs.  Pieces outside the volume get an offset beyond num_records: the hardware
   //      range check returns zeros for them, so zero padding costs neither a branch nor a select.
-  const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.bytes_x, 0x00020000);
+  // (one resource per SAMPLE, so only a single sample has to stay below the 4 GB a 32-bit offset can address)
+  const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)n * a.id * a.ih * a.iw * a.cin), 0, a.bytes_x, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFF00u;
   unsigned goff[IN_ROUNDS];
 #pragma unroll
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
     const int gz = STRIDE * tz0 - 1 + hz, gy = STRIDE * ty0 - 1 + hy, gx = STRIDE * tx0 - 1 + hx;
     const bool in_vol = v < NV && gz >= 0 && gz < a.id && gy >= 0 && gy < a.ih && gx >= 0 && gx < a.iw;
-    goff[it] = in_vol ? (unsigned)((((n * a.id + gz) * a.ih + gy) * a.iw + gx) * a.cin + hh * 8) * 2u : OOB;
+    goff[it] = in_vol ? ((unsigned)((gz * a.ih + gy) * a.iw + gx) * (unsigned)a.cin + hh * 8) * 2u : OOB;
   }
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)cb * a.nkc * W_CHUNKS;
 
@@ -603,8 +604,11 @@ int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, int cin, int 
   return check_launch("pack_mfma");
 }
 
-// the kernels address the activation tensor through a buffer resource with 32-bit byte offsets
-bool conv_mfma_fits(int n, int d, int h, int w, int c) { return (double)n * d * h * w * c * 2.0 < 4294960000.0; }
+// the kernels address ONE SAMPLE of the activation tensor through a buffer resource with 32-bit byte offsets
+bool conv_mfma_fits(int n, int d, int h, int w, int c) {
+  (void)n;
+  return (double)d * h * w * c * 2.0 < 4294960000.0;
+}
 bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int x_layout, int y_layout, bool bias) {
   return ksize == 3 && cin % 16 == 0 && cout % 16 == 0 && x_dtype == MEDNET_BF16 && y_dtype == MEDNET_BF16 &&
          x_layout == MEDNET_NDHWC && y_layout == MEDNET_NDHWC && !bias;
@@ -630,7 +634,7 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
   a.nkc = cin / 16;
   a.ncb = (cout + 31) / 32;
-  a.bytes_x = (unsigned)((size_t)n * id * ih * iw * cin * 2);
+  a.bytes_x = (unsigned)((size_t)id * ih * iw * cin * 2);
   const unsigned grid = (unsigned)((a.ntiles + 7) / 8) * 8 * a.ncb;
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[STRIDE]) {
@@ -827,8 +831,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, hk = lane >> 5;
   const int coloff = (16 * (g & 1) + 4 * p) * 2;
 
-  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, a.bytesA, 0x00020000);
-  const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, a.bytesB, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFF00u;
   u32x4 regA[A_ROUNDS], regB[B_ROUNDS];
   auto fetch = [&](int tile) {
@@ -839,13 +841,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
     tt /= a.tiles_y;
     const int tz0 = (tt % a.tiles_z) * TZ;
     const int n = tt / a.tiles_z;
+    // one resource per sample (wave-uniform): 32-bit offsets only have to span a single sample
+    const size_t svox = (size_t)n * a.d * a.h * a.w;
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + svox * a.ka), 0, a.bytesA, 0x00020000);
+    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + svox * a.kb), 0, a.bytesB, 0x00020000);
 #pragma unroll
     for (int it = 0; it < A_ROUNDS; ++it) {
       const int c = it * 512 + tid;
       const int v = c >> 2, part = c & 3;
       const int gz = tz0 + v / (TX * TY), gy = ty0 + (v / TX) % TY, gx = tx0 + v % TX;
       const bool in_vol = gz < a.d && gy < a.h && gx < a.w && ab * 32 + part * 8 < a.ka;
-      const unsigned off = in_vol ? (unsigned)((((n * a.d + gz) * a.h + gy) * a.w + gx) * a.ka + ab * 32 + part * 8) * 2u : OOB;
+      const unsigned off = in_vol ? ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.ka + ab * 32 + part * 8) * 2u : OOB;
       regA[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0);
     }
 #pragma unroll
@@ -854,7 +860,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
       const int v = c >> 2, part = c & 3;
       const int gz = tz0 - 1 + v / (HX * HY), gy = ty0 - 1 + (v / HX) % HY, gx = tx0 - 1 + v % HX;
       const bool in_vol = c < NB * 4 && gz >= 0 && gz < a.d && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w && bb * 32 + part * 8 < a.kb;
-      const unsigned off = in_vol ? (unsigned)((((n * a.d + gz) * a.h + gy) * a.w + gx) * a.kb + bb * 32 + part * 8) * 2u : OOB;
+      const unsigned off = in_vol ? ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.kb + bb * 32 + part * 8) * 2u : OOB;
       regB[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, 0, 0);
     }
   };
@@ -960,7 +966,8 @@ bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtyp
 }
 // the kernel addresses its operands through buffer resources with 32-bit byte offsets
 bool wgrad_mfma_fits(int n, int d, int h, int w, int cmax, int scale) {
-  return (double)n * d * h * w * scale * cmax * 2.0 < 4294960000.0;
+  (void)n;
+  return (double)d * h * w * scale * cmax * 2.0 < 4294960000.0;
 }
 
 template <int STRIDE>
@@ -1038,8 +1045,8 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
   a.part = (float*)ws;
   a.n = n; a.d = d; a.h = h; a.w = w; a.ka = cout; a.kb = cin;
   wgrad2_plan(n, d, h, w, cout, cin, a);
-  a.bytesA = (unsigned)((size_t)n * d * h * w * cout * 2);
-  a.bytesB = (unsigned)((size_t)n * d * h * w * cin * 2);
+  a.bytesA = (unsigned)((size_t)d * h * w * cout * 2);  // per sample
+  a.bytesB = (unsigned)((size_t)d * h * w * cin * 2);
   const size_t need = (size_t)a.nab * a.nbb * a.splits * 2 * 27 * 1024 * sizeof(float);
   MEDNET_REQUIRE(ws_bytes >= need, MEDNET_E_WORKSPACE, "wgrad_mfma2: workspace %zu < %zu", ws_bytes, need);
   static bool attr_set = false;
