@@ -54,7 +54,9 @@ int mednet_conv3d_pack(const float* w, void* packed, int cin, int cout, int ksiz
  * dgrad=1 runs the data gradient with the same kernel: pass x := dy, cin := Cout, cout := Cin of the layer. */
 /* gn_partial (nullable): when the call takes the MFMA path the epilogue also writes the GroupNorm partial sums of the
  * output, [n][chunks][cout][2] = {sum y, sum y^2} per brick, chunks = mednet_conv3d_fused_stats_chunks(...) (0 = this
- * call cannot fuse them); mednet_gn_finalize turns them into statistics without another pass over y. */
+ * call cannot fuse them); mednet_gn_finalize turns them into statistics without another pass over y.  The sums are
+ * kept per channel PAIR (entry 2j = channels 2j and 2j+1 together, entry 2j+1 = 0): exact for GroupNorm whenever the
+ * channels per group are even -- ask for them only then. */
 int mednet_conv3d_fused_stats_chunks(int d, int h, int w, int cin, int cout, int ksize, int x_dtype, int y_dtype,
                                      int algo);
 int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void* y, int n, int d, int h, int w,

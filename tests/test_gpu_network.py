@@ -227,6 +227,32 @@ def test_blocks_against_reference_golden(golden_dir):
                 assert_close(p.grad, torch.from_numpy(rec[f"{tag}.dp.{k}"]), 5e-4, f"{tag}.dp.{k}")
 
 
+@pytest.mark.parametrize("groups", [8, 16, 32])
+def test_fused_groupnorm_partials_any_group_size(groups):
+    """bf16 mode: the conv epilogue's GroupNorm partials are per channel PAIR; with 32 channels that is exact for 8 and
+    16 groups (4 / 2 channels per group) and must NOT be used for 32 groups (1 channel per group: stand-alone statistics
+    pass).  SingleConv 'cge' and ExtResNetBlock against the oracle on bf16-representable inputs."""
+    x = torch.from_numpy(O._rng(f"fgp{groups}").standard_normal((2, 32, 9, 11, 21)).astype(np.float32)).bfloat16().float()
+    for make_o, make_h in ((lambda: O.SingleConv(32, 32, 3, "cge", groups), lambda: HC.SingleConv(32, 32, 3, "cge", groups)),
+                           (lambda: O.ExtResNetBlock(32, 32, order="cge", num_groups=groups),
+                            lambda: HC.ExtResNetBlock(32, 32, order="cge", num_groups=groups))):
+        ora = O.keyed_init_(make_o())
+        xo = x.clone().requires_grad_(True)
+        yo = ora(xo)
+        g = torch.from_numpy(O._rng("fgpcot").standard_normal(tuple(yo.shape)).astype(np.float32))
+        (yo * g).sum().backward()
+        with mednet_hip.precision("bf16"):
+            net = O.keyed_init_(make_h()).to(DEV)
+            xg = x.to(DEV).requires_grad_(True)
+            yg = net(xg)
+            (yg.float() * g.to(DEV)).sum().backward()
+        assert_close(yg, yo, 2e-2, f"y groups={groups}")
+        assert_close(xg.grad, xo.grad, 4e-2, f"dx groups={groups}")
+        for (k, a), (_, b) in zip(net.named_parameters(), ora.named_parameters()):
+            if a.numel() >= 1024:
+                assert_close(a.grad, b.grad, 4e-2, f"{k} groups={groups}")
+
+
 def test_bitwise_reproducible_step():
     """No float atomics anywhere: two runs of the same step give identical bits (race screen)."""
     ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64])

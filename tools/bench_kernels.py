@@ -39,6 +39,12 @@ def conv_case(cin, cout, s):
     def fwd():
         L.check(lib.mednet_conv3d_fwd(x.data_ptr(), pk.data_ptr(), None, y.data_ptr(), N, s, s, s, cin, cout, 3, 1, 0, 1, 0, 0, 2, None, st), "fwd")
 
+    chunks = lib.mednet_conv3d_fused_stats_chunks(s, s, s, cin, cout, 3, 1, 1, 2)
+    part = torch.empty(N, max(chunks, 1), cout, 2, device=dev)
+
+    def fwd_stats():
+        L.check(lib.mednet_conv3d_fwd(x.data_ptr(), pk.data_ptr(), None, y.data_ptr(), N, s, s, s, cin, cout, 3, 1, 0, 1, 0, 0, 2, part.data_ptr(), st), "fwd")
+
     def wg():
         L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, N, s, s, s, cin, cout, 3, 1, 0, 1, 0, 2,
                                         ws.data_ptr(), ws.numel(), st), "wgrad")
@@ -48,6 +54,8 @@ def conv_case(cin, cout, s):
     for rnd in range(3):
         for pv in variants:
             res.append((pv, timeit(fwd)))
+    ts = min(timeit(fwd_stats) for _ in range(3))
+    print(f"   fwd + fused GroupNorm partials: {ts*1e3:6.1f} us {flop/ts/1e9:6.1f} TF/s")
     tw = timeit(wg)
     wres = {}
     for rnd in range(3):

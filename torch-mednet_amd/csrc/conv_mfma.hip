@@ -168,24 +168,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     // Software-pipelined over the 27 taps: the fragments of tap t+1 (1 weight + NTW input ds_read_b128) are in flight
     // while tap t is on the matrix cores; sched_group_barrier pins that interleave (hipcc otherwise sinks each read to
     // just in front of its MFMA and exposes the LDS latency 108 times per chunk).
-    bf16x8 wa[2], xb[2][NTW];
-    wa[0] = __builtin_bit_cast(bf16x8, w_lds[h * 32 + r]);
+    constexpr int PD = 1;  // prefetch distance in taps (PD + 1 operand sets in registers); 2 measured no faster (+20 VGPRs)
+    bf16x8 wa[PD + 1], xb[PD + 1][NTW];
+    auto tap_off = [&](int t1) { return ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3; };
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) xb[0][t] = __builtin_bit_cast(bf16x8, in_lds[lbase[t]]);
+    for (int p = 0; p < PD; ++p) {
+      wa[p] = __builtin_bit_cast(bf16x8, w_lds[(p * 2 + h) * 32 + r]);
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) xb[p][t] = __builtin_bit_cast(bf16x8, in_lds[lbase[t] + tap_off(p)]);
+    }
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
-      const int cur = tap & 1, nxt = cur ^ 1;
-      if (tap + 1 < 27) {
-        const int t1 = tap + 1;
-        const int toff = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3;
+      const int cur = tap % (PD + 1), nxt = (tap + PD) % (PD + 1);
+      if (tap + PD < 27) {
+        const int t1 = tap + PD;
+        const int toff = tap_off(t1);
         wa[nxt] = __builtin_bit_cast(bf16x8, w_lds[(t1 * 2 + h) * 32 + r]);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) xb[nxt][t] = __builtin_bit_cast(bf16x8, in_lds[lbase[t] + toff]);
       }
 #pragma unroll
       for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur], xb[cur][t], acc[t], 0, 0, 0);
-      if (tap + 1 < 27) __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);  // DS reads of tap+1 first ...
-      __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                         // ... then the MFMAs of tap
+      if (tap + PD < 27) __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);  // DS reads of tap+PD first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                          // ... then the MFMAs of tap
     }
   }
 
@@ -211,9 +216,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     }
   }
   __syncthreads();
-  float gs[8], gq[8];
+  // GroupNorm partials are kept per channel PAIR (v_dot2c_f32_bf16: two exact bf16 products + fp32 add per instruction,
+  // 8 instructions per 8-channel piece instead of 24): entry 2j of the partial row gets the sums of channels 2j and
+  // 2j+1, entry 2j+1 is zero.  GroupNorm only ever adds the channels of a group, so this is exact whenever the
+  // channels per group are even (the host asks for fused partials only then).
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  const bf16x2 ones = {(bf16)1.0f, (bf16)1.0f};
+  float gs[4], gq[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) gs[k] = gq[k] = 0.f;
+  for (int k = 0; k < 4; ++k) gs[k] = gq[k] = 0.f;
   const int pj = tid & 3;
   const size_t ovol = (size_t)a.od * a.oh * a.ow;
 #pragma unroll
@@ -225,12 +236,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     const int oz = tz0 + vl / (TY * TX), oy = ty0 + (vl / TX) % TY, ox = tx0 + vl % TX;
     if (oz < a.od && oy < a.oh && ox < a.ow && cb * 32 + pj * 8 < a.cout) {  // (a 16-channel layer fills half a block)
       *reinterpret_cast<bf16x8*>(a.y + ((size_t)n * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.cout + cb * 32 + pj * 8) = v;
-      if (a.gn_partial) {
+      if (a.gn_partial) {  // statistics of what is stored (the rounded values), exactly like the stand-alone pass
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float f = (float)v[k];  // statistics of what is stored, exactly like the stand-alone pass
-          gs[k] += f;
-          gq[k] = fmaf(f, f, gq[k]);
+        for (int k = 0; k < 4; ++k) {
+          const bf16x2 pr = {v[2 * k], v[2 * k + 1]};
+          gs[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, gs[k], false);
+          gq[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, gq[k], false);
         }
       }
     }
@@ -240,23 +251,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 #pragma unroll
     for (int m = 4; m < 64; m <<= 1)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < 4; ++k) {
         gs[k] += __shfl_xor(gs[k], m, 64);
         gq[k] += __shfl_xor(gq[k], m, 64);
       }
     if (lane < 4) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        st_lds[((wv * 4 + pj) * 8 + k) * 2] = gs[k];
-        st_lds[((wv * 4 + pj) * 8 + k) * 2 + 1] = gq[k];
+      for (int k = 0; k < 4; ++k) {
+        st_lds[((wv * 4 + pj) * 4 + k) * 2] = gs[k];
+        st_lds[((wv * 4 + pj) * 4 + k) * 2 + 1] = gq[k];
       }
     }
     __syncthreads();
     if (tid < 64) {
       const int co = tid >> 1, which = tid & 1;
       float tot = 0.f;
+      if (!(co & 1)) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) tot += st_lds[((k * 4 + (co >> 3)) * 8 + (co & 7)) * 2 + which];
+        for (int k = 0; k < 4; ++k) tot += st_lds[((k * 4 + (co >> 3)) * 4 + ((co & 7) >> 1)) * 2 + which];
+      }
       if (cb * 32 + co < a.cout)
         a.gn_partial[(((size_t)n * tiles_per_sample + tis) * a.cout + cb * 32 + co) * 2 + which] = tot;
     }

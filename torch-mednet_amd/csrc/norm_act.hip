@@ -205,20 +205,24 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const TX* __restrict__ 
     act_apply_n<VEC>(out.v, act);
   };
   size_t v = v0 + L.row;
-  for (; v + (size_t)L.rows < v1; v += 2 * (size_t)L.rows) {  // two voxels per trip: 2-4 loads in flight per lane
-    const size_t i0 = off + v * c, i1 = off + (v + L.rows) * c;
-    const F8 x0 = VecIO<TX, VEC>::load(x, i0), x1 = VecIO<TX, VEC>::load(x, i1);
-    F8 r0, r1, z0, z1;
+  const size_t R = (size_t)L.rows;
+  for (; v + 3 * R < v1; v += 4 * R) {  // four voxels per trip: 4-8 loads in flight per lane
+    size_t i[4];
+    F8 xi[4], ri[4], zo[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) i[u] = off + (v + u * R) * c;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xi[u] = VecIO<TX, VEC>::load(x, i[u]);
     if (res) {
-      r0 = VecIO<TZ, VEC>::load(res, i0);
-      r1 = VecIO<TZ, VEC>::load(res, i1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ri[u] = VecIO<TZ, VEC>::load(res, i[u]);
     }
-    one(x0, r0, z0);
-    one(x1, r1, z1);
-    VecIO<TZ, VEC>::store(z, i0, z0);
-    VecIO<TZ, VEC>::store(z, i1, z1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(xi[u], ri[u], zo[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) VecIO<TZ, VEC>::store(z, i[u], zo[u]);
   }
-  for (; v < v1; v += L.rows) {
+  for (; v < v1; v += R) {
     const size_t i = off + v * c;
     const F8 xv = VecIO<TX, VEC>::load(x, i);
     F8 rv, zv;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict
       }
     };
     size_t v = v0 + L.row;
-    for (; v + (size_t)L.rows < v1; v += 2 * (size_t)L.rows) {
+    for (; v + (size_t)L.rows < v1; v += 2 * (size_t)L.rows) {  // (four per trip measured 7 % slower)
       one(off + v * c);
       one(off + (v + L.rows) * c);
     }

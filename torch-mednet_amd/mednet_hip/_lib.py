@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmednet_hip.so")
+LIB_PATH = os.environ.get("MEDNET_LIB_PATH") or os.path.join(_HERE, "libmednet_hip.so")  # (override: A/B of two builds)
 
 F32, BF16 = 0, 1
 NDHWC, NCDHW = 0, 1

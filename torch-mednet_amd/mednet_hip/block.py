@@ -110,11 +110,12 @@ class ResBlockFn(Function):
         x = ops._as_act(x)
         xin = x.contiguous() if x.shape[1] == 1 else ops.to_cl(x)  # Cin == 1: NCDHW and NDHWC coincide
         cout = w1.shape[0]
-        y1, p1 = _conv_fwd(xin, pk1, cout, True)
+        fuse = (cout // groups) % 2 == 0  # fused partials are per channel pair (include/mednet_hip.h)
+        y1, p1 = _conv_fwd(xin, pk1, cout, fuse)
         z1, s1, c1 = _gn_fwd(y1, p1, g1, b1, groups, eps, act, None)
-        y2, p2 = _conv_fwd(z1, pk2, cout, True)
+        y2, p2 = _conv_fwd(z1, pk2, cout, fuse)
         z2, s2, c2 = _gn_fwd(y2, p2, g2, b2, groups, eps, act, None)
-        y3, p3 = _conv_fwd(z2, pk3, cout, True)
+        y3, p3 = _conv_fwd(z2, pk3, cout, fuse)
         out, s3, c3 = _gn_fwd(y3, p3, g3, b3, groups, eps, act, z1)
         ctx.save_for_backward(xin, y1, z1, y2, z2, y3, out, s1, c1, s2, c2, s3, c3, pk1, pk2, pk3)
         ctx.params = (w1, g1, b1, w2, g2, b2, w3, g3, b3)

@@ -82,7 +82,7 @@ class SingleConv(nn.Sequential):
                 continue
             partial = None
             if isinstance(m, hnn.Conv3d) and i + 1 < len(mods) and isinstance(mods[i + 1], hnn.GroupNorm) \
-                    and m.bias is None and x.is_cuda:
+                    and m.bias is None and x.is_cuda and (m.out_channels // mods[i + 1].num_groups) % 2 == 0:
                 x, partial = m.forward_with_stats(x)
             elif isinstance(m, nn.BatchNorm3d):
                 x = m(x.float().contiguous()).to(memory_format=ops.CL)
