@@ -46,6 +46,10 @@ struct FwdTile<2> {  // ConvTranspose3d data gradient: in = 2*out - 1 + tap
   static constexpr int TZ = 2, TY = 4, TX = 16;
 };
 
+// x / d for launch constants d: the host passes ceil(2^32 / d); exact while x * d < 2^32 (checked by the launcher).
+// d == 1 has no 32-bit reciprocal and is passed through.
+__device__ __forceinline__ int fastdiv(int x, int d, unsigned rcp) { return d == 1 ? x : (int)__umulhi((unsigned)x, rcp); }
+
 // ================================================================================================== forward kernel
 struct FwdArgs {
   const bf16* x;
@@ -56,9 +60,22 @@ struct FwdArgs {
   int cin, cout;
   int tiles_z, tiles_y, tiles_x, ntiles;  // per sample * n
   int nkc, ncb;
+  unsigned rcp_tiles_x, rcp_tiles_y, rcp_tiles_z, rcp_ncb;  // ceil(2^32 / d): x / d == umulhi(x, rcp) for x * d < 2^32
   unsigned bytes_x;  // size of ONE SAMPLE of x for the buffer resource (< 4 GB)
+  unsigned bytes_y;  // same for y
   float* gn_partial;  // nullable: [n][bricks per sample][cout][2] = per-brick {sum y, sum y^2} of the STORED (rounded) outputs
+#ifdef MEDNET_CONV_TIMING
+  long long* dbg;  // [workgroup][16] s_memtime stamps of wave 0 (tools/probes/conv_timing.py)
+#endif
 };
+#ifdef MEDNET_CONV_TIMING
+#define STAMP(i)                                                                  \
+  do {                                                                            \
+    if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 template <int STRIDE>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
@@ -78,6 +95,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
+  STAMP(0);
 
   // ---- work item: (brick, channel block).  All channel blocks of a brick run on the same XCD (ids 8 apart share an L2).
   const int bid = blockIdx.x;
@@ -85,15 +103,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   const int tile = (local / a.ncb) * 8 + xcd;
   const int cb = local % a.ncb;
   if (tile >= a.ntiles) return;
+  // (divisions by launch constants go through host-made reciprocals: a runtime scalar division costs ~30 dependent
+  //  instructions, five of them were a fifth of a workgroup's start-up)
   const int tiles_per_sample = a.tiles_x * a.tiles_y * a.tiles_z;
-  const int tis = tile % tiles_per_sample;
   int tt = tile;
-  const int tx0 = (tt % a.tiles_x) * TX;
-  tt /= a.tiles_x;
-  const int ty0 = (tt % a.tiles_y) * TY;
-  tt /= a.tiles_y;
-  const int tz0 = (tt % a.tiles_z) * TZ;
-  const int n = tt / a.tiles_z;
+  int qd = fastdiv(tt, a.tiles_x, a.rcp_tiles_x);
+  const int tx0 = (tt - qd * a.tiles_x) * TX;
+  tt = qd;
+  qd = fastdiv(tt, a.tiles_y, a.rcp_tiles_y);
+  const int ty0 = (tt - qd * a.tiles_y) * TY;
+  tt = qd;
+  qd = fastdiv(tt, a.tiles_z, a.rcp_tiles_z);
+  const int tz0 = (tt - qd * a.tiles_z) * TZ;
+  const int n = qd;
+  const int tis = tile - n * tiles_per_sample;
 
   // ---- staging plan (independent of the K chunk): 32-bit BYTE offset of each 16-byte piece for a buffer load whose
   //      resource descriptor sits in SGPRs.  Pieces outside the volume get an offset beyond num_records: the hardware
@@ -108,21 +131,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     const int v = p >> 1, hh = p & 1;
     const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
     const int gz = STRIDE * tz0 - 1 + hz, gy = STRIDE * ty0 - 1 + hy, gx = STRIDE * tx0 - 1 + hx;
-    const bool in_vol = v < NV && gz >= 0 && gz < a.id && gy >= 0 && gy < a.ih && gx >= 0 && gx < a.iw;
-    goff[it] = in_vol ? ((unsigned)((gz * a.ih + gy) * a.iw + gx) * (unsigned)a.cin + hh * 8) * 2u : OOB;
+    // branch-free: one unsigned compare per axis covers both bounds; '&' (not '&&') keeps hipcc from building a branch
+    // ladder around the address arithmetic
+    const bool in_vol = (v < NV) & ((unsigned)gz < (unsigned)a.id) & ((unsigned)gy < (unsigned)a.ih) & ((unsigned)gx < (unsigned)a.iw);
+    const unsigned off = ((unsigned)((gz * a.ih + gy) * a.iw + gx) * (unsigned)a.cin + hh * 8) * 2u;
+    goff[it] = in_vol ? off : OOB;
   }
-  const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)cb * a.nkc * W_CHUNKS;
+  // the weight slice of (cb, kc) is one linear 27 KB run: thread t takes pieces t, t+256, ... (scalar offsets); the last
+  // round is cut off by the resource's size instead of a clamp
+  const bf16* wsrc = a.wpk + (size_t)cb * a.nkc * (W_CHUNKS * 8);
 
   u32x4 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
   auto prefetch = [&](int kc) {  // 16 loads issued back to back, nothing waits on them until commit()
 #pragma unroll
     for (int it = 0; it < IN_ROUNDS; ++it) in_reg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, goff[it], kc * 32, 0);
-    const u32x4* ws = wsrc + (size_t)kc * W_CHUNKS;
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(wsrc + (size_t)kc * (W_CHUNKS * 8)), 0, W_CHUNKS * 16, 0x00020000);
 #pragma unroll
-    for (int it = 0; it < W_ROUNDS; ++it) {
-      const int c = it * 256 + tid;
-      w_reg[it] = ws[c < W_CHUNKS ? c : W_CHUNKS - 1];
-    }
+    for (int it = 0; it < W_ROUNDS; ++it)  // (the round is part of voffset: the hardware range check does not see soffset)
+      w_reg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16 + it * 4096, 0, 0);
   };
   auto commit = [&]() {
 #pragma unroll
@@ -159,12 +185,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
+  STAMP(1);
   prefetch(0);
+  STAMP(2);
   for (int kc = 0; kc < a.nkc; ++kc) {
     __syncthreads();  // every wave is done reading the previous chunk's LDS image
+    if (kc < 2) STAMP(3 + 4 * kc);
     commit();
+    if (kc < 2) STAMP(4 + 4 * kc);
     __syncthreads();
     if (kc + 1 < a.nkc) prefetch(kc + 1);  // in flight while the matrix cores work on chunk kc
+    if (kc < 2) STAMP(5 + 4 * kc);
     // Software-pipelined over the 27 taps: the fragments of tap t+1 (1 weight + NTW input ds_read_b128) are in flight
     // while tap t is on the matrix cores; sched_group_barrier pins that interleave (hipcc otherwise sinks each read to
     // just in front of its MFMA and exposes the LDS latency 108 times per chunk).
@@ -192,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       if (tap + PD < 27) __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);  // DS reads of tap+PD first ...
       __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                          // ... then the MFMAs of tap
     }
+    if (kc < 2) STAMP(6 + 4 * kc);
   }
 
   // ---- epilogue through LDS.  D[row = co][col = voxel]: the accumulator layout gives every lane four 8-byte pieces of
@@ -201,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   // when Cout = 32.  The GroupNorm partial sums come from the same LDS image (8 channels per lane).
   bf16* out_lds = reinterpret_cast<bf16*>(smem);  // [TZ*TY*TX voxels][32 co], reuses the input image
   __syncthreads();                                // every wave is done with the MFMA reads of the last chunk
+  STAMP(11);
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     int lz, ly, lx;
@@ -216,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     }
   }
   __syncthreads();
+  STAMP(12);
   // GroupNorm partials are kept per channel PAIR (v_dot2c_f32_bf16: two exact bf16 products + fp32 add per instruction,
   // 8 instructions per 8-channel piece instead of 24): entry 2j of the partial row gets the sums of channels 2j and
   // 2j+1, entry 2j+1 is zero.  GroupNorm only ever adds the channels of a group, so this is exact whenever the
@@ -227,25 +261,34 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   for (int k = 0; k < 4; ++k) gs[k] = gq[k] = 0.f;
   const int pj = tid & 3;
   const size_t ovol = (size_t)a.od * a.oh * a.ow;
+  // Row stores: lane = (voxel et of 64, 16-byte piece pj of 4).  The 64 voxels of round `it` are 4 x-rows of 16, so the
+  // per-round part of the address is a SCALAR (soffset of a buffer store whose resource is this sample) and the lane part
+  // is computed once; lanes outside the volume / past Cout get an out-of-range voffset and the hardware drops the store.
+  static_assert(TX == 16 && TY % 4 == 0, "row decomposition of the epilogue");
+  const int et = tid >> 2, ex = et & 15, ey = et >> 4;
+  const bool lane_ok = (tx0 + ex < a.ow) & (cb * 32 + pj * 8 < a.cout);  // (a 16-channel layer fills half a block)
+  const unsigned vbase = (unsigned)((ey * a.ow + ex) * a.cout + pj * 8) * 2u;
+  const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
+  const int swl = (et >> 1) & 7;  // (vl >> 1) & 7 does not depend on the round: 64 voxels per round
+  const bf16* rd = out_lds + et * 32 + (pj ^ (swl >> 1)) * 8;
 #pragma unroll
   for (int it = 0; it < (TZ * TY * TX * 4) / 256; ++it) {
-    const int vl = it * 64 + (tid >> 2);
-    const int sw = (vl >> 1) & 7;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(out_lds + vl * 32 + (pj ^ (sw >> 1)) * 8);
-    if (sw & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
-    const int oz = tz0 + vl / (TY * TX), oy = ty0 + (vl / TX) % TY, ox = tx0 + vl % TX;
-    if (oz < a.od && oy < a.oh && ox < a.ow && cb * 32 + pj * 8 < a.cout) {  // (a 16-channel layer fills half a block)
-      *reinterpret_cast<bf16x8*>(a.y + ((size_t)n * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.cout + cb * 32 + pj * 8) = v;
-      if (a.gn_partial) {  // statistics of what is stored (the rounded values), exactly like the stand-alone pass
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(rd + it * 64 * 32);
+    if (swl & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
+    const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
+    const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
+    const unsigned soff = (unsigned)(((oz * a.oh + oyb) * a.ow + tx0) * a.cout + cb * 32) * 2u;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_y, ok ? vbase : OOB, soff, 0);
+    if (ok && a.gn_partial) {  // statistics of what is stored (the rounded values), exactly like the stand-alone pass
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const bf16x2 pr = {v[2 * k], v[2 * k + 1]};
-          gs[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, gs[k], false);
-          gq[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, gq[k], false);
-        }
+      for (int k = 0; k < 4; ++k) {
+        const bf16x2 pr = {v[2 * k], v[2 * k + 1]};
+        gs[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, gs[k], false);
+        gq[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, gq[k], false);
       }
     }
   }
+  STAMP(13);
   if (a.gn_partial) {
     // GroupNorm statistics fused into the producer (components.py:57 follows every conv of the 'c g .' orders)
 #pragma unroll
@@ -274,6 +317,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
         a.gn_partial[(((size_t)n * tiles_per_sample + tis) * a.cout + cb * 32 + co) * 2 + which] = tot;
     }
   }
+#ifdef MEDNET_CONV_TIMING
+  __builtin_amdgcn_s_waitcnt(0);  // all stores of this wave acknowledged
+  STAMP(14);
+#endif
 }
 
 // ================================================================================================== ConvTranspose3d forward
@@ -636,6 +683,9 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   static_assert(lds <= 80 * 1024, "two workgroups must fit one CU");
   FwdArgs a;
   a.gn_partial = gn_partial;
+#ifdef MEDNET_CONV_TIMING
+  a.dbg = (long long*)(((unsigned long long)(unsigned)tuning_option("conv_dbg_hi", 0) << 32) | (unsigned)tuning_option("conv_dbg_lo", 0));
+#endif
   a.x = (const bf16*)x;
   a.wpk = (const bf16*)sec;
   a.y = (bf16*)y;
@@ -647,7 +697,12 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
   a.nkc = cin / 16;
   a.ncb = (cout + 31) / 32;
+  auto rcp = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+  a.rcp_tiles_x = rcp(a.tiles_x); a.rcp_tiles_y = rcp(a.tiles_y); a.rcp_tiles_z = rcp(a.tiles_z); a.rcp_ncb = rcp(a.ncb);
+  MEDNET_REQUIRE((double)a.ntiles * a.ncb * 8.0 * 1024.0 < 4294967296.0, MEDNET_E_UNSUPPORTED, "conv_mfma: grid too large");
   a.bytes_x = (unsigned)((size_t)id * ih * iw * cin * 2);
+  MEDNET_REQUIRE((double)od * oh * ow * cout * 2.0 < 4294960000.0, MEDNET_E_UNSUPPORTED, "conv_mfma: one output sample must stay below 4 GB");
+  a.bytes_y = (unsigned)((size_t)od * oh * ow * cout * 2);
   const unsigned grid = (unsigned)((a.ntiles + 7) / 8) * 8 * a.ncb;
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[STRIDE]) {
