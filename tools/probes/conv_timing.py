@@ -18,7 +18,7 @@ pk = ops.pack_conv_weight(w, 3, False)
 y = torch.empty(N, cout, s, s, s, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
 chunks = lib.mednet_conv3d_fused_stats_chunks(s, s, s, cin, cout, 3, 1, 1, 2)
 part = torch.empty(N, chunks, cout, 2, device=dev)
-nwg = ((N * chunks + 7) // 8) * 8 * ((cout + 31) // 32)
+nwg = ((N * chunks + 7) // 8) * 8 * ((cout + 31) // 32)  # (>= the grid of either launch form)
 dbg = torch.zeros(nwg, 16, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 for with_stats in (0, 1):
@@ -32,9 +32,10 @@ for with_stats in (0, 1):
         torch.cuda.synchronize()
     t = dbg.cpu().double()
     t = t[t[:, 0] > 0]
-    life = (t[:, 14] - t[:, 0])
-    span = (t[:, 14].max() - t[:, 0].min()).item()
-    print(f"stats={with_stats}: {t.shape[0]} workgroups, kernel span {span:.0f} ticks, mean workgroup life {life.mean():.0f} ticks")
+    life = (t[:, 15] - t[:, 0])
+    span = (t[:, 15].max() - t[:, 0].min()).item()
+    print(f"stats={with_stats}: {t.shape[0]} workgroups, kernel span {span:.0f} ticks, mean workgroup life {life.mean():.0f} ticks "
+          f"(phases 3..14: the workgroup's 9th item, or its only one)")
     names = ["plan", "issue loads", "barrier", "wait data + commit k0", "barrier + prefetch", "taps k0", "barrier", "commit k1",
              "barrier", "taps k1", "-", "epilogue barrier", "acc->LDS + barrier", "rows -> global (+stats dot2)", "stats reduce + store ack"]
     for i in range(14):

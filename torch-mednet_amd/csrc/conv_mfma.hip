@@ -60,6 +60,7 @@ struct FwdArgs {
   int cin, cout;
   int tiles_z, tiles_y, tiles_x, ntiles;  // per sample * n
   int nkc, ncb;
+  int nitems;  // ((ntiles + 7) / 8) * 8 * ncb work items (the last brick group may hold padding items)
   unsigned rcp_tiles_x, rcp_tiles_y, rcp_tiles_z, rcp_ncb;  // ceil(2^32 / d): x / d == umulhi(x, rcp) for x * d < 2^32
   unsigned bytes_x;  // size of ONE SAMPLE of x for the buffer resource (< 4 GB)
   unsigned bytes_y;  // same for y
@@ -69,9 +70,11 @@ struct FwdArgs {
 #endif
 };
 #ifdef MEDNET_CONV_TIMING
+// (stamps 3..14 are taken for ONE item of a workgroup: the 9th when it has that many, else its first)
 #define STAMP(i)                                                                  \
   do {                                                                            \
-    if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
+    if (a.dbg && threadIdx.x == 0 && ((i) < 3 || (i) == 15 || stamp_item))        \
+      a.dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define STAMP(i) do { } while (0)
@@ -88,67 +91,88 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   constexpr int W_CHUNKS = 27 * 2 * 32;  // 16-byte pieces of one weight slice
   constexpr int W_ROUNDS = (W_CHUNKS + 255) / 256;
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u32x4* in_lds = reinterpret_cast<u32x4*>(smem);                  // [2][NV] 16-byte pieces (8 bf16 channels)
   u32x4* w_lds = reinterpret_cast<u32x4*>(smem) + 2 * NV;          // [27][2][32]
-  float* st_lds = reinterpret_cast<float*>(smem + ((size_t)2 * NV + W_CHUNKS) * 16);  // [4 waves][4][8][2]
+  float* st_lds = reinterpret_cast<float*>(smem + ((size_t)2 * NV + W_CHUNKS) * 16);  // [4 waves][4][4][2]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
+#ifdef MEDNET_CONV_TIMING
+  bool stamp_item = false;
+  int item_no = 0;
+#endif
   STAMP(0);
 
-  // ---- work item: (brick, channel block).  All channel blocks of a brick run on the same XCD (ids 8 apart share an L2).
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, local = bid >> 3;
-  const int tile = (local / a.ncb) * 8 + xcd;
-  const int cb = local % a.ncb;
-  if (tile >= a.ntiles) return;
+  // ---- work items: (brick, channel block), numbered so that all channel blocks of a brick run on the same XCD (ids 8
+  //      apart share an L2).  A workgroup takes items blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8, so it
+  //      stays on its XCD).  The launcher gives either every item its own workgroup, or 2 workgroups per CU that stream
+  //      through the items with the NEXT item's first K chunk already in flight while the last chunk of the current one
+  //      is on the matrix cores (no exposed load latency per brick).
   // (divisions by launch constants go through host-made reciprocals: a runtime scalar division costs ~30 dependent
-  //  instructions, five of them were a fifth of a workgroup's start-up)
+  //  instructions)
   const int tiles_per_sample = a.tiles_x * a.tiles_y * a.tiles_z;
-  int tt = tile;
-  int qd = fastdiv(tt, a.tiles_x, a.rcp_tiles_x);
-  const int tx0 = (tt - qd * a.tiles_x) * TX;
-  tt = qd;
-  qd = fastdiv(tt, a.tiles_y, a.rcp_tiles_y);
-  const int ty0 = (tt - qd * a.tiles_y) * TY;
-  tt = qd;
-  qd = fastdiv(tt, a.tiles_z, a.rcp_tiles_z);
-  const int tz0 = (tt - qd * a.tiles_z) * TZ;
-  const int n = qd;
-  const int tis = tile - n * tiles_per_sample;
+  auto decode = [&](int bid, int& tile, int& cb) {
+    const int local = bid >> 3;
+    const int lq = fastdiv(local, a.ncb, a.rcp_ncb);
+    tile = lq * 8 + (bid & 7);
+    cb = local - lq * a.ncb;
+  };
+  auto origin = [&](int tile, int& n, int& tz0, int& ty0, int& tx0) {
+    int tt = tile;
+    int qd = fastdiv(tt, a.tiles_x, a.rcp_tiles_x);
+    tx0 = (tt - qd * a.tiles_x) * TX;
+    tt = qd;
+    qd = fastdiv(tt, a.tiles_y, a.rcp_tiles_y);
+    ty0 = (tt - qd * a.tiles_y) * TY;
+    tt = qd;
+    qd = fastdiv(tt, a.tiles_z, a.rcp_tiles_z);
+    tz0 = (tt - qd * a.tiles_z) * TZ;
+    n = qd;
+  };
+  int cur_bid = blockIdx.x, ctile, ccb;
+  decode(cur_bid, ctile, ccb);
+  if (ctile >= a.ntiles) return;  // (padding items of the last brick group; workgroup-uniform)
 
-  // ---- staging plan (independent of the K chunk): 32-bit BYTE offset of each 16-byte piece for a buffer load whose
-  //      resource descriptor sits in SGPRs.  Pieces outside the volume get an offset beyond num_records: the hardware
-  //      range check returns zeros for them, so zero padding costs neither a branch nor a select.
-  // (one resource per SAMPLE, so only a single sample has to stay below the 4 GB a 32-bit offset can address)
-  const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)n * a.id * a.ih * a.iw * a.cin), 0, a.bytes_x, 0x00020000);
+  // ---- staging plan: this thread's halo pieces are the same for every brick (hpos); per brick they become 32-bit BYTE
+  //      offsets for buffer loads whose resource descriptor (one SAMPLE, so only a sample has to stay below 4 GB) sits in
+  //      SGPRs.  Pieces outside the volume get an offset beyond num_records: the hardware range check returns zeros for
+  //      them, so zero padding costs neither a branch nor a select.
   constexpr unsigned OOB = 0xFFFFFF00u;
-  unsigned goff[IN_ROUNDS];
+  int hpos[IN_ROUNDS];  // hz << 16 | hy << 8 | hx; slots past the halo get coordinates that fail every range check
 #pragma unroll
   for (int it = 0; it < IN_ROUNDS; ++it) {
-    const int p = it * 256 + tid;
-    const int v = p >> 1, hh = p & 1;
-    const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
-    const int gz = STRIDE * tz0 - 1 + hz, gy = STRIDE * ty0 - 1 + hy, gx = STRIDE * tx0 - 1 + hx;
-    // branch-free: one unsigned compare per axis covers both bounds; '&' (not '&&') keeps hipcc from building a branch
-    // ladder around the address arithmetic
-    const bool in_vol = (v < NV) & ((unsigned)gz < (unsigned)a.id) & ((unsigned)gy < (unsigned)a.ih) & ((unsigned)gx < (unsigned)a.iw);
-    const unsigned off = ((unsigned)((gz * a.ih + gy) * a.iw + gx) * (unsigned)a.cin + hh * 8) * 2u;
-    goff[it] = in_vol ? off : OOB;
+    const int v = (it * 256 + tid) >> 1;
+    hpos[it] = v < NV ? ((v / (HX * HY)) << 16) | (((v / HX) % HY) << 8) | (v % HX) : 0x7FFF0000;
   }
-  // the weight slice of (cb, kc) is one linear 27 KB run: thread t takes pieces t, t+256, ... (scalar offsets); the last
-  // round is cut off by the resource's size instead of a clamp
-  const bf16* wsrc = a.wpk + (size_t)cb * a.nkc * (W_CHUNKS * 8);
+  const int hh = tid & 1;
+  unsigned goff[IN_ROUNDS];
+  int pn = 0;  // sample of the brick the plan (and the loads in flight) belong to
+  auto plan = [&](int tile) {
+    int tz0, ty0, tx0;
+    origin(tile, pn, tz0, ty0, tx0);
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) {
+      const int gz = STRIDE * tz0 - 1 + (hpos[it] >> 16), gy = STRIDE * ty0 - 1 + ((hpos[it] >> 8) & 255),
+                gx = STRIDE * tx0 - 1 + (hpos[it] & 255);
+      // branch-free: one unsigned compare per axis covers both bounds ('&', not '&&': no branch ladder)
+      const bool in_vol = ((unsigned)gz < (unsigned)a.id) & ((unsigned)gy < (unsigned)a.ih) & ((unsigned)gx < (unsigned)a.iw);
+      const unsigned off = ((unsigned)((gz * a.ih + gy) * a.iw + gx) * (unsigned)a.cin + hh * 8) * 2u;
+      goff[it] = in_vol ? off : OOB;
+    }
+  };
 
   u32x4 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
-  auto prefetch = [&](int kc) {  // 16 loads issued back to back, nothing waits on them until commit()
+  auto prefetch = [&](int cb, int kc) {  // 15 loads issued back to back, nothing waits on them until commit()
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)pn * a.id * a.ih * a.iw * a.cin), 0, a.bytes_x, 0x00020000);
 #pragma unroll
     for (int it = 0; it < IN_ROUNDS; ++it) in_reg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, goff[it], kc * 32, 0);
-    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(wsrc + (size_t)kc * (W_CHUNKS * 8)), 0, W_CHUNKS * 16, 0x00020000);
+    // the weight slice of (cb, kc) is one linear 27 KB run: thread t takes pieces t, t+256, ...; the last round is cut
+    // off by the resource's size (the round is part of voffset: the hardware range check does not see soffset)
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + ((size_t)cb * a.nkc + kc) * (W_CHUNKS * 8)), 0, W_CHUNKS * 16, 0x00020000);
 #pragma unroll
-    for (int it = 0; it < W_ROUNDS; ++it)  // (the round is part of voffset: the hardware range check does not see soffset)
-      w_reg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16 + it * 4096, 0, 0);
+    for (int it = 0; it < W_ROUNDS; ++it) w_reg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16 + it * 4096, 0, 0);
   };
   auto commit = [&]() {
 #pragma unroll
@@ -164,162 +188,208 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   };
 
   // ---- this lane's voxel in each of the wave's N-tiles (2 rows x 16 voxels), row-rotated for conflict-free reads
-  auto tile_voxel = [&](int t, int& lz, int& ly, int& lx) {
-    const int g = wv * NTW + t;
-    lz = g / (TY / 2);
-    ly = (g % (TY / 2)) * 2 + (r >> 4);
-    const int i = r & 15;
-    lx = STRIDE == 1 ? ((i - (r >> 4) * HX) & 15) : i;
-  };
   int lbase[NTW];  // LDS piece index of tap (0,0,0) for this lane
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
-    int lz, ly, lx;
-    tile_voxel(t, lz, ly, lx);
+    const int g = wv * NTW + t;
+    const int lz = g / (TY / 2), ly = (g % (TY / 2)) * 2 + (r >> 4);
+    const int lx = STRIDE == 1 ? (((r & 15) - (r >> 4) * HX) & 15) : (r & 15);
     lbase[t] = ((STRIDE * lz) * HY + STRIDE * ly) * HX + STRIDE * lx + h * NV;
   }
-
-  f32x16 acc[NTW];
-#pragma unroll
-  for (int t = 0; t < NTW; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-  STAMP(1);
-  prefetch(0);
-  STAMP(2);
-  for (int kc = 0; kc < a.nkc; ++kc) {
-    __syncthreads();  // every wave is done reading the previous chunk's LDS image
-    if (kc < 2) STAMP(3 + 4 * kc);
-    commit();
-    if (kc < 2) STAMP(4 + 4 * kc);
-    __syncthreads();
-    if (kc + 1 < a.nkc) prefetch(kc + 1);  // in flight while the matrix cores work on chunk kc
-    if (kc < 2) STAMP(5 + 4 * kc);
-    // Software-pipelined over the 27 taps: the fragments of tap t+1 (1 weight + NTW input ds_read_b128) are in flight
-    // while tap t is on the matrix cores; sched_group_barrier pins that interleave (hipcc otherwise sinks each read to
-    // just in front of its MFMA and exposes the LDS latency 108 times per chunk).
-    constexpr int PD = 1;  // prefetch distance in taps (PD + 1 operand sets in registers); 2 measured no faster (+20 VGPRs)
-    bf16x8 wa[PD + 1], xb[PD + 1][NTW];
-    auto tap_off = [&](int t1) { return ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3; };
-#pragma unroll
-    for (int p = 0; p < PD; ++p) {
-      wa[p] = __builtin_bit_cast(bf16x8, w_lds[(p * 2 + h) * 32 + r]);
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) xb[p][t] = __builtin_bit_cast(bf16x8, in_lds[lbase[t] + tap_off(p)]);
-    }
-#pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
-      const int cur = tap % (PD + 1), nxt = (tap + PD) % (PD + 1);
-      if (tap + PD < 27) {
-        const int t1 = tap + PD;
-        const int toff = tap_off(t1);
-        wa[nxt] = __builtin_bit_cast(bf16x8, w_lds[(t1 * 2 + h) * 32 + r]);
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) xb[nxt][t] = __builtin_bit_cast(bf16x8, in_lds[lbase[t] + toff]);
-      }
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur], xb[cur][t], acc[t], 0, 0, 0);
-      if (tap + PD < 27) __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);  // DS reads of tap+PD first ...
-      __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                          // ... then the MFMAs of tap
-    }
-    if (kc < 2) STAMP(6 + 4 * kc);
-  }
-
-  // ---- epilogue through LDS.  D[row = co][col = voxel]: the accumulator layout gives every lane four 8-byte pieces of
-  // its voxel's 64-byte channel row, so a direct store instruction would touch 32 rows with 8 bytes each.  Instead the
-  // brick's output is assembled in LDS (8-byte chunks XOR-swizzled by voxel so both the ds_write_b64 and the ds_read_b128
-  // are conflict-free) and written out as whole rows: 4 lanes per voxel, 16 voxels = 1 KB contiguous per wave instruction
-  // when Cout = 32.  The GroupNorm partial sums come from the same LDS image (8 channels per lane).
-  bf16* out_lds = reinterpret_cast<bf16*>(smem);  // [TZ*TY*TX voxels][32 co], reuses the input image
-  __syncthreads();                                // every wave is done with the MFMA reads of the last chunk
-  STAMP(11);
-#pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    int lz, ly, lx;
-    tile_voxel(t, lz, ly, lx);
-    const int vl = (lz * TY + ly) * TX + lx;
-    const int sw = (vl >> 1) & 7;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      bf16x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[t][q * 4 + j];  // co = 8q + 4h + j
-      *reinterpret_cast<bf16x4*>(out_lds + vl * 32 + ((2 * q + h) ^ sw) * 4) = o;
-    }
-  }
-  __syncthreads();
-  STAMP(12);
-  // GroupNorm partials are kept per channel PAIR (v_dot2c_f32_bf16: two exact bf16 products + fp32 add per instruction,
-  // 8 instructions per 8-channel piece instead of 24): entry 2j of the partial row gets the sums of channels 2j and
-  // 2j+1, entry 2j+1 is zero.  GroupNorm only ever adds the channels of a group, so this is exact whenever the
-  // channels per group are even (the host asks for fused partials only then).
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   const bf16x2 ones = {(bf16)1.0f, (bf16)1.0f};
-  float gs[4], gq[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) gs[k] = gq[k] = 0.f;
-  const int pj = tid & 3;
   const size_t ovol = (size_t)a.od * a.oh * a.ow;
-  // Row stores: lane = (voxel et of 64, 16-byte piece pj of 4).  The 64 voxels of round `it` are 4 x-rows of 16, so the
-  // per-round part of the address is a SCALAR (soffset of a buffer store whose resource is this sample) and the lane part
-  // is computed once; lanes outside the volume / past Cout get an out-of-range voffset and the hardware drops the store.
-  static_assert(TX == 16 && TY % 4 == 0, "row decomposition of the epilogue");
-  const int et = tid >> 2, ex = et & 15, ey = et >> 4;
-  const bool lane_ok = (tx0 + ex < a.ow) & (cb * 32 + pj * 8 < a.cout);  // (a 16-channel layer fills half a block)
-  const unsigned vbase = (unsigned)((ey * a.ow + ex) * a.cout + pj * 8) * 2u;
-  const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
-  const int swl = (et >> 1) & 7;  // (vl >> 1) & 7 does not depend on the round: 64 voxels per round
-  const bf16* rd = out_lds + et * 32 + (pj ^ (swl >> 1)) * 8;
-#pragma unroll
-  for (int it = 0; it < (TZ * TY * TX * 4) / 256; ++it) {
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(rd + it * 64 * 32);
-    if (swl & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
-    const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
-    const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
-    const unsigned soff = (unsigned)(((oz * a.oh + oyb) * a.ow + tx0) * a.cout + cb * 32) * 2u;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_y, ok ? vbase : OOB, soff, 0);
-    if (ok && a.gn_partial) {  // statistics of what is stored (the rounded values), exactly like the stand-alone pass
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bf16x2 pr = {v[2 * k], v[2 * k + 1]};
-        gs[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, gs[k], false);
-        gq[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, gq[k], false);
-      }
+  STAMP(1);
+
+  plan(ctile);
+  prefetch(ccb, 0);
+  STAMP(2);
+  while (true) {
+    int n, tz0, ty0, tx0;
+    origin(ctile, n, tz0, ty0, tx0);
+    const int tis = ctile - n * tiles_per_sample;
+    const int cb = ccb;
+#ifdef MEDNET_CONV_TIMING
+    stamp_item = item_no == 8 || (item_no == 0 && (int)blockIdx.x + 8 * (int)gridDim.x >= a.nitems);
+    ++item_no;
+#endif
+    // the item after this one
+    const int nbid = cur_bid + (int)gridDim.x;
+    int ntile = 0, ncb2 = 0;
+    bool has_next = false;
+    if (nbid < a.nitems) {
+      decode(nbid, ntile, ncb2);
+      has_next = ntile < a.ntiles;
     }
-  }
-  STAMP(13);
-  if (a.gn_partial) {
-    // GroupNorm statistics fused into the producer (components.py:57 follows every conv of the 'c g .' orders)
+
+    f32x16 acc[NTW];
 #pragma unroll
-    for (int m = 4; m < 64; m <<= 1)
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        gs[k] += __shfl_xor(gs[k], m, 64);
-        gq[k] += __shfl_xor(gq[k], m, 64);
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    for (int kc = 0; kc < a.nkc; ++kc) {
+      __syncthreads();  // every wave is done reading the previous LDS image (MFMA operands or the epilogue's rows)
+      if (kc < 2) STAMP(3 + 4 * kc);
+      commit();
+      if (kc < 2) STAMP(4 + 4 * kc);
+      __syncthreads();
+      // What flies while chunk kc is on the matrix cores: the next chunk of this item, or the first chunk of the next
+      // item.  Its 15 loads are NOT issued in one burst (measured: a burst blocks the wave's issue for ~3000 cycles
+      // behind the CU's one texture-address path, which both workgroups share); they are dealt out one per tap, so the
+      // wave keeps feeding the matrix cores.  No branch inside the tap loop (it would end the scheduling region): when
+      // there is nothing to fetch the offsets are pushed out of range and the loads return zeros without touching memory.
+      bool do_pf = true;
+      int pf_cb = cb, pf_kc = kc + 1;
+      if (kc + 1 >= a.nkc) {
+        pf_kc = 0;
+        pf_cb = ncb2;
+        do_pf = has_next;
+        if (has_next) plan(ntile);
       }
-    if (lane < 4) {
+      const unsigned kill = do_pf ? 0u : OOB;
+      const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)pn * a.id * a.ih * a.iw * a.cin), 0, a.bytes_x, 0x00020000);
+      const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + ((size_t)pf_cb * a.nkc + pf_kc) * (W_CHUNKS * 8)), 0, W_CHUNKS * 16, 0x00020000);
+      if (kc < 2) STAMP(5 + 4 * kc);
+      // Software-pipelined over the 27 taps: the fragments of tap t+1 (1 weight + NTW input ds_read_b128) are in flight
+      // while tap t is on the matrix cores; sched_group_barrier pins that interleave (hipcc otherwise sinks each read to
+      // just in front of its MFMA and exposes the LDS latency 108 times per chunk).
+      constexpr int PD = 1;  // prefetch distance in taps (PD + 1 operand sets in registers); 2 measured no faster (+20 VGPRs)
+      bf16x8 wa[PD + 1], xb[PD + 1][NTW];
+      auto tap_off = [&](int t1) { return ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3; };
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        st_lds[((wv * 4 + pj) * 4 + k) * 2] = gs[k];
-        st_lds[((wv * 4 + pj) * 4 + k) * 2 + 1] = gq[k];
+      for (int p = 0; p < PD; ++p) {
+        wa[p] = __builtin_bit_cast(bf16x8, w_lds[(p * 2 + h) * 32 + r]);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) xb[p][t] = __builtin_bit_cast(bf16x8, in_lds[lbase[t] + tap_off(p)]);
+      }
+      static_assert(IN_ROUNDS + W_ROUNDS <= 27, "one staging load per tap");
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        const int cur = tap % (PD + 1), nxt = (tap + PD) % (PD + 1);
+        if (tap + PD < 27) {
+          const int t1 = tap + PD;
+          const int toff = tap_off(t1);
+          wa[nxt] = __builtin_bit_cast(bf16x8, w_lds[(t1 * 2 + h) * 32 + r]);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) xb[nxt][t] = __builtin_bit_cast(bf16x8, in_lds[lbase[t] + toff]);
+        }
+        if (tap < IN_ROUNDS)
+          in_reg[tap] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, goff[tap] | kill, pf_kc * 32, 0);
+        else if (tap < IN_ROUNDS + W_ROUNDS)
+          w_reg[tap - IN_ROUNDS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(tid * 16 + (tap - IN_ROUNDS) * 4096) | kill, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur], xb[cur][t], acc[t], 0, 0, 0);
+        if (tap + PD < 27) __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);  // DS reads of tap+PD first ...
+        if (tap < IN_ROUNDS + W_ROUNDS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // ... one staging load ...
+        __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                          // ... then the MFMAs of tap
+      }
+      if (kc < 2) STAMP(6 + 4 * kc);
+    }
+
+    // ---- epilogue through LDS.  D[row = co][col = voxel]: the accumulator layout gives every lane four 8-byte pieces of
+    // its voxel's 64-byte channel row, so a direct store instruction would touch 32 rows with 8 bytes each.  Instead the
+    // brick's output is assembled in LDS (8-byte chunks XOR-swizzled by voxel so both the ds_write_b64 and the
+    // ds_read_b128 are conflict-free) and written out as whole rows: 4 lanes per voxel, 16 voxels = 1 KB contiguous per
+    // wave instruction when Cout = 32.  The GroupNorm partial sums come from the same LDS image (8 channels per lane).
+    bf16* out_lds = reinterpret_cast<bf16*>(smem);  // [TZ*TY*TX voxels][32 co], reuses the input image
+    __syncthreads();                                // every wave is done with the MFMA reads of the last chunk
+    STAMP(11);
+    // (an opaque copy of the thread id: without it the compiler hoists the epilogue's ~30 addresses, which are the same
+    //  for every item, out of the item loop and pays for that with spills in the tap loop)
+    int etid = tid;
+    asm volatile("" : "+v"(etid));
+    const int e_lane = etid & 63, e_wv = etid >> 6, e_r = e_lane & 31, e_h = e_lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int g = e_wv * NTW + t;
+      const int lz = g / (TY / 2), ly = (g % (TY / 2)) * 2 + (e_r >> 4);
+      const int lx = STRIDE == 1 ? (((e_r & 15) - (e_r >> 4) * HX) & 15) : (e_r & 15);
+      const int vl = (lz * TY + ly) * TX + lx;
+      const int sw = (vl >> 1) & 7;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[t][q * 4 + j];  // co = 8q + 4h + j
+        *reinterpret_cast<bf16x4*>(out_lds + vl * 32 + ((2 * q + e_h) ^ sw) * 4) = o;
       }
     }
     __syncthreads();
-    if (tid < 64) {
-      const int co = tid >> 1, which = tid & 1;
-      float tot = 0.f;
-      if (!(co & 1)) {
+    STAMP(12);
+    // GroupNorm partials are kept per channel PAIR (v_dot2c_f32_bf16: two exact bf16 products + fp32 add per
+    // instruction, 8 instructions per 8-channel piece instead of 24): entry 2j of the partial row gets the sums of
+    // channels 2j and 2j+1, entry 2j+1 is zero.  GroupNorm only ever adds the channels of a group, so this is exact
+    // whenever the channels per group are even (the host asks for fused partials only then).
+    float gs[4], gq[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) tot += st_lds[((k * 4 + (co >> 3)) * 4 + ((co & 7) >> 1)) * 2 + which];
+    for (int k = 0; k < 4; ++k) gs[k] = gq[k] = 0.f;
+    const int pj = etid & 3;
+    // Row stores: lane = (voxel et of 64, 16-byte piece pj of 4).  The 64 voxels of round `it` are 4 x-rows of 16, so
+    // the per-round part of the address is a SCALAR (soffset of a buffer store whose resource is this sample) and the
+    // lane part is computed once; lanes outside the volume / past Cout get an out-of-range voffset and the hardware
+    // drops the store.
+    static_assert(TX == 16 && TY % 4 == 0, "row decomposition of the epilogue");
+    const int et = etid >> 2, ex = et & 15, ey = et >> 4;
+    const bool lane_ok = (tx0 + ex < a.ow) & (cb * 32 + pj * 8 < a.cout);  // (a 16-channel layer fills half a block)
+    const unsigned vbase = (unsigned)((ey * a.ow + ex) * a.cout + pj * 8) * 2u;
+    const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
+    const int swl = (et >> 1) & 7;  // (vl >> 1) & 7 does not depend on the round: 64 voxels per round
+    const bf16* rd = out_lds + et * 32 + (pj ^ (swl >> 1)) * 8;
+#pragma unroll
+    for (int it = 0; it < (TZ * TY * TX * 4) / 256; ++it) {
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(rd + it * 64 * 32);
+      if (swl & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
+      const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
+      const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
+      const unsigned soff = (unsigned)(((oz * a.oh + oyb) * a.ow + tx0) * a.cout + cb * 32) * 2u;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_y, ok ? vbase : OOB, soff, 0);
+      if (ok && a.gn_partial) {  // statistics of what is stored (the rounded values), exactly like the stand-alone pass
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bf16x2 pr = {v[2 * k], v[2 * k + 1]};
+          gs[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, gs[k], false);
+          gq[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, gq[k], false);
+        }
       }
-      if (cb * 32 + co < a.cout)
-        a.gn_partial[(((size_t)n * tiles_per_sample + tis) * a.cout + cb * 32 + co) * 2 + which] = tot;
     }
+    STAMP(13);
+    if (a.gn_partial) {
+      // GroupNorm statistics fused into the producer (components.py:57 follows every conv of the 'c g .' orders)
+#pragma unroll
+      for (int m = 4; m < 64; m <<= 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          gs[k] += __shfl_xor(gs[k], m, 64);
+          gq[k] += __shfl_xor(gq[k], m, 64);
+        }
+      if (e_lane < 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          st_lds[((e_wv * 4 + pj) * 4 + k) * 2] = gs[k];
+          st_lds[((e_wv * 4 + pj) * 4 + k) * 2 + 1] = gq[k];
+        }
+      }
+      __syncthreads();
+      if (etid < 64) {
+        const int co = etid >> 1, which = etid & 1;
+        float tot = 0.f;
+        if (!(co & 1)) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) tot += st_lds[((k * 4 + (co >> 3)) * 4 + ((co & 7) >> 1)) * 2 + which];
+        }
+        if (cb * 32 + co < a.cout)
+          a.gn_partial[(((size_t)n * tiles_per_sample + tis) * a.cout + cb * 32 + co) * 2 + which] = tot;
+      }
+    }
+    STAMP(14);
+    if (!has_next) break;
+    cur_bid = nbid;
+    ctile = ntile;
+    ccb = ncb2;
   }
 #ifdef MEDNET_CONV_TIMING
   __builtin_amdgcn_s_waitcnt(0);  // all stores of this wave acknowledged
-  STAMP(14);
+  STAMP(15);
 #endif
 }
 
@@ -703,7 +773,10 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   a.bytes_x = (unsigned)((size_t)id * ih * iw * cin * 2);
   MEDNET_REQUIRE((double)od * oh * ow * cout * 2.0 < 4294960000.0, MEDNET_E_UNSUPPORTED, "conv_mfma: one output sample must stay below 4 GB");
   a.bytes_y = (unsigned)((size_t)od * oh * ow * cout * 2);
-  const unsigned grid = (unsigned)((a.ntiles + 7) / 8) * 8 * a.ncb;
+  a.nitems = ((a.ntiles + 7) / 8) * 8 * a.ncb;
+  // persistent form: 2 workgroups per CU stream through the items (option conv_persist=0: one workgroup per item)
+  unsigned grid = (unsigned)a.nitems;
+  if (tuning_option("conv_persist", 1) && grid > 512u) grid = 512u;
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[STRIDE]) {
     if (hipFuncSetAttribute((const void*)conv_mfma_kernel<STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
