@@ -64,7 +64,7 @@ struct FwdArgs {
   unsigned rcp_tiles_x, rcp_tiles_y, rcp_tiles_z, rcp_ncb;  // ceil(2^32 / d): x / d == umulhi(x, rcp) for x * d < 2^32
   unsigned bytes_x;  // size of ONE SAMPLE of x for the buffer resource (< 4 GB)
   unsigned bytes_y;  // same for y
-  float* gn_partial;  // nullable: [n][bricks per sample][cout][2] = per-brick {sum y, sum y^2} of the STORED (rounded) outputs
+  float* gn_partial;  // nullable: [n][4 * bricks per sample][cout][2] = per-wave {sum y, sum y^2} of the STORED (rounded) outputs
 #ifdef MEDNET_CONV_TIMING
   long long* dbg;  // [workgroup][16] s_memtime stamps of wave 0 (tools/probes/conv_timing.py)
 #endif
@@ -95,7 +95,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u32x4* in_lds = reinterpret_cast<u32x4*>(smem);                  // [2][NV] 16-byte pieces (8 bf16 channels)
   u32x4* w_lds = reinterpret_cast<u32x4*>(smem) + 2 * NV;          // [27][2][32]
-  float* st_lds = reinterpret_cast<float*>(smem + ((size_t)2 * NV + W_CHUNKS) * 16);  // [4 waves][4][4][2]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -362,23 +361,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
           gs[k] += __shfl_xor(gs[k], m, 64);
           gq[k] += __shfl_xor(gq[k], m, 64);
         }
-      if (e_lane < 4) {
+      // one partial row per WAVE (4 per brick): no cross-wave reduction, so no barrier at the end of an item; lanes 0..3
+      // hold the sums of their 8-channel piece and write {sum, sumsq, 0, 0} per channel pair
+      if (e_lane < 4 && cb * 32 + pj * 8 < a.cout) {
+        float* dst = a.gn_partial + ((((size_t)n * tiles_per_sample + tis) * 4 + e_wv) * a.cout + cb * 32 + pj * 8) * 2;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          st_lds[((e_wv * 4 + pj) * 4 + k) * 2] = gs[k];
-          st_lds[((e_wv * 4 + pj) * 4 + k) * 2 + 1] = gq[k];
+          const f32x4 o = {gs[k], gq[k], 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(dst + k * 4) = o;
         }
-      }
-      __syncthreads();
-      if (etid < 64) {
-        const int co = etid >> 1, which = etid & 1;
-        float tot = 0.f;
-        if (!(co & 1)) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) tot += st_lds[((k * 4 + (co >> 3)) * 4 + ((co & 7) >> 1)) * 2 + which];
-        }
-        if (cb * 32 + co < a.cout)
-          a.gn_partial[(((size_t)n * tiles_per_sample + tis) * a.cout + cb * 32 + co) * 2 + which] = tot;
       }
     }
     STAMP(14);
@@ -749,7 +740,7 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
                       int cin, int cout, float* gn_partial, hipStream_t s) {
   using G = FwdTile<STRIDE>;
   constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
-  constexpr size_t lds = ((size_t)2 * HZ * HY * HX + 27 * 2 * 32) * 16 + 1024;  // + GroupNorm partial scratch
+  constexpr size_t lds = ((size_t)2 * HZ * HY * HX + 27 * 2 * 32) * 16;
   static_assert(lds <= 80 * 1024, "two workgroups must fit one CU");
   FwdArgs a;
   a.gn_partial = gn_partial;
@@ -795,7 +786,7 @@ int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, 
 }
 int conv_mfma_stats_chunks(int d, int h, int w) {
   using G = FwdTile<1>;
-  return ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
+  return 4 * ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);  // one row per wave
 }
 
 int launch_convt_dgrad_mfma(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin,

@@ -143,18 +143,41 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   __shared__ double sh[2][4];
   const int n = blockIdx.x / groups, g = blockIdx.x % groups;
   const int cg = c / groups, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // a thread walks chunk rows t, t+256, ... and adds the group's cg {sum, sumsq} pairs of each row (32 contiguous bytes
+  // when cg = 4), four rows in flight; fp64, fixed order => bitwise reproducible
   double s = 0.0, q = 0.0;
-  for (int i = wv; i < cg; i += 4) {
-    const int cc = g * cg + i;
-    double a = 0.0, b = 0.0;
-    for (int ch = lane; ch < chunks; ch += 64) {
-      const float* p = partial + (((size_t)n * chunks + ch) * c + cc) * 2;
-      a += (double)p[0];
-      b += (double)p[1];
+  const float* base = partial + (size_t)n * chunks * c * 2 + (size_t)g * cg * 2;
+  const size_t row = (size_t)c * 2;
+  if (cg % 2 == 0) {
+    auto add_row = [&](const float* p, double& ss, double& qq) {
+      for (int i = 0; i < cg / 2; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * i);
+        ss += (double)v[0] + (double)v[2];
+        qq += (double)v[1] + (double)v[3];
+      }
+    };
+    double s1 = 0.0, q1 = 0.0, s2 = 0.0, q2 = 0.0, s3 = 0.0, q3 = 0.0;
+    int ch = threadIdx.x;
+    for (; ch + 768 < chunks; ch += 1024) {
+      add_row(base + (size_t)ch * row, s, q);
+      add_row(base + (size_t)(ch + 256) * row, s1, q1);
+      add_row(base + (size_t)(ch + 512) * row, s2, q2);
+      add_row(base + (size_t)(ch + 768) * row, s3, q3);
     }
-    s += wave_sum(a);
-    q += wave_sum(b);
+    for (; ch < chunks; ch += 256) add_row(base + (size_t)ch * row, s, q);
+    s = (s + s1) + (s2 + s3);
+    q = (q + q1) + (q2 + q3);
+  } else {
+    for (int ch = threadIdx.x; ch < chunks; ch += 256) {
+      const float* p = base + (size_t)ch * row;
+      for (int i = 0; i < cg; ++i) {
+        s += (double)p[2 * i];
+        q += (double)p[2 * i + 1];
+      }
+    }
   }
+  s = wave_sum(s);
+  q = wave_sum(q);
   if (lane == 0) {
     sh[0][wv] = s;
     sh[1][wv] = q;
