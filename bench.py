@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("MEDNET_GRAPH", "0")),
+                    help="1: replay forward+loss+backward as one captured hipGraph per step (train._GraphedStep)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,7 +132,7 @@ def main():
     assert _lib.lib().mednet_device_ok() == 1, "libmednet_hip.so sees no gfx950 device"
     mednet_hip.set_precision(a.precision)
     model = keyed_init_(ResidualUNet3D(1, 4, False, f_maps=F_MAPS)).to(dev)
-    step = SegmentationStep(model, loss_weight=[0.05, 1.0, 1.0, 1.0], lr=1e-3, world_size=world)
+    step = SegmentationStep(model, loss_weight=[0.05, 1.0, 1.0, 1.0], lr=1e-3, world_size=world, graph=bool(a.graph))
     P = a.patch
     batch = {k: v.to(dev) for k, v in synthetic_batch(a.batch, 1, (P, P, P), 4, 0, seed=1234 + rank).items()}
 
@@ -154,6 +156,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step(batch)
+    t_issue = time.perf_counter() - t0  # host time to ENQUEUE the steps (the GPU runs behind; sync() below waits for it)
     sync()
     dt = time.perf_counter() - t0
     ops.PROFILE["enabled"] = False
@@ -172,7 +175,9 @@ def main():
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": f"ResidualUNet3D f_maps={F_MAPS} 4-class, {P}^3 patches, batch {a.batch}/GPU, "
                                    f"fwd+DiceLoss+bwd+allreduce+Adam (BASELINE config {'2' if world == 1 else '3'})",
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "loss": round(final_loss, 6)},
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "loss": round(final_loss, 6),
+                       "graph_replay": bool(a.graph)},
+            "host_enqueue_ms_per_step": round(1e3 * t_issue / a.steps, 3),
         }
         if P == 128 and a.precision == "bf16":
             out["model_flops_utilization"] = round(patches / dt * FLOP_PER_PATCH / (world * MFMA_PEAK_TFLOPS["bf16"] * 1e12), 4)

@@ -52,9 +52,12 @@ class _OnSide:
             side.wait_stream(main)
             for t in self.tensors:
                 if t is not None:
-                    t.record_stream(side)  # keep the allocator from recycling operands the side stream still reads
-                    # ... and keep autograd from accumulating INTO them: a gradient handed on to autograd (ConvTranspose's
-                    # skip gradient is `dy` itself) is summed in place with later arrivals when nobody else holds it
+                    # Operands stay referenced until join_side_stream(), i.e. until the main stream has been made to
+                    # wait for the side stream: (1) the caching allocator cannot recycle memory the side stream still
+                    # reads (no Tensor.record_stream: its per-block events made every later allocation poll hundreds of
+                    # events -- 9 of the host's 15 ms per step), and (2) autograd cannot accumulate INTO them: a
+                    # gradient handed on to autograd (ConvTranspose's skip gradient is `dy` itself) is summed in place
+                    # with later arrivals when nobody else holds it.
                     SIDE["keepalive"].append(t)
             self.ctx = torch.cuda.stream(side)
             self.ctx.__enter__()

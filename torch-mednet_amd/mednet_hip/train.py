@@ -86,10 +86,46 @@ def allreduce_gradients(flat_grad: torch.Tensor, world_size: int, force: bool = 
     return 1.0 / world_size
 
 
-class SegmentationStep:
+class _GraphedStep:
+    """hipGraph capture of forward + loss + backward (everything up to the gradient exchange).
+
+    A step is ~330 kernel launches from Python; the GPU stays ahead of the host only while the host is not disturbed.
+    After `warm` eager calls the launch sequence of `_fwd_bwd` (both streams: the weight-gradient side stream forks from
+    and re-joins the capture stream) is captured once and replayed with one call per step.  The all-reduce and the
+    Adam launch stay outside the graph (Adam's bias correction is computed on the host from the step count).
+    Shapes and dtypes of the batch must not change after capture; a new batch tensor is copied into the static one."""
+
+    GRAPH_DEFAULT = os.environ.get("MEDNET_GRAPH", "0") == "1"
+
+    def _init_graph(self, graph, warm=2):
+        self.use_graph = self.GRAPH_DEFAULT if graph is None else bool(graph)
+        self._calls, self._warm, self._graph, self._static = 0, warm, None, None
+
+    def _run(self, batch):
+        """-> tuple of detached loss tensors of this step's forward/backward (gradients are in self.flat.grad)."""
+        if not self.use_graph:
+            return self._fwd_bwd(batch)
+        self._calls += 1
+        if self._graph is None:
+            if self._calls <= self._warm:
+                return self._fwd_bwd(batch)
+            ops.PROFILE["enabled"] = False  # timing events cannot be recorded into a graph
+            self._static = {k: v for k, v in batch.items()}
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._out = self._fwd_bwd(self._static)
+        for k, v in batch.items():
+            if v is not self._static[k]:
+                self._static[k].copy_(v)
+        self._graph.replay()
+        return self._out
+
+
+class SegmentationStep(_GraphedStep):
     """One data-parallel training step of SegmentationNet (segmentation.py:58-65) on the MI355X path."""
 
-    def __init__(self, model, loss_weight=None, lr=1e-3, loss="DICE", world_size=1):
+    def __init__(self, model, loss_weight=None, lr=1e-3, loss="DICE", world_size=1, graph=None):
         self.model = model
         dev = next(model.parameters()).device
         w = None if loss_weight is None else torch.tensor(loss_weight, dtype=torch.float32, device=dev)
@@ -98,23 +134,28 @@ class SegmentationStep:
         self.opt = FlatAdam(self.flat, lr=lr)
         self.world = world_size
         ops.SIDE["enabled"] = os.environ.get("MEDNET_SIDE_STREAM", "1") == "1"
+        self._init_graph(graph)
 
-    def __call__(self, batch):
+    def _fwd_bwd(self, batch):
         inputs = batch["data"].float()
         labels = batch["label"][:, -1, ...].long()
         outputs = self.model(inputs)
         loss = self.loss(outputs, labels)
         loss.backward()
         finish_backward()
+        return (loss.detach(),)
+
+    def __call__(self, batch):
+        (loss,) = self._run(batch)
         scale = allreduce_gradients(self.flat.grad, self.world, getattr(self, "force_allreduce", False))  # 1/world folded into Adam
         self.opt.step(grad_scale=scale)
-        return loss.detach()
+        return loss
 
 
-class LandmarkStep:
+class LandmarkStep(_GraphedStep):
     """LandmarkNet.training_step (landmarks.py:66-83, loss :125-134) with the per-channel regression loop fused."""
 
-    def __init__(self, model, class_weight, regression_weight, regression="L2", lr=1e-3, world_size=1):
+    def __init__(self, model, class_weight, regression_weight, regression="L2", lr=1e-3, world_size=1, graph=None):
         self.model = model
         dev = next(model.parameters()).device
         self.loss_class = HL.DiceLoss(weight=torch.tensor(class_weight, dtype=torch.float32, device=dev)).to(dev)
@@ -122,8 +163,9 @@ class LandmarkStep:
         self.flat = FlatParams(model)
         self.opt = FlatAdam(self.flat, lr=lr)
         self.world = world_size
+        self._init_graph(graph)
 
-    def __call__(self, batch):
+    def _fwd_bwd(self, batch):
         inputs = batch["data"].float()
         heatmaps = batch["label"][:, :-1, ...]  # uint8 is consumed directly by the fused regression kernel
         nh = heatmaps.shape[1]
@@ -134,6 +176,10 @@ class LandmarkStep:
         loss = regression_loss + class_loss
         loss.backward()
         finish_backward()
+        return loss.detach(), class_loss.detach(), regression_loss.detach()
+
+    def __call__(self, batch):
+        out = self._run(batch)
         scale = allreduce_gradients(self.flat.grad, self.world)
         self.opt.step(grad_scale=scale)
-        return loss.detach(), class_loss.detach(), regression_loss.detach()
+        return out
