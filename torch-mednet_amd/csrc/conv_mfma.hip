@@ -942,6 +942,7 @@ struct Wg2Args {
   int n, d, h, w, ka, kb;
   int tiles_z, tiles_y, tiles_x, ntiles;
   int nab, nbb, splits;
+  unsigned rcp_tiles_x, rcp_tiles_y, rcp_tiles_z;  // ceil(2^32 / d), see fastdiv
   unsigned bytesA, bytesB;
 };
 
@@ -965,35 +966,48 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
 
   constexpr unsigned OOB = 0xFFFFFF00u;
   u32x4 regA[A_ROUNDS], regB[B_ROUNDS];
-  auto fetch = [&](int tile) {
-    int tt = tile;
-    const int tx0 = (tt % a.tiles_x) * TX;
-    tt /= a.tiles_x;
-    const int ty0 = (tt % a.tiles_y) * TY;
-    tt /= a.tiles_y;
-    const int tz0 = (tt % a.tiles_z) * TZ;
-    const int n = tt / a.tiles_z;
-    // one resource per sample (wave-uniform): 32-bit offsets only have to span a single sample
-    const size_t svox = (size_t)n * a.d * a.h * a.w;
-    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + svox * a.ka), 0, a.bytesA, 0x00020000);
-    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + svox * a.kb), 0, a.bytesB, 0x00020000);
-#pragma unroll
-    for (int it = 0; it < A_ROUNDS; ++it) {
+  // Staging of one brick = A_ROUNDS + B_ROUNDS (4 + 9) buffer loads per thread.  `Next` holds the wave-uniform part
+  // (brick origin, per-sample resources); fetch_one(j) issues load j.  Branch-free: one unsigned compare per axis, and a
+  // piece outside the volume / past the channel count / past the brick list gets an out-of-range offset (hardware zero).
+  struct Next {
+    int tz0, ty0, tx0;
+    unsigned kill;
+    __amdgpu_buffer_rsrc_t rA, rB;
+  };
+  auto plan_next = [&](int tile, bool valid) {
+    Next nx;
+    int tt = valid ? tile : 0;
+    int qd = fastdiv(tt, a.tiles_x, a.rcp_tiles_x);
+    nx.tx0 = (tt - qd * a.tiles_x) * TX;
+    tt = qd;
+    qd = fastdiv(tt, a.tiles_y, a.rcp_tiles_y);
+    nx.ty0 = (tt - qd * a.tiles_y) * TY;
+    tt = qd;
+    qd = fastdiv(tt, a.tiles_z, a.rcp_tiles_z);
+    nx.tz0 = (tt - qd * a.tiles_z) * TZ;
+    const size_t svox = (size_t)qd * a.d * a.h * a.w;  // one resource per sample: 32-bit offsets span a single sample
+    nx.rA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + svox * a.ka), 0, a.bytesA, 0x00020000);
+    nx.rB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + svox * a.kb), 0, a.bytesB, 0x00020000);
+    nx.kill = valid ? 0u : OOB;
+    return nx;
+  };
+  auto fetch_one = [&](int j, const Next& nx) {
+    if (j < A_ROUNDS) {
+      const int c = j * 512 + tid;
+      const int v = c >> 2, part = c & 3;
+      const int gz = nx.tz0 + v / (TX * TY), gy = nx.ty0 + (v / TX) % TY, gx = nx.tx0 + v % TX;
+      const bool in_vol = (gz < a.d) & (gy < a.h) & (gx < a.w) & (ab * 32 + part * 8 < a.ka);
+      const unsigned off = ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.ka + ab * 32 + part * 8) * 2u;
+      regA[j] = __builtin_amdgcn_raw_buffer_load_b128(nx.rA, (in_vol ? off : OOB) | nx.kill, 0, 0);
+    } else {
+      const int it = j - A_ROUNDS;
       const int c = it * 512 + tid;
       const int v = c >> 2, part = c & 3;
-      const int gz = tz0 + v / (TX * TY), gy = ty0 + (v / TX) % TY, gx = tx0 + v % TX;
-      const bool in_vol = gz < a.d && gy < a.h && gx < a.w && ab * 32 + part * 8 < a.ka;
-      const unsigned off = in_vol ? ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.ka + ab * 32 + part * 8) * 2u : OOB;
-      regA[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < B_ROUNDS; ++it) {
-      const int c = it * 512 + tid;
-      const int v = c >> 2, part = c & 3;
-      const int gz = tz0 - 1 + v / (HX * HY), gy = ty0 - 1 + (v / HX) % HY, gx = tx0 - 1 + v % HX;
-      const bool in_vol = c < NB * 4 && gz >= 0 && gz < a.d && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w && bb * 32 + part * 8 < a.kb;
-      const unsigned off = in_vol ? ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.kb + bb * 32 + part * 8) * 2u : OOB;
-      regB[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, 0, 0);
+      const int gz = nx.tz0 - 1 + v / (HX * HY), gy = nx.ty0 - 1 + (v / HX) % HY, gx = nx.tx0 - 1 + v % HX;
+      const bool in_vol = (c < NB * 4) & ((unsigned)gz < (unsigned)a.d) & ((unsigned)gy < (unsigned)a.h) &
+                          ((unsigned)gx < (unsigned)a.w) & (bb * 32 + part * 8 < a.kb);
+      const unsigned off = ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.kb + bb * 32 + part * 8) * 2u;
+      regB[it] = __builtin_amdgcn_raw_buffer_load_b128(nx.rB, (in_vol ? off : OOB) | nx.kill, 0, 0);
     }
   };
   auto commit = [&]() {
@@ -1021,12 +1035,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
   }
 
   int tile = split;
-  if (tile < a.ntiles) fetch(tile);
+  if (tile < a.ntiles) {
+    const Next first = plan_next(tile, true);
+#pragma unroll
+    for (int j = 0; j < A_ROUNDS + B_ROUNDS; ++j) fetch_one(j, first);
+  }
+  static_assert(A_ROUNDS + B_ROUNDS <= KSTEPS / 2, "one staging load per k-step");
   for (; tile < a.ntiles; tile += a.splits) {
     __syncthreads();  // previous brick fully consumed
     commit();
     __syncthreads();
-    if (tile + a.splits < a.ntiles) fetch(tile + a.splits);  // flies while this brick is on the matrix cores
+    // the next brick flies while this one is on the matrix cores: its 13 loads are dealt out one per k-step (a burst
+    // blocks the wave's instruction issue behind the CU's texture-address path for thousands of cycles)
+    const Next nx = plan_next(tile + a.splits, tile + a.splits < a.ntiles);
+#pragma unroll
     for (int k2 = 0; k2 < KSTEPS / 2; ++k2) {
       const int ks = 2 * k2 + kgrp;  // the two wave groups interleave the brick's k-steps
       const bf16x8 fa = tr_operand(Ab + (ks * TX + 8 * hk + q) * 64, 4 * 64);
@@ -1034,6 +1056,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
       bf16x8 fb[7];
 #pragma unroll
       for (int i = 0; i < 7; ++i) fb[i] = tr_operand(brow + toff[i], 4 * 64);
+      if (k2 < A_ROUNDS + B_ROUNDS) fetch_one(k2, nx);
 #pragma unroll
       for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[i], acc[i], 0, 0, 0);
     }
@@ -1055,6 +1078,8 @@ static void wgrad2_plan(int n, int d, int h, int w, int ka, int kb, Wg2Args& a) 
   a.tiles_y = (h + 7) / 8;
   a.tiles_x = (w + 15) / 16;
   a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
+  auto rcp = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+  a.rcp_tiles_x = rcp(a.tiles_x); a.rcp_tiles_y = rcp(a.tiles_y); a.rcp_tiles_z = rcp(a.tiles_z);
   a.nab = (ka + 31) / 32;  // a 16-channel operand is zero-padded to a 32-wide block by the buffer loads
   a.nbb = (kb + 31) / 32;
   const int pairs = a.nab * a.nbb;
