@@ -334,9 +334,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
     const int swl = (et >> 1) & 7;  // (vl >> 1) & 7 does not depend on the round: 64 voxels per round
     const bf16* rd = out_lds + et * 32 + (pj ^ (swl >> 1)) * 8;
+    constexpr int ROUNDS = (TZ * TY * TX * 4) / 256;
+    bf16x8 rows[ROUNDS];  // all LDS reads first (the accumulators' registers are free now), then the stores back to back:
+#pragma unroll            // read -> wait -> store per round exposed the LDS latency eight times
+    for (int it = 0; it < ROUNDS; ++it) rows[it] = *reinterpret_cast<const bf16x8*>(rd + it * 64 * 32);
 #pragma unroll
-    for (int it = 0; it < (TZ * TY * TX * 4) / 256; ++it) {
-      bf16x8 v = *reinterpret_cast<const bf16x8*>(rd + it * 64 * 32);
+    for (int it = 0; it < ROUNDS; ++it) {
+      bf16x8 v = rows[it];
       if (swl & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
       const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
       const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
