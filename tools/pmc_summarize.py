@@ -1,0 +1,54 @@
+"""Summarise the rocprofv3 passes of tools/gpu_profile.sh into profiles/:
+  r01_kernel_stats_bench_steps5.csv   (copy of the newest --kernel-trace --stats summary)
+  r01_pmc_hbm_traffic.json            HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, per (kernel, grid):
+                                      separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, FETCH_SIZE doubled on gfx950 as
+                                      MI355X_MICROARCH.md prescribes.
+The persistent conv kernel launches every large layer with the same grid (2 workgroups per CU), so its launches are split
+by duration: the 32->32 @128^3 layers (the dominant kernel bench.py reports) are the ones within 40 % of the longest."""
+import csv, glob, json, os, shutil, sys, collections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+
+
+def newest(pattern):
+    fs = glob.glob(os.path.join(G, pattern))
+    return max(fs, key=os.path.getmtime) if fs else None
+
+
+def per_kernel(path):
+    agg = collections.defaultdict(list)
+    rows = list(csv.DictReader(open(path)))
+    conv = [r for r in rows if "conv_mfma_kernel<1>" in r["Kernel_Name"] and r["Grid_Size"] == "131072"]
+    dmax = max((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in conv), default=0)
+    for r in rows:
+        name = r["Kernel_Name"].split("(")[0]
+        key = f"{name} grid={r['Grid_Size']}"
+        if r in conv and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) >= 0.6 * dmax:
+            key = "mednet::conv_mfma_kernel<1> 32->32@128^3 (persistent grid=131072, longest launches)"
+        agg[key].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    st = newest("prof_stats/*/*kernel_stats.csv")
+    if st:
+        shutil.copy(st, os.path.join(ROOT, "profiles", "r01_kernel_stats_bench_steps5.csv"))
+    f, w = newest("pmc_fetch/*/*counter_collection.csv"), newest("pmc_write/*/*counter_collection.csv")
+    if not (f and w):
+        sys.exit("no PMC passes under gpurun_out/")
+    fa, wa = per_kernel(f), per_kernel(w)
+    out = {}
+    for k in sorted(set(fa) & set(wa)):
+        if "mednet" not in k:
+            continue
+        fk, wk = sum(fa[k]) / len(fa[k]), sum(wa[k]) / len(wa[k])
+        out[k] = {"FETCH_SIZE_KB_avg": round(fk, 1), "WRITE_SIZE_KB_avg": round(wk, 1),
+                  "hbm_bytes_per_launch": int((2 * fk + wk) * 1024), "launches_fetch": len(fa[k]), "launches_write": len(wa[k])}
+    json.dump(out, open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json"), "w"), indent=1)
+    k = "mednet::conv_mfma_kernel<1> 32->32@128^3 (persistent grid=131072, longest launches)"
+    print(k, out.get(k))
+
+
+if __name__ == "__main__":
+    main()

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
       const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
       const unsigned soff = (unsigned)(((oz * a.oh + oyb) * a.ow + tx0) * a.cout + cb * 32) * 2u;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_y, ok ? vbase : OOB, soff, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_y, ok ? vbase : OOB, soff, 2);  // aux 2 = nt: streamed output must not push the input rows (read again by the next K chunk) out of L2
       if (ok && a.gn_partial) {  // statistics of what is stored (the rounded values), exactly like the stand-alone pass
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1039,19 +1039,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
   }
 
   int tile = split;
-  if (tile < a.ntiles) {
+  const int t_step = a.splits, t_end = a.ntiles;
+  if (tile < t_end) {
     const Next first = plan_next(tile, true);
 #pragma unroll
     for (int j = 0; j < A_ROUNDS + B_ROUNDS; ++j) fetch_one(j, first);
   }
   static_assert(A_ROUNDS + B_ROUNDS <= KSTEPS / 2, "one staging load per k-step");
-  for (; tile < a.ntiles; tile += a.splits) {
+  for (; tile < t_end; tile += t_step) {
     __syncthreads();  // previous brick fully consumed
     commit();
     __syncthreads();
     // the next brick flies while this one is on the matrix cores: its 13 loads are dealt out one per k-step (a burst
     // blocks the wave's instruction issue behind the CU's texture-address path for thousands of cycles)
-    const Next nx = plan_next(tile + a.splits, tile + a.splits < a.ntiles);
+    const Next nx = plan_next(tile + t_step, tile + t_step < t_end);
 #pragma unroll
     for (int k2 = 0; k2 < KSTEPS / 2; ++k2) {
       const int ks = 2 * k2 + kgrp;  // the two wave groups interleave the brick's k-steps
