@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
 struct Wg2Args {
   const bf16* A;
   const bf16* B;
-  float* part;  // [wg][2 k-groups][27][32][32]
+  float* part;  // [wg][27][32][32]
   int n, d, h, w, ka, kb;
   int tiles_z, tiles_y, tiles_x, ntiles;
   int nab, nbb, splits;
@@ -1066,14 +1066,37 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
       for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[i], acc[i], 0, 0, 0);
     }
   }
-  float* out = a.part + ((size_t)blockIdx.x * 2 + kgrp) * 27 * 1024;
-  const int col = lane & 31;
+  // The two k-groups merge their accumulators through LDS (k-group 1 parks them, k-group 0 adds in a fixed order), so a
+  // workgroup writes ONE partial slab: half the partial traffic of this kernel and of the reduce kernel.  The LDS holds
+  // 4 tap slots of the 4 tap-waves at a time (64 KB), so it takes two rounds.
+  float* mlds = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int tap = tw + 4 * i;
-    if (tap < 27) {
+  for (int i0 = 0; i0 < 7; i0 += 4) {
+    __syncthreads();  // the bricks' operands (first round) / the previous round's sums are no longer needed
+    if (kgrp == 1) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) out[((size_t)tap * 32 + (j & 3) + 8 * (j >> 2) + 4 * hk) * 32 + col] = acc[i][j];
+      for (int i = i0; i < (i0 + 4 < 7 ? i0 + 4 : 7); ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mlds[((tw * 4 + (i - i0)) * 16 + j) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (kgrp == 0) {
+#pragma unroll
+      for (int i = i0; i < (i0 + 4 < 7 ? i0 + 4 : 7); ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] += mlds[((tw * 4 + (i - i0)) * 16 + j) * 64 + lane];
+    }
+  }
+  if (kgrp == 0) {
+    float* out = a.part + (size_t)blockIdx.x * 27 * 1024;
+    const int col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int tap = tw + 4 * i;
+      if (tap < 27) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) out[((size_t)tap * 32 + (j & 3) + 8 * (j >> 2) + 4 * hk) * 32 + col] = acc[i][j];
+      }
     }
   }
 }
@@ -1096,7 +1119,7 @@ static void wgrad2_plan(int n, int d, int h, int w, int ka, int kb, Wg2Args& a) 
 static size_t wgrad2_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
   Wg2Args a;
   wgrad2_plan(n, d, h, w, cout, cin, a);
-  return (size_t)a.nab * a.nbb * a.splits * 2 * 27 * 1024 * sizeof(float);
+  return (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
 }
 
 // dw[(a*KB + b)*27 + tap] = sum_split part[(pair*splits + split)][tap][a%32][b%32]
@@ -1209,7 +1232,7 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
   wgrad2_plan(n, d, h, w, cout, cin, a);
   a.bytesA = (unsigned)((size_t)d * h * w * cout * 2);  // per sample
   a.bytesB = (unsigned)((size_t)d * h * w * cin * 2);
-  const size_t need = (size_t)a.nab * a.nbb * a.splits * 2 * 27 * 1024 * sizeof(float);
+  const size_t need = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
   MEDNET_REQUIRE(ws_bytes >= need, MEDNET_E_WORKSPACE, "wgrad_mfma2: workspace %zu < %zu", ws_bytes, need);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1221,9 +1244,8 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
   int rc = check_launch("wgrad_mfma2");
   if (rc) return rc;
   const size_t total = (size_t)a.nab * a.nbb * 1024 * 27;
-  // the reduce kernel sees the two k-groups of a workgroup as two consecutive splits
   hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, cout, cin,
-                     a.nbb, a.splits * 2);
+                     a.nbb, a.splits);
   return check_launch("wgrad_mfma_reduce");
 }
 
