@@ -88,3 +88,34 @@ if "conv" in which:
 if "gn" in which:
     for c, s in ((32, 128), (64, 64)):
         gn_case(c, s)
+
+
+def convt_case(cin, cout, s):
+    """ConvTranspose3d(k3,s2,p1,op1) cin -> cout from s^3 to (2s)^3: forward (+skip), data gradient, weight gradient."""
+    x = torch.randn(N, cin, s, s, s, device=dev).bfloat16().contiguous(memory_format=CL)
+    skip = torch.randn(N, cout, 2 * s, 2 * s, 2 * s, device=dev).bfloat16().contiguous(memory_format=CL)
+    w = torch.randn(cin, cout, 3, 3, 3, device=dev) * 0.05
+    b = torch.zeros(cout, device=dev)
+    pk = ops.pack_conv_weight(w, 3, True)
+    y = torch.empty_like(skip)
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    ws = torch.empty(lib.mednet_convt3d_wgrad_ws_bytes(N, s, s, s, cin, cout), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    flop = 2.0 * N * s ** 3 * cin * cout * 27
+    f = lambda: L.check(lib.mednet_convt3d_fwd(x.data_ptr(), pk.data_ptr(), b.data_ptr(), skip.data_ptr(), y.data_ptr(), N, s, s, s, cin, cout, 1, 1, 2, st), "ctf")
+    d = lambda: L.check(lib.mednet_convt3d_dgrad(y.data_ptr(), pk.data_ptr(), dx.data_ptr(), N, s, s, s, cin, cout, 1, 1, 2, st), "ctd")
+    g = lambda: L.check(lib.mednet_convt3d_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, N, s, s, s, cin, cout, 1, 1, 2, ws.data_ptr(), ws.numel(), st), "ctw")
+    tf, td = min(timeit(f) for _ in range(3)), min(timeit(d) for _ in range(3))
+    res = {}
+    for v in (0, 1):
+        lib.mednet_set_option(b"convt_wgrad_v2", v)
+        res[v] = min(timeit(g) for _ in range(3))
+    lib.mednet_set_option(b"convt_wgrad_v2", 1)
+    print(f"convT {cin:3d}->{cout:3d} @{s:3d}^3->{2*s}^3 N={N}: fwd {tf*1e3:6.1f} us {flop/tf/1e9:6.1f} TF/s | dgrad {td*1e3:6.1f} us {flop/td/1e9:6.1f} TF/s"
+          f" | wgrad v1 {res[0]*1e3:6.1f} us {flop/res[0]/1e9:6.1f} TF/s  v2 {res[1]*1e3:6.1f} us {flop/res[1]/1e9:6.1f} TF/s", flush=True)
+
+
+if "convt" in which:
+    for cin, cout, s in ((64, 32, 64), (128, 64, 32), (256, 128, 16)):
+        convt_case(cin, cout, s)

@@ -1249,17 +1249,252 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
   return check_launch("wgrad_mfma_reduce");
 }
 
+// ---- ConvTranspose3d weight gradient, second generation: output-parity classes ------------------------------------
+//   dW[k][ci][co] = sum_i x[i][ci] * dy[2i - 1 + k][co]          (per dimension: k=1 -> dy[2i], k=2 -> dy[2i+1], k=0 -> dy[2i-1])
+// With E[j] = dy[2j], O[j] = dy[2j+1] per dimension:  k=1: x[j] E[j],  k=2: x[j] O[j],  k=0: x[j+1] O[j].  So a workgroup
+// that owns the low-resolution brick j in [j0, j0+T) needs exactly the 2T x 2T x 2T block of dy that starts at 2 j0 -- NO
+// halo on the big tensor, every dy voxel is staged once by one workgroup -- plus the (T+1)^3-ish halo brick of x.  The
+// first kernel staged a (2T+1)^3 halo of dy per brick (2.8x at 1x4x16) and was bound by that.  In LDS dy is stored by
+// parity class [8][128 voxels][32 ch]; tap (kz,ky,kx) reads class (k != 1) and x shifted by (k == 0).
+// 512 threads: 4 tap-waves x 2 k-groups as in wgrad_mfma2.  Taps are dealt so that the taps of a wave share few x
+// shifts (slots 0-3 one shift, 4-5 one, 6 one => 3 A operands + 7 B operands per k-step):
+//   wave 0: 13 14 16 17 | 22 23 | 25     (shift 000 throughout)
+//   wave 1: 12 15 21 24 |  1  2 |  0     (shifts 001, 110, 111)
+//   wave 2: 10 11 19 20 |  3  6 | 26     (shifts 010, 101, 000)
+//   wave 3:  4  5  7  8 |  9 18 | (18)   (shifts 100, 011; the 7th slot is a discarded duplicate)
+struct Ct2Args {
+  const bf16* A;  // x  (n, d, h, w, ka)
+  const bf16* B;  // dy (n, 2d, 2h, 2w, kb)
+  float* part;    // [wg][27][32][32]
+  int n, d, h, w, ka, kb;
+  int tiles_z, tiles_y, tiles_x, ntiles;
+  int nab, nbb, splits;
+  unsigned rcp_tiles_x, rcp_tiles_y, rcp_tiles_z;
+  unsigned bytesA, bytesB;  // per sample
+};
+
+__global__ __launch_bounds__(512, 2) void convt_wgrad_mfma2_kernel(Ct2Args a) {
+  constexpr int TZ = 2, TY = 4, TX = 16, HZ = TZ + 1, HY = TY + 1, HX = TX + 1;
+  constexpr int NJ = TZ * TY * TX, NAH = HZ * HY * HX;      // 128 brick voxels, 255 halo voxels of x
+  constexpr int A_ROUNDS = (NAH * 4 + 511) / 512, B_ROUNDS = 8 * NJ * 4 / 512;  // 2 + 8 loads per thread
+  constexpr int KSTEPS = NJ / 16;
+  constexpr int A_BYTES = 16384;  // 255 x 64 B rounded up
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* A_lds = smem;             // [HZ][HY][HX][32 ch]
+  char* B_lds = smem + A_BYTES;   // [8 classes][TZ][TY][TX][32 ch]
+
+  const int pair = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
+  const int ab = pair / a.nbb, bb = pair % a.nbb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kgrp = wvu >> 2, tw = wvu & 3;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, hk = lane >> 5;
+  const int coloff = (16 * (g & 1) + 4 * p) * 2;
+
+  // ---- this wave's 7 taps: byte offsets of their dy class image and of their x shift (wave-uniform => SGPRs)
+  int tap_of[7], boff[7], aoff[3];
+  {
+    const int t0 = tw == 0 ? 13 : tw == 1 ? 12 : tw == 2 ? 10 : 4;
+    const int t1 = tw == 0 ? 14 : tw == 1 ? 15 : tw == 2 ? 11 : 5;
+    const int t2 = tw == 0 ? 16 : tw == 1 ? 21 : tw == 2 ? 19 : 7;
+    const int t3 = tw == 0 ? 17 : tw == 1 ? 24 : tw == 2 ? 20 : 8;
+    const int t4 = tw == 0 ? 22 : tw == 1 ? 1 : tw == 2 ? 3 : 9;
+    const int t5 = tw == 0 ? 23 : tw == 1 ? 2 : tw == 2 ? 6 : 18;
+    const int t6 = tw == 0 ? 25 : tw == 1 ? 0 : tw == 2 ? 26 : 18;
+    const int tt[7] = {t0, t1, t2, t3, t4, t5, t6};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int kz = tt[i] / 9, ky = (tt[i] / 3) % 3, kx = tt[i] % 3;
+      tap_of[i] = tt[i];
+      boff[i] = (((kz != 1) * 4 + (ky != 1) * 2 + (kx != 1)) * NJ) * 64;
+      if (i == 0 || i == 4 || i == 6) aoff[i == 0 ? 0 : i == 4 ? 1 : 2] = (((kz == 0) * HY + (ky == 0)) * HX + (kx == 0)) * 64;
+    }
+  }
+
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  u32x4 regA[A_ROUNDS], regB[B_ROUNDS];
+  struct Next {
+    int tz0, ty0, tx0;
+    unsigned kill;
+    __amdgpu_buffer_rsrc_t rA, rB;
+  };
+  auto plan_next = [&](int tile, bool valid) {
+    Next nx;
+    int tt = valid ? tile : 0;
+    int qd = fastdiv(tt, a.tiles_x, a.rcp_tiles_x);
+    nx.tx0 = (tt - qd * a.tiles_x) * TX;
+    tt = qd;
+    qd = fastdiv(tt, a.tiles_y, a.rcp_tiles_y);
+    nx.ty0 = (tt - qd * a.tiles_y) * TY;
+    tt = qd;
+    qd = fastdiv(tt, a.tiles_z, a.rcp_tiles_z);
+    nx.tz0 = (tt - qd * a.tiles_z) * TZ;
+    const size_t svox = (size_t)qd * a.d * a.h * a.w;  // one resource per sample
+    nx.rA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + svox * a.ka), 0, a.bytesA, 0x00020000);
+    nx.rB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + svox * 8 * a.kb), 0, a.bytesB, 0x00020000);
+    nx.kill = valid ? 0u : OOB;
+    return nx;
+  };
+  auto fetch_one = [&](int j, const Next& nx) {
+    if (j < B_ROUNDS) {  // dy: 16 consecutive high-resolution voxels (1 KB contiguous) per wave instruction
+      const int c = j * 512 + tid;
+      const int part = c & 3, vx = (c >> 2) & 31, vy = (c >> 7) & 7, vz = c >> 10;
+      const int gz = 2 * nx.tz0 + vz, gy = 2 * nx.ty0 + vy, gx = 2 * nx.tx0 + vx;
+      const bool in_vol = (gz < 2 * a.d) & (gy < 2 * a.h) & (gx < 2 * a.w) & (bb * 32 + part * 8 < a.kb);
+      const unsigned off = ((unsigned)((gz * 2 * a.h + gy) * 2 * a.w + gx) * (unsigned)a.kb + bb * 32 + part * 8) * 2u;
+      regB[j] = __builtin_amdgcn_raw_buffer_load_b128(nx.rB, (in_vol ? off : OOB) | nx.kill, 0, 0);
+    } else {  // x halo brick (the +1 planes are beyond the volume at its far faces: hardware zeros)
+      const int it = j - B_ROUNDS;
+      const int c = it * 512 + tid;
+      const int part = c & 3, v = c >> 2;
+      const int gz = nx.tz0 + v / (HX * HY), gy = nx.ty0 + (v / HX) % HY, gx = nx.tx0 + v % HX;
+      const bool in_vol = (v < NAH) & (gz < a.d) & (gy < a.h) & (gx < a.w) & (ab * 32 + part * 8 < a.ka);
+      const unsigned off = ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.ka + ab * 32 + part * 8) * 2u;
+      regA[it] = __builtin_amdgcn_raw_buffer_load_b128(nx.rA, (in_vol ? off : OOB) | nx.kill, 0, 0);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < B_ROUNDS; ++it) {
+      const int c = it * 512 + tid;
+      const int part = c & 3, vx = (c >> 2) & 31, vy = (c >> 7) & 7, vz = c >> 10;
+      const int cls = (vz & 1) * 4 + (vy & 1) * 2 + (vx & 1);
+      const int j = ((vz >> 1) * TY + (vy >> 1)) * TX + (vx >> 1);
+      *reinterpret_cast<u32x4*>(B_lds + ((cls * NJ + j) * 4 + part) * 16) = regB[it];
+    }
+#pragma unroll
+    for (int it = 0; it < A_ROUNDS; ++it) {
+      const int c = it * 512 + tid;
+      if (c < NAH * 4) *reinterpret_cast<u32x4*>(A_lds + c * 16) = regA[it];
+    }
+  };
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  const char* Ab = A_lds + coloff + (8 * hk + q) * 64;
+  const char* Bb = B_lds + coloff + (8 * hk + q) * 64;
+
+  int tile = split;
+  const int t_step = a.splits, t_end = a.ntiles;
+  if (tile < t_end) {
+    const Next first = plan_next(tile, true);
+#pragma unroll
+    for (int j = 0; j < A_ROUNDS + B_ROUNDS; ++j) fetch_one(j, first);
+  }
+  constexpr int LOADS_PER_STEP = (A_ROUNDS + B_ROUNDS + KSTEPS / 2 - 1) / (KSTEPS / 2);
+  for (; tile < t_end; tile += t_step) {
+    __syncthreads();  // previous brick fully consumed
+    commit();
+    __syncthreads();
+    const Next nx = plan_next(tile + t_step, tile + t_step < t_end);  // flies while this brick is on the matrix cores
+#pragma unroll
+    for (int k2 = 0; k2 < KSTEPS / 2; ++k2) {
+      const int ks = 2 * k2 + kgrp;  // the two wave groups interleave the brick's k-steps (rows of 16 x-voxels)
+      const char* arow = Ab + (((ks / TY) * HY + ks % TY) * HX) * 64;
+      const char* brow = Bb + (ks * TX) * 64;
+      bf16x8 fa[3], fb[7];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) fa[i] = tr_operand(arow + aoff[i], 4 * 64);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) fb[i] = tr_operand(brow + boff[i], 4 * 64);
+#pragma unroll
+      for (int l = 0; l < LOADS_PER_STEP; ++l)
+        if (k2 * LOADS_PER_STEP + l < A_ROUNDS + B_ROUNDS) fetch_one(k2 * LOADS_PER_STEP + l, nx);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i < 4 ? 0 : i < 6 ? 1 : 2], fb[i], acc[i], 0, 0, 0);
+    }
+  }
+  // k-group merge through LDS and write-out: as in wgrad_mfma2
+  float* mlds = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i0 = 0; i0 < 7; i0 += 4) {
+    __syncthreads();
+    if (kgrp == 1) {
+#pragma unroll
+      for (int i = i0; i < (i0 + 4 < 7 ? i0 + 4 : 7); ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mlds[((tw * 4 + (i - i0)) * 16 + j) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (kgrp == 0) {
+#pragma unroll
+      for (int i = i0; i < (i0 + 4 < 7 ? i0 + 4 : 7); ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] += mlds[((tw * 4 + (i - i0)) * 16 + j) * 64 + lane];
+    }
+  }
+  if (kgrp == 0) {
+    float* out = a.part + (size_t)blockIdx.x * 27 * 1024;
+    const int col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      if (tw == 3 && i == 6) continue;  // the duplicate slot
+#pragma unroll
+      for (int j = 0; j < 16; ++j) out[((size_t)tap_of[i] * 32 + (j & 3) + 8 * (j >> 2) + 4 * hk) * 32 + col] = acc[i][j];
+    }
+  }
+}
+
+static void ct2_plan(int n, int d, int h, int w, int ka, int kb, Ct2Args& a) {
+  a.tiles_z = (d + 1) / 2;
+  a.tiles_y = (h + 3) / 4;
+  a.tiles_x = (w + 15) / 16;
+  a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
+  auto rcp = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+  a.rcp_tiles_x = rcp(a.tiles_x); a.rcp_tiles_y = rcp(a.tiles_y); a.rcp_tiles_z = rcp(a.tiles_z);
+  a.nab = (ka + 31) / 32;
+  a.nbb = (kb + 31) / 32;
+  const int pairs = a.nab * a.nbb;
+  int splits = (256 + pairs - 1) / pairs;  // one workgroup per CU
+  if (splits > a.ntiles) splits = a.ntiles;
+  if (splits < 1) splits = 1;
+  a.splits = splits;
+}
+
 size_t convt_wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
   if (cin % 32 || cout % 32) return 0;
   WgArgs a;
   wgrad_plan<2>(n, d, h, w, cin, cout, a);
-  return (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+  const size_t v1 = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+  Ct2Args b;
+  ct2_plan(n, d, h, w, cin, cout, b);
+  const size_t v2 = (size_t)b.nab * b.nbb * b.splits * 27 * 1024 * sizeof(float);
+  return v1 > v2 ? v1 : v2;
 }
 
 int launch_convt_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout,
                             void* ws, size_t ws_bytes, hipStream_t s) {
   // convT: A = x (Cin rows) on the (d,h,w) grid, B = dy (Cout cols) on the (2d,2h,2w) grid at 2v - 1 + tap
-  return launch_wg<2>(x, dy, dw, n, d, h, w, 2 * d, 2 * h, 2 * w, cin, cout, ws, ws_bytes, s);
+  if (!tuning_option("convt_wgrad_v2", 1))
+    return launch_wg<2>(x, dy, dw, n, d, h, w, 2 * d, 2 * h, 2 * w, cin, cout, ws, ws_bytes, s);
+  constexpr size_t lds = 16384 + 8 * 128 * 64;
+  Ct2Args a;
+  a.A = (const bf16*)x;
+  a.B = (const bf16*)dy;
+  a.part = (float*)ws;
+  a.n = n; a.d = d; a.h = h; a.w = w; a.ka = cin; a.kb = cout;
+  ct2_plan(n, d, h, w, cin, cout, a);
+  a.bytesA = (unsigned)((size_t)d * h * w * cin * 2);
+  a.bytesB = (unsigned)((size_t)8 * d * h * w * cout * 2);
+  const size_t need = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+  MEDNET_REQUIRE(ws_bytes >= need, MEDNET_E_WORKSPACE, "convt_wgrad_mfma2: workspace %zu < %zu", ws_bytes, need);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)convt_wgrad_mfma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(MEDNET_E_HIP, "convt_wgrad_mfma2: cannot raise dynamic LDS to %zu", lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(convt_wgrad_mfma2_kernel, dim3(a.nab * a.nbb * a.splits), dim3(512), lds, s, a);
+  int rc = check_launch("convt_wgrad_mfma2");
+  if (rc) return rc;
+  const size_t total = (size_t)a.nab * a.nbb * 1024 * 27;
+  hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, cin, cout,
+                     a.nbb, a.splits);
+  return check_launch("wgrad_mfma_reduce");
 }
 
 }  // namespace mednet
