@@ -511,27 +511,56 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
     }
   }
 
-  // ---- epilogue: + bias + skip, 8 parity classes
-  const int jz = tz0 + lz, jy = ty0 + ly, jx = tx0 + lx;
-  if (jz < a.id && jy < a.ih && jx < a.iw) {
-    const int od = 2 * a.id, oh = 2 * a.ih, ow = 2 * a.iw;
-    float bv[16];
+  // ---- epilogue: + bias + skip, through LDS.  A lane holds, per parity class, four 4-channel pieces of ONE output voxel,
+  // and the voxels of neighbouring lanes are 128 B apart in memory: written straight from the accumulators that is 64
+  // eight-byte requests per instruction (and as many 8-byte reads of the skip tensor).  Instead the 4x8x32 output block is
+  // assembled as an fp32 image in LDS, one z-parity at a time (512 voxels x 32 ch x 4 B = 64 KB), and streamed out as whole
+  // 64-byte channel rows: 16-byte skip load + add + ONE rounding + 16-byte store per lane, 1 KB contiguous per instruction.
+  // 16-byte chunks of a row are XOR-swizzled by the input x index so the ds_write_b128 groups (8 lanes) do not collide.
+  float* out_lds = reinterpret_cast<float*>(smem);  // [2 lz][8 oy][32 ox][32 co] floats, reuses the staging images
+  float bv[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bv[q * 4 + j] = a.bias ? a.bias[cb * 32 + 8 * q + 4 * h + j] : 0.f;
+    for (int j = 0; j < 4; ++j) bv[q * 4 + j] = a.bias ? a.bias[cb * 32 + 8 * q + 4 * h + j] : 0.f;
+  const int od = 2 * a.id, oh = 2 * a.ih, ow = 2 * a.iw;
+  typedef __attribute__((ext_vector_type(4))) float f4;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int oz = 2 * jz + (p >> 2), oy = 2 * jy + ((p >> 1) & 1), ox = 2 * jx + (p & 1);
-      const size_t o = ((((size_t)n * od + oz) * oh + oy) * ow + ox) * a.cout + cb * 32 + 4 * h;
+  for (int pz = 0; pz < 2; ++pz) {
+    __syncthreads();  // MFMA operand reads (first half) / the previous half's row reads are done
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int p = pz * 4 + pp;
+      const int vox = (lz * 8 + 2 * ly + (pp >> 1)) * 32 + 2 * lx + (pp & 1);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        bf16x4 sk = {0, 0, 0, 0};
-        if (a.skip) sk = *reinterpret_cast<const bf16x4*>(a.skip + o + 8 * q);
-        bf16x4 ov;
+        f4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ov[j] = (bf16)(acc[p][q * 4 + j] + bv[q * 4 + j] + (float)sk[j]);
-        *reinterpret_cast<bf16x4*>(a.y + o + 8 * q) = ov;
+        for (int j = 0; j < 4; ++j) o[j] = acc[p][q * 4 + j] + bv[q * 4 + j];  // co = 8q + 4h + j
+        *reinterpret_cast<f4*>(out_lds + vox * 32 + (((2 * q + h) ^ (lx & 7)) * 4)) = o;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * 256 + tid;
+      const int vox = idx >> 2, piece = idx & 3;
+      const int ox_l = vox & 31, oy_l = (vox >> 5) & 7, lz2 = vox >> 8;
+      const int key = (ox_l >> 1) & 7;
+      const f4 lo = *reinterpret_cast<const f4*>(out_lds + vox * 32 + (((2 * piece) ^ key) * 4));
+      const f4 hi = *reinterpret_cast<const f4*>(out_lds + vox * 32 + (((2 * piece + 1) ^ key) * 4));
+      const int oz = 2 * (tz0 + lz2) + pz, oy = 2 * ty0 + oy_l, ox = 2 * tx0 + ox_l;
+      if (oz < od && oy < oh && ox < ow) {
+        const size_t o = ((((size_t)n * od + oz) * oh + oy) * ow + ox) * a.cout + cb * 32 + piece * 8;
+        bf16x8 sk = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (a.skip) sk = *reinterpret_cast<const bf16x8*>(a.skip + o);
+        bf16x8 ov;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ov[j] = (bf16)(lo[j] + (float)sk[j]);
+          ov[4 + j] = (bf16)(hi[j] + (float)sk[4 + j]);
+        }
+        *reinterpret_cast<bf16x8*>(a.y + o) = ov;
       }
     }
   }
@@ -539,7 +568,8 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
 
 int launch_convt_fwd_mfma(const void* x, const void* sec, const float* bias, const void* skip, void* y, int n, int d,
                           int h, int w, int cin, int cout, hipStream_t s) {
-  constexpr size_t lds = ((size_t)2 * 3 * 5 * 17 + 27 * 2 * 32) * 16;
+  constexpr size_t lds = 512 * 32 * 4;  // the epilogue's fp32 half-block (64 KB) > staging images (36 KB); 2 workgroups per CU
+  static_assert(lds >= ((size_t)2 * 3 * 5 * 17 + 27 * 2 * 32) * 16 && lds <= 80 * 1024, "LDS plan of convt_fwd");
   CtArgs a;
   a.x = (const bf16*)x;
   a.wpk = (const bf16*)sec;
@@ -554,6 +584,12 @@ int launch_convt_fwd_mfma(const void* x, const void* sec, const float* bias, con
   a.nkc = cin / 16;
   a.ncb = cout / 32;
   const unsigned grid = (unsigned)((a.ntiles + 7) / 8) * 8 * a.ncb;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)convt_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(MEDNET_E_HIP, "convt_fwd_mfma: cannot raise dynamic LDS to %zu", lds);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(convt_fwd_mfma_kernel, dim3(grid), dim3(256), lds, s, a);
   return check_launch("convt_fwd_mfma");
 }
