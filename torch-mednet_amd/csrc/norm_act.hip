@@ -7,6 +7,9 @@
 // :208-212 (pooling), :277-280 (interpolate + cat).
 #include "common.h"
 
+#ifndef GN_WAVES
+#define GN_WAVES 4  // waves per SIMD the streaming GroupNorm kernels are compiled for (register cap 512 / GN_WAVES)
+#endif
 namespace mednet {
 
 // "column persistent" thread layout over a channels-last tensor: a thread keeps the same VEC channels for its
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void gn_act_fwd_kernel(const TX* __restrict__ 
 // ---------------------------------------------------------------------------------------------- GN backward
 // pass 1: partial[n][chunk][c][2] = {sum du, sum du * xhat},  du = (dz + dz2) * act'(z)
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict__ dz, const T* __restrict__ dz2,
+__global__ __launch_bounds__(256, GN_WAVES) void gn_bwd_partial_kernel(const T* __restrict__ dz, const T* __restrict__ dz2,
                                                              const T* __restrict__ x, const T* __restrict__ z,
                                                              const float* __restrict__ coef,
                                                              const float* __restrict__ stats,
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(256) void gn_bwd_params_kernel(const float* __restr
 }
 // pass 3: apply
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ dz2,
+__global__ __launch_bounds__(256, GN_WAVES) void gn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ dz2,
                                                            const T* __restrict__ x, const T* __restrict__ z,
                                                            const float* __restrict__ coef,
                                                            const float* __restrict__ bcoef, T* __restrict__ dx,
