@@ -122,6 +122,10 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
   if (!dgrad && algo != MEDNET_ALGO_DIRECT && x_layout == MEDNET_NDHWC &&
       conv_c1_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, y_layout, bias != nullptr))
     return launch_conv_c1_mfma(x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, s);
+  // 1x1x1 head forward (channels-last features -> planar fp32 logits): the packed backward image Pb[t=0][co][ci] = W[m][k]
+  if (!dgrad && algo != MEDNET_ALGO_DIRECT && ksize == 1 && x_layout == MEDNET_NDHWC && y_layout == MEDNET_NCDHW &&
+      y_dtype == MEDNET_F32 && head_vox_supported(cin))
+    return launch_head_fwd_vox(x, (const float*)(base + L.f32_bwd), bias, (float*)y, n, (size_t)d * h * w, cin, cout, x_dtype, s);
   // data gradient of the 1x1x1 head: the packed backward image Pb[t=0][co][ci] is exactly W[m][k]
   if (dgrad && !bias && algo != MEDNET_ALGO_DIRECT && head_dgrad_supported(cin, cout, ksize, x_dtype, x_layout, y_layout))
     return launch_head_dgrad(x, (const float*)(base + L.f32_bwd), y, n, (size_t)d * h * w, cin, cout, y_dtype, s);

@@ -44,6 +44,9 @@ int launch_channel_sum(const void* x, float* out, int n, size_t spatial, int c, 
 bool head_dgrad_supported(int cin, int cout, int ksize, int x_dtype, int x_layout, int y_layout);
 int launch_head_dgrad(const void* dy, const float* Pb, void* dz, int n, size_t spatial, int m, int k, int out_dtype,
                       hipStream_t s);
+bool head_vox_supported(int k);
+int launch_head_fwd_vox(const void* z, const float* Pb, const float* bias, float* y, int n, size_t spatial, int k, int m,
+                        int z_dtype, hipStream_t s);
 bool wgrad_1x1_supported(int cin, int cout, int ksize, int x_layout, int dy_layout, int dy_dtype);
 size_t wgrad_1x1_ws_bytes(int n, size_t spatial, int cin, int cout);
 int launch_wgrad_1x1(const void* z, const void* dy, float* dw, int n, size_t spatial, int cin, int cout, int z_dtype,

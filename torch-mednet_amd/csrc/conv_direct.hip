@@ -477,13 +477,88 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
     st8(dz, ((size_t)n * spatial + v) * k + col * 8, o);
   }
 }
+// ---- 1x1x1 head, one voxel per lane (any class count; K = 16/32/64 feature channels) -------------------------------
+// The weights are wave-uniform, so every FMA takes its weight from an SGPR (scalar loads, no LDS, no per-lane weight
+// registers -- the column-register kernel above spills once M x 8 weights no longer fit, e.g. the 18 outputs of the
+// landmark net).  Planar fp32 logits (or their gradient) are read / written fully coalesced: consecutive lanes are
+// consecutive voxels of one class plane.  Both kernels are HBM-bound (one pass over the K-channel tensor and the planes).
+template <typename TI, int K>
+__global__ __launch_bounds__(256) void head_fwd_vox_kernel(const TI* __restrict__ z, const float* __restrict__ Pb /*[m][K]*/,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           size_t spatial, int m) {
+  const int n = blockIdx.y;
+  const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= spatial) return;
+  float zv[K];
+#pragma unroll
+  for (int q = 0; q < K / 8; ++q) {
+    const F8 t = ld8(z, ((size_t)n * spatial + v) * K + q * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zv[q * 8 + j] = t.v[j];
+  }
+  for (int i = 0; i < m; ++i) {
+    float s0 = bias ? bias[i] : 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; j += 2) {
+      s0 = fmaf(zv[j], Pb[(size_t)i * K + j], s0);
+      s1 = fmaf(zv[j + 1], Pb[(size_t)i * K + j + 1], s1);
+    }
+    y[((size_t)n * m + i) * spatial + v] = s0 + s1;
+  }
+}
+template <typename TO, int K>
+__global__ __launch_bounds__(256) void head_dgrad_vox_kernel(const float* __restrict__ dy, const float* __restrict__ Pb /*[m][K]*/,
+                                                             TO* __restrict__ dz, size_t spatial, int m) {
+  const int n = blockIdx.y;
+  const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= spatial) return;
+  float o[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) o[j] = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < m; ++i) {
+    const float d = dy[((size_t)n * m + i) * spatial + v];
+#pragma unroll
+    for (int j = 0; j < K; ++j) o[j] = fmaf(d, Pb[(size_t)i * K + j], o[j]);
+  }
+#pragma unroll
+  for (int q = 0; q < K / 8; ++q) {
+    F8 t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t.v[j] = o[q * 8 + j];
+    st8(dz, ((size_t)n * spatial + v) * K + q * 8, t);
+  }
+}
+bool head_vox_supported(int k) { return k == 16 || k == 32 || k == 64; }
+int launch_head_fwd_vox(const void* z, const float* Pb, const float* bias, float* y, int n, size_t spatial, int k, int m,
+                        int z_dtype, hipStream_t s) {
+  const dim3 grid((unsigned)((spatial + 255) / 256), n);
+#define HF_GO(TI_, K_) hipLaunchKernelGGL((head_fwd_vox_kernel<TI_, K_>), grid, dim3(256), 0, s, (const TI_*)z, Pb, bias, y, spatial, m)
+#define HF_K(TI_) do { if (k == 16) HF_GO(TI_, 16); else if (k == 32) HF_GO(TI_, 32); else HF_GO(TI_, 64); } while (0)
+  if (z_dtype == MEDNET_F32) HF_K(float);
+  else HF_K(bf16);
+#undef HF_K
+#undef HF_GO
+  return check_launch("head_fwd_vox");
+}
+
 bool head_dgrad_supported(int cin /*dy channels = layer Cout*/, int cout /*dz channels = layer Cin*/, int ksize, int x_dtype,
                           int x_layout, int y_layout) {
   return ksize == 1 && x_dtype == MEDNET_F32 && x_layout == MEDNET_NCDHW && y_layout == MEDNET_NDHWC && cout % 8 == 0 &&
-         cout / 8 <= 256 && cin <= 32;
+         cout / 8 <= 256 && (cin <= 32 || head_vox_supported(cout));
 }
 int launch_head_dgrad(const void* dy, const float* Pb, void* dz, int n, size_t spatial, int m, int k, int out_dtype,
                       hipStream_t s) {
+  if (head_vox_supported(k)) {
+    const dim3 grid((unsigned)((spatial + 255) / 256), n);
+#define HV_GO(TO_, K_) hipLaunchKernelGGL((head_dgrad_vox_kernel<TO_, K_>), grid, dim3(256), 0, s, (const float*)dy, Pb, (TO_*)dz, spatial, m)
+#define HV_K(TO_) do { if (k == 16) HV_GO(TO_, 16); else if (k == 32) HV_GO(TO_, 32); else HV_GO(TO_, 64); } while (0)
+    if (out_dtype == MEDNET_F32) HV_K(float);
+    else HV_K(bf16);
+#undef HV_K
+#undef HV_GO
+    return check_launch("head_dgrad_vox");
+  }
   const int rows = 256 / (k / 8);
   size_t cv = (spatial + 1023) / 1024;
   if (cv < (size_t)rows * 8) cv = (size_t)rows * 8;
