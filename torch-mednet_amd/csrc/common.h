@@ -58,6 +58,25 @@ __device__ __forceinline__ F8 ld8(const bf16* p, size_t i) {
   for (int k = 0; k < 8; ++k) r.v[k] = (float)a[k];
   return r;
 }
+// last-use streaming loads (nt): the line is not kept in L2 once delivered
+__device__ __forceinline__ F8 ld8_nt(const float* p, size_t i) {
+  F8 r;
+  const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i));
+  const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i + 4));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    r.v[k] = a[k];
+    r.v[k + 4] = b[k];
+  }
+  return r;
+}
+__device__ __forceinline__ F8 ld8_nt(const bf16* p, size_t i) {
+  F8 r;
+  const bf16x8 a = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p + i));
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r.v[k] = (float)a[k];
+  return r;
+}
 __device__ __forceinline__ void st8(float* p, size_t i, const F8& r) {
   f32x4 a, b;
 #pragma unroll

@@ -7,6 +7,9 @@
 // :208-212 (pooling), :277-280 (interpolate + cat).
 #include "common.h"
 
+#ifndef GN_NT
+#define GN_NT 1  // GroupNorm backward's apply pass reads dz and y for the last time: non-temporal loads
+#endif
 #ifndef GN_WAVES
 #define GN_WAVES 4  // waves per SIMD the streaming GroupNorm kernels are compiled for (register cap 512 / GN_WAVES)
 #endif
@@ -32,6 +35,7 @@ struct VecIO;
 template <typename T>
 struct VecIO<T, 8> {
   static __device__ __forceinline__ F8 load(const T* p, size_t i) { return ld8(p, i); }
+  static __device__ __forceinline__ F8 load_last(const T* p, size_t i) { return GN_NT ? ld8_nt(p, i) : ld8(p, i); }
   static __device__ __forceinline__ void store(T* p, size_t i, const F8& v) { st8(p, i, v); }
 };
 template <typename T>
@@ -41,6 +45,7 @@ struct VecIO<T, 1> {
     r.v[0] = ld(p, i);
     return r;
   }
+  static __device__ __forceinline__ F8 load_last(const T* p, size_t i) { return load(p, i); }
   static __device__ __forceinline__ void store(T* p, size_t i, const F8& v) { st(p, i, v.v[0]); }
 };
 
@@ -389,11 +394,11 @@ __global__ __launch_bounds__(256, GN_WAVES) void gn_bwd_apply_kernel(const T* __
   }
   const size_t off = (size_t)n * spatial * c + (size_t)L.col * VEC;
   auto one = [&](size_t i) {
-    F8 g1 = VecIO<T, VEC>::load(dz, i);
+    F8 g1 = VecIO<T, VEC>::load_last(dz, i);
     F8 g2, zv;
-    if (dz2) g2 = VecIO<T, VEC>::load(dz2, i);
+    if (dz2) g2 = VecIO<T, VEC>::load_last(dz2, i);
     if (act != MEDNET_ACT_NONE && z) zv = VecIO<T, VEC>::load(z, i);
-    const F8 xv = VecIO<T, VEC>::load(x, i);
+    const F8 xv = VecIO<T, VEC>::load_last(x, i);
     if (dz2) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) g1.v[k] += g2.v[k];
