@@ -464,6 +464,31 @@ def test_first_layer_mfma_keeps_fp32_input_precision(n, cout, shape):
     assert_close(y, bf16_round(yr), 4e-4, "y vs correctly rounded reference")
 
 
+@pytest.mark.parametrize("n,cout,shape", [(1, 32, (4, 8, 16)), (2, 32, (9, 11, 21)), (2, 64, (5, 6, 7)), (1, 32, (20, 24, 40))])
+def test_first_layer_weight_gradient_on_matrix_cores(n, cout, shape):
+    """Cin=1 weight gradient: contraction over voxels with x gathered per tap and split into bf16 hi+lo.  The cotangent is
+    bf16-representable, so the result must match the fp32 oracle to fp32-accumulation accuracy, and the VALU kernel."""
+    tag = f"w1{n}{cout}{shape}"
+    x = rnd(tag + "x", n, 1, *shape)                      # full fp32 input
+    cot = bf16_round(rnd(tag + "g", n, cout, *shape))
+    wr = torch.zeros(cout, 1, 3, 3, 3, requires_grad=True)
+    (F.conv3d(x, wr, None, padding=1) * cot).sum().backward()
+    lib = L.lib()
+    res = {}
+    for opt in (1, 0):
+        lib.mednet_set_option(b"wgrad_c1_mfma", opt)
+        try:
+            with mednet_hip.precision("bf16"):
+                conv = hnn.Conv3d(1, cout, 3, bias=False).to(DEV)
+                y = conv(x.to(DEV))
+                y.backward(cot.to(DEV).bfloat16())
+                res[opt] = conv.weight.grad.cpu().clone()
+        finally:
+            lib.mednet_set_option(b"wgrad_c1_mfma", 1)
+    assert_close(res[1], wr.grad, 2e-5, "dw (matrix cores) vs oracle")
+    assert_close(res[1], res[0], 2e-5, "dw (matrix cores) vs VALU kernel")
+
+
 @pytest.mark.parametrize("cin,cout", [(32, 4), (32, 18), (64, 2)])
 def test_head_dgrad_kernel(cin, cout):
     x = bf16_round(rnd(f"hd{cin}{cout}x", 2, cin, 6, 8, 10))

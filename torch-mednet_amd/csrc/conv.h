@@ -55,6 +55,9 @@ bool wgrad_c1_supported(int cin, int cout, int ksize, int x_layout, int dy_layou
 size_t wgrad_c1_ws_bytes(int n, int d, int h, int w, int cout);
 int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cout, int x_dtype,
                     int dy_dtype, void* ws, size_t ws_bytes, hipStream_t s);
+bool wgrad_c1_mfma_supported(int cout, int x_dtype, int dy_dtype);
+int wgrad_c1_mfma_blocks(int n, int d, int h, int w);
+int launch_wgrad_c1_mfma(const void* x, const void* dy, float* part, int n, int d, int h, int w, int cout, hipStream_t s);
 int launch_pack_f32(const float* w, float* Pf, float* Pb, int cin, int cout, int T, int transposed_src, hipStream_t s);
 
 // MFMA (bf16 matrix-core) kernels, conv_mfma.hip

@@ -684,15 +684,24 @@ bool wgrad_c1_supported(int cin, int cout, int ksize, int x_layout, int dy_layou
 static int wgrad_c1_blocks(int ntiles) { return ntiles < 1024 ? ntiles : 1024; }
 size_t wgrad_c1_ws_bytes(int n, int d, int h, int w, int cout) {
   const int nt = n * ((d + W1_TZ - 1) / W1_TZ) * ((h + W1_TY - 1) / W1_TY) * ((w + W1_TX - 1) / W1_TX);
-  return (size_t)wgrad_c1_blocks(nt) * 27 * cout * sizeof(float);
+  const int b1 = wgrad_c1_blocks(nt), b2 = wgrad_c1_mfma_blocks(n, d, h, w);  // VALU and matrix-core forms
+  return (size_t)(b1 > b2 ? b1 : b2) * 27 * cout * sizeof(float);
 }
 int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cout, int x_dtype,
                     int dy_dtype, void* ws, size_t ws_bytes, hipStream_t s) {
   const int tz = (d + W1_TZ - 1) / W1_TZ, ty = (h + W1_TY - 1) / W1_TY, tx = (w + W1_TX - 1) / W1_TX;
   const int nt = n * tz * ty * tx;
-  const int blocks = wgrad_c1_blocks(nt);
+  int blocks = wgrad_c1_blocks(nt);
   MEDNET_REQUIRE(ws_bytes >= (size_t)blocks * 27 * cout * sizeof(float), MEDNET_E_WORKSPACE, "wgrad_c1: workspace too small");
   float* part = (float*)ws;
+  if (tuning_option("wgrad_c1_mfma", 1) && wgrad_c1_mfma_supported(cout, x_dtype, dy_dtype)) {  // matrix-core form (bf16 mode)
+    blocks = wgrad_c1_mfma_blocks(n, d, h, w);
+    int rc = launch_wgrad_c1_mfma(x, dy, part, n, d, h, w, cout, s);
+    if (rc) return rc;
+    const size_t count = (size_t)27 * cout;
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part, dw, count, blocks);
+    return check_launch("wgrad_c1_reduce");
+  }
 #define W1_GO(TX__, TDY__, CO__)                                                                                       \
   hipLaunchKernelGGL((wgrad_c1_kernel<TX__, TDY__, CO__>), dim3(blocks), dim3(256), 0, s, (const TX__*)x, (const TDY__*)dy, \
                      part, n, d, h, w, tz, ty, tx, nt)
