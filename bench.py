@@ -97,12 +97,12 @@ def pmc_traffic(batch: int, patch: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="patches per GPU per step (config 2: 4)")
     ap.add_argument("--patch", type=int, default=128)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("MEDNET_GRAPH", "0")),
                     help="1: replay forward+loss+backward as one captured hipGraph per step (train._GraphedStep)")

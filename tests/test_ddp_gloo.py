@@ -50,6 +50,54 @@ def test_flat_gradient_allreduce_world2(tmp_path):
     assert torch.equal(r0["reduced"], r1["reduced"])  # every rank applies the same update
 
 
+def _bucket_worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "torch-mednet_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MEDNET_BUCKETS="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle import ref_cpu as O
+    from mednet_hip.train import FlatParams, BucketedExchange, late_bucket_split
+    batch = O.synthetic_batch(1, 1, (16, 16, 16), 2, 0, seed=77 + rank)
+    crit = O.DiceLoss(weight=torch.tensor([0.05, 1.0]))
+    # plain local gradients
+    ref = O.keyed_init_(O.ResidualUNet3D(1, 2, False, f_maps=[8, 16, 32]))
+    O.seg_training_step(ref, crit, batch).backward()
+    local = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    # bucketed exchange: gradients accumulate straight into the flat buffer (p.grad aliases its slice)
+    model = O.keyed_init_(O.ResidualUNet3D(1, 2, False, f_maps=[8, 16, 32]))
+    flat = FlatParams(model)
+    ex = BucketedExchange(model, flat, world)
+    split = late_bucket_split(model, flat)
+    assert ex.enabled and 0 < split < flat.total
+    n_late = sum(p.numel() for enc in list(model.encoders)[:2] for p in enc.parameters())
+    assert split >= n_late and split - n_late < 64 * len(flat.params)  # (slices are padded to 64 elements)
+    flat.grads_as_attr()
+    fired = []
+    ex_on_grad = ex._on_grad
+    ex._on_grad = lambda g: (fired.append(1), ex_on_grad(g))[1]
+    O.seg_training_step(model, crit, batch).backward()
+    assert fired and ex.work is not None  # the early bucket was launched from inside backward
+    scale = ex.finish()
+    got = torch.cat([flat.grad[o:o + p.numel()] for p, o in zip(flat.params, flat.offsets)]) * scale
+    torch.save({"local": local, "reduced": got}, os.path.join(out, f"b{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_exchange_overlapped_with_backward_world2(tmp_path):
+    """train.BucketedExchange: the early bucket (everything but the first two encoders) is all-reduced from a gradient
+    hook INSIDE backward, the rest afterwards; the result is the mean of the per-rank gradients on every rank."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_bucket_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "b0.pt")
+    r1 = torch.load(tmp_path / "b1.pt")
+    mean = 0.5 * (r0["local"] + r1["local"])
+    assert torch.allclose(r0["reduced"], mean, rtol=1e-6, atol=1e-9)
+    assert torch.equal(r0["reduced"], r1["reduced"])
+
+
 def test_synth_generators_match_oracle():
     from oracle import ref_cpu as O
     from mednet_hip import synth

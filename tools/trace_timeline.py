@@ -1,6 +1,7 @@
 """Summarise one training step from a rocprofv3 kernel trace: per-queue busy time, overlap, and the longest kernels."""
 import csv, glob, sys, collections
-f = sorted(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'))[-1]
+import os
+f = max(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'), key=os.path.getmtime)
 rows = [r for r in csv.DictReader(open(f))]
 for r in rows:
     r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp'])
