@@ -1,0 +1,100 @@
+"""BENCH.md from the artefacts of tools/gpu_profile.sh (rocprofv3 kernel trace + the two PMC passes under gpurun_out/)
+and profiles/r01_bench_line.json / profiles/r01_configs.json.  Per (kernel, grid): launches per step, mean duration in
+the step, HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), TB/s, and TFLOP/s where the launch shape is known."""
+import csv, glob, json, os, collections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+
+
+def newest(pattern):
+    fs = glob.glob(os.path.join(G, pattern))
+    return max(fs, key=os.path.getmtime) if fs else None
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "").replace("mednet::", "")
+    if n.startswith("_ZN6mednet"):
+        import re
+        m = re.match(r"_ZN6mednet(\d+)", n)
+        k = int(m.group(1))
+        n = n[len(m.group(0)):len(m.group(0)) + k]
+    return n
+
+
+def main():
+    trace = newest("prof_stats/*/*kernel_trace.csv")
+    rows = list(csv.DictReader(open(trace)))
+    for r in rows:
+        r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    rows.sort(key=lambda r: r["s"])
+    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+    nsteps = len(adam) - 1
+    steps = rows[adam[0] + 1:adam[-1] + 1]
+    wall = (steps[-1]["e"] - steps[0]["s"]) / nsteps / 1e6
+    slots_b = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_slots.json")))
+    # per kernel: durations of its i-th launch in a step, averaged over the traced steps
+    per_step = []
+    for i in range(nsteps):
+        seg = rows[adam[i] + 1:adam[i + 1] + 1]
+        d = collections.defaultdict(list)
+        for r in seg:
+            d[r["Kernel_Name"].split("(")[0]].append(((r["e"] - r["s"]) / 1e3, r["Grid_Size_X"]))
+        per_step.append(d)
+    FLOP_L0 = 2.0 * 27 * 32 * 32 * 4 * 128 ** 3
+    # classes: launches of one kernel whose HBM bytes agree within ~12 % are the same layer shape
+    import math
+    agg = collections.defaultdict(lambda: {"us": [], "bytes": [], "grid": None})
+    for k in per_step[0]:
+        n = len(per_step[0][k])
+        if any(len(ps[k]) != n for ps in per_step):
+            continue
+        bts = slots_b.get(k)
+        for i in range(n):
+            us = sum(ps[k][i][0] for ps in per_step) / nsteps
+            b = bts[i] if bts and len(bts) == n else None
+            cls = round(math.log(max(b, 1)) * 4) if b else -1
+            key = (short(k), cls)
+            agg[key]["us"].append(us)
+            agg[key]["grid"] = per_step[0][k][i][1]
+            if b:
+                agg[key]["bytes"].append(b)
+    out = []
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_line.json")))
+    out.append("# BENCH — measured on 1x MI355X (gfx950), round 1\n")
+    out.append("Produced by `tools/make_bench_md.py` from `tools/gpu_profile.sh` (bench.py, then `rocprofv3 --kernel-trace --stats`,"
+               " then separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the same command).\n")
+    out.append("## Headline (BASELINE config 2: ResidualUNet3D [32,64,128,256], 4 classes, 128^3, batch 4, bf16 storage)\n")
+    out.append("```json\n" + json.dumps(line, indent=1) + "\n```\n")
+    cfgp = os.path.join(ROOT, "profiles", "r01_configs.json")
+    if os.path.exists(cfgp):
+        out.append("## Other configurations (same kernels; `tools/run_configs.py`)\n")
+        out.append("| configuration | patches/s | ms/step | peak memory (GB) |\n|---|---|---|---|")
+        for c in json.load(open(cfgp)):
+            out.append(f"| {c['config']} | {c['patches_per_s']} | {c['ms_per_step']} | {c['max_mem_GB']} |")
+        out.append("")
+    out.append(f"## Kernels of one training step (rocprofv3 trace, {nsteps} steps averaged; step wall time {wall:.2f} ms;"
+               " the weight gradients run on a second stream, so the durations add up to more than the wall time)\n")
+    out.append("| kernel | grid (threads) | launches/step | mean us | ms/step | HBM MB/launch (PMC) | TB/s | TFLOP/s |\n|---|---|---|---|---|---|---|---|")
+    tot = 0.0
+    for (name, cls), v in sorted(agg.items(), key=lambda kv: -sum(kv[1]["us"])):
+        ms = sum(v["us"]) / 1e3
+        tot += ms
+        if ms < 0.02:
+            continue
+        mean = sum(v["us"]) / len(v["us"])
+        mb = tbs = ""
+        if v["bytes"]:
+            b = sum(v["bytes"]) / len(v["bytes"])
+            mb, tbs = f"{b / 1e6:.0f}", f"{b / (mean * 1e-6) / 1e12:.2f}"
+        tf = ""
+        if name == "conv_mfma_kernel<1>" and v["bytes"] and 1.4e9 < sum(v["bytes"]) / len(v["bytes"]) < 2.0e9:
+            tf = f"{FLOP_L0 / (mean * 1e-6) / 1e12:.0f} (32->32 @128^3)"
+        out.append(f"| `{name}` | {v['grid']} | {len(v['us'])} | {mean:.1f} | {ms:.3f} | {mb} | {tbs} | {tf} |")
+    out.append(f"\nSum of kernel durations: {tot:.1f} ms per step.\n")
+    open(os.path.join(ROOT, "BENCH.md"), "w").write("\n".join(out) + "\n")
+    print("BENCH.md written:", len(out), "lines; step wall", round(wall, 2), "ms")
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,18 @@ def per_kernel(path):
     return agg
 
 
+def per_slot(path):
+    """{kernel: [counter value of its i-th launch in the LAST full step]} -- the launch sequence of a step is deterministic,
+    so the i-th launch of a kernel is the same layer in every run (trace, FETCH_SIZE pass, WRITE_SIZE pass)."""
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+    step = rows[adam[-2] + 1:adam[-1] + 1]
+    slots = collections.defaultdict(list)
+    for r in step:
+        slots[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return slots
+
+
 def main():
     st = newest("prof_stats/*/*kernel_stats.csv")
     if st:
@@ -46,6 +58,9 @@ def main():
         out[k] = {"FETCH_SIZE_KB_avg": round(fk, 1), "WRITE_SIZE_KB_avg": round(wk, 1),
                   "hbm_bytes_per_launch": int((2 * fk + wk) * 1024), "launches_fetch": len(fa[k]), "launches_write": len(wa[k])}
     json.dump(out, open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json"), "w"), indent=1)
+    fs, wsl = per_slot(f), per_slot(w)
+    slots = {k: [int((2 * a + b) * 1024) for a, b in zip(fs[k], wsl[k])] for k in fs if k in wsl and len(fs[k]) == len(wsl[k])}
+    json.dump(slots, open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_slots.json"), "w"))
     k = "mednet::conv_mfma_kernel<1> 32->32@128^3 (persistent grid=131072, longest launches)"
     print(k, out.get(k))
 
