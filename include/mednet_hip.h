@@ -112,9 +112,10 @@ int mednet_add(const void* a, const void* b, void* out, size_t count, int dtype,
 /* ---- nn.MaxPool3d(2) / nn.AvgPool3d(2)  components.py:208-212 ----------------------------------------------- */
 int mednet_pool2_fwd(const void* x, void* y, int n, int d, int h, int w, int c, int mode, int dtype,
                      mednet_stream stream);
-/* dx has the INPUT shape; ties route to the first maximum in (z,y,x) scan order like ATen. */
-int mednet_pool2_bwd(const void* dy, const void* x, void* dx, int n, int d, int h, int w, int c, int mode,
-                     int dtype, mednet_stream stream);
+/* dx has the INPUT shape; ties route to the first maximum in (z,y,x) scan order like ATen.  `add` (nullable, input
+ * shape): a second gradient of the same tensor -- the decoder's skip join of model.py:199-205 -- summed in the same pass. */
+int mednet_pool2_bwd(const void* dy, const void* x, const void* add, void* dx, int n, int d, int h, int w, int c,
+                     int mode, int dtype, mednet_stream stream);
 
 /* ---- F.interpolate(nearest, size=enc) + torch.cat((enc, x), 1)  components.py:277-280 (UNet3D decoder) ------- */
 int mednet_upcat_fwd(const void* enc, const void* x, void* out, int n, int d, int h, int w, int c_enc, int xd,

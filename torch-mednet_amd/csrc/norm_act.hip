@@ -511,7 +511,8 @@ __global__ __launch_bounds__(256) void pool2_fwd_kernel(const T* __restrict__ x,
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void pool2_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                        T* __restrict__ dx, int n, int d, int h, int w, int c, int mode) {
+                                                        const T* __restrict__ add, T* __restrict__ dx, int n, int d,
+                                                        int h, int w, int c, int mode) {
   const int od = d / 2, oh = h / 2, ow = w / 2, cv = c / VEC;
   const size_t total = (size_t)n * od * oh * ow * cv;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -555,6 +556,11 @@ __global__ __launch_bounds__(256) void pool2_bwd_kernel(const T* __restrict__ dy
 #pragma unroll
     for (int k = 0; k < VEC; ++k)
       o.v[k] = mode == MEDNET_POOL_MAX ? (arg[k] == t ? g.v[k] : 0.f) : 0.125f * g.v[k];
+    if (add) {  // the other consumer's gradient of the same tensor (the decoder's skip join): one pass instead of an add kernel
+      const F8 a = VecIO<T, VEC>::load(add, dst);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) o.v[k] += a.v[k];
+    }
     VecIO<T, VEC>::store(dx, dst, o);
   }
 }
@@ -818,18 +824,19 @@ extern "C" int mednet_pool2_fwd(const void* x, void* y, int n, int d, int h, int
 #undef GO
   return check_launch("pool2_fwd");
 }
-extern "C" int mednet_pool2_bwd(const void* dy, const void* x, void* dx, int n, int d, int h, int w, int c, int mode,
-                                int dtype, mednet_stream stream) {
+extern "C" int mednet_pool2_bwd(const void* dy, const void* x, const void* add, void* dx, int n, int d, int h, int w,
+                                int c, int mode, int dtype, mednet_stream stream) {
   MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "pool2_bwd: bad dtype");
   hipStream_t s = (hipStream_t)stream;
-  if ((d | h | w) & 1) {  // odd tails are never pooled: their gradient is zero
-    if (hipMemsetAsync(dx, 0, (size_t)n * d * h * w * c * dtype_size(dtype), s) != hipSuccess)
-      return fail(MEDNET_E_HIP, "pool2_bwd: memset failed");
+  if ((d | h | w) & 1) {  // odd tails are never pooled: their gradient is zero (or just `add`)
+    const size_t bytes = (size_t)n * d * h * w * c * dtype_size(dtype);
+    const hipError_t e = add ? hipMemcpyAsync(dx, add, bytes, hipMemcpyDeviceToDevice, s) : hipMemsetAsync(dx, 0, bytes, s);
+    if (e != hipSuccess) return fail(MEDNET_E_HIP, "pool2_bwd: tail fill failed");
   }
   const int vec = c % 8 == 0 ? 8 : 1;
   const size_t total = (size_t)n * (d / 2) * (h / 2) * (w / 2) * (c / vec);
   const dim3 grid((unsigned)((total + 255) / 256));
-#define GO(T, V) hipLaunchKernelGGL((pool2_bwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, (T*)dx, n, d, h, w, c, mode)
+#define GO(T, V) hipLaunchKernelGGL((pool2_bwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, n, d, h, w, c, mode)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
   else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
 #undef GO

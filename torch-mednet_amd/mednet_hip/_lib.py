@@ -49,7 +49,7 @@ SIGNATURES = {
     "mednet_act_bwd": (_i, [_vp, _vp, _vp, _sz, _i, _i, _vp]),
     "mednet_add": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "mednet_pool2_fwd": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
-    "mednet_pool2_bwd": (_i, [_vp, _vp, _vp] + [_i] * 7 + [_vp]),
+    "mednet_pool2_bwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
     "mednet_upcat_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "mednet_upcat_bwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "mednet_loss_ws_bytes": (_sz, [_i, _i, _sz]),

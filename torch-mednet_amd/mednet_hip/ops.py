@@ -397,13 +397,48 @@ class Pool2Fn(Function):
         n, c, d, h, w = x.shape
         dy = to_cl(dy.to(x.dtype))
         dx = torch.empty_like(x, memory_format=CL)
-        L.check(L.lib().mednet_pool2_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), n, d, h, w, c, ctx.mode, L.dt(x),
+        L.check(L.lib().mednet_pool2_bwd(dy.data_ptr(), x.data_ptr(), None, dx.data_ptr(), n, d, h, w, c, ctx.mode, L.dt(x),
                                          L.stream()), "pool2_bwd")
         return dx, None
 
 
 def pool2(x, mode=L.POOL_MAX):
     return Pool2Fn.apply(x, mode)
+
+
+class SkipPool2Fn(Function):
+    """(skip, pooled) = (x, pool(x)): the encoder output that feeds both the next level's pooling and the decoder's
+    skip join (model.py:194-205).  As ONE node its backward receives both gradients and sums them inside the pooling
+    backward kernel, instead of autograd adding two full-resolution tensors with a separate kernel."""
+
+    @staticmethod
+    def forward(ctx, x, mode):
+        L.require_gpu(x, "pool3d")
+        x = to_cl(_as_act(x))
+        n, c, d, h, w = x.shape
+        y = empty_cl(n, c, d // 2, h // 2, w // 2, x.dtype, x.device)
+        L.check(L.lib().mednet_pool2_fwd(x.data_ptr(), y.data_ptr(), n, d, h, w, c, mode, L.dt(x), L.stream()), "pool2_fwd")
+        ctx.save_for_backward(x)
+        ctx.mode = mode
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dskip, dy):
+        (x,) = ctx.saved_tensors
+        n, c, d, h, w = x.shape
+        if dy is None:
+            return dskip, None
+        dy = to_cl(dy.to(x.dtype))
+        if dskip is not None:
+            dskip = to_cl(dskip.to(x.dtype))
+        dx = torch.empty_like(x, memory_format=CL)
+        L.check(L.lib().mednet_pool2_bwd(dy.data_ptr(), x.data_ptr(), L.ptr(dskip), dx.data_ptr(), n, d, h, w, c, ctx.mode,
+                                         L.dt(x), L.stream()), "pool2_bwd")
+        return dx, None
+
+
+def skip_pool2(x, mode=L.POOL_MAX):
+    return SkipPool2Fn.apply(x, mode)
 
 
 # ------------------------------------------------------------------------------------------------- nearest upsample + concat

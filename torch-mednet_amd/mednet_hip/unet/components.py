@@ -11,6 +11,8 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+import os
+
 from .. import _lib as L
 from .. import block
 from .. import nn as hnn
@@ -145,6 +147,9 @@ class ExtResNetBlock(nn.Module):
         return self.conv3(out, residual=residual, final_act=self.non_linearity.code)
 
 
+_FUSE_SKIP_POOL = os.environ.get("MEDNET_SKIP_POOL", "1") == "1"  # A/B knob
+
+
 class Encoder(nn.Module):
     def __init__(self, in_channels, out_channels, conv_kernel_size=3, apply_pooling=True, pool_kernel_size=(2, 2, 2),
                  pool_type="max", basic_module=DoubleConv, conv_layer_order="crg", num_groups=8):
@@ -161,6 +166,15 @@ class Encoder(nn.Module):
         if self.pooling is not None:
             x = self.pooling(x)
         return self.basic_module(x)
+
+    def forward_with_skip(self, x):
+        """-> (skip, out): `skip` is x as the decoder will use it, `out` = forward(x).  With the 2x2x2 pooling of this
+        package the split is one autograd node (ops.SkipPool2Fn), so the two gradients of x meet inside the pooling
+        backward kernel; any other pooling module falls back to the plain path (autograd adds them)."""
+        if _FUSE_SKIP_POOL and isinstance(self.pooling, hnn._Pool2) and torch.is_tensor(x) and x.is_cuda and x.requires_grad:
+            skip, pooled = ops.skip_pool2(x, self.pooling.mode)
+            return skip, self.basic_module(pooled)
+        return x, self.forward(x)
 
 
 class Decoder(nn.Module):

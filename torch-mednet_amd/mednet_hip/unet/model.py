@@ -49,8 +49,11 @@ class _UNetCore(_Base):
 
     def forward(self, x):
         skips = []
-        for enc in self.encoders:
-            x = enc(x)
+        for i, enc in enumerate(self.encoders):
+            if i == 0:
+                x = enc(x)
+            else:  # x is both the previous level's skip tensor and this level's pooling input (model.py:194-199)
+                skips[0], x = enc.forward_with_skip(x)
             skips.insert(0, x)
         for dec, skip in zip(self.decoders, skips[1:]):
             x = dec(skip, x)
