@@ -376,6 +376,32 @@ class AddFn(Function):
         return g, g
 
 
+# ------------------------------------------------------------------------------------------------- channel split
+class SplitChannelsFn(Function):
+    """(x[:, :k], x[:, k:]) as ONE autograd node (landmarks.py:71-72 slices the network output into heat-map and class
+    channels): backward is a single concatenation of the two gradients instead of autograd's zero-fill + copy per slice
+    + add over the full logits tensor."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k, ctx.shape = k, x.shape
+        return x[:, :k], x[:, k:]
+
+    @staticmethod
+    def backward(ctx, d0, d1):
+        k, shape = ctx.k, ctx.shape
+        ref = d0 if d0 is not None else d1
+        if d0 is None:
+            d0 = ref.new_zeros((shape[0], k) + tuple(shape[2:]))
+        if d1 is None:
+            d1 = ref.new_zeros((shape[0], shape[1] - k) + tuple(shape[2:]))
+        return torch.cat((d0, d1), dim=1), None
+
+
+def split_channels(x, k):
+    return SplitChannelsFn.apply(x, k)
+
+
 # ------------------------------------------------------------------------------------------------- pooling
 class Pool2Fn(Function):
     """nn.MaxPool3d(2) / nn.AvgPool3d(2)  -- components.py:208-212."""

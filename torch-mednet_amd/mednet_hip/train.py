@@ -241,8 +241,9 @@ class LandmarkStep(_GraphedStep):
         nh = heatmaps.shape[1]
         labels = batch["label"][:, -1, ...].long()
         outputs = self.model(inputs)
-        class_loss = self.loss_class(outputs[:, nh:, ...], labels)
-        regression_loss = self.loss_reg(outputs[:, :nh, ...], heatmaps)
+        out_hm, out_cls = ops.split_channels(outputs, nh)  # (= outputs[:, :nh], outputs[:, nh:]; one gradient join)
+        class_loss = self.loss_class(out_cls, labels)
+        regression_loss = self.loss_reg(out_hm, heatmaps)
         loss = regression_loss + class_loss
         loss.backward()
         finish_backward()
