@@ -145,3 +145,24 @@ def test_oracle_caller_steps(golden_dir):
     assert abs(float(tot) - float(rec["ldmk.loss"])) <= 1e-4 * float(rec["ldmk.loss"])
     assert abs(float(cl) - float(rec["ldmk.class_loss"])) <= 1e-5
     assert abs(float(rg) - float(rec["ldmk.regression_loss"])) <= 1e-4 * float(rec["ldmk.regression_loss"])
+
+
+def test_predict_oracle_matches_reference_golden(golden_dir):
+    """Row N2: oracle/ref_predict.py (grid patches, post-processing, stitching with the reference's crop rule) against
+    tests/golden/predict.npz, which tools/make_golden.py wrote only after the reference's own functions agreed."""
+    import os
+    from oracle import ref_predict as P
+    rec = np.load(os.path.join(golden_dir, "predict.npz"))
+    for tag, shape, patch, ov, mode, nh, ncls, bs in P.PREDICT_CASES:
+        img, logits_for = P.predict_inputs(tag, shape, patch, nh, ncls)
+        patches = list(P.grid_patch_generator(img, patch, ov, mode=mode))
+        assert len(patches) == int(rec[f"{tag}.npatches"])
+        assert np.array_equal(np.stack([i for _, i, _ in patches]), rec[f"{tag}.pos"])
+        assert np.allclose([float(np.asarray(a, dtype=np.float64).sum()) for a, _, _ in patches], rec[f"{tag}.patch_sums"])
+        assert np.array_equal(patches[0][0], rec[f"{tag}.first_patch"]) and np.array_equal(patches[-1][0], rec[f"{tag}.last_patch"])
+        result = np.zeros((nh + 1,) + tuple(shape[1:]), dtype=np.uint8)
+        for b0 in range(0, len(patches), bs):
+            chunk = patches[b0:b0 + bs]
+            out = P.postprocess(np.stack([logits_for(c) for _, _, c in chunk]), nh)
+            P.add_processed_batch(result, out, np.stack([i for _, i, _ in chunk]), ov)
+        assert np.array_equal(result, rec[f"{tag}.result"]), tag

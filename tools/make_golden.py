@@ -400,6 +400,74 @@ def caller_cases(out):
     print(f"[make_golden] callers: seg loss={float(res['loss']):.8f} ldmk loss={float(res2['loss']):.6f} ok")
 
 
+def predict_cases(out):
+    """Row N2: the reference's grid_patch_generator / GridPatchSampler.add_processed_batch (dataset.py) and
+    the post-processing lines of examples/predict.py, run on deterministic inputs; oracle/ref_predict.py must agree
+    exactly.  h5py / zarr / nibabel are absent here: dataset.py imports them at module level only, so they are stubbed
+    (zarr.group() -> a dict of numpy-backed datasets, which is all add_processed_batch uses)."""
+    import torch.nn.functional as F
+    from oracle import ref_predict as P
+    PREDICT_CASES, predict_inputs = P.PREDICT_CASES, P.predict_inputs
+
+    class _DS:
+        def __init__(self, shape, dtype):
+            self.a, self.attrs = np.zeros(tuple(int(v) for v in shape), dtype=dtype), {}
+
+        def __setitem__(self, k, v):
+            self.a[k] = v
+
+        def __getitem__(self, k):
+            return self.a[k]
+
+    class _Group(dict):
+        def require_dataset(self, key, shape, dtype, chunks=False):
+            if key not in self:
+                self[key] = _DS(shape, dtype)
+            return self[key]
+
+    for name in ["nibabel", "h5py", "zarr"]:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["zarr"].group = _Group
+    sys.path.insert(0, REF)
+    import midasmednet.dataset as rds
+
+    rec = {}
+    for tag, shape, patch, ov, mode, nh, ncls, bs in PREDICT_CASES:
+        img, logits_for = predict_inputs(tag, shape, patch, nh, ncls)
+        ref_p = list(rds.grid_patch_generator(img, patch, ov, mode=mode))
+        ora_p = list(P.grid_patch_generator(img, patch, ov, mode=mode))
+        assert len(ref_p) == len(ora_p) > 0
+        for (a, ia, ca), (b, ib, cb) in zip(ref_p, ora_p):
+            assert np.array_equal(a, b) and np.array_equal(ia, ib) and ca == cb, tag
+        # the reference sampler without its file readers: only what add_processed_batch touches (dataset.py:446-474)
+        gs = object.__new__(rds.GridPatchSampler)
+        gs.patch_overlap, gs.out_channels, gs.out_dtype = ov, nh + 1, np.uint8
+        gs.data_shape, gs.data_affine, gs.results = {"s": np.array(shape)}, {"s": np.eye(4)}, _Group()
+        result_o = np.zeros((nh + 1,) + tuple(shape[1:]), dtype=np.uint8)
+        for b0 in range(0, len(ref_p), bs):
+            chunk = ref_p[b0:b0 + bs]
+            logits = torch.from_numpy(np.stack([logits_for(c) for _, _, c in chunk]))
+            # examples/predict.py:88-95, verbatim semantics
+            oc = torch.argmax(F.softmax(logits[:, nh:, ...], dim=1), dim=1, keepdim=True).numpy()
+            oh = np.clip(logits[:, :nh, ...].numpy(), 0.0, 255.0)
+            output = np.concatenate([oh.astype(np.uint8), oc.astype(np.uint8)], axis=1)
+            assert np.array_equal(output, P.postprocess(logits.numpy(), nh)), tag
+            pos = np.stack([i for _, i, _ in chunk])
+            gs.add_processed_batch({"subject_key": ["s"] * len(chunk), "pos": pos, "data": output})
+            P.add_processed_batch(result_o, output, pos, ov)
+        result_r = gs.results["s"].a
+        assert np.array_equal(result_r, result_o), tag
+        rec[f"{tag}.result"] = result_r
+        rec[f"{tag}.npatches"] = np.array(len(ref_p))
+        rec[f"{tag}.pos"] = np.stack([i for _, i, _ in ref_p])
+        rec[f"{tag}.patch_sums"] = np.array([float(np.asarray(a, dtype=np.float64).sum()) for a, _, _ in ref_p])
+        rec[f"{tag}.first_patch"] = np.asarray(ref_p[0][0])
+        rec[f"{tag}.last_patch"] = np.asarray(ref_p[-1][0])
+        print(f"predict[{tag}]: {len(ref_p)} patches, result {result_r.shape} bit-identical reference == oracle")
+    np.savez_compressed(os.path.join(out, "predict.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
@@ -420,6 +488,8 @@ def main():
         loss_cases(a.out, rloss)
     if want("callers"):
         caller_cases(a.out)
+    if want("predict"):
+        predict_cases(a.out)
     R, U = (rmodel.ResidualUNet3D, O.ResidualUNet3D), (rmodel.UNet3D, O.UNet3D)
     seg_w4 = [0.05, 1.0, 1.0, 1.0]
     nets = [
