@@ -156,6 +156,22 @@ int mednet_adam_step(float* p, const float* g, float* m, float* v, size_t count,
                      float beta2, float eps, float weight_decay, int step, float grad_scale,
                      mednet_stream stream);
 
+/* ---- inference path ------------------------------------------------------------------------ */
+enum { MEDNET_PAD_CONSTANT = 0, MEDNET_PAD_SYMMETRIC = 1 };
+/* midasmednet/dataset.py:349-390 (grid_patch_generator): patch b = padded(volume)[:, pos[b] : pos[b] + patch] where the
+ * volume (C x D x H x W, fp32) is padded by the overlap in front (np.pad constant-0 or symmetric); pos = B x 3 int32 grid
+ * positions on the device.  out: B x C x pD x pH x pW fp32 (what predict.py:85 feeds the network). */
+int mednet_grid_gather(const float* volume, const int* pos, float* out, int batch, int c, int d, int h, int w, int pd,
+                       int ph, int pw, int ov0, int ov1, int ov2, int pad_mode, mednet_stream stream);
+/* examples/predict.py:88-95 + GridPatchSampler.add_processed_batch (dataset.py:446-474) in one pass: logits B x (H +
+ * classes) x pD x pH x pW (planar fp32) -> result (H + 1) x D x H x W uint8 (heat maps clipped to 0..255 and truncated,
+ * then the arg-max class); only the crop window [crop_start, crop_start + crop_shape) of each patch is written, at
+ * pos[b] + offset, and what hangs over the volume is dropped.  The caller derives the window from the reference's slicing
+ * (`data[:, o0:-o1, o1:-o1, o2:-o2]`, dataset.py:452-455). */
+int mednet_predict_assemble(const float* logits, const int* pos, uint8_t* result, int batch, int num_heatmaps,
+                            int num_classes, int d, int h, int w, int pd, int ph, int pw, int crop_start0, int crop_start1,
+                            int crop_start2, int crop_d, int crop_h, int crop_w, mednet_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

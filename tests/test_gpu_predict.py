@@ -1,0 +1,93 @@
+"""Row N2 (inference path) on the GPU: the device-side patch gather and the fused post-processing + stitching kernel
+against the CPU oracle (oracle/ref_predict.py) and the reference's golden result -- bit-exact (byte / index work)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mednet_hip
+from mednet_hip import predict as HP
+from mednet_hip.unet import model as HM
+from oracle import ref_cpu as O
+from oracle import ref_predict as P
+
+from gpu_util import DEV
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", P.PREDICT_CASES, ids=[c[0] for c in P.PREDICT_CASES])
+def test_grid_gather_matches_reference_patches(case, golden_dir):
+    tag, shape, patch, ov, mode, nh, ncls, bs = case
+    rec = np.load(os.path.join(golden_dir, "predict.npz"))
+    img, _ = P.predict_inputs(tag, shape, patch, nh, ncls)
+    ora = list(P.grid_patch_generator(img, patch, ov, mode=mode))
+    pos = torch.from_numpy(HP.grid_positions(shape[1:], patch, ov)).to(DEV)
+    assert np.array_equal(pos.cpu().numpy(), rec[f"{tag}.pos"])
+    got = HP.gather_patches(torch.from_numpy(img).to(DEV).float(), pos, patch, ov, mode).cpu().numpy()
+    assert got.shape[0] == int(rec[f"{tag}.npatches"])
+    for i, (p, _, _) in enumerate(ora):
+        assert np.array_equal(got[i], np.asarray(p, dtype=np.float32)), (tag, i)
+    assert np.array_equal(got[0], rec[f"{tag}.first_patch"].astype(np.float32))
+    assert np.array_equal(got[-1], rec[f"{tag}.last_patch"].astype(np.float32))
+
+
+@pytest.mark.parametrize("case", P.PREDICT_CASES, ids=[c[0] for c in P.PREDICT_CASES])
+def test_postprocess_and_stitch_match_reference_result(case, golden_dir):
+    tag, shape, patch, ov, mode, nh, ncls, bs = case
+    rec = np.load(os.path.join(golden_dir, "predict.npz"))
+    _, logits_for = P.predict_inputs(tag, shape, patch, nh, ncls)
+    pos_all = HP.grid_positions(shape[1:], patch, ov)
+    result = torch.zeros((nh + 1,) + tuple(shape[1:]), dtype=torch.uint8, device=DEV)
+    for b0 in range(0, len(pos_all), bs):
+        logits = torch.from_numpy(np.stack([logits_for(c) for c in range(b0, min(b0 + bs, len(pos_all)))])).to(DEV)
+        HP.assemble(logits, torch.from_numpy(pos_all[b0:b0 + bs]).to(DEV), result, nh, ov)
+    assert np.array_equal(result.cpu().numpy(), rec[f"{tag}.result"]), tag
+
+
+def test_ties_and_clip_edges():
+    """first maximum on ties; clip at 0 and 255 with truncation (np.clip(..).astype(uint8))."""
+    lg = torch.zeros(1, 3, 8, 8, 8)
+    lg[0, 0] = torch.linspace(-3.0, 300.0, 512).reshape(8, 8, 8)   # heat map
+    lg[0, 1] = 1.5
+    lg[0, 2] = 1.5                                                # tie -> class 0
+    lg[0, 2, 4:] = 1.5000001
+    out = P.postprocess(lg.numpy(), 1)
+    res = np.zeros((2, 8, 8, 8), dtype=np.uint8)
+    P.add_processed_batch(res, out, np.zeros((1, 3), dtype=int), [1, 1, 1])
+    got = torch.zeros((2, 8, 8, 8), dtype=torch.uint8, device=DEV)
+    HP.assemble(lg.to(DEV), torch.zeros((1, 3), dtype=torch.int32, device=DEV), got, 1, [1, 1, 1])
+    assert np.array_equal(got.cpu().numpy(), res)
+
+
+def test_grid_predictor_end_to_end_matches_oracle_loop():
+    """GridPredictor (device gather -> HIP forward -> fused arg-max / clip / stitch) against the oracle's restatement of
+    predict.py's loop around the CPU oracle network, fp32 mode: the uint8 volumes agree except where a logit sits within
+    float noise of a decision boundary."""
+    ctor = dict(in_channels=1, out_channels=5, final_sigmoid=False, f_maps=[8, 16])
+    nh, patch, ov = 2, [16, 16, 16], [2, 3, 4]
+    img = (O._rng("predict:e2e").standard_normal((1, 21, 30, 19)) * 2).astype(np.float16)
+    ora = O.keyed_init_(O.ResidualUNet3D(**ctor)).eval()
+
+    def fwd(x):
+        with torch.no_grad():
+            return (ora(torch.from_numpy(x)) * 40.0).numpy()
+
+    want = P.predict_volume(fwd, img, patch, ov, nh, batch_size=3, pad_kwargs={"mode": "symmetric"})
+    with mednet_hip.precision("fp32"):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+
+        class Scaled(torch.nn.Module):
+            def __init__(self, m):
+                super().__init__()
+                self.m = m
+
+            def forward(self, x):
+                return self.m(x) * 40.0
+
+        got = HP.GridPredictor(Scaled(net), patch, ov, num_heatmaps=nh, pad_mode="symmetric", batch_size=3)(img).cpu().numpy()
+    assert got.shape == want.shape and got.dtype == np.uint8
+    assert (got[nh] != want[nh]).mean() < 2e-3                      # labels
+    d = np.abs(got[:nh].astype(int) - want[:nh].astype(int))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3                 # heat maps: truncation flips only

@@ -116,3 +116,21 @@ def test_one_hot_and_generic_dice_helpers_match_oracle():
     t = O.expand_as_one_hot(y, 4)
     assert torch.equal(HL.compute_per_channel_dice(p, t), O.compute_per_channel_dice(p, t))
     assert torch.equal(HL.flatten(p), O.flatten(p))
+
+
+def test_predict_grid_and_crop_window_follow_the_reference():
+    """mednet_hip.predict host logic (no GPU): grid positions and the crop window of the reference's slicing."""
+    import numpy as np
+    from mednet_hip import predict as HP
+    from oracle import ref_predict as P
+    for tag, shape, patch, ov, mode, nh, ncls, bs in P.PREDICT_CASES:
+        img, _ = P.predict_inputs(tag, shape, patch, nh, ncls)
+        ref = np.stack([i for _, i, _ in P.grid_patch_generator(img, patch, ov, mode=mode)])
+        assert np.array_equal(HP.grid_positions(shape[1:], patch, ov), ref), tag
+        s0, n0 = HP.crop_window(patch, ov)
+        s1, n1 = P.crop_window(patch, ov)
+        assert list(s0) == list(s1) and list(n0) == list(n1)
+    assert HP.crop_window([8, 8, 8], [0, 2, 2]) == ([0, 2, 2], [6, 4, 4])  # the reference's first-axis quirk (dataset.py:453)
+    import pytest
+    with pytest.raises(ValueError):
+        HP.grid_positions([8, 8, 8], [4, 4, 4], [2, 2, 2])

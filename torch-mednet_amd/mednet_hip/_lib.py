@@ -20,6 +20,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3
 POOL_MAX, POOL_AVG = 0, 1
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
 REG_L2, REG_L1 = 0, 1
+PAD_CONSTANT, PAD_SYMMETRIC = 0, 1
 NO_IGNORE = -(2 ** 31)
 
 _vp, _i, _sz, _f, _i64 = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_int64
@@ -60,6 +61,8 @@ SIGNATURES = {
     "mednet_heatmap_loss_fwd": (_i, [_vp] * 4 + [_i, _i, _sz, _i64, _i64, _i, _i, _vp, _sz, _vp]),
     "mednet_heatmap_loss_bwd": (_i, [_vp] * 5 + [_i, _i, _sz, _i64, _i64, _i, _i, _vp]),
     "mednet_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    "mednet_grid_gather": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp]),
+    "mednet_predict_assemble": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),
 }
 
 _lib = None
