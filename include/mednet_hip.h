@@ -172,6 +172,16 @@ int mednet_predict_assemble(const float* logits, const int* pos, uint8_t* result
                             int num_classes, int d, int h, int w, int pd, int ph, int pw, int crop_start0, int crop_start1,
                             int crop_start2, int crop_d, int crop_h, int crop_w, mednet_stream stream);
 
+/* ---- training-patch sampler ------------------------------------------------------------------ */
+enum { MEDNET_F16 = 2, MEDNET_U8 = 3 }; /* storage types of the resident volumes (only mednet_crop_patches takes them) */
+/* MedDataset.__getitem__'s crop + cast (dataset.py:313-331) from a device-resident volume src (C x D x H x W; f16 / f32
+ * images, u8 labels or heat maps): for i < count,
+ *   out[slot[i]][c_off + c][z][y][x] = cast(src[c][pos[i][0] + z][pos[i][1] + y][pos[i][2] + x])
+ * out: B x c_total x pD x pH x pW (f32 for images, u8 for labels); pos (count x 3) and slot (count) are int32 on the device.
+ * Positions come from the host-side restatement of the reference's sampling (same numpy generator calls). */
+int mednet_crop_patches(const void* src, int src_dtype, const int* pos, const int* slot, int count, void* out, int dst_dtype,
+                        int c, int d, int h, int w, int c_total, int c_off, int pd, int ph, int pw, mednet_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,3 +91,33 @@ def test_grid_predictor_end_to_end_matches_oracle_loop():
     assert (got[nh] != want[nh]).mean() < 2e-3                      # labels
     d = np.abs(got[:nh].astype(int) - want[:nh].astype(int))
     assert d.max() <= 1 and (d != 0).mean() < 2e-3                 # heat maps: truncation flips only
+
+
+# ---------------------------------------------------------------------------------------------- row N1: patch sampler
+@pytest.mark.parametrize("case", __import__("oracle.ref_sampler", fromlist=["x"]).SAMPLER_CASES,
+                         ids=[c[0] for c in __import__("oracle.ref_sampler", fromlist=["x"]).SAMPLER_CASES])
+def test_device_patch_sampler_reproduces_reference_batches(case, golden_dir):
+    """DevicePatchSampler (host position logic + mednet_crop_patches) seeded like the reference: same subjects, positions,
+    classes, and bit-identical 'data' (fp32) / 'label' (uint8) tensors as the oracle, whose run equals the reference's."""
+    from mednet_hip.sampler import DevicePatchSampler
+    from oracle import ref_sampler as S
+    tag, shapes, c_img, n_hm, patch, probs, draws, seed = case
+    rec = np.load(os.path.join(golden_dir, "sampler.npz"))
+    images, labels, heatmaps = S.sampler_volumes(tag, shapes, c_img, n_hm, len(probs) if probs else 3)
+    ora = S.PatchSampler(images, labels, patch, samples_per_subject=4, heatmaps=heatmaps, class_probabilities=probs)
+    dev = DevicePatchSampler(images, labels, patch, samples_per_subject=4, heatmaps=heatmaps, class_probabilities=probs, device=DEV)
+    np.random.seed(seed)
+    items = [ora[i] for i in range(draws)]
+    np.random.seed(seed)
+    got = []
+    for b0 in range(0, draws, 5):  # batches of 5 (mixing subjects inside a batch)
+        got.append(dev.batch(list(range(b0, min(b0 + 5, draws)))))
+    pos = np.concatenate([g["patch_position"] for g in got])
+    assert np.array_equal(pos, rec[f"{tag}.pos"])
+    assert np.array_equal(np.concatenate([g["selected_class"] for g in got]), rec[f"{tag}.cls"])
+    data = torch.cat([g["data"] for g in got]).cpu().numpy()
+    label = torch.cat([g["label"] for g in got]).cpu().numpy()
+    assert data.dtype == np.float32 and label.dtype == np.uint8
+    for i, it in enumerate(items):
+        assert np.array_equal(data[i], it["data"]) and np.array_equal(label[i], it["label"]), (tag, i)
+    assert np.array_equal(data[0], rec[f"{tag}.first_data"]) and np.array_equal(label[0], rec[f"{tag}.first_label"])

@@ -166,3 +166,21 @@ def test_predict_oracle_matches_reference_golden(golden_dir):
             out = P.postprocess(np.stack([logits_for(c) for _, _, c in chunk]), nh)
             P.add_processed_batch(result, out, np.stack([i for _, i, _ in chunk]), ov)
         assert np.array_equal(result, rec[f"{tag}.result"]), tag
+
+
+def test_sampler_oracle_matches_reference_golden(golden_dir):
+    """Row N1: oracle/ref_sampler.py seeded like the reference run of tools/make_golden.py reproduces its patches."""
+    import os
+    from oracle import ref_sampler as S
+    rec = np.load(os.path.join(golden_dir, "sampler.npz"))
+    for tag, shapes, c_img, n_hm, patch, probs, draws, seed in S.SAMPLER_CASES:
+        images, labels, heatmaps = S.sampler_volumes(tag, shapes, c_img, n_hm, len(probs) if probs else 3)
+        ora = S.PatchSampler(images, labels, patch, samples_per_subject=4, heatmaps=heatmaps, class_probabilities=probs)
+        np.random.seed(seed)
+        items = [ora[i] for i in range(draws)]
+        assert np.array_equal(np.stack([a["patch_position"] for a in items]), rec[f"{tag}.pos"])
+        assert np.array_equal([int(a["selected_class"]) for a in items], rec[f"{tag}.cls"])
+        assert np.array_equal([int(a["subject_key"]) for a in items], rec[f"{tag}.subj"])
+        assert np.allclose([float(a["data"].astype(np.float64).sum()) for a in items], rec[f"{tag}.data_sum"])
+        assert np.array_equal([int(a["label"].astype(np.int64).sum()) for a in items], rec[f"{tag}.label_sum"])
+        assert np.array_equal(items[0]["data"], rec[f"{tag}.first_data"]) and np.array_equal(items[0]["label"], rec[f"{tag}.first_label"])

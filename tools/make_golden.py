@@ -468,6 +468,57 @@ def predict_cases(out):
     np.savez_compressed(os.path.join(out, "predict.npz"), **rec)
 
 
+def sampler_cases(out):
+    """Row N1: the reference's MedDataset.__getitem__ / get_labeled_position / get_random_patch_indices
+    (dataset.py) with numpy's global generator seeded, against oracle/ref_sampler.py seeded the same way.  The reference
+    uses `np.int`, which numpy 2 no longer has: it is restored as the builtin int for the import.  MedDataset's readers
+    are bypassed (object.__new__ + the attributes __getitem__ touches): the volumes are given in memory."""
+    from oracle import ref_sampler as S
+    if not hasattr(np, "int"):
+        np.int = int
+    for name in ["nibabel", "h5py", "zarr"]:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.path.insert(0, REF)
+    import midasmednet.dataset as rds
+
+    rec = {}
+    for tag, shapes, c_img, n_hm, patch, probs, draws, seed in S.SAMPLER_CASES:
+        n_classes = len(probs) if probs else 3
+        images, labels, heatmaps = S.sampler_volumes(tag, shapes, c_img, n_hm, n_classes)
+        ora = S.PatchSampler(images, labels, patch, samples_per_subject=4, heatmaps=heatmaps, class_probabilities=probs)
+        ref = object.__new__(rds.MedDataset)
+        ref.images, ref.labels, ref.transform = images, labels, None
+        ref.heatmap_group = "heatmaps" if heatmaps is not None else None
+        if heatmaps is not None:
+            ref.heatmaps = heatmaps
+        ref.patch_size = np.array(patch, dtype=int)
+        ref.subject_keys = [str(i) for i in range(len(images))]
+        ref.samples_per_subject = 4
+        ref.class_probabilities = None if probs is None else probs / np.sum(probs)
+        ref._label_ax2_any = []
+        if probs:
+            for idx in range(len(labels)):
+                ref._label_ax2_any.append([np.any(labels[idx][-1, ...] == c, axis=2) for c in range(len(probs))])
+        np.random.seed(seed)
+        r_items = [ref[i] for i in range(draws)]
+        np.random.seed(seed)
+        o_items = [ora[i] for i in range(draws)]
+        for a, b in zip(r_items, o_items):
+            assert a["subject_key"] == b["subject_key"] and int(a["selected_class"]) == int(b["selected_class"]), tag
+            assert np.array_equal(a["patch_position"], b["patch_position"]), tag
+            assert a["data"].dtype == b["data"].dtype == np.float32 and np.array_equal(a["data"], b["data"]), tag
+            assert a["label"].dtype == b["label"].dtype == np.uint8 and np.array_equal(a["label"], b["label"]), tag
+        rec[f"{tag}.pos"] = np.stack([a["patch_position"] for a in r_items])
+        rec[f"{tag}.cls"] = np.array([int(a["selected_class"]) for a in r_items])
+        rec[f"{tag}.subj"] = np.array([int(a["subject_key"]) for a in r_items])
+        rec[f"{tag}.data_sum"] = np.array([float(a["data"].astype(np.float64).sum()) for a in r_items])
+        rec[f"{tag}.label_sum"] = np.array([int(a["label"].astype(np.int64).sum()) for a in r_items])
+        rec[f"{tag}.first_data"], rec[f"{tag}.first_label"] = r_items[0]["data"], r_items[0]["label"]
+        print(f"sampler[{tag}]: {draws} draws bit-identical reference == oracle; classes {sorted(set(rec[f'{tag}.cls'].tolist()))}")
+    np.savez_compressed(os.path.join(out, "sampler.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
@@ -490,6 +541,8 @@ def main():
         caller_cases(a.out)
     if want("predict"):
         predict_cases(a.out)
+    if want("sampler"):
+        sampler_cases(a.out)
     R, U = (rmodel.ResidualUNet3D, O.ResidualUNet3D), (rmodel.UNet3D, O.UNet3D)
     seg_w4 = [0.05, 1.0, 1.0, 1.0]
     nets = [

@@ -72,9 +72,48 @@ __global__ __launch_bounds__(256) void predict_assemble_kernel(const float* __re
   result[(size_t)nh * vox + dst] = (uint8_t)best;
 }
 
+// ---- training-patch crop: MedDataset.__getitem__'s `vol[:, i0:i1, j0:j1, k0:k1].astype(..)`
+//      (dataset.py:313-331) from a device-resident volume straight into a slot / channel range of the batch tensors
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void crop_patches_kernel(const TS* __restrict__ src, const int* __restrict__ pos,
+                                                           const int* __restrict__ slot, TD* __restrict__ out, int c, int d,
+                                                           int h, int w, int c_total, int c_off, int pd, int ph, int pw) {
+  const size_t per = (size_t)c * pd * ph * pw;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per) return;
+  const int b = blockIdx.y;
+  const int x = (int)(i % pw);
+  size_t r = i / pw;
+  const int y = (int)(r % ph);
+  r /= ph;
+  const int z = (int)(r % pd);
+  const int cc = (int)(r / pd);
+  const TS v = src[(((size_t)cc * d + pos[b * 3] + z) * h + pos[b * 3 + 1] + y) * w + pos[b * 3 + 2] + x];
+  out[(((size_t)slot[b] * c_total + c_off + cc) * pd + z) * ph * pw + (size_t)y * pw + x] = (TD)v;
+}
+
 }  // namespace mednet
 
 using namespace mednet;
+
+extern "C" int mednet_crop_patches(const void* src, int src_dtype, const int* pos, const int* slot, int count, void* out,
+                                   int dst_dtype, int c, int d, int h, int w, int c_total, int c_off, int pd, int ph, int pw,
+                                   mednet_stream stream) {
+  MEDNET_REQUIRE(count > 0 && c > 0 && pd > 0 && ph > 0 && pw > 0 && pd <= d && ph <= h && pw <= w && c_off >= 0 &&
+                     c_off + c <= c_total,
+                 MEDNET_E_SHAPE, "crop_patches: bad shape (patch %dx%dx%d in %dx%dx%d, channels %d+%d of %d)", pd, ph, pw, d, h, w,
+                 c_off, c, c_total);
+  const size_t per = (size_t)c * pd * ph * pw;
+  const dim3 grid((unsigned)((per + 255) / 256), count);
+  hipStream_t s = (hipStream_t)stream;
+#define CP_GO(TS_, TD_) hipLaunchKernelGGL((crop_patches_kernel<TS_, TD_>), grid, dim3(256), 0, s, (const TS_*)src, pos, slot, (TD_*)out, c, d, h, w, c_total, c_off, pd, ph, pw)
+  if (src_dtype == MEDNET_F16 && dst_dtype == MEDNET_F32) CP_GO(_Float16, float);
+  else if (src_dtype == MEDNET_F32 && dst_dtype == MEDNET_F32) CP_GO(float, float);
+  else if (src_dtype == MEDNET_U8 && dst_dtype == MEDNET_U8) CP_GO(uint8_t, uint8_t);
+  else return fail(MEDNET_E_DTYPE, "crop_patches: %d -> %d (supported: f16->f32, f32->f32, u8->u8)", src_dtype, dst_dtype);
+#undef CP_GO
+  return check_launch("crop_patches");
+}
 
 extern "C" int mednet_grid_gather(const float* volume, const int* pos, float* out, int batch, int c, int d, int h, int w,
                                   int pd, int ph, int pw, int ov0, int ov1, int ov2, int pad_mode, mednet_stream stream) {

@@ -21,6 +21,7 @@ POOL_MAX, POOL_AVG = 0, 1
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
 REG_L2, REG_L1 = 0, 1
 PAD_CONSTANT, PAD_SYMMETRIC = 0, 1
+F16, U8 = 2, 3  # storage types of resident volumes (mednet_crop_patches only)
 NO_IGNORE = -(2 ** 31)
 
 _vp, _i, _sz, _f, _i64 = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_int64
@@ -63,6 +64,7 @@ SIGNATURES = {
     "mednet_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "mednet_grid_gather": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "mednet_predict_assemble": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),
+    "mednet_crop_patches": (_i, [_vp, _i, _vp, _vp, _i, _vp] + [_i] * 10 + [_vp]),
 }
 
 _lib = None
