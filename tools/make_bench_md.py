@@ -77,6 +77,10 @@ def main():
     if os.path.exists(pp):
         out.append("## Inference path (SURVEY 8f row N2; `tools/run_predict.py --cpu`)\n")
         out.append("```json\n" + json.dumps(json.load(open(pp)), indent=1) + "\n```\n")
+    sp = os.path.join(ROOT, "profiles", "r01_sampler_line.json")
+    if os.path.exists(sp):
+        out.append("## Training-patch sampler (SURVEY 8f row N1; `tools/run_sampler.py`)\n")
+        out.append("```json\n" + json.dumps(json.load(open(sp)), indent=1) + "\n```\n")
     out.append(f"## Kernels of one training step (rocprofv3 trace, {nsteps} steps averaged; step wall time {wall:.2f} ms;"
                " the weight gradients run on a second stream, so the durations add up to more than the wall time)\n")
     out.append("| kernel | grid (threads) | launches/step | mean us | ms/step | HBM MB/launch (PMC) | TB/s | TFLOP/s |\n|---|---|---|---|---|---|---|---|")
