@@ -374,6 +374,25 @@ def seg_training_step(model, loss_fn, batch):
     return loss_fn(model(x), y)
 
 
+def seg_validation_step(model, loss_fn, batch):
+    """segmentation.py:94-110 without the sample logging: {'val_loss', 'val_dice0', ...} (unnormalised network output,
+    DiceLoss / CE as configured, dice_metric = unweighted per-channel Dice of the softmax)."""
+    x = batch["data"].float()
+    y = batch["label"][:, -1, ...].long()
+    with torch.no_grad():
+        out = model(x)
+        res = {"val_loss": loss_fn(out, y)}
+        dm = dice_metric(out, y)
+    for c in range(out.shape[1]):
+        res[f"val_dice{c}"] = dm[c]
+    return res
+
+
+def validation_epoch_end(outputs):
+    """segmentation.py:112-118: plain means over the epoch's step results."""
+    return {k: torch.stack([o[k] for o in outputs]).mean() for k in outputs[0]}
+
+
 def ldmk_training_step(model, loss_class, loss_regression, reg_weights, batch):
     """landmarks.py:66-83."""
     x = batch["data"].float()

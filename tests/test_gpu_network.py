@@ -369,3 +369,22 @@ def test_graph_replay_matches_eager_steps():
             step.flat.release()
     assert res[True][0] == res[False][0], (res[True][0], res[False][0])
     assert torch.equal(res[True][1], res[False][1])
+
+
+def test_validation_step_matches_reference_golden(golden_dir):
+    """Row N3: train.SegmentationValidation (forward + fused DiceLoss + fused dice_metric, device scalars) against the
+    oracle and the reference's validation_epoch_end values (callers.npz), fp32 mode."""
+    from mednet_hip.train import SegmentationValidation
+    rec = np.load(os.path.join(golden_dir, "callers.npz"))
+    ora = O.keyed_init_(O.ResidualUNet3D(1, 2, False, f_maps=[8])).eval()
+    batches = [O.synthetic_batch(2, 1, (32, 32, 32), 2, 0, seed=600 + i) for i in range(2)]
+    want = O.validation_epoch_end([O.seg_validation_step(ora, O.DiceLoss(weight=torch.tensor([0.05, 1.0])), b) for b in batches])
+    with mednet_hip.precision("fp32"):
+        net = O.keyed_init_(HM.ResidualUNet3D(1, 2, False, f_maps=[8])).to(DEV)
+        val = SegmentationValidation(net, loss_weight=[0.05, 1.0])
+        outs = [val.validation_step({k: v.to(DEV) for k, v in b.items()}, i) for i, b in enumerate(batches)]
+        end = val.validation_epoch_end(outs)
+    assert sorted(end["log"].keys()) == ["val_dice0", "val_dice1", "val_loss"]
+    for k, v in want.items():
+        assert abs(float(end["log"][k]) - float(v)) <= 2e-5 * max(1.0, abs(float(v))), k
+        assert abs(float(end["log"][k]) - float(rec["seg.val." + k])) <= 2e-5 * max(1.0, abs(float(v))), k

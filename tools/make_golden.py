@@ -382,6 +382,22 @@ def caller_cases(out):
     assert isinstance(opt, torch.optim.Adam)
     d = opt.defaults
     rec["seg.adam"] = np.array([d["lr"], d["betas"][0], d["betas"][1], d["eps"], d["weight_decay"]])
+    # row N3: validation_step / validation_epoch_end (segmentation.py:94-118); log_interval keeps the plotting branch off
+    net.log_interval = 10 ** 9
+    net.eval()
+    vb = [O.synthetic_batch(2, 1, (32, 32, 32), 2, 0, seed=600 + i) for i in range(2)]
+    with torch.no_grad():
+        vres = [net.validation_step(b, 1 + i) for i, b in enumerate(vb)]
+    vora = [O.seg_validation_step(ora.eval(), O.DiceLoss(weight=torch.tensor([0.05, 1.0])), b) for b in vb]
+    for a, b in zip(vres, vora):
+        assert sorted(a.keys()) == sorted(b.keys()) == ["val_dice0", "val_dice1", "val_loss"]
+        for k in a:
+            assert_same("seg_val." + k, a[k].detach(), b[k].detach())
+    vend, oend = net.validation_epoch_end(vres), O.validation_epoch_end(vora)
+    for k in oend:
+        assert_same("seg_val_end." + k, vend["log"][k], oend[k])
+        rec["seg.val." + k] = oend[k].numpy()
+    net.train()
     hp2 = types.SimpleNamespace(in_channels=1, out_channels=5, fmaps=[8], learning_rate=1e-3, num_workers=0,
                                 batch_size=2, loss_class="DICE", loss_class_weight=[0.05, 1.0],
                                 loss_regression="L2", loss_regression_weight=[0.015, 0.015, 0.015])

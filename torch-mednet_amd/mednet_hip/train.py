@@ -221,6 +221,39 @@ class SegmentationStep(_GraphedStep):
         return loss
 
 
+class SegmentationValidation:
+    """SegmentationNet.validation_step / validation_epoch_end (segmentation.py:94-118) on the MI355X
+    path: forward kernels only, the configured loss and `dice_metric` each as ONE fused pass over the logits, results as
+    device scalars (no host synchronisation per batch; the reference's sample plotting is not part of it)."""
+
+    def __init__(self, model, loss_weight=None, loss="DICE"):
+        self.model = model
+        dev = next(model.parameters()).device
+        w = None if loss_weight is None else torch.tensor(loss_weight, dtype=torch.float32, device=dev)
+        self.loss = (HL.DiceLoss(weight=w) if loss == "DICE" else HL.CrossEntropyLoss(weight=w)).to(dev)
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_nb=0):
+        inputs = batch["data"].float()
+        labels = batch["label"][:, -1, ...].long()
+        was_training = self.model.training
+        self.model.eval()
+        try:
+            outputs = self.model(inputs)
+        finally:
+            self.model.train(was_training)
+        results = {"val_loss": self.loss(outputs, labels)}
+        per_channel_dice = HL.dice_metric(outputs, labels)
+        for c in range(outputs.shape[1]):
+            results[f"val_dice{c}"] = per_channel_dice[c]
+        return results
+
+    @staticmethod
+    def validation_epoch_end(outputs):
+        logs = {k: torch.stack([o[k] for o in outputs]).mean() for k in outputs[0]}
+        return {"val_loss": logs["val_loss"], "log": logs, "progress_bar": logs}
+
+
 class LandmarkStep(_GraphedStep):
     """LandmarkNet.training_step (landmarks.py:66-83, loss :125-134) with the per-channel regression loop fused."""
 
