@@ -1147,7 +1147,8 @@ static void wgrad2_plan(int n, int d, int h, int w, int ka, int kb, Wg2Args& a) 
   a.nab = (ka + 31) / 32;  // a 16-channel operand is zero-padded to a 32-wide block by the buffer loads
   a.nbb = (kb + 31) / 32;
   const int pairs = a.nab * a.nbb;
-  int splits = (256 + pairs - 1) / pairs;  // one workgroup per CU
+  const int target = tuning_option("wgrad_wgs", 256);  // workgroups per launch (256 = one per CU)
+  int splits = (target + pairs - 1) / pairs;
   if (splits > a.ntiles) splits = a.ntiles;
   if (splits < 1) splits = 1;
   a.splits = splits;
