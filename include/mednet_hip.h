@@ -57,8 +57,8 @@ int mednet_conv3d_pack(const float* w, void* packed, int cin, int cout, int ksiz
  * call cannot fuse them); mednet_gn_finalize turns them into statistics without another pass over y.  The sums are
  * kept per channel PAIR (entry 2j = channels 2j and 2j+1 together, entry 2j+1 = 0): exact for GroupNorm whenever the
  * channels per group are even -- ask for them only then. */
-int mednet_conv3d_fused_stats_chunks(int d, int h, int w, int cin, int cout, int ksize, int x_dtype, int y_dtype,
-                                     int algo);
+int mednet_conv3d_fused_stats_chunks(int n, int d, int h, int w, int cin, int cout, int ksize, int x_dtype,
+                                     int y_dtype, int algo);
 int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void* y, int n, int d, int h, int w,
                       int cin, int cout, int ksize, int x_dtype, int x_layout, int y_dtype, int y_layout,
                       int dgrad, int algo, float* gn_partial, mednet_stream stream);

@@ -39,7 +39,7 @@ def conv_case(cin, cout, s):
     def fwd():
         L.check(lib.mednet_conv3d_fwd(x.data_ptr(), pk.data_ptr(), None, y.data_ptr(), N, s, s, s, cin, cout, 3, 1, 0, 1, 0, 0, 2, None, st), "fwd")
 
-    chunks = lib.mednet_conv3d_fused_stats_chunks(s, s, s, cin, cout, 3, 1, 1, 2)
+    chunks = lib.mednet_conv3d_fused_stats_chunks(N, s, s, s, cin, cout, 3, 1, 1, 2)
     part = torch.empty(N, max(chunks, 1), cout, 2, device=dev)
 
     def fwd_stats():

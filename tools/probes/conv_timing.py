@@ -16,7 +16,7 @@ x = torch.randn(N, cin, s, s, s, device=dev).bfloat16().contiguous(memory_format
 w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
 pk = ops.pack_conv_weight(w, 3, False)
 y = torch.empty(N, cout, s, s, s, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
-chunks = lib.mednet_conv3d_fused_stats_chunks(s, s, s, cin, cout, 3, 1, 1, 2)
+chunks = lib.mednet_conv3d_fused_stats_chunks(N, s, s, s, cin, cout, 3, 1, 1, 2)
 part = torch.empty(N, chunks, cout, 2, device=dev)
 nwg = ((N * chunks + 7) // 8) * 8 * ((cout + 31) // 32)  # (>= the grid of either launch form)
 dbg = torch.zeros(nwg, 16, dtype=torch.int64, device=dev)

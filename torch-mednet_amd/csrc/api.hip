@@ -78,10 +78,10 @@ extern "C" int mednet_conv3d_pack(const float* w, void* packed, int cin, int cou
   const PackLayout L = pack_layout(cin, cout, ksize);
   char* base = (char*)packed;
   hipStream_t s = (hipStream_t)stream;
-  int rc = launch_pack_f32(w, (float*)(base + L.f32_fwd), (float*)(base + L.f32_bwd), cin, cout, L.taps, transposed_src, s);
-  if (rc) return rc;
-  if (L.mfma_bytes) rc = launch_pack_mfma(w, base + L.mfma_fwd, base + L.mfma_bwd, cin, cout, L.taps, transposed_src, s);
-  return rc;
+  if (L.mfma_bytes)  // one launch writes the two bf16 fragment images and the two fp32 images
+    return launch_pack_mfma(w, base + L.mfma_fwd, base + L.mfma_bwd, (float*)(base + L.f32_fwd), (float*)(base + L.f32_bwd),
+                            cin, cout, L.taps, transposed_src, s);
+  return launch_pack_f32(w, (float*)(base + L.f32_fwd), (float*)(base + L.f32_bwd), cin, cout, L.taps, transposed_src, s);
 }
 
 static int conv_common_checks(const char* who, int n, int d, int h, int w, int cin, int cout, int ksize, int dt1, int dt2) {
@@ -92,11 +92,11 @@ static int conv_common_checks(const char* who, int n, int d, int h, int w, int c
   return MEDNET_OK;
 }
 
-extern "C" int mednet_conv3d_fused_stats_chunks(int d, int h, int w, int cin, int cout, int ksize, int x_dtype,
+extern "C" int mednet_conv3d_fused_stats_chunks(int n, int d, int h, int w, int cin, int cout, int ksize, int x_dtype,
                                                 int y_dtype, int algo) {
   if (algo == MEDNET_ALGO_DIRECT || !tuning_option("conv_fuse_stats", 1)) return 0;
   if (!conv_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, MEDNET_NDHWC, false)) return 0;
-  return conv_mfma_stats_chunks(d, h, w);
+  return conv_mfma_stats_chunks(n, d, h, w, cout);
 }
 
 extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void* y, int n, int d, int h,

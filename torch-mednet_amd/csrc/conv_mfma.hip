@@ -64,7 +64,10 @@ struct FwdArgs {
   unsigned rcp_tiles_x, rcp_tiles_y, rcp_tiles_z, rcp_ncb;  // ceil(2^32 / d): x / d == umulhi(x, rcp) for x * d < 2^32
   unsigned bytes_x;  // size of ONE SAMPLE of x for the buffer resource (< 4 GB)
   unsigned bytes_y;  // same for y
-  float* gn_partial;  // nullable: [n][4 * bricks per sample][cout][2] = per-wave {sum y, sum y^2} of the STORED (rounded) outputs
+  float* gn_partial;  // nullable: [n][stats_rows][cout][2] = {sum y, sum y^2} of the STORED (rounded) outputs, see stats_accum
+  int stats_accum;    // 1: a wave keeps its sums over all its items of a sample and writes ONE row per sample (row =
+                      //    4 * workgroup-group + wave); 0: one row per wave and brick (row = 4 * brick + wave)
+  int stats_rows;     // rows per sample of gn_partial
 #ifdef MEDNET_CONV_TIMING
   long long* dbg;  // [workgroup][16] s_memtime stamps of wave 0 (tools/probes/conv_timing.py)
 #endif
@@ -199,6 +202,41 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   const size_t ovol = (size_t)a.od * a.oh * a.ow;
   STAMP(1);
 
+  // fused GroupNorm statistics (see the epilogue): per channel PAIR, kept across the items of one sample when stats_accum
+  float gs[4], gq[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) gs[k] = gq[k] = 0.f;
+  int acc_n = 0;  // sample the running sums belong to
+  auto flush_stats = [&](int nn, int row, int cbk) {  // reduce over the wave, lanes 0..3 write {sum, sumsq, 0, 0} per pair
+    float rs[4], rq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      rs[k] = gs[k];
+      rq[k] = gq[k];
+    }
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        rs[k] += __shfl_xor(rs[k], m, 64);
+        rq[k] += __shfl_xor(rq[k], m, 64);
+      }
+    const int pjl = lane & 3;
+    if (lane < 4 && cbk * 32 + pjl * 8 < a.cout) {
+      float* dst = a.gn_partial + (((size_t)nn * a.stats_rows + row) * a.cout + cbk * 32 + pjl * 8) * 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 o = {rs[k], rq[k], 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(dst + k * 4) = o;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gs[k] = gq[k] = 0.f;
+  };
+  // row of this wave in accumulate mode: workgroups that share (id >> 3) / ncb and the XCD form one row group; they differ
+  // in the channel block (which is constant per workgroup when ncb divides 64: the launcher checks that)
+  const int acc_row = ((((int)blockIdx.x >> 3) / a.ncb) * 8 + ((int)blockIdx.x & 7)) * 4 + wv;
+
   plan(ctile);
   prefetch(ccb, 0);
   STAMP(2);
@@ -319,9 +357,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     // instruction, 8 instructions per 8-channel piece instead of 24): entry 2j of the partial row gets the sums of
     // channels 2j and 2j+1, entry 2j+1 is zero.  GroupNorm only ever adds the channels of a group, so this is exact
     // whenever the channels per group are even (the host asks for fused partials only then).
-    float gs[4], gq[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) gs[k] = gq[k] = 0.f;
+    if (a.gn_partial && a.stats_accum) {
+      while (acc_n < n) {  // the sample changed: write the finished sample's row (zeros for samples this wave skipped)
+        flush_stats(acc_n, acc_row, cb);
+        ++acc_n;
+      }
+    }
     const int pj = etid & 3;
     // Row stores: lane = (voxel et of 64, 16-byte piece pj of 4).  The 64 voxels of round `it` are 4 x-rows of 16, so
     // the per-round part of the address is a SCALAR (soffset of a buffer store whose resource is this sample) and the
@@ -356,28 +397,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       }
     }
     STAMP(13);
-    if (a.gn_partial) {
-      // GroupNorm statistics fused into the producer (components.py:57 follows every conv of the 'c g .' orders)
-#pragma unroll
-      for (int m = 4; m < 64; m <<= 1)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          gs[k] += __shfl_xor(gs[k], m, 64);
-          gq[k] += __shfl_xor(gq[k], m, 64);
-        }
-      // one partial row per WAVE (4 per brick): no cross-wave reduction, so no barrier at the end of an item; lanes 0..3
-      // hold the sums of their 8-channel piece and write {sum, sumsq, 0, 0} per channel pair
-      if (e_lane < 4 && cb * 32 + pj * 8 < a.cout) {
-        float* dst = a.gn_partial + ((((size_t)n * tiles_per_sample + tis) * 4 + e_wv) * a.cout + cb * 32 + pj * 8) * 2;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const f32x4 o = {gs[k], gq[k], 0.f, 0.f};
-          *reinterpret_cast<f32x4*>(dst + k * 4) = o;
+    // GroupNorm statistics fused into the producer (components.py:57 follows every conv of the 'c g .' orders): one row
+    // per wave and brick, or -- accumulate mode -- nothing here: the sums stay in registers until the sample changes
+    if (a.gn_partial && !a.stats_accum) flush_stats(n, tis * 4 + e_wv, cb);
+    STAMP(14);
+    if (!has_next) {
+      if (a.gn_partial && a.stats_accum) {
+        while (acc_n < a.n) {  // the last sample of this wave, then zero rows for the samples after it
+          flush_stats(acc_n, acc_row, cb);
+          ++acc_n;
         }
       }
+      break;
     }
-    STAMP(14);
-    if (!has_next) break;
     cur_bid = nbid;
     ctile = ntile;
     ccb = ncb2;
@@ -707,12 +739,28 @@ int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d,
 // mode 2: convT fwd     Weff[m][k][t] = Wt[k][m][t]           (Wt: Cin,Cout,27) M=Cout K=Cin
 // mode 3: convT dgrad   Weff[m][k][t] = Wt[m][k][t]                             M=Cin  K=Cout
 __global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict__ w, bf16* __restrict__ out0,
-                                                        bf16* __restrict__ out1, int M0, int K0, int mode0, int mode1) {
+                                                        bf16* __restrict__ out1, int M0, int K0, int mode0, int mode1,
+                                                        float* __restrict__ Pf, float* __restrict__ Pb, int transposed_src) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.y == 2) {  // the fp32 tap-major images of the direct kernels ride along in the same launch
+    const int cin = K0, cout = M0, T = 27;
+    if (e >= (size_t)cin * cout * T) return;
+    const int t = (int)(e % T);
+    if (!transposed_src) {  // w[co][ci][t]
+      const int ci = (int)((e / T) % cin), co = (int)(e / ((size_t)T * cin));
+      Pf[((size_t)t * cin + ci) * cout + co] = w[e];
+      Pb[((size_t)(T - 1 - t) * cout + co) * cin + ci] = w[e];
+    } else {  // w[ci][co][t]
+      const int co = (int)((e / T) % cout), ci = (int)(e / ((size_t)T * cout));
+      Pf[((size_t)t * cin + ci) * cout + co] = w[e];
+      Pb[((size_t)t * cout + co) * cin + ci] = w[e];
+    }
+    return;
+  }
   // blockIdx.y = 0: forward image (M0 x K0), 1: data-gradient image (K0 x M0): one launch for both
   const int M = blockIdx.y ? K0 : M0, K = blockIdx.y ? M0 : K0, mode = blockIdx.y ? mode1 : mode0;
   bf16* out = blockIdx.y ? out1 : out0;
   const size_t total = (size_t)((M + 31) / 32 * 32) * K * 27;  // rows beyond M (a 16-channel side) are zero padding
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   size_t q = e;
   const int j = (int)(q % 8);
@@ -753,15 +801,15 @@ PackLayout pack_layout(int cin, int cout, int ksize) {
   return L;
 }
 
-int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, int cin, int cout, int T, int transposed_src,
-                     hipStream_t s) {
+int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, float* Pf, float* Pb, int cin, int cout, int T,
+                     int transposed_src, hipStream_t s) {
   if (T != 27) return MEDNET_OK;
   const int cmax = cin > cout ? cin : cout, cmin = cin > cout ? cout : cin;
   const size_t total = (size_t)((cmax + 31) / 32 * 32) * ((cmin + 31) / 32 * 32) * 27;  // covers both padded images
-  const dim3 grid((unsigned)((total + 255) / 256), 2);
+  const dim3 grid((unsigned)((total + 255) / 256), 3);  // y = 0/1: the two bf16 fragment images, 2: the fp32 images
   // forward image: M = cout, K = cin; backward (data-gradient) image: M = cin, K = cout
   hipLaunchKernelGGL(pack_mfma_kernel, grid, dim3(256), 0, s, w, (bf16*)sec_fwd, (bf16*)sec_bwd, cout, cin,
-                     transposed_src ? 2 : 0, transposed_src ? 3 : 1);
+                     transposed_src ? 2 : 0, transposed_src ? 3 : 1, Pf, Pb, transposed_src);
   return check_launch("pack_mfma");
 }
 
@@ -773,6 +821,20 @@ bool conv_mfma_fits(int n, int d, int h, int w, int c) {
 bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int x_layout, int y_layout, bool bias) {
   return ksize == 3 && cin % 16 == 0 && cout % 16 == 0 && x_dtype == MEDNET_BF16 && y_dtype == MEDNET_BF16 &&
          x_layout == MEDNET_NDHWC && y_layout == MEDNET_NDHWC && !bias;
+}
+
+// Rows per sample of the fused GroupNorm partials and whether the persistent kernel accumulates over a workgroup's items.
+// Accumulate mode needs: the persistent launch form (more items than the 512 resident workgroups, with margin so that every
+// workgroup starts on a valid item), brick count a multiple of 8 (no padding items), and ncb | 64 (a workgroup's channel
+// block never changes).
+static void conv_stats_plan(int n, int d, int h, int w, int cout, int& rows, int& accum) {
+  using G = FwdTile<1>;
+  const int tps = ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
+  const int ncb = (cout + 31) / 32, ntiles = n * tps;
+  const int nitems = ((ntiles + 7) / 8) * 8 * ncb;
+  accum = tuning_option("conv_persist", 1) && tuning_option("conv_stats_accum", 1) && nitems >= 1024 && ntiles % 8 == 0 &&
+          64 % ncb == 0;
+  rows = accum ? (512 / ncb) * 4 : 4 * tps;
 }
 
 template <int STRIDE>
@@ -808,6 +870,9 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   // persistent form: 2 workgroups per CU stream through the items (option conv_persist=0: one workgroup per item)
   unsigned grid = (unsigned)a.nitems;
   if (tuning_option("conv_persist", 1) && grid > 512u) grid = 512u;
+  a.stats_accum = 0;
+  a.stats_rows = 4 * a.tiles_z * a.tiles_y * a.tiles_x;
+  if (gn_partial && STRIDE == 1) conv_stats_plan(n, od, oh, ow, cout, a.stats_rows, a.stats_accum);
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[STRIDE]) {
     if (hipFuncSetAttribute((const void*)conv_mfma_kernel<STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -824,9 +889,10 @@ int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, 
   (void)y_dtype;
   return launch_fwd<1>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, gn_partial, s);
 }
-int conv_mfma_stats_chunks(int d, int h, int w) {
-  using G = FwdTile<1>;
-  return 4 * ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);  // one row per wave
+int conv_mfma_stats_chunks(int n, int d, int h, int w, int cout) {
+  int rows, accum;
+  conv_stats_plan(n, d, h, w, cout, rows, accum);
+  return rows;
 }
 
 int launch_convt_dgrad_mfma(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin,

@@ -34,7 +34,7 @@ SIGNATURES = {
     "mednet_set_option": (_i, [C.c_char_p, _i]),
     "mednet_conv3d_pack_bytes": (_sz, [_i, _i, _i]),
     "mednet_conv3d_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "mednet_conv3d_fused_stats_chunks": (_i, [_i] * 9),
+    "mednet_conv3d_fused_stats_chunks": (_i, [_i] * 10),
     "mednet_conv3d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp]),
     "mednet_gn_finalize": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _f, _vp, _sz, _vp]),
     "mednet_conv3d_wgrad_ws_bytes": (_sz, [_i] * 7),

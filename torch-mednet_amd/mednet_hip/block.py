@@ -28,7 +28,7 @@ def _conv_fwd(x, packed, cout, want_stats):
     y = ops.empty_cl(n, cout, d, h, w, config.act_dtype(), x.device)
     partial = None
     if want_stats:
-        chunks = lib.mednet_conv3d_fused_stats_chunks(d, h, w, cin, cout, 3, L.dt(x), L.dt(y), config.conv_algo())
+        chunks = lib.mednet_conv3d_fused_stats_chunks(n, d, h, w, cin, cout, 3, L.dt(x), L.dt(y), config.conv_algo())
         if chunks > 0:
             partial = torch.empty((n, chunks, cout, 2), dtype=torch.float32, device=x.device)
     with ops.profiled_conv(3, cin, cout, n, d, h, w):

@@ -153,7 +153,7 @@ class Conv3dFn(Function):
         # GroupNorm partial sums from the conv epilogue (when the MFMA kernel takes this call): saves a pass over y
         partial = None
         if want_stats and bias is None and not out_planar:
-            chunks = L.lib().mednet_conv3d_fused_stats_chunks(d, h, w, cin, cout, ksize, L.dt(xin), L.dt(y), config.conv_algo())
+            chunks = L.lib().mednet_conv3d_fused_stats_chunks(n, d, h, w, cin, cout, ksize, L.dt(xin), L.dt(y), config.conv_algo())
             if chunks > 0:
                 partial = torch.empty((n, chunks, cout, 2), dtype=torch.float32, device=x.device)
         with profiled_conv(ksize, cin, cout, n, d, h, w):
