@@ -95,6 +95,7 @@ static int conv_common_checks(const char* who, int n, int d, int h, int w, int c
 extern "C" int mednet_conv3d_fused_stats_chunks(int n, int d, int h, int w, int cin, int cout, int ksize, int x_dtype,
                                                 int y_dtype, int algo) {
   if (algo == MEDNET_ALGO_DIRECT || !tuning_option("conv_fuse_stats", 1)) return 0;
+  if (conv_c1_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, false)) return conv_c1_stats_chunks(d, h, w);
   if (!conv_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, MEDNET_NDHWC, false)) return 0;
   return conv_mfma_stats_chunks(n, d, h, w, cout);
 }
@@ -116,12 +117,12 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
     return launch_conv_mfma(x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), y, n, d, h, w, cin, cout, x_dtype, y_dtype,
                             gn_partial, s);
-  MEDNET_REQUIRE(gn_partial == nullptr, MEDNET_E_UNSUPPORTED,
-                 "conv3d_fwd: fused GroupNorm partials are only produced by the MFMA path (ask mednet_conv3d_fused_stats_chunks)");
   // first layer (one input channel): contraction over the 27 taps on the matrix cores
   if (!dgrad && algo != MEDNET_ALGO_DIRECT && x_layout == MEDNET_NDHWC &&
       conv_c1_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, y_layout, bias != nullptr))
-    return launch_conv_c1_mfma(x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, s);
+    return launch_conv_c1_mfma(x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, gn_partial, s);
+  MEDNET_REQUIRE(gn_partial == nullptr, MEDNET_E_UNSUPPORTED,
+                 "conv3d_fwd: fused GroupNorm partials are only produced by the MFMA paths (ask mednet_conv3d_fused_stats_chunks)");
   // 1x1x1 head forward (channels-last features -> planar fp32 logits): the packed backward image Pb[t=0][co][ci] = W[m][k]
   if (!dgrad && algo != MEDNET_ALGO_DIRECT && ksize == 1 && x_layout == MEDNET_NDHWC && y_layout == MEDNET_NCDHW &&
       y_dtype == MEDNET_F32 && head_vox_supported(cin))

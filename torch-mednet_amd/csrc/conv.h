@@ -74,7 +74,9 @@ size_t wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ks
 int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, int dtype,
                       void* ws, size_t ws_bytes, hipStream_t s);
 bool conv_c1_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int y_layout, bool bias);
-int launch_conv_c1_mfma(const void* x, const float* w_pt, void* y, int n, int d, int h, int w, int cout, hipStream_t s);
+int conv_c1_stats_chunks(int d, int h, int w);
+int launch_conv_c1_mfma(const void* x, const float* w_pt, void* y, int n, int d, int h, int w, int cout, float* gn_partial,
+                        hipStream_t s);
 int launch_convt_fwd_mfma(const void* x, const void* sec, const float* bias, const void* skip, void* y, int n, int d,
                           int h, int w, int cin, int cout, hipStream_t s);
 int launch_convt_dgrad_mfma(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin,

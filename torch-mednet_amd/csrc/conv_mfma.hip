@@ -636,6 +636,7 @@ struct C1Args {
   const float* x;    // N x D x H x W (one channel)
   const float* w;    // packed forward image Pf[tap][co] (fp32)
   bf16* y;           // NDHWC
+  float* gn_partial; // nullable: [n][4 * bricks per sample][cout][2] per-wave {sum y, sum y^2} of the stored values
   int n, d, h, w_, cout;
   int tiles_z, tiles_y, tiles_x, ntiles, ncb;
 };
@@ -679,6 +680,9 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
   }
   __syncthreads();
   const size_t vol = (size_t)a.d * a.h * a.w_;
+  float ssum[16], ssq[16];  // fused GroupNorm statistics of this lane's 16 channels over the wave's 4 N-tiles
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ssum[i] = ssq[i] = 0.f;
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const int g = wv * NTW + t;
@@ -706,9 +710,34 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
       for (int q = 0; q < 4; ++q) {
         bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[q * 4 + j];
+        for (int j = 0; j < 4; ++j) {
+          o[j] = (bf16)acc[q * 4 + j];
+          const float f = (float)o[j];  // statistics of what is stored
+          ssum[q * 4 + j] += f;
+          ssq[q * 4 + j] = fmaf(f, f, ssq[q * 4 + j]);
+        }
         *reinterpret_cast<bf16x4*>(yp + 8 * q) = o;
       }
+    }
+  }
+  if (a.gn_partial) {  // one row per wave: sum over the 32 voxel lanes of each k-half, lanes r == 0 write their 16 channels
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        ssum[i] += __shfl_xor(ssum[i], m, 64);
+        ssq[i] += __shfl_xor(ssq[i], m, 64);
+      }
+    if (r == 0) {
+      const int tps = a.tiles_x * a.tiles_y * a.tiles_z;
+      float* dst = a.gn_partial + ((((size_t)n * tps + tile % tps) * 4 + wv) * a.cout + cb * 32) * 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dst[(8 * q + 4 * h + j) * 2] = ssum[q * 4 + j];
+          dst[(8 * q + 4 * h + j) * 2 + 1] = ssq[q * 4 + j];
+        }
     }
   }
 }
@@ -717,8 +746,11 @@ bool conv_c1_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dty
   return cin == 1 && ksize == 3 && cout % 32 == 0 && x_dtype == MEDNET_F32 && y_dtype == MEDNET_BF16 &&
          y_layout == MEDNET_NDHWC && !bias;
 }
-int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d, int h, int w, int cout, hipStream_t s) {
+int conv_c1_stats_chunks(int d, int h, int w) { return 4 * ((d + 3) / 4) * ((h + 7) / 8) * ((w + 15) / 16); }
+int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d, int h, int w, int cout, float* gn_partial,
+                        hipStream_t s) {
   C1Args a;
+  a.gn_partial = gn_partial;
   a.x = (const float*)x;
   a.w = w_pf;
   a.y = (bf16*)y;
