@@ -162,6 +162,33 @@ def test_cfg2_128_against_reference_golden(golden_dir):
         assert np.linalg.norm(g[: head.size] - head) <= 2e-3 * max(np.linalg.norm(head), 1e-3 * norm / np.sqrt(g.size) * 8), name
 
 
+def test_cfg4_128_landmark_against_reference_golden(golden_dir):
+    """BASELINE config 4 (landmark path: 16 heat maps + 2 classes, landmarks.py:66-83,125-134) on a full 128^3 patch, fp32
+    storage, against the reference's golden vectors: strided logits, the three losses, norm / projection of every gradient."""
+    from mednet_hip.train import LandmarkStep
+    rec = np.load(os.path.join(golden_dir, "res_cfg4_128.npz"))
+    ctor = dict(in_channels=1, out_channels=18, final_sigmoid=False, f_maps=[32, 64, 128, 256])
+    batch = O.synthetic_batch(1, 1, (128, 128, 128), 2, 16, seed=int(rec["meta.seed"]))
+    with mednet_hip.precision("fp32"):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+        step = LandmarkStep(net, [0.05, 1.0], [0.015] * 16, "L2")
+        lg = net(batch["data"].float().to(DEV))
+        tot, cl, rg = step._fwd_bwd({k: v.to(DEV) for k, v in batch.items()})
+        torch.cuda.synchronize()
+    s = int(rec["meta.stride"])
+    assert_close(lg[..., ::s, ::s, ::s], torch.from_numpy(rec["logits.strided"]), 1e-3, "strided logits")
+    for got, key in ((tot, "loss"), (cl, "class_loss"), (rg, "regression_loss")):
+        assert abs(float(got) - float(rec[key])) <= 1e-4 * max(1.0, abs(float(rec[key]))), key
+    step.flat.grads_as_attr()
+    for name, p in net.named_parameters():
+        g = p.grad.detach().double().cpu().numpy().reshape(-1)
+        norm = float(rec[f"grad.{name}.norm"])
+        assert abs(np.sqrt((g * g).sum()) - norm) <= 1e-3 * norm, name
+        pv = np.random.Generator(np.random.PCG64(zlib.crc32(("proj:" + name).encode()))).standard_normal(g.size)
+        assert abs(g @ pv - float(rec[f"grad.{name}.proj"])) <= 4e-3 * norm, name
+    step.flat.release()
+
+
 def test_training_steps_track_oracle(golden_dir):
     """segmentation.py:58-65 + :119-120: three Adam steps on cfg1; parameters must track the oracle's."""
     ctor = dict(in_channels=1, out_channels=2, final_sigmoid=False, f_maps=[8])

@@ -587,6 +587,8 @@ def main():
          (32, 32, 32), 1, 4, 0, "dice", seg_w4, 1 << 18, None, False, False),
         ("res_cfg2_128", R, dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64, 128, 256]),
          (128, 128, 128), 1, 4, 0, "dice", seg_w4, 0, 16, False, True),
+        ("res_cfg4_128", R, dict(in_channels=1, out_channels=18, final_sigmoid=False, f_maps=[32, 64, 128, 256]),
+         (128, 128, 128), 1, 2, 16, "ldmk", [0.05, 1.0], 0, 16, False, True),
         ("res_cfg5_small", R, dict(in_channels=1, out_channels=4, final_sigmoid=False,
                                    f_maps=[64, 128, 256, 512, 1024]), (32, 32, 16), 1, 4, 0, "dice", seg_w4, 0, 8,
          False, True),
