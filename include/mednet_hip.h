@@ -62,6 +62,13 @@ int mednet_conv3d_fused_stats_chunks(int n, int d, int h, int w, int cin, int co
 int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void* y, int n, int d, int h, int w,
                       int cin, int cout, int ksize, int x_dtype, int x_layout, int y_dtype, int y_layout,
                       int dgrad, int algo, float* gn_partial, mednet_stream stream);
+/* conv 3x3x3 without bias + activation (MEDNET_ACT_*) in the epilogue, bf16 NDHWC in and out, matrix-core path only:
+ * the conv -> ReLU / LeakyReLU / ELU step of the 'gcr'-style orders (components.py:12-67; UNet3D's default).  gn_partial as
+ * in mednet_conv3d_fwd; the statistics are those of the ACTIVATED output (the next GroupNorm's input).  Ask
+ * mednet_conv3d_act_supported first; unsupported shapes return MEDNET_E_UNSUPPORTED (use conv3d_fwd + act_fwd). */
+int mednet_conv3d_act_supported(int n, int d, int h, int w, int cin, int cout, int algo);
+int mednet_conv3d_act_fwd(const void* x, const void* packed, void* y, int n, int d, int h, int w, int cin, int cout,
+                          int act, int algo, float* gn_partial, mednet_stream stream);
 size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
 /* dw[co,ci,tap] = sum_{n,v} dy[n,v,co] * x[n,v+tap,ci]; dbias[co] = sum dy (nullable). */
 int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,

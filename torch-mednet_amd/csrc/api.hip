@@ -182,6 +182,24 @@ extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, flo
   return launch_wgrad_direct(dy, x, dw, g, dy_dtype, x_dtype, ws, ws_bytes, s);
 }
 
+// conv 3x3x3 (no bias) + activation in the epilogue: the 'gcr' / 'gcl' / 'gce' orders of components.py:12-67 (UNet3D)
+extern "C" int mednet_conv3d_act_supported(int n, int d, int h, int w, int cin, int cout, int algo) {
+  return algo != MEDNET_ALGO_DIRECT &&
+         conv_mfma_supported(cin, cout, 3, MEDNET_BF16, MEDNET_BF16, MEDNET_NDHWC, MEDNET_NDHWC, false) &&
+         conv_mfma_fits(n, d, h, w, cin) && conv_mfma_fits(n, d, h, w, cout);
+}
+extern "C" int mednet_conv3d_act_fwd(const void* x, const void* packed, void* y, int n, int d, int h, int w, int cin,
+                                     int cout, int act, int algo, float* gn_partial, mednet_stream stream) {
+  int rc = conv_common_checks("conv3d_act_fwd", n, d, h, w, cin, cout, 3, MEDNET_BF16, MEDNET_BF16);
+  if (rc) return rc;
+  MEDNET_REQUIRE(act >= MEDNET_ACT_NONE && act <= MEDNET_ACT_ELU, MEDNET_E_UNSUPPORTED, "conv3d_act_fwd: activation %d", act);
+  if (!mednet_conv3d_act_supported(n, d, h, w, cin, cout, algo))
+    return fail(MEDNET_E_UNSUPPORTED, "conv3d_act_fwd: only the bf16 matrix-core path fuses the activation (cin=%d cout=%d)", cin, cout);
+  const PackLayout L = pack_layout(cin, cout, 3);
+  return launch_conv_mfma(x, (const char*)packed + L.mfma_fwd, y, n, d, h, w, cin, cout, MEDNET_BF16, MEDNET_BF16, gn_partial,
+                          (hipStream_t)stream, act);
+}
+
 // ---- ConvTranspose3d(k3,s2,p1,op1) ------------------------------------------------------------------------------------
 extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float* bias, const void* skip, void* y, int n,
                                   int d, int h, int w, int cin, int cout, int x_dtype, int y_dtype, int algo,

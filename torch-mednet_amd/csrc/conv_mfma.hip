@@ -64,6 +64,8 @@ struct FwdArgs {
   unsigned rcp_tiles_x, rcp_tiles_y, rcp_tiles_z, rcp_ncb;  // ceil(2^32 / d): x / d == umulhi(x, rcp) for x * d < 2^32
   unsigned bytes_x;  // size of ONE SAMPLE of x for the buffer resource (< 4 GB)
   unsigned bytes_y;  // same for y
+  int act;            // MEDNET_ACT_*: applied to the fp32 accumulators before the bf16 store (conv -> ReLU/LeakyReLU/ELU of the
+                      // 'gcr' orders, components.py:36-40); the fused statistics are then those of the ACTIVATED output
   float* gn_partial;  // nullable: [n][stats_rows][cout][2] = {sum y, sum y^2} of the STORED (rounded) outputs, see stats_accum
   int stats_accum;    // 1: a wave keeps its sums over all its items of a sample and writes ONE row per sample (row =
                       //    4 * workgroup-group + wave); 0: one row per wave and brick (row = 4 * brick + wave)
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       for (int q = 0; q < 4; ++q) {
         bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[t][q * 4 + j];  // co = 8q + 4h + j
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)act_apply(acc[t][q * 4 + j], a.act);  // co = 8q + 4h + j
         *reinterpret_cast<bf16x4*>(out_lds + vl * 32 + ((2 * q + e_h) ^ sw) * 4) = o;
       }
     }
@@ -871,13 +873,14 @@ static void conv_stats_plan(int n, int d, int h, int w, int cout, int& rows, int
 
 template <int STRIDE>
 static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, int oh, int ow, int id, int ih, int iw,
-                      int cin, int cout, float* gn_partial, hipStream_t s) {
+                      int cin, int cout, float* gn_partial, hipStream_t s, int act = MEDNET_ACT_NONE) {
   using G = FwdTile<STRIDE>;
   constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
   constexpr size_t lds = ((size_t)2 * HZ * HY * HX + 27 * 2 * 32) * 16;
   static_assert(lds <= 80 * 1024, "two workgroups must fit one CU");
   FwdArgs a;
   a.gn_partial = gn_partial;
+  a.act = act;
 #ifdef MEDNET_CONV_TIMING
   a.dbg = (long long*)(((unsigned long long)(unsigned)tuning_option("conv_dbg_hi", 0) << 32) | (unsigned)tuning_option("conv_dbg_lo", 0));
 #endif
@@ -916,10 +919,10 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
 }
 
 int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, int d, int h, int w, int cin, int cout,
-                     int x_dtype, int y_dtype, float* gn_partial, hipStream_t s) {
+                     int x_dtype, int y_dtype, float* gn_partial, hipStream_t s, int act) {
   (void)x_dtype;
   (void)y_dtype;
-  return launch_fwd<1>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, gn_partial, s);
+  return launch_fwd<1>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, gn_partial, s, act);
 }
 int conv_mfma_stats_chunks(int n, int d, int h, int w, int cout) {
   int rows, accum;

@@ -210,6 +210,60 @@ def conv3d_with_stats(x, weight, bias, packed, ksize):
     return y, (partial if partial.numel() else None)
 
 
+class ConvActFn(Function):
+    """conv 3x3x3 (no bias) -> ReLU / LeakyReLU / ELU in ONE kernel (the conv's epilogue): the 'gcr'-style orders of
+    components.py:12-67 (UNet3D).  Optionally also the GroupNorm partial sums of the ACTIVATED output, for the GroupNorm
+    that opens the next SingleConv.  Backward: activation' from the saved output, then the conv's two gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, packed, act, want_stats):
+        L.require_gpu(x, "conv3d+act")
+        xin = to_cl(_as_act(x))
+        n, cin, d, h, w = xin.shape
+        cout = weight.shape[0]
+        lib = L.lib()
+        z = empty_cl(n, cout, d, h, w, config.act_dtype(), x.device)
+        partial = None
+        if want_stats:
+            chunks = lib.mednet_conv3d_fused_stats_chunks(n, d, h, w, cin, cout, 3, L.dt(xin), L.dt(z), config.conv_algo())
+            if chunks > 0:
+                partial = torch.empty((n, chunks, cout, 2), dtype=torch.float32, device=x.device)
+        with profiled_conv(3, cin, cout, n, d, h, w):
+            L.check(lib.mednet_conv3d_act_fwd(xin.data_ptr(), packed.data_ptr(), z.data_ptr(), n, d, h, w, cin, cout, act,
+                                              config.conv_algo(), L.ptr(partial), L.stream()), "conv3d_act_fwd")
+        ctx.save_for_backward(xin, packed, z)
+        ctx.act = act
+        ctx.weight = weight
+        if partial is None:
+            partial = torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(partial)
+        return z, partial
+
+    @staticmethod
+    def backward(ctx, dz, _dpartial=None):
+        from . import block  # (block imports ops)
+        xin, packed, z = ctx.saved_tensors
+        dz = to_cl(dz.to(z.dtype))
+        du = torch.empty_like(z, memory_format=CL)
+        L.check(L.lib().mednet_act_bwd(dz.data_ptr(), z.data_ptr(), du.data_ptr(), z.numel(), ctx.act, L.dt(z), L.stream()),
+                "act_bwd")
+        dx, dw = block._conv_bwd(xin, du, packed, ctx.weight, ctx.needs_input_grad[0])
+        return dx, dw, None, None, None
+
+
+def conv3d_act_supported(x, cin, cout):
+    if not (x.is_cuda and config.act_dtype() == torch.bfloat16 and x.dim() == 5):
+        return False
+    n, _, d, h, w = x.shape
+    return bool(L.lib().mednet_conv3d_act_supported(n, d, h, w, cin, cout, config.conv_algo()))
+
+
+def conv3d_act(x, weight, packed, act, want_stats=False):
+    """-> (activated output, GroupNorm partials of it or None)."""
+    z, partial = ConvActFn.apply(x, weight, packed, act, want_stats)
+    return z, (partial if partial.numel() else None)
+
+
 # ------------------------------------------------------------------------------------------------- ConvTranspose3d (+ skip add)
 class ConvT3dFn(Function):
     """nn.ConvTranspose3d(k=3,s=2,p=1,output_padding=1) with the decoder's `x += encoder_features` fused into the

@@ -60,12 +60,16 @@ class SingleConv(nn.Sequential):
         for name, module in create_conv(in_channels, out_channels, kernel_size, order, num_groups, padding=padding):
             self.add_module(name, module)
 
-    def forward(self, x, residual=None, final_act=L.ACT_NONE):
-        """`residual`/`final_act` let ExtResNetBlock fold `out += residual; act(out)` into the last GroupNorm."""
+    def forward(self, x, residual=None, final_act=L.ACT_NONE, partial=None, stats_for=None):
+        """`residual`/`final_act` let ExtResNetBlock fold `out += residual; act(out)` into the last GroupNorm.
+        `partial`: GroupNorm partial sums of the INPUT x (from the kernel that produced it), used when this layer opens with
+        a GroupNorm ('gcr').  `stats_for`: the GroupNorm module that will consume this layer's output (DoubleConv passes
+        the next SingleConv's); when the layer ends in conv -> activation fused into one kernel, that kernel also writes
+        the partial sums for it and forward returns (out, partial)."""
         mods = list(self._modules.values())
         i = 0
         fused_res = False
-        partial = None  # GroupNorm partial sums of the tensor in `x`, when the conv that produced it supplied them
+        out_partial = None
         while i < len(mods):
             m = mods[i]
             if isinstance(m, hnn.GroupNorm):
@@ -83,9 +87,21 @@ class SingleConv(nn.Sequential):
                 partial = None
                 continue
             partial = None
-            if isinstance(m, hnn.Conv3d) and i + 1 < len(mods) and isinstance(mods[i + 1], hnn.GroupNorm) \
-                    and m.bias is None and x.is_cuda and (m.out_channels // mods[i + 1].num_groups) % 2 == 0:
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(m, hnn.Conv3d) and isinstance(nxt, hnn.GroupNorm) \
+                    and m.bias is None and x.is_cuda and (m.out_channels // nxt.num_groups) % 2 == 0:
                 x, partial = m.forward_with_stats(x)
+            elif isinstance(m, hnn.Conv3d) and isinstance(nxt, hnn._Act) and m.bias is None and m.kernel_size[0] == 3 \
+                    and not m.planar_output and ops.conv3d_act_supported(x, m.in_channels, m.out_channels):
+                # conv -> activation in one kernel; if it is the end of the layer, also the next GroupNorm's statistics
+                last = i + 2 == len(mods)
+                want = last and stats_for is not None and stats_for.num_channels == m.out_channels \
+                    and (m.out_channels // stats_for.num_groups) % 2 == 0
+                x, p = ops.conv3d_act(x, m.weight, m._packed(), nxt.code, want)
+                if last:
+                    out_partial = p
+                i += 2
+                continue
             elif isinstance(m, nn.BatchNorm3d):
                 x = m(x.float().contiguous()).to(memory_format=ops.CL)
             else:
@@ -93,6 +109,8 @@ class SingleConv(nn.Sequential):
             i += 1
         if residual is not None and not fused_res:
             x = ops.activation(ops.AddFn.apply(x, residual), final_act)
+        if stats_for is not None:
+            return x, out_partial
         return x
 
 
@@ -106,6 +124,16 @@ class DoubleConv(nn.Sequential):
             c1_in, c1_out, c2_in, c2_out = in_channels, out_channels, out_channels, out_channels
         self.add_module("SingleConv1", SingleConv(c1_in, c1_out, kernel_size, order, num_groups))
         self.add_module("SingleConv2", SingleConv(c2_in, c2_out, kernel_size, order, num_groups))
+
+    def forward(self, x):
+        """SingleConv1 -> SingleConv2 (components.py:93-133).  When SingleConv2 opens with a GroupNorm ('gcr'), the kernel
+        that ends SingleConv1 (conv + activation) also produces that GroupNorm's partial sums."""
+        sc1, sc2 = self.SingleConv1, self.SingleConv2
+        first2 = next(iter(sc2._modules.values()))
+        if isinstance(first2, hnn.GroupNorm) and torch.is_tensor(x) and x.is_cuda:
+            x, partial = sc1(x, stats_for=first2)
+            return sc2(x, partial=partial)
+        return sc2(sc1(x))
 
 
 class ExtResNetBlock(nn.Module):
