@@ -410,6 +410,32 @@ def test_conv_transpose_mfma_dgrad_wgrad(n, cin, cout, shape):
     assert_close(up.weight.grad, wr.grad, 2e-4, "dw (MFMA, transposing LDS reads)")
 
 
+@pytest.mark.parametrize("n,cin,cout,shape", [(3, 32, 32, (64, 64, 128)),    # accumulate mode, sample changes inside a workgroup's item list
+                                              (2, 32, 64, (64, 64, 64)),     # accumulate mode with two channel blocks
+                                              (2, 32, 32, (20, 24, 36))])    # ragged bricks: one row per wave and brick
+def test_fused_groupnorm_partials_sum_to_the_output_statistics(n, cin, cout, shape):
+    """The conv epilogue's GroupNorm partials (per channel PAIR; in the persistent kernel accumulated over a workgroup's bricks
+    of a sample) must add up to sum(y) and sum(y^2) of the STORED bf16 output, per sample and channel pair."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(n, cin, *shape, device=DEV, dtype=torch.bfloat16, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    w = (torch.randn(cout, cin, 3, 3, 3, device=DEV, generator=g) * 0.05)
+    mednet_hip.set_conv_algo("mfma")
+    try:
+        with mednet_hip.precision("bf16"):
+            y, partial = ops.conv3d_with_stats(x, w, None, ops.pack_conv_weight(w, 3, False), 3)
+    finally:
+        mednet_hip.set_conv_algo("auto")
+    assert partial is not None and partial.shape[0] == n and partial.shape[2] == cout
+    tot = partial.double().sum(dim=1)                               # n x cout x 2, pair sums at even channels
+    yd = y.double()
+    s = yd.sum(dim=(2, 3, 4)).reshape(n, cout // 2, 2).sum(-1)
+    q = (yd * yd).sum(dim=(2, 3, 4)).reshape(n, cout // 2, 2).sum(-1)
+    assert torch.all(tot[:, 1::2] == 0)
+    scale = q.sqrt() * (yd[0, 0].numel() ** 0.5)
+    assert torch.all((tot[:, 0::2, 0] - s).abs() <= 2e-5 * scale + 1e-3)
+    assert torch.all((tot[:, 0::2, 1] - q).abs() <= 2e-5 * q)
+
+
 def test_conv3d_mfma_batch_larger_than_4GB():
     """A batch whose activation tensor exceeds 4 GB (34 x 128^3 x 32 ch bf16 = 4.6 GB): the MFMA kernels address one
     SAMPLE per buffer resource, so the last sample must come out bit-identical to the same sample run alone, and the
