@@ -69,6 +69,13 @@ int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void
 int mednet_conv3d_act_supported(int n, int d, int h, int w, int cin, int cout, int algo);
 int mednet_conv3d_act_fwd(const void* x, const void* packed, void* y, int n, int d, int h, int w, int cin, int cout,
                           int act, int algo, float* gn_partial, mednet_stream stream);
+/* dx = dgrad(dy) + add: the data gradient of a 3x3x3 conv (layer Cin -> Cout; dy has Cout channels, dx and add have Cin)
+ * with a second gradient of the same tensor summed in the epilogue (fp32 add, one bf16 rounding): in ExtResNetBlock the
+ * first conv's output feeds conv2 AND the residual add (components.py:170-178), so its two gradients meet here instead
+ * of in two more tensor reads of the GroupNorm backward.  bf16 NDHWC, matrix-core path only
+ * (mednet_conv3d_act_supported(n,d,h,w,Cout,Cin,algo) tells). */
+int mednet_conv3d_dgrad_add(const void* dy, const void* packed, const void* add, void* dx, int n, int d, int h, int w,
+                            int cin, int cout, int algo, mednet_stream stream);
 size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
 /* dw[co,ci,tap] = sum_{n,v} dy[n,v,co] * x[n,v+tap,ci]; dbias[co] = sum dy (nullable). */
 int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,

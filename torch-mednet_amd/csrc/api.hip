@@ -200,6 +200,19 @@ extern "C" int mednet_conv3d_act_fwd(const void* x, const void* packed, void* y,
                           (hipStream_t)stream, act);
 }
 
+// data gradient of a 3x3x3 conv with a second gradient of the same tensor summed in the epilogue (matrix-core path only)
+extern "C" int mednet_conv3d_dgrad_add(const void* dy, const void* packed, const void* add, void* dx, int n, int d, int h,
+                                       int w, int cin, int cout, int algo, mednet_stream stream) {
+  int rc = conv_common_checks("conv3d_dgrad_add", n, d, h, w, cin, cout, 3, MEDNET_BF16, MEDNET_BF16);
+  if (rc) return rc;
+  // (roles swapped as in mednet_conv3d_fwd(dgrad=1): the kernel reads dy with Cout channels and writes Cin channels)
+  if (!mednet_conv3d_act_supported(n, d, h, w, cout, cin, algo))
+    return fail(MEDNET_E_UNSUPPORTED, "conv3d_dgrad_add: only the bf16 matrix-core path fuses the add (cin=%d cout=%d)", cin, cout);
+  const PackLayout L = pack_layout(cin, cout, 3);
+  return launch_conv_mfma(dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cout, cin, MEDNET_BF16, MEDNET_BF16, nullptr,
+                          (hipStream_t)stream, MEDNET_ACT_NONE, add);
+}
+
 // ---- ConvTranspose3d(k3,s2,p1,op1) ------------------------------------------------------------------------------------
 extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float* bias, const void* skip, void* y, int n,
                                   int d, int h, int w, int cin, int cout, int x_dtype, int y_dtype, int algo,

@@ -64,7 +64,8 @@ int launch_pack_f32(const float* w, float* Pf, float* Pb, int cin, int cout, int
 bool conv_mfma_fits(int n, int d, int h, int w, int c);
 bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int x_layout, int y_layout, bool bias);
 int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, int d, int h, int w, int cin, int cout,
-                     int x_dtype, int y_dtype, float* gn_partial, hipStream_t s, int act = MEDNET_ACT_NONE);
+                     int x_dtype, int y_dtype, float* gn_partial, hipStream_t s, int act = MEDNET_ACT_NONE,
+                     const void* add = nullptr);
 int conv_mfma_stats_chunks(int n, int d, int h, int w, int cout);
 int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, float* Pf, float* Pb, int cin, int cout, int T,
                      int transposed_src, hipStream_t s);

@@ -64,6 +64,8 @@ struct FwdArgs {
   unsigned rcp_tiles_x, rcp_tiles_y, rcp_tiles_z, rcp_ncb;  // ceil(2^32 / d): x / d == umulhi(x, rcp) for x * d < 2^32
   unsigned bytes_x;  // size of ONE SAMPLE of x for the buffer resource (< 4 GB)
   unsigned bytes_y;  // same for y
+  const bf16* add;    // nullable, shape of y: summed into the output in the epilogue (fp32 add, one rounding) -- the residual
+                      // branch's gradient joining the data gradient of ExtResNetBlock's second conv (components.py:170-178)
   int act;            // MEDNET_ACT_*: applied to the fp32 accumulators before the bf16 store (conv -> ReLU/LeakyReLU/ELU of the
                       // 'gcr' orders, components.py:36-40); the fused statistics are then those of the ACTIVATED output
   float* gn_partial;  // nullable: [n][stats_rows][cout][2] = {sum y, sum y^2} of the STORED (rounded) outputs, see stats_accum
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     const bool lane_ok = (tx0 + ex < a.ow) & (cb * 32 + pj * 8 < a.cout);  // (a 16-channel layer fills half a block)
     const unsigned vbase = (unsigned)((ey * a.ow + ex) * a.cout + pj * 8) * 2u;
     const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
+    const auto rsrc_add = __builtin_amdgcn_make_buffer_rsrc((void*)((a.add ? a.add : a.y) + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
     const int swl = (et >> 1) & 7;  // (vl >> 1) & 7 does not depend on the round: 64 voxels per round
     const bf16* rd = out_lds + et * 32 + (pj ^ (swl >> 1)) * 8;
     constexpr int ROUNDS = (TZ * TY * TX * 4) / 256;
@@ -388,6 +391,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
       const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
       const unsigned soff = (unsigned)(((oz * a.oh + oyb) * a.ow + tx0) * a.cout + cb * 32) * 2u;
+      if (a.add) {  // (wave-uniform) y += add: 16-byte row pieces at the same offsets, out-of-range lanes read zeros
+        const bf16x8 ad = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_add, ok ? vbase : OOB, soff, 0));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)ad[k]);
+      }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_y, ok ? vbase : OOB, soff, 2);  // aux 2 = nt: streamed output must not push the input rows (read again by the next K chunk) out of L2
       if (ok && a.gn_partial) {  // statistics of what is stored (the rounded values), exactly like the stand-alone pass
 #pragma unroll
@@ -873,7 +881,8 @@ static void conv_stats_plan(int n, int d, int h, int w, int cout, int& rows, int
 
 template <int STRIDE>
 static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, int oh, int ow, int id, int ih, int iw,
-                      int cin, int cout, float* gn_partial, hipStream_t s, int act = MEDNET_ACT_NONE) {
+                      int cin, int cout, float* gn_partial, hipStream_t s, int act = MEDNET_ACT_NONE,
+                      const void* add = nullptr) {
   using G = FwdTile<STRIDE>;
   constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
   constexpr size_t lds = ((size_t)2 * HZ * HY * HX + 27 * 2 * 32) * 16;
@@ -881,6 +890,7 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   FwdArgs a;
   a.gn_partial = gn_partial;
   a.act = act;
+  a.add = (const bf16*)add;
 #ifdef MEDNET_CONV_TIMING
   a.dbg = (long long*)(((unsigned long long)(unsigned)tuning_option("conv_dbg_hi", 0) << 32) | (unsigned)tuning_option("conv_dbg_lo", 0));
 #endif
@@ -919,10 +929,10 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
 }
 
 int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, int d, int h, int w, int cin, int cout,
-                     int x_dtype, int y_dtype, float* gn_partial, hipStream_t s, int act) {
+                     int x_dtype, int y_dtype, float* gn_partial, hipStream_t s, int act, const void* add) {
   (void)x_dtype;
   (void)y_dtype;
-  return launch_fwd<1>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, gn_partial, s, act);
+  return launch_fwd<1>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, gn_partial, s, act, add);
 }
 int conv_mfma_stats_chunks(int n, int d, int h, int w, int cout) {
   int rows, accum;

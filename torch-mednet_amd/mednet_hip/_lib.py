@@ -39,6 +39,7 @@ SIGNATURES = {
     "mednet_gn_finalize": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _f, _vp, _sz, _vp]),
     "mednet_conv3d_act_supported": (_i, [_i] * 7),
     "mednet_conv3d_act_fwd": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp, _vp]),
+    "mednet_conv3d_dgrad_add": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
     "mednet_conv3d_wgrad_ws_bytes": (_sz, [_i] * 7),
     "mednet_conv3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp, _sz, _vp]),
     "mednet_convt3d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),

@@ -73,8 +73,12 @@ def _gn_bwd(dz, dz2, y, z, coef, stats, gamma_p, beta_p, groups, act, want_dres)
     return dy, dres, (None if dg_direct else dgamma), (None if db_direct else dbeta)
 
 
-def _conv_bwd(x, dy, packed, weight_p, need_dx):
-    """Weight gradient (side stream in trainer mode) + data gradient.  Returns (dx, dw-or-None)."""
+FUSE_DRES = os.environ.get("MEDNET_FUSE_DRES", "1") == "1"  # A/B knob: residual gradient summed in conv2's data gradient
+
+
+def _conv_bwd(x, dy, packed, weight_p, need_dx, add=None):
+    """Weight gradient (side stream in trainer mode) + data gradient (+ `add`, a second gradient of x, summed in the
+    data-gradient kernel's epilogue when given).  Returns (dx, dw-or-None)."""
     n, cin, d, h, w = x.shape
     cout = dy.shape[1]
     lib = L.lib()
@@ -86,9 +90,13 @@ def _conv_bwd(x, dy, packed, weight_p, need_dx):
         nonlocal dx
         if need_dx:
             dx = ops.empty_cl(n, cin, d, h, w, x.dtype if x.dtype in (torch.float32, torch.bfloat16) else config.act_dtype(), dy.device)
-            L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin, 3,
-                                          L.dt(dy), L.NDHWC, L.dt(dx), L.NDHWC, 1, config.conv_algo(), None, L.stream()),
-                    "conv3d_dgrad")
+            if add is not None:
+                L.check(lib.mednet_conv3d_dgrad_add(dy.data_ptr(), packed.data_ptr(), add.data_ptr(), dx.data_ptr(), n, d, h, w,
+                                                    cin, cout, config.conv_algo(), L.stream()), "conv3d_dgrad_add")
+            else:
+                L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin, 3,
+                                              L.dt(dy), L.NDHWC, L.dt(dx), L.NDHWC, 1, config.conv_algo(), None, L.stream()),
+                        "conv3d_dgrad")
 
     if not WGRAD_FIRST:
         dgrad()
@@ -132,9 +140,13 @@ class ResBlockFn(Function):
         dy3, dres, dg3, db3 = _gn_bwd(dout, None, y3, out, c3, s3, g3, b3, groups, act, True)
         dz2, dw3 = _conv_bwd(z2, dy3, pk3, w3, True)
         dy2, _, dg2, db2 = _gn_bwd(dz2, None, y2, None, c2, s2, g2, b2, groups, act, False)
-        dz1, dw2 = _conv_bwd(z1, dy2, pk2, w2, True)
-        # z1 feeds conv2 AND the residual add: both gradient streams are summed inside GroupNorm-1's backward
-        dy1, _, dg1, db1 = _gn_bwd(dz1, dres, y1, None, c1, s1, g1, b1, groups, act, False)
+        # z1 feeds conv2 AND the residual add: the two gradients are summed in the epilogue of conv2's data gradient (bf16
+        # matrix-core path), otherwise inside GroupNorm-1's backward (two more tensor reads)
+        n_, c_, d_, h_, w_ = z1.shape
+        fuse = FUSE_DRES and dy2.dtype == torch.bfloat16 and dres.dtype == torch.bfloat16 and bool(
+            L.lib().mednet_conv3d_act_supported(n_, d_, h_, w_, c_, c_, config.conv_algo()))
+        dz1, dw2 = _conv_bwd(z1, dy2, pk2, w2, True, add=dres if fuse else None)
+        dy1, _, dg1, db1 = _gn_bwd(dz1, None if fuse else dres, y1, None, c1, s1, g1, b1, groups, act, False)
         dx, dw1 = _conv_bwd(xin, dy1, pk1, w1, ctx.needs_input_grad[0])
         return (dx, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + (None,) * 6
 
