@@ -380,8 +380,14 @@ def test_conv3d_mfma_fwd_dgrad_wgrad(n, cin, cout, shape):
     assert_close(dw, dwd, 2e-4, "dw vs direct kernel")
 
 
+def _fuzz_cases_ct(k, seed):
+    rng = np.random.default_rng(seed)
+    return [(int(rng.integers(1, 3)), int(rng.choice([32, 64, 96])), int(rng.choice([32, 64])),
+             tuple(int(v) for v in rng.integers(1, 21, 3))) for _ in range(k)]
+
+
 @pytest.mark.parametrize("n,cin,cout,shape", [(1, 64, 32, (2, 4, 16)), (2, 64, 32, (3, 5, 9)), (1, 256, 128, (4, 4, 4)),
-                                              (1, 32, 32, (5, 9, 17))])
+                                              (1, 32, 32, (5, 9, 17))] + _fuzz_cases_ct(10, 77))
 def test_conv_transpose_mfma_dgrad_wgrad(n, cin, cout, shape):
     tag = f"ctm{n}{cin}{cout}{shape}"
     oshape = tuple(2 * s for s in shape)
@@ -434,6 +440,51 @@ def test_fused_groupnorm_partials_sum_to_the_output_statistics(n, cin, cout, sha
     scale = q.sqrt() * (yd[0, 0].numel() ** 0.5)
     assert torch.all((tot[:, 0::2, 0] - s).abs() <= 2e-5 * scale + 1e-3)
     assert torch.all((tot[:, 0::2, 1] - q).abs() <= 2e-5 * q)
+
+
+def _fuzz_cases(k, seed):
+    rng = np.random.default_rng(seed)
+    chans = [16, 32, 48, 64, 96]
+    out = []
+    for _ in range(k):
+        out.append((int(rng.integers(1, 4)), int(rng.choice(chans)), int(rng.choice(chans)),
+                    tuple(int(v) for v in rng.integers(1, 41, 3))))
+    return out
+
+
+@pytest.mark.parametrize("n,cin,cout,shape", _fuzz_cases(16, 2026))
+def test_conv3d_mfma_random_shapes_against_direct_kernels(n, cin, cout, shape):
+    """Random channel counts (multiples of 16) and volume sizes (1..40 per axis: thinner than a brick, ragged, many bricks):
+    the matrix-core conv / data gradient / weight gradient / fused statistics against the direct kernels on the same bf16
+    inputs.  Catches indexing slips of the persistent item walk, the padded channel blocks and the hardware zero fill."""
+    tag = f"fz{n}{cin}{cout}{shape}"
+    x, w, cot = _conv_case(n, cin, cout, shape, tag)
+    res = {}
+    for algo in ("mfma", "direct"):
+        mednet_hip.set_conv_algo(algo)
+        try:
+            with mednet_hip.precision("bf16"):
+                conv = hnn.Conv3d(cin, cout, 3, bias=False).to(DEV)
+                with torch.no_grad():
+                    conv.weight.copy_(w)
+                xg = x.to(DEV).bfloat16().requires_grad_(True)
+                y, partial = conv.forward_with_stats(xg)
+                y.backward(cot.to(DEV).bfloat16())
+                res[algo] = (y.detach().float().cpu(), xg.grad.float().cpu(), conv.weight.grad.cpu(), partial)
+        finally:
+            mednet_hip.set_conv_algo("auto")
+    y, dx, dw, partial = res["mfma"]
+    yd, dxd, dwd, _ = res["direct"]
+    assert_close(y, yd, 5e-3, "y vs direct kernel")
+    assert_close(dx, dxd, 5e-3, "dx vs direct kernel")
+    assert_close(dw, dwd, 3e-4, "dw vs direct kernel")
+    assert partial is not None
+    tot = partial.double().sum(dim=1).cpu()
+    s_ref = y.double().sum(dim=(2, 3, 4)).reshape(n, cout // 2, 2).sum(-1)
+    q_ref = (y.double() ** 2).sum(dim=(2, 3, 4)).reshape(n, cout // 2, 2).sum(-1)
+    nv = float(np.prod(shape))
+    assert torch.all((tot[:, 0::2, 0] - s_ref).abs() <= 1e-4 * (q_ref * nv).sqrt() + 1e-3)
+    assert torch.all((tot[:, 0::2, 1] - q_ref).abs() <= 1e-4 * q_ref + 1e-6)
 
 
 def test_conv3d_mfma_batch_larger_than_4GB():
