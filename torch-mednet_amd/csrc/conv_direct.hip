@@ -279,7 +279,17 @@ __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const T* __res
     const size_t v0 = (size_t)blockIdx.x * CS_ITEMS;
     const size_t v1 = v0 + CS_ITEMS < spatial ? v0 + CS_ITEMS : spatial;
     float s = 0.f;
-    for (size_t v = v0 + threadIdx.x; v < v1; v += 256) s += ld(p, v);
+    if (spatial % 8 == 0) {  // 8 elements (16 / 32 bytes) per load: one element per load ran at 0.5 TB/s
+      float s1 = 0.f;
+      for (size_t v = v0 + (size_t)threadIdx.x * 8; v + 8 <= v1; v += 256 * 8) {
+        const F8 t = ld8(p, v);
+        s += (t.v[0] + t.v[1]) + (t.v[2] + t.v[3]);
+        s1 += (t.v[4] + t.v[5]) + (t.v[6] + t.v[7]);
+      }
+      s += s1;
+    } else {
+      for (size_t v = v0 + threadIdx.x; v < v1; v += 256) s += ld(p, v);
+    }
     s = block_sum<4>(s, scratch);
     if (threadIdx.x == 0) part[((size_t)n * gridDim.x + blockIdx.x) * c + ch] = s;
   } else if (c % 8 == 0 && c <= 2048) {
