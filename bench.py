@@ -76,22 +76,90 @@ def cpu_baseline(steps: int):
         times.append(time.perf_counter() - t0)
     timed = sorted(times[1:])
     med = timed[len(timed) // 2]
-    return {"value": round(1.0 / med, 5), "unit": "patches/s", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / med, 5), "unit": "patches/s", "cores": cores, "cpu_model": cpu_model(),
+            "cores_visible": os.cpu_count(), "kind": "port",
             "sample": f"oracle ResidualUNet3D {F_MAPS} 4-class, one 128^3 patch (N=1), fp32, fwd+Dice+bwd+Adam, "
                       f"1 warm-up + {steps} timed steps (median {med:.2f} s/step)"}
 
 
-def pmc_traffic(batch: int, patch: int):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with
-    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; FETCH_SIZE doubled as the gfx950 guide prescribes).  PMC cannot be
-    collected from inside the timed run, so this is the last profiled value for this exact launch shape, else null."""
+DOMINANT_KEY = "mednet::conv_mfma_kernel<1> 32->32@128^3 (persistent grid=131072, longest launches)"
+KERNEL_SOURCE = os.path.join(ROOT, "torch-mednet_amd", "csrc", "conv_mfma.hip")
+
+
+def cpu_model() -> str:
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-        if batch != 4 or patch != 128:
-            return None
-        return d["mednet::conv_mfma_kernel<1> 32->32@128^3 (persistent grid=131072, longest launches)"]["hbm_bytes_per_launch"]
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
     except Exception:
-        return None
+        pass
+    return "unknown"
+
+
+def source_sha256(path: str = KERNEL_SOURCE) -> str:
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def pmc_traffic(batch: int, patch: int):
+    """-> (HBM bytes per launch of the dominant kernel or None, where that number comes from).
+
+    PMC counters cannot be collected from inside the timed run, so `traffic` is the value of the newest committed rocprofv3
+    PMC profile (profiles/rNN_pmc_hbm_traffic.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command,
+    FETCH_SIZE doubled as the gfx950 guide prescribes) -- and ONLY if that profile was taken from the kernel source that is
+    being timed now: the profile records the sha256 of csrc/conv_mfma.hip; on a mismatch the number is stale and null is
+    reported instead."""
+    import glob
+    if batch != 4 or patch != 128:
+        return None, "no PMC profile for this launch shape"
+    now = source_sha256()
+    stale = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            meta = d.get("_meta", {})
+            name = os.path.relpath(path, ROOT)
+            if meta.get("kernel_source_sha256") != now:
+                stale.append(name)
+                continue
+            return d[DOMINANT_KEY]["hbm_bytes_per_launch"], (
+                f"{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py`, git {meta.get('git_head', '?')}, "
+                f"conv_mfma.hip sha256 {now[:12]})")
+        except Exception:
+            continue
+    return None, ("stale: csrc/conv_mfma.hip (sha256 " + now[:12] + ") is newer than " +
+                  (", ".join(stale) if stale else "every profile under profiles/") + "; re-run tools/gpu_profile.sh")
+
+
+def fp32_parity_mode(dev, batch: int, patch: int, steps: int):
+    """The SAME step in the fp32 storage mode -- the mode that meets the north star's 1e-3 on logits and gradients
+    (tests: test_cfg2_128_against_reference_golden) -- timed the same way, as a sub-record."""
+    import mednet_hip
+    from mednet_hip.train import SegmentationStep
+    from mednet_hip.unet.model import ResidualUNet3D
+    from mednet_hip.synth import keyed_init_, synthetic_batch
+    with mednet_hip.precision("fp32"):
+        model = keyed_init_(ResidualUNet3D(1, 4, False, f_maps=F_MAPS)).to(dev)
+        step = SegmentationStep(model, loss_weight=[0.05, 1.0, 1.0, 1.0], lr=1e-3)
+        b = {k: v.to(dev) for k, v in synthetic_batch(batch, 1, (patch, patch, patch), 4, 0, seed=1234).items()}
+        step(b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step(b)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        step.flat.release()
+    pps = batch * steps / dt
+    rec = {"value": round(pps, 3), "unit": "patches/s", "ms_per_step": round(1e3 * dt / steps, 2), "steps": steps,
+           "dtype": "fp32", "loss": round(float(loss), 6),
+           "tolerance_met": "1e-3 rel-L2 on logits and every gradient vs the reference (fp32 storage, fp32 matrix-core "
+                            "contraction v_mfma_f32_32x32x2_f32)"}
+    if patch == 128:
+        rec["frac_of_fp32_mfma_peak"] = round(pps * FLOP_PER_PATCH / (MFMA_PEAK_TFLOPS["fp32"] * 1e12), 4)
+    del model, step
+    torch.cuda.empty_cache()
+    return rec
 
 
 def main():
@@ -104,6 +172,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--fp32-steps", type=int, default=3,
+                    help="timed steps of the fp32 (1e-3 parity) mode for the fp32_parity_mode sub-record (0 = skip)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("MEDNET_GRAPH", "0")),
                     help="1: replay forward+loss+backward as one captured hipGraph per step (train._GraphedStep)")
     a = ap.parse_args()
@@ -191,10 +261,15 @@ def main():
             avg = sum(ms) / len(ms)
             peak = MFMA_PEAK_TFLOPS[a.precision]
             ach = flops / (avg * 1e-3) / 1e12
+            traffic, traffic_source = pmc_traffic(a.batch, P)
             out["roofline"] = {"kernel": "conv_mfma_kernel<1>: conv3d 3x3x3 32->32 @128^3 (fwd launches)", "bound": "mfma",
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": pmc_traffic(a.batch, P), "launches": len(ms), "avg_ms": round(avg, 4),
-                               "flop_per_launch": flops}
+                               "traffic": traffic, "traffic_source": traffic_source, "launches": len(ms),
+                               "avg_ms": round(avg, 4), "flop_per_launch": flops}
+        if a.fp32_steps > 0 and world == 1 and a.precision == "bf16":
+            del step, model
+            torch.cuda.empty_cache()
+            out["fp32_parity_mode"] = fp32_parity_mode(dev, a.batch, P, a.fp32_steps)
         if a.cpu_steps > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.cpu_steps)
         print(json.dumps(out), flush=True)

@@ -50,6 +50,30 @@ def test_flat_gradient_allreduce_world2(tmp_path):
     assert torch.equal(r0["reduced"], r1["reduced"])  # every rank applies the same update
 
 
+def _cpu_hybrid_of_product_model(O):
+    """mednet_hip's ResidualUNet3D skeleton with the oracle's CPU leaf modules plugged in (same parameter order), so the
+    product's own forward control flow runs without a GPU."""
+    import torch.nn as nn
+    from mednet_hip.unet import model as HM
+
+    class UpWithSkip(nn.Module):  # the product's Decoder calls upsample(x, skip=...) (ConvTranspose3d + skip in one kernel)
+        def __init__(self, up):
+            super().__init__()
+            self.up = up
+
+        def forward(self, x, skip=None):
+            return self.up(x) + skip
+
+    ora = O.keyed_init_(O.ResidualUNet3D(1, 2, False, f_maps=[8, 16, 32]))
+    net = HM.ResidualUNet3D(1, 2, False, f_maps=[8, 16, 32])
+    for he, oe in zip(net.encoders, ora.encoders):
+        he.basic_module, he.pooling = oe.basic_module, oe.pooling
+    for hd, od in zip(net.decoders, ora.decoders):
+        hd.basic_module, hd.upsample = od.basic_module, UpWithSkip(od.upsample)
+    net.final_conv = ora.final_conv
+    return net
+
+
 def _bucket_worker(rank, world, port, out):
     for p in (ROOT, os.path.join(ROOT, "torch-mednet_amd")):
         if p not in sys.path:
@@ -81,7 +105,21 @@ def _bucket_worker(rank, world, port, out):
     assert fired and ex.work is not None  # the early bucket was launched from inside backward
     scale = ex.finish()
     got = torch.cat([flat.grad[o:o + p.numel()] for p, o in zip(flat.params, flat.offsets)]) * scale
-    torch.save({"local": local, "reduced": got}, os.path.join(out, f"b{rank}.pt"))
+    # The product model drives its encoders through Encoder.forward(x, with_skip=True) (-> a tuple), not enc(x): the same
+    # exchange on the product's module skeleton (_UNetCore.forward, Encoder, Decoder) over CPU leaf blocks must fire too.
+    hyb = _cpu_hybrid_of_product_model(O)
+    flat2 = FlatParams(hyb)
+    ex2 = BucketedExchange(hyb, flat2, world)
+    assert ex2.enabled
+    flat2.grads_as_attr()
+    fired2 = []
+    ex2_on_grad = ex2._on_grad
+    ex2._on_grad = lambda g: (fired2.append(1), ex2_on_grad(g))[1]
+    crit(hyb(batch["data"].float()), batch["label"][:, -1].long()).backward()
+    assert fired2 and ex2.work is not None, "BucketedExchange did not fire on the product model's forward path"
+    scale2 = ex2.finish()
+    got2 = torch.cat([flat2.grad[o:o + p.numel()] for p, o in zip(flat2.params, flat2.offsets)]) * scale2
+    torch.save({"local": local, "reduced": got, "reduced_product_skeleton": got2}, os.path.join(out, f"b{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -96,6 +134,8 @@ def test_bucketed_exchange_overlapped_with_backward_world2(tmp_path):
     mean = 0.5 * (r0["local"] + r1["local"])
     assert torch.allclose(r0["reduced"], mean, rtol=1e-6, atol=1e-9)
     assert torch.equal(r0["reduced"], r1["reduced"])
+    assert torch.allclose(r0["reduced_product_skeleton"], mean, rtol=1e-5, atol=1e-8)
+    assert torch.equal(r0["reduced_product_skeleton"], r1["reduced_product_skeleton"])
 
 
 def test_synth_generators_match_oracle():

@@ -290,6 +290,28 @@ def test_cross_entropy(weight, golden_dir):
     assert_close(zg.grad, torch.from_numpy(rec[tag + ".grad"]), 1e-5, "dlogits")
 
 
+def test_out_of_range_labels_poison_the_loss():
+    """The reference raises on a label outside [0, C) (scatter_ in expand_as_one_hot, loss.py:81-86; nll_loss for CE).  A
+    kernel cannot raise without a host sync per step, so the fused losses turn NaN instead (loss and every gradient):
+    corrupt label volumes cannot train silently.  ignore_index stays legal for cross-entropy."""
+    z = rnd("oorz", 2, 4, 6, 7, 8).to(DEV).requires_grad_(True)
+    y = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).integers(0, 4, size=(2, 6, 7, 8))).to(DEV)
+    ok = HL.DiceLoss().to(DEV)(z, y)
+    assert torch.isfinite(ok)
+    for badval in (4, -1, 255):
+        yb = y.clone()
+        yb[1, 2, 3, 4] = badval
+        zb = z.detach().clone().requires_grad_(True)
+        lb = HL.DiceLoss().to(DEV)(zb, yb)
+        lb.backward()
+        assert torch.isnan(lb) and torch.isnan(zb.grad).any(), badval
+        assert torch.isnan(HL.CrossEntropyLoss().to(DEV)(z, yb)), badval
+        assert torch.isnan(HL.dice_metric(z, yb)).any()
+    yi = y.clone()
+    yi[0, 0, 0, 0] = -100  # nn.CrossEntropyLoss's default ignore_index
+    assert torch.isfinite(HL.CrossEntropyLoss().to(DEV)(z, yi))
+
+
 @pytest.mark.parametrize("kind", ["L2", "L1"])
 def test_landmark_loss_composition(kind, golden_dir):
     """LandmarkNet.loss (landmarks.py:125-134): Dice on the class slice + weighted per-channel regression."""

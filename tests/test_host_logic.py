@@ -83,6 +83,49 @@ def test_import_alias_resolves_to_hip_modules():
         assert hasattr(l, name)
 
 
+def test_overlay_keeps_the_rest_of_the_reference_package_importable(tmp_path):
+    """The shipped `midasmednet/` overlay must shadow ONLY `midasmednet.unet.*`: with it first on the path and a second
+    `midasmednet` tree behind it (a stub standing in for the reference checkout: its own unet/, segmentation, dataset,
+    utils), the callers' import lines (segmentation.py:16-18) get the MI355X classes while `midasmednet.segmentation`,
+    `.dataset`, `.utils.*` still resolve from the second tree.  Fresh interpreter: `__path__` is fixed at first import."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    ref = tmp_path / "refcheckout" / "midasmednet"
+    (ref / "unet").mkdir(parents=True)
+    (ref / "utils").mkdir()
+    (ref / "__init__.py").write_text("")
+    (ref / "unet" / "__init__.py").write_text("")
+    (ref / "unet" / "model.py").write_text("class ResidualUNet3D:\n    STUB = True\n")
+    (ref / "unet" / "loss.py").write_text("STUB = True\n")
+    (ref / "utils" / "__init__.py").write_text("")
+    (ref / "utils" / "misc.py").write_text("WHERE = 'second tree'\n")
+    (ref / "dataset.py").write_text("WHERE = 'second tree'\n")
+    (ref / "segmentation.py").write_text(textwrap.dedent("""
+        from midasmednet.unet.model import ResidualUNet3D
+        from midasmednet.unet.loss import DiceLoss, WeightedCrossEntropyLoss, dice_metric
+        from midasmednet.unet.loss import expand_as_one_hot
+        from midasmednet.dataset import WHERE
+        class SegmentationNet(ResidualUNet3D):
+            pass
+    """))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "torch-mednet_amd"), str(ref.parent)]),
+               PYTHONDONTWRITEBYTECODE="1")
+    code = textwrap.dedent("""
+        import midasmednet, midasmednet.segmentation as s, midasmednet.dataset as d, midasmednet.utils.misc as u
+        import midasmednet.unet.model as m, mednet_hip.unet.model as hm, mednet_hip.unet.loss as hl
+        assert m.ResidualUNet3D is hm.ResidualUNet3D and not hasattr(m.ResidualUNet3D, "STUB")
+        assert s.SegmentationNet.__mro__[1] is hm.ResidualUNet3D and s.DiceLoss is hl.DiceLoss
+        assert d.WHERE == u.WHERE == s.WHERE == "second tree"
+        assert len(midasmednet.__path__) == 2
+        print("overlay ok")
+    """)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "overlay ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_no_cpu_fallback():
     net = HM.ResidualUNet3D(1, 2, False, f_maps=[8])
     with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const float* __restrict__
   __shared__ float scratch[4];
   const int n = blockIdx.y;
   float I[MAXC], D[MAXC];
+  bool bad = false;
 #pragma unroll
   for (int k = 0; k < MAXC; ++k) I[k] = D[k] = 0.f;
   const size_t v0 = (size_t)blockIdx.x * LOSS_BLOCK_VOX;
@@ -62,6 +63,9 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const float* __restrict__
       float p[MAXC];
       probs_of<MAXC>(lg, (size_t)n * sn + v, sc, c, sigmoid, p);
       const int y = (int)lab[(size_t)n * spatial + v];
+      // A label outside [0, C) makes the reference raise (scatter_ index error, loss.py:81-86).  Raising from a kernel
+      // would cost a host sync per step; instead the loss (and with it every gradient) becomes NaN: loud, not silent.
+      bad |= (unsigned)y >= (unsigned)c;
 #pragma unroll
       for (int k = 0; k < MAXC; ++k)
         if (k < c) {
@@ -73,6 +77,7 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const float* __restrict__
         }
     }
   }
+  if (bad) I[0] = D[0] = __builtin_nanf("");
   float* out = partial + ((size_t)n * gridDim.x + blockIdx.x) * c * 2;
 #pragma unroll
   for (int k = 0; k < MAXC; ++k)
@@ -184,6 +189,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     const size_t v = v0 + (size_t)it * 256 + threadIdx.x;
     if (v < spatial) {
       const int y = (int)lab[(size_t)n * spatial + v];
+      // nll_loss raises for a class index outside [0, C) that is not ignore_index; here the loss becomes NaN (see dice_fwd)
+      if (y != ignore && (unsigned)y >= (unsigned)c) num = __builtin_nanf("");
       if (y != ignore && y >= 0 && y < c) {
         const size_t base = (size_t)n * sn + v;
         float mx = -INFINITY, zy = 0.f;

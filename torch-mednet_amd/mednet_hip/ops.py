@@ -252,7 +252,9 @@ class ConvActFn(Function):
 
 
 def conv3d_act_supported(x, cin, cout):
-    if not (x.is_cuda and config.act_dtype() == torch.bfloat16 and x.dim() == 5):
+    # mednet_conv3d_act_fwd has no dtype argument: it reads bf16.  An fp32 tensor handed to a bf16-mode layer (a block
+    # called stand-alone, a 16/32-channel network input) takes the unfused conv, which passes its dtypes.
+    if not (x.is_cuda and config.act_dtype() == torch.bfloat16 and x.dtype == torch.bfloat16 and x.dim() == 5):
         return False
     n, _, d, h, w = x.shape
     return bool(L.lib().mednet_conv3d_act_supported(n, d, h, w, cin, cout, config.conv_algo()))

@@ -123,6 +123,8 @@ class BucketedExchange:
             list(model.encoders)[levels - 1].register_forward_hook(self._on_forward)
 
     def _on_forward(self, module, inputs, output):
+        if isinstance(output, tuple):  # Encoder(x, with_skip=True) -> (skip, out): the hook belongs on the level's output
+            output = output[-1]
         if self.enabled and torch.is_tensor(output) and output.requires_grad:
             output.register_hook(self._on_grad)
 

@@ -190,19 +190,22 @@ class Encoder(nn.Module):
         self.basic_module = basic_module(in_channels, out_channels, encoder=True, kernel_size=conv_kernel_size,
                                          order=conv_layer_order, num_groups=num_groups)
 
-    def forward(self, x):
-        if self.pooling is not None:
-            x = self.pooling(x)
-        return self.basic_module(x)
-
-    def forward_with_skip(self, x):
-        """-> (skip, out): `skip` is x as the decoder will use it, `out` = forward(x).  With the 2x2x2 pooling of this
-        package the split is one autograd node (ops.SkipPool2Fn), so the two gradients of x meet inside the pooling
-        backward kernel; any other pooling module falls back to the plain path (autograd adds them)."""
+    def forward(self, x, with_skip=False):
+        """forward(x) is the reference's Encoder.forward (components.py:222-226).  `with_skip=True` -> (skip, out): `skip` is
+        x as the decoder will use it, `out` = forward(x).  With the 2x2x2 pooling of this package the split is one autograd
+        node (ops.SkipPool2Fn), so the two gradients of x meet inside the pooling backward kernel; any other pooling module
+        takes the plain path (autograd adds them).  Both forms go through `__call__`, so module hooks see every level."""
+        if not with_skip:
+            if self.pooling is not None:
+                x = self.pooling(x)
+            return self.basic_module(x)
         if _FUSE_SKIP_POOL and isinstance(self.pooling, hnn._Pool2) and torch.is_tensor(x) and x.is_cuda and x.requires_grad:
             skip, pooled = ops.skip_pool2(x, self.pooling.mode)
             return skip, self.basic_module(pooled)
         return x, self.forward(x)
+
+    def forward_with_skip(self, x):
+        return self(x, with_skip=True)
 
 
 class Decoder(nn.Module):

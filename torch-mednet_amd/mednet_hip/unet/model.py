@@ -53,7 +53,7 @@ class _UNetCore(_Base):
             if i == 0:
                 x = enc(x)
             else:  # x is both the previous level's skip tensor and this level's pooling input (model.py:194-199)
-                skips[0], x = enc.forward_with_skip(x)
+                skips[0], x = enc(x, with_skip=True)
             skips.insert(0, x)
         for dec, skip in zip(self.decoders, skips[1:]):
             x = dec(skip, x)
