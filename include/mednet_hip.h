@@ -76,6 +76,16 @@ int mednet_conv3d_act_fwd(const void* x, const void* packed, void* y, int n, int
  * (mednet_conv3d_act_supported(n,d,h,w,Cout,Cin,algo) tells). */
 int mednet_conv3d_dgrad_add(const void* dy, const void* packed, const void* add, void* dx, int n, int d, int h, int w,
                             int cin, int cout, int algo, mednet_stream stream);
+/* mednet_conv3d_dgrad_add (add nullable) that ALSO takes the first pass of the backward of the GroupNorm (+ activation)
+ * in front of the layer (components.py:57,36-40: `SingleConv` k-1 of the block produced this conv's input): with gn_y the
+ * conv output that GroupNorm normalised (shape of dx), gn_coef[n][Cin] = {ca, cb} its forward affine (mednet_gn_stats /
+ * _finalize) and gn_act its activation, the epilogue forms du = dx * act'(ca * gn_y + cb) from the stored dx rows and writes
+ * gn_partial[n][rows][Cin][2] = per-channel {sum du, sum du * gn_y} (rows = mednet_conv3d_dgrad_gn_rows(...), 0 = not
+ * supported for this shape).  mednet_gn_act_bwd_fused consumes it: no stand-alone pass re-reads dx and gn_y. */
+int mednet_conv3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int algo);
+int mednet_conv3d_dgrad_gn(const void* dy, const void* packed, const void* add, void* dx, const void* gn_y,
+                           const float* gn_coef, int gn_act, float* gn_partial, int n, int d, int h, int w, int cin,
+                           int cout, int algo, mednet_stream stream);
 size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
 /* dw[co,ci,tap] = sum_{n,v} dy[n,v,co] * x[n,v+tap,ci]; dbias[co] = sum dy (nullable). */
 int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
@@ -116,6 +126,12 @@ int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x, const void
                       const float* stats, const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, int n,
                       size_t spatial, int c, int groups, int act, int dtype, void* ws, size_t ws_bytes,
                       mednet_stream stream);
+/* mednet_gn_act_bwd without its first pass: `partial` [n][rows][c][2] = per-channel {sum du, sum du * x} comes from the
+ * kernel that produced dz (mednet_conv3d_dgrad_gn); act' is recomputed from x and `coef` (z is not read). */
+int mednet_gn_act_bwd_fused(const void* dz, const void* x, const float* coef, const float* stats, const float* gamma,
+                            const float* partial, int rows, void* dx, float* dgamma, float* dbeta, int n,
+                            size_t spatial, int c, int groups, int act, int dtype, void* ws, size_t ws_bytes,
+                            mednet_stream stream);
 /* stand-alone activation (orders such as 'cr', 'crg'); in-place allowed (x == z). */
 int mednet_act_fwd(const void* x, void* z, size_t count, int act, int dtype, mednet_stream stream);
 int mednet_act_bwd(const void* dz, const void* z, void* dx, size_t count, int act, int dtype,

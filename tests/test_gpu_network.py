@@ -20,12 +20,16 @@ from test_oracle_golden import NETS
 
 pytestmark = pytest.mark.gpu
 
-NET_TOL = {"fp32": (1e-3, 1e-3), "bf16": (3e-2, 8e-2)}  # (logits, grads) rel-L2
-# UNet3D ('gcr': GroupNorm -> conv -> ReLU, max-pooled ReLU maps) under bf16 STORAGE: rounding the pooled activations
-# to 8 significant bits creates ties inside 2x2x2 windows, the arg-max then routes the gradient to a different voxel
-# than the fp32 reference does, and a fraction f of misrouted gradient costs ~sqrt(2f) in rel-L2.  That is a property of
-# bf16 storage (ATen's own bf16 max-pool does the same), not of the kernels: the fp32 mode of the same code meets 1e-3.
-# The perf mode is therefore held to a sanity bound for this secondary model; the measured drift is printed.
+# (logits, per-tensor gradient / cond) rel-L2.  bf16: measured on MI355X over all residual-network cases: logits <= 6.8e-3,
+# per-tensor gradient / cond <= 1.84e-2, concatenated gradient <= 1.24e-2; the bounds are those times two (rounded up).
+NET_TOL = {"fp32": (1e-3, 1e-3), "bf16": (1.5e-2, 4e-2)}
+NET_TOL_BF16_CONCAT = 3e-2
+# UNet3D ('gcr': GroupNorm -> conv -> ReLU, max-pooled ReLU maps) under bf16 STORAGE takes discrete decisions (ReLU masks,
+# pooling arg-max) that flip against the fp32 reference near ties; a fraction f of gradient routed differently costs
+# ~sqrt(2f) in rel-L2.  That is a property of bf16 storage, not of the kernels: the fp32 mode of the same code meets 1e-3,
+# and test_unet3d_bf16_gradients_once_discrete_decisions_are_equalised shows the gradients agree at the residual network's
+# tolerance once the oracle takes the same decisions.  Against the UNMODIFIED oracle the perf mode is therefore held to a
+# sanity bound for this secondary model; the measured drift is printed (0.25 % .. 36 % depending on the case).
 UNET3D_BF16_GRAD_TOL = 0.45
 # Logits of the plain (non-residual) 14-conv UNet3D chain with bf16 activations AND bf16 matrix-core operands in every
 # 3x3x3 layer (the 16-channel layers included): measured 3.1e-2 at 32^3, against 3e-2 allowed for the residual net.
@@ -124,7 +128,7 @@ def test_network_parity(tag, mode, golden_dir):
         worst = max(worst, r / (lim / tg)) if lim != float("inf") else worst
         assert r <= lim, f"{tag} grad {name}: rel-L2 {r:.3e} > {lim:.1e} (cond {ora.cond[name]:.1f})"
     total = (num / den) ** 0.5
-    glob_tol = 1e-3 if mode == "fp32" else (UNET3D_BF16_GRAD_TOL if tag.startswith("unet") else 5e-2)
+    glob_tol = 1e-3 if mode == "fp32" else (UNET3D_BF16_GRAD_TOL if tag.startswith("unet") else NET_TOL_BF16_CONCAT)
     assert total <= glob_tol, f"{tag}: concatenated-gradient rel-L2 {total:.3e} > {glob_tol:.1e}"
     report["grads"] = total
     # and against what the REFERENCE produced (golden): loss + logits
@@ -193,10 +197,12 @@ def test_cfg4_128_landmark_against_reference_golden(golden_dir):
 # bricks, GroupNorm-backward sums from the data-gradient epilogue, weight gradients on the side stream, flat gradient
 # buffers) at the size it is timed at.  Tolerances: what was measured on an MI355X (printed below) times two; the reference's
 # own bf16 drift at 32^3 is 8.3e-3 (logits) / 1.8e-2 (gradients), SURVEY F7.
-BF16_128_LOGITS = 3e-2      # strided logits, rel-L2
-BF16_128_LOSS = 1e-2        # |loss - golden|
-BF16_128_GRAD_NORM = 6e-2   # | ||g|| - ||g_ref|| | / ||g_ref||  per tensor
-BF16_128_GRAD_PROJ = 0.25   # |<g - g_ref, r>| / ||g_ref||, r ~ N(0, I): a relative error e moves it by ~e (std), 4 sigma kept
+# measured (round 2, cfg2 / cfg4): strided logits 6.7e-3 / 6.2e-3, loss diff 1.2e-5, gradient norms 6.3e-3 / 3.4e-3,
+# projections 3.0e-2 / 1.9e-2
+BF16_128_LOGITS = 1.5e-2    # strided logits, rel-L2
+BF16_128_LOSS = 1e-3        # |loss - golden| (relative to max(1, |golden|))
+BF16_128_GRAD_NORM = 1.5e-2 # | ||g|| - ||g_ref|| | / ||g_ref||  per tensor
+BF16_128_GRAD_PROJ = 6e-2   # |<g - g_ref, r>| / ||g_ref||, r ~ N(0, I): a relative error e moves it by ~e (one sigma)
 
 
 def _check_grads_against_golden_summaries(net, rec, norm_tol, proj_tol, what):
@@ -292,33 +298,55 @@ def test_cfg5_full_size_properties():
     print(f"[cfg5 full size] bf16 loss {runs[0][0]:.6f}  fp32-mode loss {float(loss32):.6f}")
 
 
-@pytest.mark.parametrize("tag", ["unet_small", "unet_cfg2_32"])
-def test_unet3d_bf16_gradients_once_pool_routing_is_equalised(tag, golden_dir):
-    """Why UNet3D's bf16 gradients are only held to a sanity bound in test_network_parity: under bf16 STORAGE the values a
-    2x2x2 max-pool sees are rounded to 8 significant bits, ties appear inside windows, and the arg-max routes the gradient
-    to a different voxel than in the fp32 reference.  Demonstration: give the ORACLE the values the HIP path stored at every
-    level output (the pooling inputs), so both sides route identically (first maximum in scan order, like ATen); everything
-    between those points is still the oracle's own fp32 arithmetic.  The gradients then agree at the residual network's bf16
-    tolerance, per tensor and concatenated."""
+class _ForcedReLU(nn.Module):
+    """Test-only stand-in for the oracle's nn.ReLU: value and mask taken from what the HIP path stored for this layer, so
+    the oracle takes the same discrete decisions; the gradient still flows to the oracle's own pre-activation."""
+
+    def __init__(self, stored):
+        super().__init__()
+        self.stored = stored
+
+    def forward(self, pre):
+        mask = (self.stored > 0).to(pre.dtype)
+        return pre * mask + (self.stored - pre * mask).detach()
+
+
+@pytest.mark.parametrize("tag", ["unet_small", "unet_oddsize", "unet_cfg2_32"])
+def test_unet3d_bf16_gradients_once_discrete_decisions_are_equalised(tag, golden_dir):
+    """Why UNet3D's bf16 gradients are only held to a sanity bound in test_network_parity.  UNet3D ('gcr': GroupNorm -> conv
+    -> ReLU, max-pooled ReLU maps) takes a DISCRETE decision at every voxel of every layer -- the ReLU mask, and the arg-max
+    of each 2x2x2 pooling window.  Under bf16 storage some of them flip against the fp32 reference (a conv output within
+    rounding noise of zero; two window entries rounded to the same 8-bit mantissa: the first one wins, as in ATen), and a
+    fraction f of gradient routed differently costs ~sqrt(2f) in rel-L2 whatever the kernels do.  Demonstration: the oracle
+    is given the HIP path's stored ReLU outputs (values and masks; a level's last one is the pooling input), so both sides
+    decide identically, while every GroupNorm, convolution, interpolation/concat and loss in between is still the oracle's own
+    fp32 autograd.  The gradients then agree at the residual network's bf16 tolerance, per tensor and concatenated -- i.e.
+    the whole 'gcr' backward chain of the HIP path is checked at network level."""
     cls, ctor, ncls, nh, lk, w = NETS[tag]
     rec = np.load(os.path.join(golden_dir, tag + ".npz"))
     shape = tuple(int(v) for v in rec["meta.shape"])
     batch = O.synthetic_batch(int(rec["meta.n"]), ctor["in_channels"], shape, ncls, nh, seed=int(rec["meta.seed"]))
     x, y = batch["data"].float(), batch["label"][:, -1].long()
-    stored = []
+    stored = {}
     with mednet_hip.precision("bf16"):
         net = O.keyed_init_(HM.UNet3D(**ctor)).to(DEV)
-        hooks = [enc.register_forward_hook(lambda m, i, o: stored.append((o[-1] if isinstance(o, tuple) else o).detach().float().cpu()))
-                 for enc in list(net.encoders)[:-1]]
+        hooks = []
+        for name, m in net.named_modules():
+            if isinstance(m, HC.SingleConv):
+                hooks.append(m.register_forward_hook(
+                    lambda mod, i, o, name=name: stored.__setitem__(name, (o[0] if isinstance(o, tuple) else o).detach().float().cpu())))
         lg = net(x.to(DEV))
         _hip_loss(lk, w, nh, lg, y.to(DEV), None).backward()
         for h in hooks:
             h.remove()
-    assert len(stored) == len(net.encoders) - 1
     ora = O.keyed_init_(cls(**ctor))
-    feed = iter(stored)
-    for enc in list(ora.encoders)[:-1]:
-        enc.register_forward_hook(lambda m, i, o: o + (next(feed) - o).detach())
+    swapped = 0
+    for name, m in ora.named_modules():
+        if isinstance(m, O.SingleConv):
+            assert list(m._modules)[-1] == "ReLU" and name in stored, name
+            m.ReLU = _ForcedReLU(stored[name])
+            swapped += 1
+    assert swapped == len(stored) > 0
     _oracle_loss(lk, w, nh, ora(x), y, None).backward()
     num = den = 0.0
     worst = 0.0
@@ -330,8 +358,8 @@ def test_unet3d_bf16_gradients_once_pool_routing_is_equalised(tag, golden_dir):
             worst = max(worst, r)
             assert r <= NET_TOL["bf16"][1], f"{tag} {name}: {r:.3e}"
     total = (num / den) ** 0.5
-    print(f"[unet3d routing equalised] {tag}: concatenated-gradient rel-L2 {total:.2e}, worst tensor {worst:.2e}")
-    assert total <= 5e-2, total
+    print(f"[unet3d decisions equalised] {tag}: concatenated-gradient rel-L2 {total:.2e}, worst tensor (>=1024 elements) {worst:.2e}")
+    assert total <= NET_TOL_BF16_CONCAT, total
 
 
 def test_training_steps_track_oracle(golden_dir):
@@ -425,32 +453,74 @@ def test_fused_groupnorm_partials_any_group_size(groups):
                 assert_close(a.grad, b.grad, 4e-2, f"{k} groups={groups}")
 
 
-@pytest.mark.parametrize("order", ["gcr", "crg", "gcl", "cre"])
+@pytest.mark.parametrize("order", ["gce", "ceg", "gcr"])
 def test_conv_act_orders_bf16_without_pooling(order):
     """bf16 mode, the conv -> activation epilogue (mednet_conv3d_act_fwd) with the NEXT GroupNorm's statistics taken from
     the activated output, forward and backward (ConvActFn), isolated from max-pooling: SingleConv and DoubleConv (encoder
-    and decoder form) of UNet3D's order family against the oracle on bf16-representable inputs.  This is the path whose
-    network-level gradient check is dominated by max-pool tie routing (see test_unet3d_bf16_gradients_once_pool_routing...)."""
+    and decoder form) of UNet3D's order family against the oracle on bf16-representable inputs.  ELU orders are smooth and
+    compared as they are; for 'gcr' the oracle takes the HIP path's ReLU decisions (_ForcedReLU, see
+    test_unet3d_bf16_gradients_once_discrete_decisions_are_equalised), otherwise mask flips near zero dominate dx."""
     x = torch.from_numpy(O._rng("cab" + order).standard_normal((2, 32, 8, 12, 20)).astype(np.float32)).bfloat16().float()
     cases = [(lambda: O.SingleConv(32, 32, 3, order, 8), lambda: HC.SingleConv(32, 32, 3, order, 8)),
              (lambda: O.DoubleConv(32, 64, True, 3, order, 8), lambda: HC.DoubleConv(32, 64, True, 3, order, 8)),
              (lambda: O.DoubleConv(32, 16, False, 3, order, 8), lambda: HC.DoubleConv(32, 16, False, 3, order, 8))]
     for make_o, make_h in cases:
-        ora = O.keyed_init_(make_o())
-        xo = x.clone().requires_grad_(True)
-        yo = ora(xo)
-        g = torch.from_numpy(O._rng("cabcot").standard_normal(tuple(yo.shape)).astype(np.float32))
-        (yo * g).sum().backward()
+        stored = {}
         with mednet_hip.precision("bf16"):
             net = O.keyed_init_(make_h()).to(DEV)
+            for name, m in net.named_modules():
+                if isinstance(m, HC.SingleConv):
+                    m.register_forward_hook(lambda mod, i, o, name=name: stored.__setitem__(
+                        name, (o[0] if isinstance(o, tuple) else o).detach().float().cpu()))
             xg = x.to(DEV).bfloat16().requires_grad_(True)
             yg = net(xg)
+            g = torch.from_numpy(O._rng("cabcot").standard_normal(tuple(yg.shape)).astype(np.float32))
             (yg.float() * g.to(DEV)).sum().backward()
+        ora = O.keyed_init_(make_o())
+        if order == "gcr":
+            for name, m in ora.named_modules():
+                if isinstance(m, O.SingleConv):
+                    m.ReLU = _ForcedReLU(stored[name])
+        xo = x.clone().requires_grad_(True)
+        yo = ora(xo)
+        (yo * g).sum().backward()
         assert_close(yg, yo, 2e-2, f"{order} y")
         assert_close(xg.grad, xo.grad, 4e-2, f"{order} dx")
         for (k, a), (_, b) in zip(net.named_parameters(), ora.named_parameters()):
             if a.numel() >= 1024:
                 assert_close(a.grad, b.grad, 4e-2, f"{order} {k}")
+
+
+@pytest.mark.parametrize("n,c,shape", [(2, 32, (64, 64, 64)), (1, 32, (9, 11, 21)), (2, 64, (16, 24, 32)), (1, 16, (8, 8, 16))])
+def test_groupnorm_backward_sums_from_the_data_gradient_epilogue(n, c, shape):
+    """ExtResNetBlock backward (components.py:168-180) in bf16 mode: the first pass of GroupNorm-1/-2's backward (sum du,
+    sum du*xhat per channel) taken in the epilogue of the data-gradient conv that produces dz (mednet_conv3d_dgrad_gn +
+    mednet_gn_act_bwd_fused) against the stand-alone pass (mednet_gn_act_bwd) on the same stored tensors: same gradients up
+    to fp32 summation order.  Shapes cover the persistent kernel's accumulate mode (>= 1024 bricks), one-row-per-brick
+    mode, ragged volumes, 64 channels (two channel blocks) and a 16-channel layer (half-filled block)."""
+    from mednet_hip import block
+    x = torch.from_numpy(O._rng(f"gnb{n}{c}{shape}").standard_normal((n, c) + shape).astype(np.float32))
+    g = torch.from_numpy(O._rng("gnbcot").standard_normal((n, c) + shape).astype(np.float32))
+    res = {}
+    for fused in (True, False):
+        old = block.FUSE_GNB
+        block.FUSE_GNB = fused
+        try:
+            with mednet_hip.precision("bf16"):
+                net = O.keyed_init_(HC.ExtResNetBlock(c, c, order="cge", num_groups=8)).to(DEV)
+                xg = x.to(DEV).bfloat16().requires_grad_(True)
+                yg = net(xg)
+                (yg.float() * g.to(DEV)).sum().backward()
+                res[fused] = [xg.grad.float().clone()] + [p.grad.clone() for p in net.parameters()]
+        finally:
+            block.FUSE_GNB = old
+    names = ["dx"] + [k for k, _ in net.named_parameters()]
+    for k, a, b in zip(names, res[True], res[False]):
+        # (fp32 summation order moves the per-group coefficients by ~1e-7; a few bf16 roundings of dy flip with them)
+        assert_close(a, b, 2e-3, f"fused vs stand-alone {k}")
+    if c >= 32:  # the fused path really ran (otherwise both runs are the same code)
+        from mednet_hip import _lib as L, config
+        assert L.lib().mednet_conv3d_dgrad_gn_rows(n, *shape, c, c, config.conv_algo()) > 0
 
 
 def test_fp32_tensor_into_a_bf16_mode_conv_act_layer():

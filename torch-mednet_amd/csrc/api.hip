@@ -213,6 +213,24 @@ extern "C" int mednet_conv3d_dgrad_add(const void* dy, const void* packed, const
                           (hipStream_t)stream, MEDNET_ACT_NONE, add);
 }
 
+extern "C" int mednet_conv3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int algo) {
+  if (!tuning_option("conv_fuse_gnb", 1) || !mednet_conv3d_act_supported(n, d, h, w, cout, cin, algo)) return 0;
+  return conv_mfma_stats_chunks(n, d, h, w, cin);  // (the kernel's output channels are the layer's Cin)
+}
+extern "C" int mednet_conv3d_dgrad_gn(const void* dy, const void* packed, const void* add, void* dx, const void* gn_y,
+                                      const float* gn_coef, int gn_act, float* gn_partial, int n, int d, int h, int w,
+                                      int cin, int cout, int algo, mednet_stream stream) {
+  int rc = conv_common_checks("conv3d_dgrad_gn", n, d, h, w, cin, cout, 3, MEDNET_BF16, MEDNET_BF16);
+  if (rc) return rc;
+  MEDNET_REQUIRE(gn_y && gn_coef && gn_partial, MEDNET_E_SHAPE, "conv3d_dgrad_gn: gn_y, gn_coef and gn_partial are required");
+  MEDNET_REQUIRE(gn_act >= MEDNET_ACT_NONE && gn_act <= MEDNET_ACT_ELU, MEDNET_E_UNSUPPORTED, "conv3d_dgrad_gn: activation %d", gn_act);
+  if (mednet_conv3d_dgrad_gn_rows(n, d, h, w, cin, cout, algo) == 0)
+    return fail(MEDNET_E_UNSUPPORTED, "conv3d_dgrad_gn: only the bf16 matrix-core path fuses the GroupNorm sums (cin=%d cout=%d)", cin, cout);
+  const PackLayout L = pack_layout(cin, cout, 3);
+  return launch_conv_mfma_gnb(dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cout, cin, add, gn_y, gn_coef, gn_act,
+                              gn_partial, (hipStream_t)stream);
+}
+
 // ---- ConvTranspose3d(k3,s2,p1,op1) ------------------------------------------------------------------------------------
 extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float* bias, const void* skip, void* y, int n,
                                   int d, int h, int w, int cin, int cout, int x_dtype, int y_dtype, int algo,

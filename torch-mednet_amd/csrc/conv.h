@@ -66,6 +66,8 @@ bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype,
 int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, int d, int h, int w, int cin, int cout,
                      int x_dtype, int y_dtype, float* gn_partial, hipStream_t s, int act = MEDNET_ACT_NONE,
                      const void* add = nullptr);
+int launch_conv_mfma_gnb(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin, int cout,
+                         const void* add, const void* gn_y, const float* gn_coef, int gn_act, float* gn_partial, hipStream_t s);
 int conv_mfma_stats_chunks(int n, int d, int h, int w, int cout);
 int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, float* Pf, float* Pb, int cin, int cout, int T,
                      int transposed_src, hipStream_t s);

@@ -72,6 +72,13 @@ struct FwdArgs {
   int stats_accum;    // 1: a wave keeps its sums over all its items of a sample and writes ONE row per sample (row =
                       //    4 * workgroup-group + wave); 0: one row per wave and brick (row = 4 * brick + wave)
   int stats_rows;     // rows per sample of gn_partial
+  // GNB instantiation (data gradient whose output dz is the input gradient of a GroupNorm + activation, components.py:57,
+  // 36-40): the first pass of that GroupNorm's backward -- du = dz * act'(ca * y + cb), sums of du and du * y per channel --
+  // is taken in the epilogue from the STORED (rounded) dz rows, so no stand-alone pass re-reads dz and y.  gn_partial then
+  // holds [n][stats_rows][cout][2] = {sum du, sum du * y} per CHANNEL (the affine gradients need single channels).
+  const bf16* gnb_y;      // conv output y of the layer in front (shape of this kernel's output)
+  const float* gnb_coef;  // [n][cout][2] = {ca, cb}: its GroupNorm's forward affine, pre-activation = ca * y + cb
+  int gnb_act;            // MEDNET_ACT_*
 #ifdef MEDNET_CONV_TIMING
   long long* dbg;  // [workgroup][16] s_memtime stamps of wave 0 (tools/probes/conv_timing.py)
 #endif
@@ -87,7 +94,7 @@ struct FwdArgs {
 #define STAMP(i) do { } while (0)
 #endif
 
-template <int STRIDE>
+template <int STRIDE, bool GNB = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   using G = FwdTile<STRIDE>;
   constexpr int TZ = G::TZ, TY = G::TY, TX = G::TX;
@@ -237,6 +244,42 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) gs[k] = gq[k] = 0.f;
   };
+  // GNB: this lane's 8 channels (piece pj = lane & 3 of the channel block), {sum du, sum du * y}
+  float bs[GNB ? 8 : 1], bq[GNB ? 8 : 1];
+#pragma unroll
+  for (int k = 0; k < (GNB ? 8 : 1); ++k) bs[k] = bq[k] = 0.f;
+  auto flush_bwd = [&](int nn, int row, int cbk) {  // sum over the 16 lanes that share a piece; lanes 0..3 write 64 bytes
+    if constexpr (GNB) {
+      float rs[8], rq[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        rs[k] = bs[k];
+        rq[k] = bq[k];
+      }
+#pragma unroll
+      for (int m = 4; m < 64; m <<= 1)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          rs[k] += __shfl_xor(rs[k], m, 64);
+          rq[k] += __shfl_xor(rq[k], m, 64);
+        }
+      const int pjl = lane & 3;
+      if (lane < 4 && cbk * 32 + pjl * 8 < a.cout) {
+        float* dst = a.gn_partial + (((size_t)nn * a.stats_rows + row) * a.cout + cbk * 32 + pjl * 8) * 2;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          const f32x4 o = {rs[k], rq[k], rs[k + 1], rq[k + 1]};
+          *reinterpret_cast<f32x4*>(dst + k * 2) = o;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) bs[k] = bq[k] = 0.f;
+    }
+  };
+  auto flush_any = [&](int nn, int row, int cbk) {
+    if constexpr (GNB) flush_bwd(nn, row, cbk);
+    else flush_stats(nn, row, cbk);
+  };
   // row of this wave in accumulate mode: workgroups that share (id >> 3) / ncb and the XCD form one row group; they differ
   // in the channel block (which is constant per workgroup when ncb divides 64: the launcher checks that)
   const int acc_row = ((((int)blockIdx.x >> 3) / a.ncb) * 8 + ((int)blockIdx.x & 7)) * 4 + wv;
@@ -363,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     // whenever the channels per group are even (the host asks for fused partials only then).
     if (a.gn_partial && a.stats_accum) {
       while (acc_n < n) {  // the sample changed: write the finished sample's row (zeros for samples this wave skipped)
-        flush_stats(acc_n, acc_row, cb);
+        flush_any(acc_n, acc_row, cb);
         ++acc_n;
       }
     }
@@ -384,6 +427,30 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     bf16x8 rows[ROUNDS];  // all LDS reads first (the accumulators' registers are free now), then the stores back to back:
 #pragma unroll            // read -> wait -> store per round exposed the LDS latency eight times
     for (int it = 0; it < ROUNDS; ++it) rows[it] = *reinterpret_cast<const bf16x8*>(rd + it * 64 * 32);
+    // GNB: the rows of y at the positions this lane stores, and the GroupNorm affine of its 8 channels (both through
+    // buffer resources: positions / channels outside the tensor read zeros), all in flight before the first use
+    bf16x8 yrow[GNB ? ROUNDS : 1];
+    float ca[GNB ? 8 : 1], cbf[GNB ? 8 : 1];
+    if constexpr (GNB) {
+      const auto rsrc_gy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_y + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
+#pragma unroll
+      for (int it = 0; it < ROUNDS; ++it) {
+        const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
+        const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
+        const unsigned soff = (unsigned)(((oz * a.oh + oyb) * a.ow + tx0) * a.cout + cb * 32) * 2u;
+        yrow[it] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_gy, ok ? vbase : OOB, soff, 0));
+      }
+      const auto rsrc_cf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_coef + (size_t)n * a.cout * 2), 0, (unsigned)a.cout * 8u, 0x00020000);
+      const unsigned coff = (unsigned)(cb * 32 + pj * 8) * 8u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 c4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_cf, coff + q * 16, 0, 0));
+        ca[2 * q] = c4[0];
+        cbf[2 * q] = c4[1];
+        ca[2 * q + 1] = c4[2];
+        cbf[2 * q + 1] = c4[3];
+      }
+    }
 #pragma unroll
     for (int it = 0; it < ROUNDS; ++it) {
       bf16x8 v = rows[it];
@@ -397,7 +464,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
         for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)ad[k]);
       }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_y, ok ? vbase : OOB, soff, 2);  // aux 2 = nt: streamed output must not push the input rows (read again by the next K chunk) out of L2
-      if (ok && a.gn_partial) {  // statistics of what is stored (the rounded values), exactly like the stand-alone pass
+      if constexpr (GNB) {
+        if (ok) {  // du = dz * act'(pre-activation) from the STORED dz, exactly what the apply pass recomputes
+          float g[8], u[8], yy[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            yy[k] = (float)yrow[it][k];
+            g[k] = (float)v[k];
+            u[k] = fmaf(ca[k], yy[k], cbf[k]);
+          }
+          act_grad_pre_n<8>(g, u, a.gnb_act);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            bs[k] += g[k];
+            bq[k] = fmaf(g[k], yy[k], bq[k]);
+          }
+        }
+      } else if (ok && a.gn_partial) {  // statistics of what is stored (the rounded values), exactly like the stand-alone pass
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const bf16x2 pr = {v[2 * k], v[2 * k + 1]};
@@ -409,12 +492,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     STAMP(13);
     // GroupNorm statistics fused into the producer (components.py:57 follows every conv of the 'c g .' orders): one row
     // per wave and brick, or -- accumulate mode -- nothing here: the sums stay in registers until the sample changes
-    if (a.gn_partial && !a.stats_accum) flush_stats(n, tis * 4 + e_wv, cb);
+    if (a.gn_partial && !a.stats_accum) flush_any(n, tis * 4 + e_wv, cb);
     STAMP(14);
     if (!has_next) {
       if (a.gn_partial && a.stats_accum) {
         while (acc_n < a.n) {  // the last sample of this wave, then zero rows for the samples after it
-          flush_stats(acc_n, acc_row, cb);
+          flush_any(acc_n, acc_row, cb);
           ++acc_n;
         }
       }
@@ -879,10 +962,16 @@ static void conv_stats_plan(int n, int d, int h, int w, int cout, int& rows, int
   rows = accum ? (512 / ncb) * 4 : 4 * tps;
 }
 
+struct GnbSpec {  // fused first pass of a GroupNorm backward (see FwdArgs::gnb_y); partial goes through gn_partial
+  const void* y = nullptr;
+  const float* coef = nullptr;
+  int act = MEDNET_ACT_NONE;
+};
+
 template <int STRIDE>
 static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, int oh, int ow, int id, int ih, int iw,
                       int cin, int cout, float* gn_partial, hipStream_t s, int act = MEDNET_ACT_NONE,
-                      const void* add = nullptr) {
+                      const void* add = nullptr, GnbSpec gnb = GnbSpec()) {
   using G = FwdTile<STRIDE>;
   constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
   constexpr size_t lds = ((size_t)2 * HZ * HY * HX + 27 * 2 * 32) * 16;
@@ -891,6 +980,12 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   a.gn_partial = gn_partial;
   a.act = act;
   a.add = (const bf16*)add;
+  a.gnb_y = (const bf16*)gnb.y;
+  a.gnb_coef = gnb.coef;
+  a.gnb_act = gnb.act;
+  const bool use_gnb = gnb.y != nullptr;
+  MEDNET_REQUIRE(!use_gnb || (STRIDE == 1 && gn_partial && gnb.coef), MEDNET_E_UNSUPPORTED,
+                 "conv_mfma: fused GroupNorm-backward sums need the stride-1 kernel, a partial buffer and the forward affine");
 #ifdef MEDNET_CONV_TIMING
   a.dbg = (long long*)(((unsigned long long)(unsigned)tuning_option("conv_dbg_hi", 0) << 32) | (unsigned)tuning_option("conv_dbg_lo", 0));
 #endif
@@ -924,6 +1019,18 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
       return fail(MEDNET_E_HIP, "conv_mfma: cannot raise dynamic LDS to %zu", lds);
     attr_set[STRIDE] = true;
   }
+  if constexpr (STRIDE == 1) {
+    if (use_gnb) {
+      static bool attr_gnb = false;
+      if (!attr_gnb) {
+        if (hipFuncSetAttribute((const void*)conv_mfma_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+          return fail(MEDNET_E_HIP, "conv_mfma: cannot raise dynamic LDS to %zu", lds);
+        attr_gnb = true;
+      }
+      hipLaunchKernelGGL((conv_mfma_kernel<1, true>), dim3(grid), dim3(256), lds, s, a);
+      return check_launch("conv_mfma(gnb)");
+    }
+  }
   hipLaunchKernelGGL((conv_mfma_kernel<STRIDE>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_mfma");
 }
@@ -933,6 +1040,15 @@ int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, 
   (void)x_dtype;
   (void)y_dtype;
   return launch_fwd<1>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, gn_partial, s, act, add);
+}
+// data gradient + the first pass of the GroupNorm backward its output feeds (gn_partial: per-channel {sum du, sum du*y})
+int launch_conv_mfma_gnb(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin, int cout,
+                         const void* add, const void* gn_y, const float* gn_coef, int gn_act, float* gn_partial, hipStream_t s) {
+  GnbSpec g;
+  g.y = gn_y;
+  g.coef = gn_coef;
+  g.act = gn_act;
+  return launch_fwd<1>(dy, packed_section, dx, n, d, h, w, d, h, w, cin, cout, gn_partial, s, MEDNET_ACT_NONE, add, g);
 }
 int conv_mfma_stats_chunks(int n, int d, int h, int w, int cout) {
   int rows, accum;

@@ -141,6 +141,28 @@ __global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __rest
   }
 }
 
+// the same for per-channel {sum du, sum du * x} rows written by the data-gradient conv's epilogue (conv_mfma GNB):
+// csum[n][c] = {sum du, sum du * xhat} with sum du * xhat = rstd * (sum du * x - mean * sum du)
+__global__ __launch_bounds__(64) void reduce_partials_dux_kernel(const float* __restrict__ partial,
+                                                                 const float* __restrict__ stats, float* __restrict__ csum,
+                                                                 int c, int groups, int chunks) {
+  const int n = blockIdx.x / c, cc = blockIdx.x % c;
+  double a = 0.0, b = 0.0;
+  for (int ch = threadIdx.x; ch < chunks; ch += 64) {
+    const float* p = partial + (((size_t)n * chunks + ch) * c + cc) * 2;
+    a += (double)p[0];
+    b += (double)p[1];
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (threadIdx.x == 0) {
+    const int g = cc / (c / groups);
+    const double mean = stats[((size_t)n * groups + g) * 2], rstd = stats[((size_t)n * groups + g) * 2 + 1];
+    csum[((size_t)n * c + cc) * 2] = (float)a;
+    csum[((size_t)n * c + cc) * 2 + 1] = (float)(rstd * (b - mean * a));
+  }
+}
+
 // one 256-thread workgroup per (n, g): its 4 waves split the group's channels, each wave sums a channel's per-chunk
 // partials (fp64, fixed order); then mean, rstd and the per-channel affine the apply kernel uses.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial,
@@ -778,6 +800,39 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
     if (rc) return rc;
   }
 #define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv)
+  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+#undef GO
+  return check_launch("gn_bwd_apply");
+}
+
+extern "C" int mednet_gn_act_bwd_fused(const void* dz, const void* x, const float* coef, const float* stats,
+                                       const float* gamma, const float* fused_partial, int rows, void* dx, float* dgamma,
+                                       float* dbeta, int n, size_t spatial, int c, int groups, int act, int dtype,
+                                       void* ws, size_t ws_bytes, mednet_stream stream) {
+  MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "gn_act_bwd_fused: bad dtype");
+  MEDNET_REQUIRE(c % groups == 0 && rows > 0 && fused_partial && coef, MEDNET_E_SHAPE, "gn_act_bwd_fused: bad arguments");
+  const int vec = pick_vec(c);
+  MEDNET_REQUIRE(c / vec <= 256, MEDNET_E_UNSUPPORTED, "gn_act_bwd_fused: C=%d unsupported", c);
+  MEDNET_REQUIRE(ws_bytes >= mednet_gn_ws_bytes(n, c, spatial), MEDNET_E_WORKSPACE, "gn_act_bwd_fused: workspace too small");
+  size_t cv;
+  unsigned chunks;
+  chunk_plan(spatial, c, vec, cv, chunks);
+  float* bcoef = (float*)ws + (size_t)n * 1024 * c * 2;
+  float* csum = bcoef + (size_t)n * c * 3;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(reduce_partials_dux_kernel, dim3(n * c), dim3(64), 0, s, fused_partial, stats, csum, c, groups, rows);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, stats, gamma, bcoef, c, groups,
+                     (double)spatial * (c / groups));
+  int rc = check_launch("gn_bwd_finalize");
+  if (rc) return rc;
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((c + 255) / 256), dim3(256), 0, s, csum, dgamma, dbeta, n, c);
+    rc = check_launch("gn_bwd_params");
+    if (rc) return rc;
+  }
+  const dim3 grid(chunks, n);
+#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)nullptr, (const T*)x, (const T*)nullptr, coef, bcoef, (T*)dx, (T*)nullptr, spatial, c, act, cv)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
   else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
 #undef GO

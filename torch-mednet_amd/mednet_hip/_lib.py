@@ -40,6 +40,9 @@ SIGNATURES = {
     "mednet_conv3d_act_supported": (_i, [_i] * 7),
     "mednet_conv3d_act_fwd": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp, _vp]),
     "mednet_conv3d_dgrad_add": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
+    "mednet_conv3d_dgrad_gn_rows": (_i, [_i] * 7),
+    "mednet_conv3d_dgrad_gn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 7 + [_vp]),
+    "mednet_gn_act_bwd_fused": (_i, [_vp] * 6 + [_i, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mednet_conv3d_wgrad_ws_bytes": (_sz, [_i] * 7),
     "mednet_conv3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp, _sz, _vp]),
     "mednet_convt3d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),

@@ -57,8 +57,9 @@ def _gn_fwd(y, partial, gamma, beta, groups, eps, act, residual):
     return z, stats, coef
 
 
-def _gn_bwd(dz, dz2, y, z, coef, stats, gamma_p, beta_p, groups, act, want_dres):
-    """Returns (dy, dres, dgamma, dbeta, direct flags)."""
+def _gn_bwd(dz, dz2, y, z, coef, stats, gamma_p, beta_p, groups, act, want_dres, partial=None):
+    """Returns (dy, dres, dgamma, dbeta).  `partial`: the first pass ({sum du, sum du*y} per channel) already taken by the
+    data-gradient kernel that produced dz (mednet_conv3d_dgrad_gn)."""
     n, c, d, h, w = y.shape
     spatial = d * h * w
     lib = L.lib()
@@ -67,6 +68,13 @@ def _gn_bwd(dz, dz2, y, z, coef, stats, gamma_p, beta_p, groups, act, want_dres)
     dgamma, dg_direct = ops._grad_target(gamma_p, (c,))
     dbeta, db_direct = ops._grad_target(beta_p, (c,))
     ws = L.workspace(lib.mednet_gn_ws_bytes(n, c, spatial), y.device)
+    if partial is not None:
+        assert dz2 is None and z is None and not want_dres
+        L.check(lib.mednet_gn_act_bwd_fused(dz.data_ptr(), y.data_ptr(), coef.data_ptr(), stats.data_ptr(), gamma_p.data_ptr(),
+                                            partial.data_ptr(), partial.shape[1], dy.data_ptr(), dgamma.data_ptr(),
+                                            dbeta.data_ptr(), n, spatial, c, groups, act, L.dt(y), ws.data_ptr(), ws.numel(),
+                                            L.stream()), "gn_act_bwd_fused")
+        return dy, None, (None if dg_direct else dgamma), (None if db_direct else dbeta)
     L.check(lib.mednet_gn_act_bwd(dz.data_ptr(), L.ptr(dz2), y.data_ptr(), L.ptr(z), coef.data_ptr(), stats.data_ptr(),
                                   gamma_p.data_ptr(), dy.data_ptr(), L.ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n,
                                   spatial, c, groups, act, L.dt(y), ws.data_ptr(), ws.numel(), L.stream()), "gn_act_bwd")
@@ -76,21 +84,37 @@ def _gn_bwd(dz, dz2, y, z, coef, stats, gamma_p, beta_p, groups, act, want_dres)
 FUSE_DRES = os.environ.get("MEDNET_FUSE_DRES", "1") == "1"  # A/B knob: residual gradient summed in conv2's data gradient
 
 
-def _conv_bwd(x, dy, packed, weight_p, need_dx, add=None):
+FUSE_GNB = os.environ.get("MEDNET_FUSE_GNB", "1") == "1"  # A/B knob: GroupNorm-backward sums in the data-gradient epilogue
+
+
+def _conv_bwd(x, dy, packed, weight_p, need_dx, add=None, gnb=None):
     """Weight gradient (side stream in trainer mode) + data gradient (+ `add`, a second gradient of x, summed in the
-    data-gradient kernel's epilogue when given).  Returns (dx, dw-or-None)."""
+    data-gradient kernel's epilogue when given).  `gnb` = (y_prev, coef_prev, act): x is act(GroupNorm(y_prev)); when the
+    kernel can, it also takes the first pass of that GroupNorm's backward over the dx it stores.
+    Returns (dx, dw-or-None, partial-or-None)."""
     n, cin, d, h, w = x.shape
     cout = dy.shape[1]
     lib = L.lib()
     # data gradient first (critical path), THEN the weight gradient on the side stream: queued behind the data gradient it
     # overlaps the next GroupNorm backward (HBM-bound) instead of fighting the data gradient for the matrix cores
     dx = None
+    partial = None
 
     def dgrad():
-        nonlocal dx
+        nonlocal dx, partial
         if need_dx:
             dx = ops.empty_cl(n, cin, d, h, w, x.dtype if x.dtype in (torch.float32, torch.bfloat16) else config.act_dtype(), dy.device)
-            if add is not None:
+            rows = 0
+            if gnb is not None and FUSE_GNB and dy.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16 \
+                    and (add is None or add.dtype == torch.bfloat16):
+                rows = lib.mednet_conv3d_dgrad_gn_rows(n, d, h, w, cin, cout, config.conv_algo())
+            if rows > 0:
+                y_prev, coef_prev, act_prev = gnb
+                partial = torch.empty((n, rows, cin, 2), dtype=torch.float32, device=dy.device)
+                L.check(lib.mednet_conv3d_dgrad_gn(dy.data_ptr(), packed.data_ptr(), L.ptr(add), dx.data_ptr(), y_prev.data_ptr(),
+                                                   coef_prev.data_ptr(), act_prev, partial.data_ptr(), n, d, h, w, cin, cout,
+                                                   config.conv_algo(), L.stream()), "conv3d_dgrad_gn")
+            elif add is not None:
                 L.check(lib.mednet_conv3d_dgrad_add(dy.data_ptr(), packed.data_ptr(), add.data_ptr(), dx.data_ptr(), n, d, h, w,
                                                     cin, cout, config.conv_algo(), L.stream()), "conv3d_dgrad_add")
             else:
@@ -108,7 +132,7 @@ def _conv_bwd(x, dy, packed, weight_p, need_dx, add=None):
                 "conv3d_wgrad")
     if WGRAD_FIRST:
         dgrad()
-    return dx, (None if direct else dw)
+    return dx, (None if direct else dw), partial
 
 
 class ResBlockFn(Function):
@@ -138,16 +162,16 @@ class ResBlockFn(Function):
         dout = ops.to_cl(dout.to(out.dtype))
         # GN3 + residual + activation: act' from the block output; dres = gradient of the residual branch (into z1)
         dy3, dres, dg3, db3 = _gn_bwd(dout, None, y3, out, c3, s3, g3, b3, groups, act, True)
-        dz2, dw3 = _conv_bwd(z2, dy3, pk3, w3, True)
-        dy2, _, dg2, db2 = _gn_bwd(dz2, None, y2, None, c2, s2, g2, b2, groups, act, False)
+        dz2, dw3, part2 = _conv_bwd(z2, dy3, pk3, w3, True, gnb=(y2, c2, act))
+        dy2, _, dg2, db2 = _gn_bwd(dz2, None, y2, None, c2, s2, g2, b2, groups, act, False, partial=part2)
         # z1 feeds conv2 AND the residual add: the two gradients are summed in the epilogue of conv2's data gradient (bf16
         # matrix-core path), otherwise inside GroupNorm-1's backward (two more tensor reads)
         n_, c_, d_, h_, w_ = z1.shape
         fuse = FUSE_DRES and dy2.dtype == torch.bfloat16 and dres.dtype == torch.bfloat16 and bool(
             L.lib().mednet_conv3d_act_supported(n_, d_, h_, w_, c_, c_, config.conv_algo()))
-        dz1, dw2 = _conv_bwd(z1, dy2, pk2, w2, True, add=dres if fuse else None)
-        dy1, _, dg1, db1 = _gn_bwd(dz1, None if fuse else dres, y1, None, c1, s1, g1, b1, groups, act, False)
-        dx, dw1 = _conv_bwd(xin, dy1, pk1, w1, ctx.needs_input_grad[0])
+        dz1, dw2, part1 = _conv_bwd(z1, dy2, pk2, w2, True, add=dres if fuse else None, gnb=(y1, c1, act) if fuse else None)
+        dy1, _, dg1, db1 = _gn_bwd(dz1, None if fuse else dres, y1, None, c1, s1, g1, b1, groups, act, False, partial=part1)
+        dx, dw1, _ = _conv_bwd(xin, dy1, pk1, w1, ctx.needs_input_grad[0])
         return (dx, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + (None,) * 6
 
 

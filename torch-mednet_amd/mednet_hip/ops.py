@@ -247,7 +247,7 @@ class ConvActFn(Function):
         du = torch.empty_like(z, memory_format=CL)
         L.check(L.lib().mednet_act_bwd(dz.data_ptr(), z.data_ptr(), du.data_ptr(), z.numel(), ctx.act, L.dt(z), L.stream()),
                 "act_bwd")
-        dx, dw = block._conv_bwd(xin, du, packed, ctx.weight, ctx.needs_input_grad[0])
+        dx, dw, _ = block._conv_bwd(xin, du, packed, ctx.weight, ctx.needs_input_grad[0])
         return dx, dw, None, None, None
 
 
