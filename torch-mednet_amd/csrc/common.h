@@ -172,16 +172,71 @@ __device__ __forceinline__ void act_grad_pre_n(float* g, const float* u, int act
   }
 }
 
-// ---- reductions: wave64 shuffles, then LDS across the waves of a workgroup ----------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// ---- reductions.  Cross-lane steps are DPP / v_permlane*_swap (plain VALU), NOT __shfl_xor: hipcc lowers that to
+//      ds_bpermute_b32, an LDS-queue instruction, and a young wave's LDS requests starve while an older LDS-saturating
+//      kernel shares the CU.  Measured (tools/probes/coresidency_probe.py): next to the persistent weight-gradient kernel on
+//      the side stream, a 32-workgroup kernel with ds_bpermute shuffles took 300-430 us (it ended when the weight gradient
+//      did) against 8 us with none; every reduce / finalize kernel of the GroupNorm backward sat on the critical path.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {  // CTRL: quad_perm 0x00-0xFF, row_ror:n 0x120+n (within 16-lane rows)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// v(l) + v(l ^ 16) / v(l) + v(l ^ 32) in every lane.  v_permlane16_swap / v_permlane32_swap exchange, IN PLACE between their
+// two registers, the odd rows / upper half of the first with the even rows / lower half of the second; fed the value and
+// a copy of it, the first register ends up holding the even rows' (lower half's) values in both places and the second the
+// odd rows' (upper half's).  Inline asm, not the builtin: given two copies of one value, hipcc (ROCm 7.2) folded the
+// builtin's two results into one register and returned 2 * v (tools/probes/wave_sum_probe.hip).  The two v_nop are the
+// wait states a VALU write of either operand needs before the swap reads it (LLVM gfx950 hazard rule; nothing is padded
+// inside an asm string).
+#define MEDNET_SWAP_PAIR(INSN, lo_, hi_) asm volatile("v_nop\n\tv_nop\n\t" INSN " %0, %1" : "+v"(lo_), "+v"(hi_))
+__device__ __forceinline__ float xor16_sum(float v) {
+  float a = v, b = v;
+  MEDNET_SWAP_PAIR("v_permlane16_swap_b32", a, b);
+  return a + b;
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  float a = v, b = v;
+  MEDNET_SWAP_PAIR("v_permlane32_swap_b32", a, b);
+  return a + b;
+}
+__device__ __forceinline__ double xor16_sum(double v) {
+  int alo = __double2loint(v), ahi = __double2hiint(v), blo = alo, bhi = ahi;
+  MEDNET_SWAP_PAIR("v_permlane16_swap_b32", alo, blo);
+  MEDNET_SWAP_PAIR("v_permlane16_swap_b32", ahi, bhi);
+  return __hiloint2double(ahi, alo) + __hiloint2double(bhi, blo);
+}
+__device__ __forceinline__ double xor32_sum(double v) {
+  int alo = __double2loint(v), ahi = __double2hiint(v), blo = alo, bhi = ahi;
+  MEDNET_SWAP_PAIR("v_permlane32_swap_b32", alo, blo);
+  MEDNET_SWAP_PAIR("v_permlane32_swap_b32", ahi, bhi);
+  return __hiloint2double(ahi, alo) + __hiloint2double(bhi, blo);
+}
+// Sum over the lanes that agree in (lane % STRIDE), STRIDE a power of two <= 64; result in every lane of the class.
+// (STRIDE = 1: the whole wave.)  Must be called with all 64 lanes active.
+template <int STRIDE>
+__device__ __forceinline__ float lane_class_sum(float v) {
+  if (STRIDE <= 1) v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  if (STRIDE <= 2) v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  if (STRIDE <= 4) v += dpp_f32<0x124>(v);  // row_ror:4  } together: the four quads of a 16-lane row
+  if (STRIDE <= 8) v += dpp_f32<0x128>(v);  // row_ror:8  }
+  if (STRIDE <= 16) v = xor16_sum(v);
+  if (STRIDE <= 32) v = xor32_sum(v);
   return v;
 }
+__device__ __forceinline__ float wave_sum(float v) { return lane_class_sum<1>(v); }
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x124>(v);
+  v += dpp_f64<0x128>(v);
+  v = xor16_sum(v);
+  return xor32_sum(v);
 }
 // Sum over a workgroup of NW waves; result valid in every thread. `scratch` holds >= NW floats.
 template <int NW>

@@ -226,12 +226,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       rq[k] = gq[k];
     }
 #pragma unroll
-    for (int m = 4; m < 64; m <<= 1)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        rs[k] += __shfl_xor(rs[k], m, 64);
-        rq[k] += __shfl_xor(rq[k], m, 64);
-      }
+    for (int k = 0; k < 4; ++k) {  // the 16 lanes with the same piece (lane & 3): DPP / permlane, no LDS-queue shuffles
+      rs[k] = lane_class_sum<4>(rs[k]);
+      rq[k] = lane_class_sum<4>(rq[k]);
+    }
     const int pjl = lane & 3;
     if (lane < 4 && cbk * 32 + pjl * 8 < a.cout) {
       float* dst = a.gn_partial + (((size_t)nn * a.stats_rows + row) * a.cout + cbk * 32 + pjl * 8) * 2;
@@ -257,12 +255,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
         rq[k] = bq[k];
       }
 #pragma unroll
-      for (int m = 4; m < 64; m <<= 1)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          rs[k] += __shfl_xor(rs[k], m, 64);
-          rq[k] += __shfl_xor(rq[k], m, 64);
-        }
+      for (int k = 0; k < 8; ++k) {
+        rs[k] = lane_class_sum<4>(rs[k]);
+        rq[k] = lane_class_sum<4>(rq[k]);
+      }
       const int pjl = lane & 3;
       if (lane < 4 && cbk * 32 + pjl * 8 < a.cout) {
         float* dst = a.gn_partial + (((size_t)nn * a.stats_rows + row) * a.cout + cbk * 32 + pjl * 8) * 2;

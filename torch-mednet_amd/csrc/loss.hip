@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__
     if (k < c) {
       const float w = weight ? weight[k] : 1.f;
       const float I = saved[2 * k], D = saved[2 * k + 1];
-      const float Dc = fmaxf(D, eps);
-      gI[k] = -2.f * w / ((float)c * Dc) * go;
+      const float Dc = fmaxf(D, eps);  // (fmaxf drops a NaN: the poison of an out-of-range label is re-applied below)
+      gI[k] = -2.f * w / ((float)c * Dc) * go + ((I != I || D != D) ? __builtin_nanf("") : 0.f);
       gD[k] = (D >= eps ? 2.f * w * I / ((float)c * Dc * Dc) : 0.f) * go;
     }
   const size_t v0 = (size_t)blockIdx.x * LOSS_BLOCK_VOX;

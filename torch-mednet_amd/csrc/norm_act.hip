@@ -81,6 +81,45 @@ __device__ __forceinline__ void column_reduce(const float* vals, int cols, int r
   }
 }
 
+// The same without LDS (see common.h, "reductions": a kernel that touches the LDS queue stalls next to the weight-gradient
+// kernel on the side stream): possible when the column count is a power of two <= 64 (then the threads of a wave that share
+// a column are the lanes with equal lane % cols: DPP / permlane sums) or a multiple of 64 (a wave's lanes are distinct
+// columns).  Each WAVE writes its own partial row, so a workgroup yields rows_per_wg(cols) rows instead of one.
+static inline int lds_free_rows_per_wg(int cols) {
+  if (cols <= 64) return (cols & (cols - 1)) == 0 ? 4 : 0;  // 0: not applicable, use column_reduce
+  return cols % 64 == 0 && 256 % cols == 0 ? 256 / cols : 0;
+}
+template <int NVAL>
+__device__ __forceinline__ void column_reduce_lds_free(float* vals, int cols, int col, bool active, float* out_rows, int c2) {
+  // out_rows: first of this workgroup's rows (row stride c2 = 2 * C floats); a thread's NVAL values are consecutive in a row
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (cols <= 64) {
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k) {
+      float v = active ? vals[k] : 0.f;
+      switch (cols) {
+        case 1: v = lane_class_sum<1>(v); break;
+        case 2: v = lane_class_sum<2>(v); break;
+        case 4: v = lane_class_sum<4>(v); break;
+        case 8: v = lane_class_sum<8>(v); break;
+        case 16: v = lane_class_sum<16>(v); break;
+        case 32: v = lane_class_sum<32>(v); break;
+        default: break;
+      }
+      vals[k] = v;
+    }
+    if (lane < cols) {
+      float* o = out_rows + (size_t)wv * c2 + (size_t)lane * NVAL;
+#pragma unroll
+      for (int k = 0; k < NVAL; ++k) o[k] = vals[k];
+    }
+  } else if (active) {
+    float* o = out_rows + (size_t)(threadIdx.x / cols) * c2 + (size_t)col * NVAL;
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k) o[k] = vals[k];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- GN statistics
 // partial[n][chunk][c][2] = {sum x, sum x^2}
 template <typename T, int VEC>
@@ -293,7 +332,7 @@ __global__ __launch_bounds__(256, GN_WAVES) void gn_bwd_partial_kernel(const T* 
                                                              const float* __restrict__ coef,
                                                              const float* __restrict__ stats,
                                                              float* __restrict__ partial, size_t spatial, int c,
-                                                             int groups, int act, size_t chunk_vox) {
+                                                             int groups, int act, size_t chunk_vox, int rpw) {
   __shared__ float lds[256 * 2 * VEC];
   const Cols<VEC> L(c);
   const int n = blockIdx.y;
@@ -344,6 +383,11 @@ __global__ __launch_bounds__(256, GN_WAVES) void gn_bwd_partial_kernel(const T* 
       one(off + (v + L.rows) * c);
     }
     for (; v < v1; v += L.rows) one(off + v * c);
+  }
+  if (rpw > 0) {  // rpw rows per workgroup, no LDS
+    float* out = partial + ((size_t)n * gridDim.x + blockIdx.x) * rpw * c * 2;
+    column_reduce_lds_free<2 * VEC>(acc, L.cols, L.col, L.active, out, c * 2);
+    return;
   }
   float* out = partial + ((size_t)n * gridDim.x + blockIdx.x) * c * 2;
   column_reduce<2 * VEC>(acc, L.cols, L.rows, L.col, L.row, L.active, lds, out);
@@ -700,11 +744,18 @@ static inline unsigned flat_grid(size_t count, size_t per_block) {
   return (unsigned)b;
 }
 static inline int pick_vec(int c) { return (c % 8 == 0 && c / 8 <= 256) ? 8 : 1; }
+// upper bound of the partial rows per sample any GroupNorm pass writes for C channels (chunks <= 1024)
+static inline size_t gn_partial_rows_max(int c) {
+  const int vec = pick_vec(c), cols = c / vec;
+  const int rpw = cols <= 256 ? lds_free_rows_per_wg(cols) : 0;
+  return (size_t)1024 * (rpw > 1 ? rpw : 1);
+}
 
 extern "C" size_t mednet_gn_ws_bytes(int n, int c, size_t spatial) {
+  // partial[n][rows][c][2] (rows = chunks, or 4 * chunks / (256 / cols) * chunks for the LDS-free backward pass)
+  //   + bcoef[n][c][3] + csum[n][c][2]; the small arrays sit behind a fixed-size partial region
   (void)spatial;
-  // partial[n][<=1024 chunks][c][2] + bcoef[n][c][3] + csum[n][c][2]
-  return ((size_t)n * 1024 * c * 2 + (size_t)n * c * 5 + 64) * sizeof(float);
+  return ((size_t)n * gn_partial_rows_max(c) * c * 2 + (size_t)n * c * 5 + 64) * sizeof(float);
 }
 
 extern "C" int mednet_gn_stats(const void* x, const float* gamma, const float* beta, float* stats, float* coef,
@@ -779,17 +830,18 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
   unsigned chunks;
   chunk_plan(spatial, c, vec, cv, chunks);
   float* partial = (float*)ws;
-  float* bcoef = partial + (size_t)n * 1024 * c * 2;
+  float* bcoef = partial + (size_t)n * gn_partial_rows_max(c) * c * 2;
   float* csum = bcoef + (size_t)n * c * 3;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(chunks, n);
-#define GO(T, V) hipLaunchKernelGGL((gn_bwd_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, coef, stats, partial, spatial, c, groups, act, cv)
+  const int rpw = tuning_option("gn_lds_free", 1) ? lds_free_rows_per_wg(c / vec) : 0;
+#define GO(T, V) hipLaunchKernelGGL((gn_bwd_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, coef, stats, partial, spatial, c, groups, act, cv, rpw)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
   else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
 #undef GO
   int rc = check_launch("gn_bwd_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n * c), dim3(64), 0, s, partial, csum, c, (int)chunks);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n * c), dim3(64), 0, s, partial, csum, c, (int)chunks * (rpw > 0 ? rpw : 1));
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, stats, gamma, bcoef, c, groups,
                      (double)spatial * (c / groups));
   rc = check_launch("gn_bwd_finalize");
@@ -818,7 +870,7 @@ extern "C" int mednet_gn_act_bwd_fused(const void* dz, const void* x, const floa
   size_t cv;
   unsigned chunks;
   chunk_plan(spatial, c, vec, cv, chunks);
-  float* bcoef = (float*)ws + (size_t)n * 1024 * c * 2;
+  float* bcoef = (float*)ws + (size_t)n * gn_partial_rows_max(c) * c * 2;
   float* csum = bcoef + (size_t)n * c * 3;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(reduce_partials_dux_kernel, dim3(n * c), dim3(64), 0, s, fused_partial, stats, csum, c, groups, rows);
