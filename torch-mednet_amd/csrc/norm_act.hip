@@ -873,12 +873,16 @@ extern "C" int mednet_gn_act_bwd_fused(const void* dz, const void* x, const floa
   float* bcoef = (float*)ws + (size_t)n * gn_partial_rows_max(c) * c * 2;
   float* csum = bcoef + (size_t)n * c * 3;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(reduce_partials_dux_kernel, dim3(n * c), dim3(64), 0, s, fused_partial, stats, csum, c, groups, rows);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, stats, gamma, bcoef, c, groups,
-                     (double)spatial * (c / groups));
+  const int skip = tuning_option("gn_bwd_skip", 0);  // timing probes only (tools/probes/stall_probe.py): bit k drops sub-kernel k
+  if (!(skip & 1))
+    hipLaunchKernelGGL(reduce_partials_dux_kernel, dim3(n * c), dim3(64), 0, s, fused_partial, stats, csum, c, groups, rows);
+  if (!(skip & 2))
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, stats, gamma, bcoef, c, groups,
+                       (double)spatial * (c / groups));
   int rc = check_launch("gn_bwd_finalize");
   if (rc) return rc;
-  if (dgamma || dbeta) {
+  if (skip & 8) return MEDNET_OK;
+  if ((dgamma || dbeta) && !(skip & 4)) {
     hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((c + 255) / 256), dim3(256), 0, s, csum, dgamma, dbeta, n, c);
     rc = check_launch("gn_bwd_params");
     if (rc) return rc;
