@@ -362,6 +362,23 @@ def test_unet3d_bf16_gradients_once_discrete_decisions_are_equalised(tag, golden
     assert total <= NET_TOL_BF16_CONCAT, total
 
 
+def test_frozen_checkpoint_model_predicts_like_the_oracle(tmp_path):
+    """Row N4 (examples/predict.py:47-50,77-87): a PL-0.9-shaped checkpoint -> `load_from_checkpoint` -> `freeze()` ->
+    `.to(device)`, `eval`, `no_grad` forward; logits within the fp32-mode tolerance of the oracle that wrote the weights."""
+    from test_host_logic import _pl09_checkpoint, _segmentation_net_like_the_reference
+    path = tmp_path / "epoch=3.ckpt"
+    ora, hp = _pl09_checkpoint(path, [8, 16])
+    model = _segmentation_net_like_the_reference().load_from_checkpoint(str(path))
+    model.freeze()
+    x = O.synthetic_batch(2, 1, (16, 24, 32), 2, 0, seed=3)["data"].float()
+    with mednet_hip.precision("fp32"), torch.no_grad():
+        model = model.to(DEV)
+        model.eval()
+        lg = model(x.to(DEV))
+    assert not lg.requires_grad
+    assert_close(lg, ora(x), 1e-3, "logits of the frozen checkpoint model")
+
+
 def test_training_steps_track_oracle(golden_dir):
     """segmentation.py:58-65 + :119-120: three Adam steps on cfg1; parameters must track the oracle's."""
     ctor = dict(in_channels=1, out_channels=2, final_sigmoid=False, f_maps=[8])

@@ -126,6 +126,60 @@ def test_overlay_keeps_the_rest_of_the_reference_package_importable(tmp_path):
     assert out.returncode == 0 and "overlay ok" in out.stdout, out.stderr[-2000:]
 
 
+def _pl09_checkpoint(path, fmaps):
+    """A checkpoint shaped like pytorch_lightning 0.9.0 writes it for the reference's SegmentationNet (train_seg.py:118-132):
+    the oracle's weights (= the reference's state_dict keys) plus PL's bookkeeping keys."""
+    import argparse
+    hp = dict(in_channels=1, out_channels=2, fmaps=fmaps, learning_rate=1e-3, num_workers=0, batch_size=2, loss="DICE",
+              loss_weight=[0.05, 1.0])
+    ora = O.keyed_init_(O.ResidualUNet3D(1, 2, False, f_maps=fmaps))
+    sd = ora.state_dict()
+    sd["loss.weight"] = torch.tensor(hp["loss_weight"])  # DiceLoss registers its weight as a buffer (loss.py:99)
+    torch.save({"epoch": 3, "global_step": 120, "pytorch-lightning_version": "0.9.0", "state_dict": sd,
+                "optimizer_states": [{"state": {}, "param_groups": [{"lr": 1e-3}]}], "lr_schedulers": [],
+                "hparams_name": "hparams", "hyper_parameters": hp, "checkpoint_callback_best_model_score": 0.5}, path)
+    return ora, argparse.Namespace(**hp)
+
+
+def _segmentation_net_like_the_reference():
+    """The constructor contract of midasmednet/segmentation.py:22-49 on top of the product model (a stub of the caller, not
+    its file): hparams object in, ResidualUNet3D.__init__(in, out, final_sigmoid=False, f_maps=hparams.fmaps), loss chosen
+    from hparams."""
+    class SegmentationNet(HM.ResidualUNet3D):
+        def __init__(self, hparams, training_dataset=None, validation_dataset=None):
+            super().__init__(hparams.in_channels, hparams.out_channels, final_sigmoid=False, f_maps=hparams.fmaps)
+            self.hparams = hparams
+            self.learning_rate = hparams.learning_rate
+            self.loss = HL.DiceLoss(weight=torch.tensor(hparams.loss_weight))
+    return SegmentationNet
+
+
+def test_pl_checkpoint_interchange_and_freeze(tmp_path):
+    """examples/predict.py:47-50: `SegmentationNet.load_from_checkpoint(path)`; `model.freeze()` on a PL-0.9-shaped
+    checkpoint, with pytorch_lightning absent (the product model then supplies both with PL's semantics)."""
+    path = tmp_path / "epoch=3.ckpt"
+    ora, hp = _pl09_checkpoint(path, [8, 16])
+    Net = _segmentation_net_like_the_reference()
+    model = Net.load_from_checkpoint(str(path))
+    assert isinstance(model, HM.ResidualUNet3D) and vars(model.hparams) == vars(hp)
+    for (k, a), (k2, b) in zip(model.state_dict().items(), {**ora.state_dict(), "loss.weight": torch.tensor(hp.loss_weight)}.items()):
+        assert k == k2 and torch.equal(a, b), k
+    assert model.training
+    model.freeze()
+    assert not model.training and all(not p.requires_grad for p in model.parameters())
+    model.unfreeze()
+    assert model.training and all(p.requires_grad for p in model.parameters())
+    # a checkpoint whose state_dict does not fit must fail loudly (strict load), as in PL
+    bad = torch.load(path, weights_only=False)
+    bad["state_dict"].pop("final_conv.bias")
+    torch.save(bad, tmp_path / "bad.ckpt")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        Net.load_from_checkpoint(str(tmp_path / "bad.ckpt"))
+    # the product's own checkpoint loads back into the oracle (= the reference's module tree)
+    ora2 = O.ResidualUNet3D(1, 2, False, f_maps=[8, 16])
+    ora2.load_state_dict({k: v for k, v in model.state_dict().items() if not k.startswith("loss.")})
+
+
 def test_no_cpu_fallback():
     net = HM.ResidualUNet3D(1, 2, False, f_maps=[8])
     with pytest.raises(RuntimeError, match="no CPU fallback"):

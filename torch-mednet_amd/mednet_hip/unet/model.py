@@ -32,7 +32,52 @@ class _Softmax1(nn.Module):
         return torch.softmax(x, dim=1)
 
 
-class _UNetCore(_Base):
+class _CheckpointCompat:
+    """What the reference's callers use from pl.LightningModule besides nn.Module when pytorch_lightning is NOT installed
+    (it is only the base class, model.py:11,113): `load_from_checkpoint` and `freeze` / `unfreeze` (examples/predict.py:
+    47-50), with PL 0.9's semantics -- the class is rebuilt from the checkpoint's `hyper_parameters` (passed as the
+    constructor argument named by `hparams_name`, as an argparse.Namespace) and `state_dict` is loaded strictly."""
+
+    CHECKPOINT_HYPER_PARAMS_KEY = "hyper_parameters"
+    CHECKPOINT_HYPER_PARAMS_NAME = "hparams_name"
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, *args, map_location=None, **kwargs):
+        import argparse
+        import inspect
+        ckpt = torch.load(checkpoint_path, map_location=map_location if map_location is not None else "cpu",
+                          weights_only=False)
+        init_args = inspect.getfullargspec(cls.__init__).args[1:]
+        hp = ckpt.get(cls.CHECKPOINT_HYPER_PARAMS_KEY, ckpt.get("hparams"))
+        if hp is not None:
+            hp = dict(vars(hp)) if isinstance(hp, argparse.Namespace) else dict(hp)
+            hp.update(kwargs)
+            name = ckpt.get(cls.CHECKPOINT_HYPER_PARAMS_NAME)
+            if name is None and "hparams" in init_args:
+                name = "hparams"
+            if name == "kwargs" or name is None:
+                kwargs = {k: v for k, v in hp.items() if k in init_args} if name is None else hp
+            else:
+                kwargs = {name: argparse.Namespace(**hp)}
+        model = cls(*args, **kwargs)
+        model.load_state_dict(ckpt["state_dict"])
+        hook = getattr(model, "on_load_checkpoint", None)
+        if callable(hook):
+            hook(ckpt)
+        return model
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad = False
+        self.eval()
+
+    def unfreeze(self):
+        for p in self.parameters():
+            p.requires_grad = True
+        self.train()
+
+
+class _UNetCore(*((_Base,) if _Base is not nn.Module else (_CheckpointCompat, nn.Module))):
     def _assemble(self, in_channels, out_channels, f_maps, order, num_groups, block, default_levels):
         if isinstance(f_maps, int):
             f_maps = create_feature_maps(f_maps, number_of_fmaps=default_levels)
