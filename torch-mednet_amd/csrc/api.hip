@@ -123,6 +123,10 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
     return launch_conv_c1_mfma(x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, gn_partial, s);
   MEDNET_REQUIRE(gn_partial == nullptr, MEDNET_E_UNSUPPORTED,
                  "conv3d_fwd: fused GroupNorm partials are only produced by the MFMA paths (ask mednet_conv3d_fused_stats_chunks)");
+  // fp32 storage (the 1e-3 parity mode): 3x3x3 forward / data gradient on the fp32 matrix-core instruction
+  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32 &&
+      (x_layout == MEDNET_NDHWC || cin == 1) && y_layout == MEDNET_NDHWC)
+    return launch_conv_f32_mfma(x, (const float*)(base + (dgrad ? L.f32_bwd : L.f32_fwd)), bias, y, n, d, h, w, cin, cout, s);
   // 1x1x1 head forward (channels-last features -> planar fp32 logits): the packed backward image Pb[t=0][co][ci] = W[m][k]
   if (!dgrad && algo != MEDNET_ALGO_DIRECT && ksize == 1 && x_layout == MEDNET_NDHWC && y_layout == MEDNET_NCDHW &&
       y_dtype == MEDNET_F32 && head_vox_supported(cin))
@@ -143,7 +147,9 @@ extern "C" size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int c
   const size_t b = wgrad_mfma_ws_bytes(n, d, h, w, cin, cout, ksize);
   const size_t c1 = cin == 1 ? wgrad_c1_ws_bytes(n, d, h, w, cout) : 0;
   const size_t c2 = ksize == 1 ? wgrad_1x1_ws_bytes(n, (size_t)d * h * w, cin, cout) : 0;
+  const size_t f = ksize == 3 ? wgrad_f32_mfma_ws_bytes(n, d, h, w, cout, cin, 0) : 0;
   size_t m = a > b ? a : b;
+  if (f > m) m = f;
   if (c1 > m) m = c1;
   if (c2 > m) m = c2;
   // the bias-gradient partials live behind the weight-gradient partials
@@ -168,6 +174,9 @@ extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, flo
     return launch_wgrad_c1(x, dy, dw, n, d, h, w, cout, x_dtype, dy_dtype, ws, ws_bytes, s);
   if (algo != MEDNET_ALGO_DIRECT && wgrad_1x1_supported(cin, cout, ksize, x_layout, dy_layout, dy_dtype))
     return launch_wgrad_1x1(x, dy, dw, n, (size_t)d * h * w, cin, cout, x_dtype, ws, ws_bytes, s);
+  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32 &&
+      (x_layout == MEDNET_NDHWC || cin == 1) && dy_layout == MEDNET_NDHWC)
+    return launch_wgrad_f32_mfma(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
   const bool mfma_ok = wgrad_mfma_supported(cin, cout, ksize, x_dtype, dy_dtype, x_layout, dy_layout) &&
                        wgrad_mfma_fits(n, d, h, w, cin > cout ? cin : cout, 1);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
@@ -244,6 +253,9 @@ extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
     return launch_convt_fwd_mfma(x, (const char*)packed + L.mfma_fwd, bias, skip, y, n, d, h, w, cin, cout,
                                  (hipStream_t)stream);
+  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32)
+    return launch_convt_fwd_f32_mfma(x, (const float*)((const char*)packed + L.f32_fwd), bias, skip, y, n, d, h, w, cin, cout,
+                                     (hipStream_t)stream);
   ConvGeom g;
   g.n = n; g.od = 2 * d; g.oh = 2 * h; g.ow = 2 * w; g.id = d; g.ih = h; g.iw = w;
   g.k = cin; g.m = cout; g.ks = 3; g.in_planar = 0; g.out_planar = 0;
@@ -262,6 +274,9 @@ extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_dgrad: MFMA path does not take cin=%d cout=%d", cin, cout);
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
     return launch_convt_dgrad_mfma(dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cin, cout, (hipStream_t)stream);
+  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && dy_dtype == MEDNET_F32 && dx_dtype == MEDNET_F32)
+    return launch_convt_dgrad_f32_mfma(dy, (const float*)((const char*)packed + L.f32_bwd), dx, n, d, h, w, cin, cout,
+                                       (hipStream_t)stream);
   ConvGeom g;
   g.n = n; g.od = d; g.oh = h; g.ow = w; g.id = 2 * d; g.ih = 2 * h; g.iw = 2 * w;
   g.k = cout; g.m = cin; g.ks = 3; g.in_planar = 0; g.out_planar = 0;
@@ -271,7 +286,9 @@ extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx
 
 extern "C" size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
   const size_t a = wgrad_direct_ws_bytes((size_t)n * d * h * w, cin, cout, 3);
-  const size_t b = convt_wgrad_mfma_ws_bytes(n, d, h, w, cin, cout);
+  size_t b = convt_wgrad_mfma_ws_bytes(n, d, h, w, cin, cout);
+  const size_t f = wgrad_f32_mfma_ws_bytes(n, d, h, w, cin, cout, 1);
+  if (f > b) b = f;
   return align_up(a > b ? a : b, 256) + channel_sum_ws_bytes(n, (size_t)8 * d * h * w, cout) + 256;
 }
 
@@ -289,6 +306,8 @@ extern "C" int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, fl
     if (rc) return rc;
     ws_bytes = (ws_bytes - need) / 256 * 256;
   }
+  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32)
+    return launch_convt_wgrad_f32_mfma(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
   const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_BF16 &&
                        wgrad_mfma_fits(n, d, h, w, cin > 8 * cout ? cin : 8 * cout, 1);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)

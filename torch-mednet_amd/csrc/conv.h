@@ -88,4 +88,18 @@ size_t convt_wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout);
 int launch_convt_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout,
                             void* ws, size_t ws_bytes, hipStream_t s);
 
+// fp32 matrix-core kernels (v_mfma_f32_32x32x2_f32), conv_f32_mfma.hip: the parity mode's 3x3x3 family
+bool conv_f32_mfma_enabled();
+int launch_conv_f32_mfma(const void* x, const float* P, const float* bias, void* y, int n, int d, int h, int w, int k, int m,
+                         hipStream_t s);
+int launch_convt_dgrad_f32_mfma(const void* dy, const float* Pb, void* dx, int n, int d, int h, int w, int cin, int cout,
+                                hipStream_t s);
+int launch_convt_fwd_f32_mfma(const void* x, const float* Pf, const float* bias, const void* skip, void* y, int n, int d, int h,
+                              int w, int cin, int cout, hipStream_t s);
+size_t wgrad_f32_mfma_ws_bytes(int n, int d, int h, int w, int ka, int kb, int stride2);
+int launch_wgrad_f32_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, void* ws,
+                          size_t ws_bytes, hipStream_t s);
+int launch_convt_wgrad_f32_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, void* ws,
+                                size_t ws_bytes, hipStream_t s);
+
 }  // namespace mednet
