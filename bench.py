@@ -25,7 +25,7 @@ for p in (ROOT, os.path.join(ROOT, "torch-mednet_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense peaks, MI355X_MICROARCH.md
 F_MAPS = [32, 64, 128, 256]
 FLOP_PER_PATCH = 3447.9e9  # 6 x forward conv/convT MACs of ResidualUNet3D cfg2 at 128^3
 
@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="patches per GPU per step (config 2: 4)")
     ap.add_argument("--patch", type=int, default=128)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp16"])
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fp32-steps", type=int, default=3,

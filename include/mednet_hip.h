@@ -48,6 +48,10 @@ int mednet_set_option(const char* name, int value);
 /* Weight packing: PyTorch (Cout,Cin,k,k,k) [or ConvTranspose3d's (Cin,Cout,k,k,k) when transposed_src=1] ->
  * opaque buffer holding the tap-major layouts the forward, data-gradient and MFMA kernels read. */
 size_t mednet_conv3d_pack_bytes(int cin, int cout, int ksize);
+/* mednet_conv3d_pack writes the matrix-core fragment images in bf16; _elt takes the 16-bit storage type of the activations
+ * the layer will see (MEDNET_BF16 | MEDNET_F16: BASELINE config 5 stores fp16).  The buffer size is the same. */
+int mednet_conv3d_pack_elt(const float* w, void* packed, int cin, int cout, int ksize, int transposed_src, int elt_dtype,
+                           mednet_stream stream);
 int mednet_conv3d_pack(const float* w, void* packed, int cin, int cout, int ksize, int transposed_src,
                        mednet_stream stream);
 /* y[n,z,y,x,co] = bias[co] + sum_{tap,ci} x[n,z+dz-1,y+dy-1,x+dx-1,ci] * W[co,ci,tap].
@@ -68,14 +72,14 @@ int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void
  * mednet_conv3d_act_supported first; unsupported shapes return MEDNET_E_UNSUPPORTED (use conv3d_fwd + act_fwd). */
 int mednet_conv3d_act_supported(int n, int d, int h, int w, int cin, int cout, int algo);
 int mednet_conv3d_act_fwd(const void* x, const void* packed, void* y, int n, int d, int h, int w, int cin, int cout,
-                          int act, int algo, float* gn_partial, mednet_stream stream);
+                          int act, int algo, float* gn_partial, int dtype, mednet_stream stream);
 /* dx = dgrad(dy) + add: the data gradient of a 3x3x3 conv (layer Cin -> Cout; dy has Cout channels, dx and add have Cin)
  * with a second gradient of the same tensor summed in the epilogue (fp32 add, one bf16 rounding): in ExtResNetBlock the
  * first conv's output feeds conv2 AND the residual add (components.py:170-178), so its two gradients meet here instead
  * of in two more tensor reads of the GroupNorm backward.  bf16 NDHWC, matrix-core path only
  * (mednet_conv3d_act_supported(n,d,h,w,Cout,Cin,algo) tells). */
 int mednet_conv3d_dgrad_add(const void* dy, const void* packed, const void* add, void* dx, int n, int d, int h, int w,
-                            int cin, int cout, int algo, mednet_stream stream);
+                            int cin, int cout, int algo, int dtype, mednet_stream stream);
 /* mednet_conv3d_dgrad_add (add nullable) that ALSO takes the first pass of the backward of the GroupNorm (+ activation)
  * in front of the layer (components.py:57,36-40: `SingleConv` k-1 of the block produced this conv's input): with gn_y the
  * conv output that GroupNorm normalised (shape of dx), gn_coef[n][Cin] = {ca, cb} its forward affine (mednet_gn_stats /
@@ -85,7 +89,7 @@ int mednet_conv3d_dgrad_add(const void* dy, const void* packed, const void* add,
 int mednet_conv3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int algo);
 int mednet_conv3d_dgrad_gn(const void* dy, const void* packed, const void* add, void* dx, const void* gn_y,
                            const float* gn_coef, int gn_act, float* gn_partial, int n, int d, int h, int w, int cin,
-                           int cout, int algo, mednet_stream stream);
+                           int cout, int algo, int dtype, mednet_stream stream);
 size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
 /* dw[co,ci,tap] = sum_{n,v} dy[n,v,co] * x[n,v+tap,ci]; dbias[co] = sum dy (nullable). */
 int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
@@ -185,6 +189,15 @@ int mednet_heatmap_loss_bwd(const float* out, const void* target, const float* c
 int mednet_adam_step(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int step, float grad_scale,
                      mednet_stream stream);
+/* fp16 storage (BASELINE config 5): the same update behind dynamic loss scaling, with no host synchronisation.
+ * scaler_state (device, 4 floats) = {scale, good steps since the last change, optimizer steps taken, found_inf}; the caller
+ * multiplies the loss by scaler_state[0] on the device.  Three launches: raise found_inf if any gradient is NaN/inf; Adam
+ * on g / (scale * world) with the device-side step count, skipped entirely when found_inf; then the scale is multiplied
+ * by backoff_factor (overflow) or a good step is counted and every growth_interval of them multiply it by growth_factor
+ * (torch.cuda.amp.GradScaler's rule; the reference itself trains fp32, train_seg.py:127 has precision=16 commented out). */
+int mednet_adam_step_scaled(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, float inv_world, float* scaler_state, float growth_factor,
+                            float backoff_factor, int growth_interval, mednet_stream stream);
 
 /* ---- inference path ------------------------------------------------------------------------ */
 enum { MEDNET_PAD_CONSTANT = 0, MEDNET_PAD_SYMMETRIC = 1 };
@@ -203,7 +216,8 @@ int mednet_predict_assemble(const float* logits, const int* pos, uint8_t* result
                             int crop_start2, int crop_d, int crop_h, int crop_w, mednet_stream stream);
 
 /* ---- training-patch sampler ------------------------------------------------------------------ */
-enum { MEDNET_F16 = 2, MEDNET_U8 = 3 }; /* storage types of the resident volumes (only mednet_crop_patches takes them) */
+enum { MEDNET_F16 = 2, MEDNET_U8 = 3 }; /* F16: third activation storage type (fp16, with loss scaling: train.LossScaler) and
+                                          * the type of resident image volumes; U8: label / heat-map volumes (mednet_crop_patches) */
 /* MedDataset.__getitem__'s crop + cast (dataset.py:313-331) from a device-resident volume src (C x D x H x W; f16 / f32
  * images, u8 labels or heat maps): for i < count,
  *   out[slot[i]][c_off + c][z][y][x] = cast(src[c][pos[i][0] + z][pos[i][1] + y][pos[i][2] + x])

@@ -268,8 +268,98 @@ def test_cfg4_128_bf16_timed_path_against_reference_golden(golden_dir):
     step.flat.release()
 
 
-def test_cfg5_full_size_properties():
-    """BASELINE config 5 at its full size (5 levels, 64 base channels, 160x160x96, batch 2) in the 16-bit storage mode: no
+# fp16 storage (BASELINE config 5).  Measured on MI355X (round 2): see the printed line; bounds are those times two.
+FP16_LOGITS = 4e-3
+FP16_GRAD_NORM = 2e-2
+FP16_GRAD_PROJ = 4e-2
+
+
+def test_cfg5_fp16_with_loss_scaling_against_reference_golden(golden_dir):
+    """BASELINE config 5's topology (5 levels, 64 .. 1024 channels) in fp16 storage with the device-side dynamic loss scaler,
+    through train.SegmentationStep, at 32x32x16 against the reference's golden vectors (res_cfg5_small.npz: strided logits,
+    loss, norm and keyed projection of every gradient).  Gradients are compared after dividing by the scale the step used;
+    without scaling the reference's own fp16 run loses a third of the gradient to underflow -- the unscaled
+    run below must show that loss too, otherwise the test would not be testing the scaler."""
+    from mednet_hip.train import SegmentationStep
+    rec = np.load(os.path.join(golden_dir, "res_cfg5_small.npz"))
+    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[64, 128, 256, 512, 1024])
+    shape = tuple(int(v) for v in rec["meta.shape"])
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(int(rec["meta.n"]), 1, shape, 4, 0, seed=int(rec["meta.seed"])).items()}
+    with mednet_hip.precision("fp16"):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+        step = SegmentationStep(net, loss_weight=[0.05, 1.0, 1.0, 1.0], lr=1e-3)
+        assert step.scaler is not None
+        with torch.no_grad():
+            lg = net(batch["data"].float())
+        scale0 = step.scaler.snapshot()[0]
+        (loss,) = step._fwd_bwd(batch)
+        torch.cuda.synchronize()
+        s = int(rec["meta.stride"])
+        rl = assert_close(lg[..., ::s, ::s, ::s], torch.from_numpy(rec["logits.strided"]), FP16_LOGITS, "strided logits (fp16)")
+        assert abs(float(loss) - float(rec["loss"])) <= 1e-3
+        assert bool(torch.isfinite(step.flat.grad).all())
+        step.flat.grad.div_(scale0)
+        step.flat.grads_as_attr()
+        wn, wp = _check_grads_against_golden_summaries(net, rec, FP16_GRAD_NORM, FP16_GRAD_PROJ, "cfg5 small fp16")
+        # the same backward WITHOUT the scaler: underflow must be visible (this is what the scaler is for)
+        step.flat.grad.zero_()
+        loss2 = step.loss(net(batch["data"].float()), batch["label"][:, -1].long())
+        loss2.backward()
+        from mednet_hip.train import finish_backward
+        finish_backward()
+        torch.cuda.synchronize()
+        lost = 0
+        for name, p in net.named_parameters():
+            g = p.grad.detach().double().cpu().numpy().reshape(-1)
+            norm = float(rec[f"grad.{name}.norm"])
+            if abs(np.sqrt((g * g).sum()) - norm) > 5 * FP16_GRAD_NORM * norm:
+                lost += 1
+        step.flat.release()
+    print(f"[fp16 cfg5 small] strided logits {rl:.2e}  worst grad-norm diff {wn:.2e}  worst projection diff {wp:.2e}; "
+          f"without loss scaling {lost} of {len(list(net.parameters()))} gradient tensors are off by more than {5 * FP16_GRAD_NORM:.0e}")
+    assert lost > 0
+
+
+def test_loss_scaler_skips_overflowing_steps_and_recovers():
+    """The device-side scaler (mednet_adam_step_scaled): a step whose gradients overflow leaves parameters, Adam moments and
+    the step count untouched and halves the scale; clean steps count up and double it after `growth_interval`."""
+    from mednet_hip.train import FlatParams, FlatAdam, LossScaler
+    lin = torch.nn.Linear(64, 64).to(DEV)
+    flat = FlatParams(lin)
+    opt = FlatAdam(flat, lr=1e-2)
+    sc = LossScaler(DEV, init_scale=1024.0, growth_interval=3)
+    ref = torch.nn.Linear(64, 64).to(DEV)
+    ref.load_state_dict(lin.state_dict())
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for it in range(8):
+        true_grad = torch.randn(flat.total, generator=g).to(DEV) * 1e-3
+        flat.grad.copy_(true_grad * sc.state[0])
+        overflow = it in (2, 5)
+        if overflow:
+            flat.grad[17] = float("inf") if it == 2 else float("nan")
+        before = (flat.flat.clone(), opt.m.clone(), opt.v.clone(), sc.snapshot())
+        opt.step_scaled(sc)
+        after = sc.snapshot()
+        if overflow:
+            assert torch.equal(flat.flat, before[0]) and torch.equal(opt.m, before[1]) and torch.equal(opt.v, before[2])
+            assert after[0] == before[3][0] * 0.5 and after[1] == 0 and after[2] == before[3][2] and after[3] == 0
+        else:
+            for p, off in zip(ref.parameters(), flat.offsets):
+                p.grad = true_grad[off:off + p.numel()].view_as(p).clone()
+            ropt.step()
+            assert after[2] == before[3][2] + 1 and after[3] == 0
+    for (k, a), (_, b) in zip(lin.named_parameters(), ref.named_parameters()):
+        assert_close(a, b, 1e-5, f"params after scaled Adam steps: {k}")
+    # 6 clean steps with interval 3, interleaved with 2 backoffs: 1024 -> (2 clean) -> /2 -> (2 clean) -> /2 -> (2 clean) ...
+    assert sc.snapshot()[0] in (256.0, 512.0, 1024.0)
+    flat.release()
+
+
+@pytest.mark.parametrize("MODE16", ["fp16", "bf16"])
+def test_cfg5_full_size_properties(MODE16):
+    """BASELINE config 5 at its full size (5 levels, 64 base channels, 160x160x96, batch 2) in fp16 storage with loss scaling
+    (the mode BASELINE names) and in bf16: no
     reference vector exists at this size (the CPU oracle needs ~40 GB and minutes), so size-independent properties: every
     logit and gradient finite, two runs bitwise identical (no atomics, fixed-order reductions, two streams), and the loss
     within 2e-2 of the same network in the fp32 (1e-3 parity) mode."""
@@ -278,7 +368,7 @@ def test_cfg5_full_size_properties():
     batch = {k: v.to(DEV) for k, v in O.synthetic_batch(2, 1, (160, 160, 96), 4, 0, seed=1234).items()}
     runs = []
     for _ in range(2):
-        with mednet_hip.precision("bf16"):
+        with mednet_hip.precision(MODE16):
             net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
             step = SegmentationStep(net, loss_weight=[0.05, 1.0, 1.0, 1.0], lr=1e-3)
             (loss,) = step._fwd_bwd(batch)
@@ -295,7 +385,7 @@ def test_cfg5_full_size_properties():
         loss32 = HL.DiceLoss(weight=torch.tensor([0.05, 1, 1, 1.0], device=DEV)).to(DEV)(lg, batch["label"][:, -1].long())
     assert bool(torch.isfinite(lg).all())
     assert abs(runs[0][0] - float(loss32)) <= 2e-2, (runs[0][0], float(loss32))
-    print(f"[cfg5 full size] bf16 loss {runs[0][0]:.6f}  fp32-mode loss {float(loss32):.6f}")
+    print(f"[cfg5 full size] {MODE16} loss {runs[0][0]:.6f}  fp32-mode loss {float(loss32):.6f}")
 
 
 class _ForcedReLU(nn.Module):

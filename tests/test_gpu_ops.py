@@ -14,14 +14,14 @@ from mednet_hip import ops
 from mednet_hip.unet import loss as HL
 from oracle import ref_cpu as O
 
-from gpu_util import DEV, TOL, assert_close, bf16_round, rnd
+from gpu_util import DEV, TOL, assert_close, bf16_round, half_round, rnd
 
 pytestmark = pytest.mark.gpu
-MODES = ["fp32", "bf16"]
+MODES = ["fp32", "bf16", "fp16"]
 
 
 def _prep(mode, *ts):
-    return [bf16_round(t) if mode == "bf16" else t for t in ts]
+    return [half_round(t, mode) for t in ts]
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -110,7 +110,7 @@ def test_conv_transpose3d_with_skip(mode, n, cin, cout, shape, skip):
     assert_close(y, yr, tol, "y")
     assert_close(xg.grad, xr.grad, tol, "dx")
     assert_close(up.weight.grad, wr.grad, tol, "dw")
-    assert_close(up.bias.grad, br.grad, 1e-3 if mode == "bf16" else 1e-4, "db")
+    assert_close(up.bias.grad, br.grad, 1e-4 if mode == "fp32" else 1e-3, "db")
     if skip:
         assert_close(skg.grad, skr.grad, tol, "dskip")
 

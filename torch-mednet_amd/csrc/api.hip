@@ -4,26 +4,18 @@
 #include "common.h"
 #include "conv.h"
 
-namespace mednet {
-
 static thread_local char g_err[512] = "";
 
-void set_error(const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-}
-int fail(int code, const char* fmt, ...) {
+int mednet_internal_fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
 }
-int check_launch(const char* what) {
+int mednet_internal_check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(MEDNET_E_HIP, "%s: %s", what, hipGetErrorString(e));
+  if (e != hipSuccess) return mednet_internal_fail(MEDNET_E_HIP, "%s: %s", what, hipGetErrorString(e));
   return MEDNET_OK;
 }
 
@@ -33,15 +25,19 @@ struct Option {
 };
 static Option g_options[16];
 static int g_noptions = 0;
-int tuning_option(const char* name, int default_value) {
+int mednet_internal_tuning_option(const char* name, int default_value) {
   for (int i = 0; i < g_noptions; ++i)
     if (strcmp(g_options[i].name, name) == 0) return g_options[i].value;
   return default_value;
 }
 
-}  // namespace mednet
-
+namespace mednet_f16 {  // conv_mfma.hip compiled with -DMEDNET_ELT_F16 -Dmednet=mednet_f16 (fp16 storage)
+#include "conv_mfma_decl.inc"
+}
 using namespace mednet;
+// the 16-bit matrix-core family by element type: `dt` is the dtype of the 16-bit operand(s) of the call
+#define ELT_CALL(dt, fn, ...) ((dt) == MEDNET_F16 ? mednet_f16::fn(__VA_ARGS__) : mednet::fn(__VA_ARGS__))
+static inline bool is16(int dt) { return dt == MEDNET_BF16 || dt == MEDNET_F16; }
 
 extern "C" int mednet_set_option(const char* name, int value) {
   for (int i = 0; i < g_noptions; ++i)
@@ -71,16 +67,23 @@ extern "C" int mednet_device_ok(void) {
 // ---- packed weight buffer ---------------------------------------------------------------------------------------
 extern "C" size_t mednet_conv3d_pack_bytes(int cin, int cout, int ksize) { return pack_layout(cin, cout, ksize).total; }
 
+extern "C" int mednet_conv3d_pack_elt(const float* w, void* packed, int cin, int cout, int ksize, int transposed_src,
+                                      int elt_dtype, mednet_stream stream);
 extern "C" int mednet_conv3d_pack(const float* w, void* packed, int cin, int cout, int ksize, int transposed_src,
                                   mednet_stream stream) {
+  return mednet_conv3d_pack_elt(w, packed, cin, cout, ksize, transposed_src, MEDNET_BF16, stream);
+}
+extern "C" int mednet_conv3d_pack_elt(const float* w, void* packed, int cin, int cout, int ksize, int transposed_src,
+                                      int elt_dtype, mednet_stream stream) {
+  MEDNET_REQUIRE(is16(elt_dtype), MEDNET_E_DTYPE, "conv3d_pack: the matrix-core images are bf16 or fp16 (got dtype %d)", elt_dtype);
   MEDNET_REQUIRE(ksize == 3 || ksize == 1, MEDNET_E_UNSUPPORTED, "conv3d_pack: kernel size %d (supported: 1, 3)", ksize);
   MEDNET_REQUIRE(cin > 0 && cout > 0, MEDNET_E_SHAPE, "conv3d_pack: bad channels %d -> %d", cin, cout);
   const PackLayout L = pack_layout(cin, cout, ksize);
   char* base = (char*)packed;
   hipStream_t s = (hipStream_t)stream;
   if (L.mfma_bytes)  // one launch writes the two bf16 fragment images and the two fp32 images
-    return launch_pack_mfma(w, base + L.mfma_fwd, base + L.mfma_bwd, (float*)(base + L.f32_fwd), (float*)(base + L.f32_bwd),
-                            cin, cout, L.taps, transposed_src, s);
+    return ELT_CALL(elt_dtype, launch_pack_mfma, w, base + L.mfma_fwd, base + L.mfma_bwd, (float*)(base + L.f32_fwd),
+                    (float*)(base + L.f32_bwd), cin, cout, L.taps, transposed_src, s);
   return launch_pack_f32(w, (float*)(base + L.f32_fwd), (float*)(base + L.f32_bwd), cin, cout, L.taps, transposed_src, s);
 }
 
@@ -95,8 +98,8 @@ static int conv_common_checks(const char* who, int n, int d, int h, int w, int c
 extern "C" int mednet_conv3d_fused_stats_chunks(int n, int d, int h, int w, int cin, int cout, int ksize, int x_dtype,
                                                 int y_dtype, int algo) {
   if (algo == MEDNET_ALGO_DIRECT || !tuning_option("conv_fuse_stats", 1)) return 0;
-  if (conv_c1_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, false)) return conv_c1_stats_chunks(d, h, w);
-  if (!conv_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, MEDNET_NDHWC, false)) return 0;
+  if (ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, false)) return conv_c1_stats_chunks(d, h, w);
+  if (!ELT_CALL(y_dtype, conv_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, MEDNET_NDHWC, false)) return 0;
   return conv_mfma_stats_chunks(n, d, h, w, cout);
 }
 
@@ -109,18 +112,18 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
   const PackLayout L = dgrad ? pack_layout(cout, cin, ksize) : pack_layout(cin, cout, ksize);
   const char* base = (const char*)packed;
   hipStream_t s = (hipStream_t)stream;
-  const bool mfma_ok = conv_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, x_layout, y_layout, bias != nullptr) &&
+  const bool mfma_ok = ELT_CALL(y_dtype, conv_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, x_layout, y_layout, bias != nullptr) &&
                        conv_mfma_fits(n, d, h, w, cin);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_fwd: MFMA path does not take cin=%d cout=%d k=%d dtypes %d->%d", cin, cout,
                 ksize, x_dtype, y_dtype);
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
-    return launch_conv_mfma(x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), y, n, d, h, w, cin, cout, x_dtype, y_dtype,
-                            gn_partial, s);
+    return ELT_CALL(y_dtype, launch_conv_mfma, x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), y, n, d, h, w, cin, cout, x_dtype,
+                    y_dtype, gn_partial, s, MEDNET_ACT_NONE, nullptr);
   // first layer (one input channel): contraction over the 27 taps on the matrix cores
   if (!dgrad && algo != MEDNET_ALGO_DIRECT && x_layout == MEDNET_NDHWC &&
-      conv_c1_mfma_supported(cin, cout, ksize, x_dtype, y_dtype, y_layout, bias != nullptr))
-    return launch_conv_c1_mfma(x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, gn_partial, s);
+      ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, y_layout, bias != nullptr))
+    return ELT_CALL(y_dtype, launch_conv_c1_mfma, x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, gn_partial, s);
   MEDNET_REQUIRE(gn_partial == nullptr, MEDNET_E_UNSUPPORTED,
                  "conv3d_fwd: fused GroupNorm partials are only produced by the MFMA paths (ask mednet_conv3d_fused_stats_chunks)");
   // fp32 storage (the 1e-3 parity mode): 3x3x3 forward / data gradient on the fp32 matrix-core instruction
@@ -177,12 +180,12 @@ extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, flo
   if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32 &&
       (x_layout == MEDNET_NDHWC || cin == 1) && dy_layout == MEDNET_NDHWC)
     return launch_wgrad_f32_mfma(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
-  const bool mfma_ok = wgrad_mfma_supported(cin, cout, ksize, x_dtype, dy_dtype, x_layout, dy_layout) &&
+  const bool mfma_ok = ELT_CALL(dy_dtype, wgrad_mfma_supported, cin, cout, ksize, x_dtype, dy_dtype, x_layout, dy_layout) &&
                        wgrad_mfma_fits(n, d, h, w, cin > cout ? cin : cout, 1);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_wgrad: MFMA path does not take cin=%d cout=%d k=%d", cin, cout, ksize);
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
-    return launch_wgrad_mfma(x, dy, dw, n, d, h, w, cin, cout, x_dtype, ws, ws_bytes, s);
+    return ELT_CALL(dy_dtype, launch_wgrad_mfma, x, dy, dw, n, d, h, w, cin, cout, x_dtype, ws, ws_bytes, s);
   WgradGeom g;
   g.n = n; g.ad = d; g.ah = h; g.aw = w; g.bd = d; g.bh = h; g.bw = w;
   g.ka = cout; g.kb = cin; g.ks = ksize; g.stride2 = 0;
@@ -198,28 +201,30 @@ extern "C" int mednet_conv3d_act_supported(int n, int d, int h, int w, int cin, 
          conv_mfma_fits(n, d, h, w, cin) && conv_mfma_fits(n, d, h, w, cout);
 }
 extern "C" int mednet_conv3d_act_fwd(const void* x, const void* packed, void* y, int n, int d, int h, int w, int cin,
-                                     int cout, int act, int algo, float* gn_partial, mednet_stream stream) {
-  int rc = conv_common_checks("conv3d_act_fwd", n, d, h, w, cin, cout, 3, MEDNET_BF16, MEDNET_BF16);
+                                     int cout, int act, int algo, float* gn_partial, int dtype, mednet_stream stream) {
+  MEDNET_REQUIRE(is16(dtype), MEDNET_E_DTYPE, "conv3d_act_fwd: 16-bit storage only (dtype %d)", dtype);
+  int rc = conv_common_checks("conv3d_act_fwd", n, d, h, w, cin, cout, 3, dtype, dtype);
   if (rc) return rc;
   MEDNET_REQUIRE(act >= MEDNET_ACT_NONE && act <= MEDNET_ACT_ELU, MEDNET_E_UNSUPPORTED, "conv3d_act_fwd: activation %d", act);
   if (!mednet_conv3d_act_supported(n, d, h, w, cin, cout, algo))
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_act_fwd: only the bf16 matrix-core path fuses the activation (cin=%d cout=%d)", cin, cout);
   const PackLayout L = pack_layout(cin, cout, 3);
-  return launch_conv_mfma(x, (const char*)packed + L.mfma_fwd, y, n, d, h, w, cin, cout, MEDNET_BF16, MEDNET_BF16, gn_partial,
-                          (hipStream_t)stream, act);
+  return ELT_CALL(dtype, launch_conv_mfma, x, (const char*)packed + L.mfma_fwd, y, n, d, h, w, cin, cout, dtype, dtype,
+                  gn_partial, (hipStream_t)stream, act, nullptr);
 }
 
 // data gradient of a 3x3x3 conv with a second gradient of the same tensor summed in the epilogue (matrix-core path only)
 extern "C" int mednet_conv3d_dgrad_add(const void* dy, const void* packed, const void* add, void* dx, int n, int d, int h,
-                                       int w, int cin, int cout, int algo, mednet_stream stream) {
-  int rc = conv_common_checks("conv3d_dgrad_add", n, d, h, w, cin, cout, 3, MEDNET_BF16, MEDNET_BF16);
+                                       int w, int cin, int cout, int algo, int dtype, mednet_stream stream) {
+  MEDNET_REQUIRE(is16(dtype), MEDNET_E_DTYPE, "conv3d_dgrad_add: 16-bit storage only (dtype %d)", dtype);
+  int rc = conv_common_checks("conv3d_dgrad_add", n, d, h, w, cin, cout, 3, dtype, dtype);
   if (rc) return rc;
   // (roles swapped as in mednet_conv3d_fwd(dgrad=1): the kernel reads dy with Cout channels and writes Cin channels)
   if (!mednet_conv3d_act_supported(n, d, h, w, cout, cin, algo))
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_dgrad_add: only the bf16 matrix-core path fuses the add (cin=%d cout=%d)", cin, cout);
   const PackLayout L = pack_layout(cin, cout, 3);
-  return launch_conv_mfma(dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cout, cin, MEDNET_BF16, MEDNET_BF16, nullptr,
-                          (hipStream_t)stream, MEDNET_ACT_NONE, add);
+  return ELT_CALL(dtype, launch_conv_mfma, dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cout, cin, dtype, dtype, nullptr,
+                  (hipStream_t)stream, MEDNET_ACT_NONE, add);
 }
 
 extern "C" int mednet_conv3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int algo) {
@@ -228,16 +233,17 @@ extern "C" int mednet_conv3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, 
 }
 extern "C" int mednet_conv3d_dgrad_gn(const void* dy, const void* packed, const void* add, void* dx, const void* gn_y,
                                       const float* gn_coef, int gn_act, float* gn_partial, int n, int d, int h, int w,
-                                      int cin, int cout, int algo, mednet_stream stream) {
-  int rc = conv_common_checks("conv3d_dgrad_gn", n, d, h, w, cin, cout, 3, MEDNET_BF16, MEDNET_BF16);
+                                      int cin, int cout, int algo, int dtype, mednet_stream stream) {
+  MEDNET_REQUIRE(is16(dtype), MEDNET_E_DTYPE, "conv3d_dgrad_gn: 16-bit storage only (dtype %d)", dtype);
+  int rc = conv_common_checks("conv3d_dgrad_gn", n, d, h, w, cin, cout, 3, dtype, dtype);
   if (rc) return rc;
   MEDNET_REQUIRE(gn_y && gn_coef && gn_partial, MEDNET_E_SHAPE, "conv3d_dgrad_gn: gn_y, gn_coef and gn_partial are required");
   MEDNET_REQUIRE(gn_act >= MEDNET_ACT_NONE && gn_act <= MEDNET_ACT_ELU, MEDNET_E_UNSUPPORTED, "conv3d_dgrad_gn: activation %d", gn_act);
   if (mednet_conv3d_dgrad_gn_rows(n, d, h, w, cin, cout, algo) == 0)
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_dgrad_gn: only the bf16 matrix-core path fuses the GroupNorm sums (cin=%d cout=%d)", cin, cout);
   const PackLayout L = pack_layout(cin, cout, 3);
-  return launch_conv_mfma_gnb(dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cout, cin, add, gn_y, gn_coef, gn_act,
-                              gn_partial, (hipStream_t)stream);
+  return ELT_CALL(dtype, launch_conv_mfma_gnb, dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cout, cin, add, gn_y,
+                  gn_coef, gn_act, gn_partial, (hipStream_t)stream);
 }
 
 // ---- ConvTranspose3d(k3,s2,p1,op1) ------------------------------------------------------------------------------------
@@ -247,12 +253,12 @@ extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float
   int rc = conv_common_checks("convt3d_fwd", n, d, h, w, cin, cout, 3, x_dtype, y_dtype);
   if (rc) return rc;
   const PackLayout L = pack_layout(cin, cout, 3);
-  const bool mfma_ok = L.mfma_bytes && cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && y_dtype == MEDNET_BF16;
+  const bool mfma_ok = L.mfma_bytes && cin % 32 == 0 && cout % 32 == 0 && is16(x_dtype) && y_dtype == x_dtype;
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_fwd: MFMA path does not take cin=%d cout=%d", cin, cout);
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
-    return launch_convt_fwd_mfma(x, (const char*)packed + L.mfma_fwd, bias, skip, y, n, d, h, w, cin, cout,
-                                 (hipStream_t)stream);
+    return ELT_CALL(x_dtype, launch_convt_fwd_mfma, x, (const char*)packed + L.mfma_fwd, bias, skip, y, n, d, h, w, cin, cout,
+                    (hipStream_t)stream);
   if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32)
     return launch_convt_fwd_f32_mfma(x, (const float*)((const char*)packed + L.f32_fwd), bias, skip, y, n, d, h, w, cin, cout,
                                      (hipStream_t)stream);
@@ -268,12 +274,13 @@ extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx
   int rc = conv_common_checks("convt3d_dgrad", n, d, h, w, cin, cout, 3, dy_dtype, dx_dtype);
   if (rc) return rc;
   const PackLayout L = pack_layout(cin, cout, 3);
-  const bool mfma_ok = L.mfma_bytes && cin % 32 == 0 && cout % 32 == 0 && dy_dtype == MEDNET_BF16 && dx_dtype == MEDNET_BF16 &&
+  const bool mfma_ok = L.mfma_bytes && cin % 32 == 0 && cout % 32 == 0 && is16(dy_dtype) && dx_dtype == dy_dtype &&
                        conv_mfma_fits(n, 2 * d, 2 * h, 2 * w, cout);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_dgrad: MFMA path does not take cin=%d cout=%d", cin, cout);
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
-    return launch_convt_dgrad_mfma(dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cin, cout, (hipStream_t)stream);
+    return ELT_CALL(dy_dtype, launch_convt_dgrad_mfma, dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cin, cout,
+                    (hipStream_t)stream);
   if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && dy_dtype == MEDNET_F32 && dx_dtype == MEDNET_F32)
     return launch_convt_dgrad_f32_mfma(dy, (const float*)((const char*)packed + L.f32_bwd), dx, n, d, h, w, cin, cout,
                                        (hipStream_t)stream);
@@ -308,12 +315,12 @@ extern "C" int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, fl
   }
   if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32)
     return launch_convt_wgrad_f32_mfma(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
-  const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0 && x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_BF16 &&
+  const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0 && is16(x_dtype) && dy_dtype == x_dtype &&
                        wgrad_mfma_fits(n, d, h, w, cin > 8 * cout ? cin : 8 * cout, 1);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_wgrad: MFMA path does not take cin=%d cout=%d", cin, cout);
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
-    return launch_convt_wgrad_mfma(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
+    return ELT_CALL(x_dtype, launch_convt_wgrad_mfma, x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
   WgradGeom g;
   g.n = n; g.ad = d; g.ah = h; g.aw = w; g.bd = 2 * d; g.bh = 2 * h; g.bw = 2 * w;
   g.ka = cin; g.kb = cout; g.ks = 3; g.stride2 = 1; g.a_planar = 0; g.b_planar = 0; g.chunk = 0;

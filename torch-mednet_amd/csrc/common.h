@@ -5,36 +5,46 @@
 #include <stdio.h>
 #include "../../include/mednet_hip.h"
 
+// ---- error plumbing + tuning knobs (defined once in api.hip, global names: conv_mfma.hip is compiled a second time under
+//      a renamed namespace for the fp16 element type and must still reach them) -------------------------------------
+int mednet_internal_fail(int code, const char* fmt, ...);
+int mednet_internal_check_launch(const char* what);
+int mednet_internal_tuning_option(const char* name, int default_value);
+
 namespace mednet {
 
 typedef __bf16 bf16;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-// ---- error plumbing (host) -------------------------------------------------------------------------------
-void set_error(const char* fmt, ...);
-int fail(int code, const char* fmt, ...);
-int check_launch(const char* what);
+template <typename... A>
+static inline int fail(int code, const char* fmt, A... a) { return ::mednet_internal_fail(code, fmt, a...); }
+static inline int check_launch(const char* what) { return ::mednet_internal_check_launch(what); }
 // tuning knobs (mednet_set_option): experiments A/B kernel variants inside ONE process
-int tuning_option(const char* name, int default_value);
+static inline int tuning_option(const char* name, int default_value) { return ::mednet_internal_tuning_option(name, default_value); }
 
 #define MEDNET_REQUIRE(cond, code, ...)        \
   do {                                         \
     if (!(cond)) return fail(code, __VA_ARGS__); \
   } while (0)
 
-inline bool dtype_ok(int dt) { return dt == MEDNET_F32 || dt == MEDNET_BF16; }
-inline size_t dtype_size(int dt) { return dt == MEDNET_BF16 ? 2 : 4; }
+inline bool dtype_ok(int dt) { return dt == MEDNET_F32 || dt == MEDNET_BF16 || dt == MEDNET_F16; }
+inline size_t dtype_size(int dt) { return dt == MEDNET_F32 ? 4 : 2; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- scalar load/store with conversion ---------------------------------------------------------------------
 __device__ __forceinline__ float ld(const float* p, size_t i) { return p[i]; }
 __device__ __forceinline__ float ld(const bf16* p, size_t i) { return (float)p[i]; }
+__device__ __forceinline__ float ld(const f16* p, size_t i) { return (float)p[i]; }
 __device__ __forceinline__ float ld(const uint8_t* p, size_t i) { return (float)p[i]; }
 __device__ __forceinline__ void st(float* p, size_t i, float v) { p[i] = v; }
 __device__ __forceinline__ void st(bf16* p, size_t i, float v) { p[i] = (bf16)v; }
+__device__ __forceinline__ void st(f16* p, size_t i, float v) { p[i] = (f16)v; }
 
 // ---- 8-wide vector load/store (caller guarantees 8-element alignment) ----------------------------------------
 struct F8 {
@@ -58,6 +68,13 @@ __device__ __forceinline__ F8 ld8(const bf16* p, size_t i) {
   for (int k = 0; k < 8; ++k) r.v[k] = (float)a[k];
   return r;
 }
+__device__ __forceinline__ F8 ld8(const f16* p, size_t i) {
+  F8 r;
+  const f16x8 a = *reinterpret_cast<const f16x8*>(p + i);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r.v[k] = (float)a[k];
+  return r;
+}
 // last-use streaming loads (nt): the line is not kept in L2 once delivered
 __device__ __forceinline__ F8 ld8_nt(const float* p, size_t i) {
   F8 r;
@@ -76,6 +93,19 @@ __device__ __forceinline__ F8 ld8_nt(const bf16* p, size_t i) {
 #pragma unroll
   for (int k = 0; k < 8; ++k) r.v[k] = (float)a[k];
   return r;
+}
+__device__ __forceinline__ F8 ld8_nt(const f16* p, size_t i) {
+  F8 r;
+  const f16x8 a = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(p + i));
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r.v[k] = (float)a[k];
+  return r;
+}
+__device__ __forceinline__ void st8(f16* p, size_t i, const F8& r) {
+  f16x8 a;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = (f16)r.v[k];
+  *reinterpret_cast<f16x8*>(p + i) = a;
 }
 __device__ __forceinline__ void st8(float* p, size_t i, const F8& r) {
   f32x4 a, b;

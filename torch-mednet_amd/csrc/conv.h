@@ -22,15 +22,6 @@ struct WgradGeom {
   size_t chunk;  // voxels per chunk (filled by the launcher)
 };
 
-// Byte offsets of the sections of a packed weight buffer (mednet_conv3d_pack).
-struct PackLayout {
-  int taps;
-  size_t f32_fwd, f32_bwd;    // float [T][Cin][Cout], float [T][Cout][Cin] (taps mirrored for Conv3d sources)
-  size_t mfma_fwd, mfma_bwd;  // bf16 fragment-ordered images for the MFMA kernels (0 bytes when not applicable)
-  size_t mfma_bytes;          // size of ONE mfma section
-  size_t total;
-};
-PackLayout pack_layout(int cin, int cout, int ksize);
 
 template <int MAP>
 int launch_direct(const void* x, const float* P, const float* bias, const void* skip, void* y, const ConvGeom& g,
@@ -55,38 +46,11 @@ bool wgrad_c1_supported(int cin, int cout, int ksize, int x_layout, int dy_layou
 size_t wgrad_c1_ws_bytes(int n, int d, int h, int w, int cout);
 int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cout, int x_dtype,
                     int dy_dtype, void* ws, size_t ws_bytes, hipStream_t s);
-bool wgrad_c1_mfma_supported(int cout, int x_dtype, int dy_dtype);
-int wgrad_c1_mfma_blocks(int n, int d, int h, int w);
-int launch_wgrad_c1_mfma(const void* x, const void* dy, float* part, int n, int d, int h, int w, int cout, hipStream_t s);
 int launch_pack_f32(const float* w, float* Pf, float* Pb, int cin, int cout, int T, int transposed_src, hipStream_t s);
 
-// MFMA (bf16 matrix-core) kernels, conv_mfma.hip
-bool conv_mfma_fits(int n, int d, int h, int w, int c);
-bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int x_layout, int y_layout, bool bias);
-int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, int d, int h, int w, int cin, int cout,
-                     int x_dtype, int y_dtype, float* gn_partial, hipStream_t s, int act = MEDNET_ACT_NONE,
-                     const void* add = nullptr);
-int launch_conv_mfma_gnb(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin, int cout,
-                         const void* add, const void* gn_y, const float* gn_coef, int gn_act, float* gn_partial, hipStream_t s);
-int conv_mfma_stats_chunks(int n, int d, int h, int w, int cout);
-int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, float* Pf, float* Pb, int cin, int cout, int T,
-                     int transposed_src, hipStream_t s);
-bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtype, int x_layout, int dy_layout);
-bool wgrad_mfma_fits(int n, int d, int h, int w, int cmax, int scale);
-size_t wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
-int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, int dtype,
-                      void* ws, size_t ws_bytes, hipStream_t s);
-bool conv_c1_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int y_layout, bool bias);
-int conv_c1_stats_chunks(int d, int h, int w);
-int launch_conv_c1_mfma(const void* x, const float* w_pt, void* y, int n, int d, int h, int w, int cout, float* gn_partial,
-                        hipStream_t s);
-int launch_convt_fwd_mfma(const void* x, const void* sec, const float* bias, const void* skip, void* y, int n, int d,
-                          int h, int w, int cin, int cout, hipStream_t s);
-int launch_convt_dgrad_mfma(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin,
-                            int cout, hipStream_t s);
-size_t convt_wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout);
-int launch_convt_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout,
-                            void* ws, size_t ws_bytes, hipStream_t s);
+// 16-bit matrix-core kernels, conv_mfma.hip (namespace mednet: bf16; api.hip declares the same set in namespace mednet_f16
+// for the fp16 build of that file)
+#include "conv_mfma_decl.inc"
 
 // fp32 matrix-core kernels (v_mfma_f32_32x32x2_f32), conv_f32_mfma.hip: the parity mode's 3x3x3 family
 bool conv_f32_mfma_enabled();

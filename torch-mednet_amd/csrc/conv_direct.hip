@@ -13,6 +13,10 @@
 // take, in both storage precisions.
 #include "conv.h"
 
+namespace mednet_f16 {  // the fp16 build of conv_mfma.hip (first-layer weight gradient on the matrix cores)
+#include "conv_mfma_decl.inc"
+}
+
 namespace mednet {
 
 template <int MAP>
@@ -140,7 +144,11 @@ int launch_direct(const void* x, const float* P, const float* bias, const void* 
   if (x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32) return launch_direct_cob<float, float, MAP>(x, P, bias, skip, y, g, s);
   if (x_dtype == MEDNET_BF16 && y_dtype == MEDNET_BF16) return launch_direct_cob<bf16, bf16, MAP>(x, P, bias, skip, y, g, s);
   if (x_dtype == MEDNET_F32 && y_dtype == MEDNET_BF16) return launch_direct_cob<float, bf16, MAP>(x, P, bias, skip, y, g, s);
-  return launch_direct_cob<bf16, float, MAP>(x, P, bias, skip, y, g, s);
+  if (x_dtype == MEDNET_BF16 && y_dtype == MEDNET_F32) return launch_direct_cob<bf16, float, MAP>(x, P, bias, skip, y, g, s);
+  if (x_dtype == MEDNET_F16 && y_dtype == MEDNET_F16) return launch_direct_cob<f16, f16, MAP>(x, P, bias, skip, y, g, s);
+  if (x_dtype == MEDNET_F32 && y_dtype == MEDNET_F16) return launch_direct_cob<float, f16, MAP>(x, P, bias, skip, y, g, s);
+  if (x_dtype == MEDNET_F16 && y_dtype == MEDNET_F32) return launch_direct_cob<f16, float, MAP>(x, P, bias, skip, y, g, s);
+  return fail(MEDNET_E_DTYPE, "conv_direct: dtype pair %d -> %d", x_dtype, y_dtype);
 }
 template int launch_direct<MAP_CONV>(const void*, const float*, const float*, const void*, void*, const ConvGeom&, int, int, hipStream_t);
 template int launch_direct<MAP_CT_FWD>(const void*, const float*, const float*, const void*, void*, const ConvGeom&, int, int, hipStream_t);
@@ -256,7 +264,10 @@ int launch_wgrad_direct(const void* A, const void* B, float* dw, WgradGeom g, in
   if (a_dtype == MEDNET_F32 && b_dtype == MEDNET_F32) MEDNET_WG(float, float);
   else if (a_dtype == MEDNET_BF16 && b_dtype == MEDNET_BF16) MEDNET_WG(bf16, bf16);
   else if (a_dtype == MEDNET_F32 && b_dtype == MEDNET_BF16) MEDNET_WG(float, bf16);
-  else MEDNET_WG(bf16, float);
+  else if (a_dtype == MEDNET_BF16 && b_dtype == MEDNET_F32) MEDNET_WG(bf16, float);
+  else if (a_dtype == MEDNET_F16 && b_dtype == MEDNET_F16) MEDNET_WG(f16, f16);
+  else if (a_dtype == MEDNET_F32 && b_dtype == MEDNET_F16) MEDNET_WG(float, f16);
+  else MEDNET_WG(f16, float);
 #undef MEDNET_WG
   int rc = check_launch("wgrad_direct");
   if (rc) return rc;
@@ -373,8 +384,10 @@ int launch_channel_sum(const void* x, float* out, int n, size_t spatial, int c, 
   float* part = (float*)ws;
   if (dtype == MEDNET_F32)
     hipLaunchKernelGGL(channel_sum_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x, part, spatial, c, planar);
-  else
+  else if (dtype == MEDNET_BF16)
     hipLaunchKernelGGL(channel_sum_partial_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, part, spatial, c, planar);
+  else
+    hipLaunchKernelGGL(channel_sum_partial_kernel<f16>, grid, dim3(256), 0, s, (const f16*)x, part, spatial, c, planar);
   int rc = check_launch("channel_sum_partial");
   if (rc) return rc;
   hipLaunchKernelGGL(channel_sum_final_kernel, dim3(c), dim3(64), 0, s, part, out, (int)(n * chunks), c);
@@ -546,7 +559,8 @@ int launch_head_fwd_vox(const void* z, const float* Pb, const float* bias, float
 #define HF_GO(TI_, K_) hipLaunchKernelGGL((head_fwd_vox_kernel<TI_, K_>), grid, dim3(256), 0, s, (const TI_*)z, Pb, bias, y, spatial, m)
 #define HF_K(TI_) do { if (k == 16) HF_GO(TI_, 16); else if (k == 32) HF_GO(TI_, 32); else HF_GO(TI_, 64); } while (0)
   if (z_dtype == MEDNET_F32) HF_K(float);
-  else HF_K(bf16);
+  else if (z_dtype == MEDNET_BF16) HF_K(bf16);
+  else HF_K(f16);
 #undef HF_K
 #undef HF_GO
   return check_launch("head_fwd_vox");
@@ -564,7 +578,8 @@ int launch_head_dgrad(const void* dy, const float* Pb, void* dz, int n, size_t s
 #define HV_GO(TO_, K_) hipLaunchKernelGGL((head_dgrad_vox_kernel<TO_, K_>), grid, dim3(256), 0, s, (const float*)dy, Pb, (TO_*)dz, spatial, m)
 #define HV_K(TO_) do { if (k == 16) HV_GO(TO_, 16); else if (k == 32) HV_GO(TO_, 32); else HV_GO(TO_, 64); } while (0)
     if (out_dtype == MEDNET_F32) HV_K(float);
-    else HV_K(bf16);
+    else if (out_dtype == MEDNET_BF16) HV_K(bf16);
+    else HV_K(f16);
 #undef HV_K
 #undef HV_GO
     return check_launch("head_dgrad_vox");
@@ -583,7 +598,8 @@ int launch_head_dgrad(const void* dy, const float* Pb, void* dz, int n, size_t s
     else HD_GO(TO_, 32);              \
   } while (0)
   if (out_dtype == MEDNET_F32) HD_M(float);
-  else HD_M(bf16);
+  else if (out_dtype == MEDNET_BF16) HD_M(bf16);
+  else HD_M(f16);
 #undef HD_M
 #undef HD_GO
   return check_launch("head_dgrad");
@@ -679,8 +695,10 @@ int launch_wgrad_1x1(const void* z, const void* dy, float* dw, int n, size_t spa
   float* part = (float*)ws;
   if (z_dtype == MEDNET_F32)
     hipLaunchKernelGGL(wgrad_1x1_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)z, part, spatial, cin, cout, cv);
-  else
+  else if (z_dtype == MEDNET_BF16)
     hipLaunchKernelGGL(wgrad_1x1_kernel<bf16>, grid, dim3(256), 0, s, (const float*)dy, (const bf16*)z, part, spatial, cin, cout, cv);
+  else
+    hipLaunchKernelGGL(wgrad_1x1_kernel<f16>, grid, dim3(256), 0, s, (const float*)dy, (const f16*)z, part, spatial, cin, cout, cv);
   int rc = check_launch("wgrad_1x1");
   if (rc) return rc;
   hipLaunchKernelGGL(wgrad_1x1_final_kernel, dim3(cout * cin), dim3(64), 0, s, part, dw, (int)(n * chunks), mblocks, cin, cout);
@@ -704,9 +722,12 @@ int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int 
   int blocks = wgrad_c1_blocks(nt);
   MEDNET_REQUIRE(ws_bytes >= (size_t)blocks * 27 * cout * sizeof(float), MEDNET_E_WORKSPACE, "wgrad_c1: workspace too small");
   float* part = (float*)ws;
-  if (tuning_option("wgrad_c1_mfma", 1) && wgrad_c1_mfma_supported(cout, x_dtype, dy_dtype)) {  // matrix-core form (bf16 mode)
+  const bool c1_mfma = dy_dtype == MEDNET_F16 ? mednet_f16::wgrad_c1_mfma_supported(cout, x_dtype, dy_dtype)
+                                              : wgrad_c1_mfma_supported(cout, x_dtype, dy_dtype);
+  if (tuning_option("wgrad_c1_mfma", 1) && c1_mfma) {  // matrix-core form (16-bit modes)
     blocks = wgrad_c1_mfma_blocks(n, d, h, w);
-    int rc = launch_wgrad_c1_mfma(x, dy, part, n, d, h, w, cout, s);
+    int rc = dy_dtype == MEDNET_F16 ? mednet_f16::launch_wgrad_c1_mfma(x, dy, part, n, d, h, w, cout, s)
+                                    : launch_wgrad_c1_mfma(x, dy, part, n, d, h, w, cout, s);
     if (rc) return rc;
     const size_t count = (size_t)27 * cout;
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part, dw, count, blocks);
@@ -725,7 +746,10 @@ int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int 
   if (x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32) W1_CO(float, float);
   else if (x_dtype == MEDNET_F32 && dy_dtype == MEDNET_BF16) W1_CO(float, bf16);
   else if (x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_BF16) W1_CO(bf16, bf16);
-  else W1_CO(bf16, float);
+  else if (x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_F32) W1_CO(bf16, float);
+  else if (x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F16) W1_CO(float, f16);
+  else if (x_dtype == MEDNET_F16 && dy_dtype == MEDNET_F16) W1_CO(f16, f16);
+  else W1_CO(f16, float);
 #undef W1_CO
 #undef W1_GO
   int rc = check_launch("wgrad_c1");

@@ -1,4 +1,4 @@
-// bf16 MFMA (matrix-core) kernels for the 3x3x3 convolutions of the U-Net: forward / data-gradient (one kernel, two
+// 16-bit (bf16 / fp16) MFMA (matrix-core) kernels for the 3x3x3 convolutions of the U-Net: forward / data-gradient (one kernel, two
 // weight images) and weight-gradient.  gfx950 only: v_mfma_f32_32x32x16_bf16, ds_read_b128, ds_read_b64_tr_b16.
 //
 // ---- forward / data gradient: implicit GEMM, im2col-free ---------------------------------------------------------
@@ -20,17 +20,41 @@
 // partials are summed in a fixed order by a second kernel (deterministic, no atomics).
 #include "conv.h"
 
+// The 16-bit element type of this translation unit.  The file is compiled twice: as it stands for bf16 storage, and with
+// -DMEDNET_ELT_F16 -Dmednet=mednet_f16 for fp16 storage (BASELINE config 5): every kernel and launcher below then lives in
+// namespace mednet_f16 with the same names (declared by conv_mfma_decl.inc), and api.hip picks the namespace by dtype.
+namespace mednet {
+#ifdef MEDNET_ELT_F16
+typedef f16 elt;
+typedef f16x8 eltx8;
+typedef f16x4 eltx4;
+constexpr int ELT_DTYPE = MEDNET_F16;
+#define MEDNET_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define MEDNET_FDOT2(a, b, c, clamp) __builtin_amdgcn_fdot2(a, b, c, clamp)
+typedef __fp16 tr_v4 __attribute__((__vector_size__(8)));  // (the fp16 builtin is declared on __fp16 vectors)
+#define MEDNET_DS_READ_TR16(p) __builtin_bit_cast(eltx4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_v4*)(p)))
+#else
+typedef bf16 elt;
+typedef bf16x8 eltx8;
+typedef bf16x4 eltx4;
+constexpr int ELT_DTYPE = MEDNET_BF16;
+#define MEDNET_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define MEDNET_FDOT2(a, b, c, clamp) __builtin_amdgcn_fdot2_f32_bf16(a, b, c, clamp)
+#define MEDNET_DS_READ_TR16(p) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) eltx4*)(p))
+#endif
+}  // namespace mednet
+
 namespace mednet {
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((address_space(3))) eltx4 lds_eltx4;
 
 // One MFMA operand (8 k-values) from two transposing LDS reads.  Each lane passes the address of 4 consecutive channels
 // of ONE voxel row; the hardware hands lane i of every 16-lane group channel i of 4 voxel rows (measured mapping:
 // tools/probes/tr_probe.hip).  The whole-vector form matters: extracting the four 16-bit results one by one made
 // hipcc (ROCm 7.2) broadcast element 0.
-__device__ __forceinline__ bf16x8 tr_operand(const char* base, int second_read_byte_offset) {
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + second_read_byte_offset));
+__device__ __forceinline__ eltx8 tr_operand(const char* base, int second_read_byte_offset) {
+  const eltx4 lo = MEDNET_DS_READ_TR16(base);
+  const eltx4 hi = MEDNET_DS_READ_TR16(base + second_read_byte_offset);
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -52,9 +76,9 @@ __device__ __forceinline__ int fastdiv(int x, int d, unsigned rcp) { return d ==
 
 // ================================================================================================== forward kernel
 struct FwdArgs {
-  const bf16* x;
-  const bf16* wpk;  // [cb][kc][27][2][32][8]
-  bf16* y;
+  const elt* x;
+  const elt* wpk;  // [cb][kc][27][2][32][8]
+  elt* y;
   int n, od, oh, ow;  // output grid
   int id, ih, iw;     // input grid
   int cin, cout;
@@ -64,9 +88,9 @@ struct FwdArgs {
   unsigned rcp_tiles_x, rcp_tiles_y, rcp_tiles_z, rcp_ncb;  // ceil(2^32 / d): x / d == umulhi(x, rcp) for x * d < 2^32
   unsigned bytes_x;  // size of ONE SAMPLE of x for the buffer resource (< 4 GB)
   unsigned bytes_y;  // same for y
-  const bf16* add;    // nullable, shape of y: summed into the output in the epilogue (fp32 add, one rounding) -- the residual
+  const elt* add;    // nullable, shape of y: summed into the output in the epilogue (fp32 add, one rounding) -- the residual
                       // branch's gradient joining the data gradient of ExtResNetBlock's second conv (components.py:170-178)
-  int act;            // MEDNET_ACT_*: applied to the fp32 accumulators before the bf16 store (conv -> ReLU/LeakyReLU/ELU of the
+  int act;            // MEDNET_ACT_*: applied to the fp32 accumulators before the elt store (conv -> ReLU/LeakyReLU/ELU of the
                       // 'gcr' orders, components.py:36-40); the fused statistics are then those of the ACTIVATED output
   float* gn_partial;  // nullable: [n][stats_rows][cout][2] = {sum y, sum y^2} of the STORED (rounded) outputs, see stats_accum
   int stats_accum;    // 1: a wave keeps its sums over all its items of a sample and writes ONE row per sample (row =
@@ -76,7 +100,7 @@ struct FwdArgs {
   // 36-40): the first pass of that GroupNorm's backward -- du = dz * act'(ca * y + cb), sums of du and du * y per channel --
   // is taken in the epilogue from the STORED (rounded) dz rows, so no stand-alone pass re-reads dz and y.  gn_partial then
   // holds [n][stats_rows][cout][2] = {sum du, sum du * y} per CHANNEL (the affine gradients need single channels).
-  const bf16* gnb_y;      // conv output y of the layer in front (shape of this kernel's output)
+  const elt* gnb_y;      // conv output y of the layer in front (shape of this kernel's output)
   const float* gnb_coef;  // [n][cout][2] = {ca, cb}: its GroupNorm's forward affine, pre-activation = ca * y + cb
   int gnb_act;            // MEDNET_ACT_*
 #ifdef MEDNET_CONV_TIMING
@@ -105,9 +129,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   constexpr int W_CHUNKS = 27 * 2 * 32;  // 16-byte pieces of one weight slice
   constexpr int W_ROUNDS = (W_CHUNKS + 255) / 256;
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  typedef __attribute__((ext_vector_type(2))) elt eltx2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  u32x4* in_lds = reinterpret_cast<u32x4*>(smem);                  // [2][NV] 16-byte pieces (8 bf16 channels)
+  u32x4* in_lds = reinterpret_cast<u32x4*>(smem);                  // [2][NV] 16-byte pieces (8 elt channels)
   u32x4* w_lds = reinterpret_cast<u32x4*>(smem) + 2 * NV;          // [27][2][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -209,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     const int lx = STRIDE == 1 ? (((r & 15) - (r >> 4) * HX) & 15) : (r & 15);
     lbase[t] = ((STRIDE * lz) * HY + STRIDE * ly) * HX + STRIDE * lx + h * NV;
   }
-  const bf16x2 ones = {(bf16)1.0f, (bf16)1.0f};
+  const eltx2 ones = {(elt)1.0f, (elt)1.0f};
   const size_t ovol = (size_t)a.od * a.oh * a.ow;
   STAMP(1);
 
@@ -334,13 +358,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       // while tap t is on the matrix cores; sched_group_barrier pins that interleave (hipcc otherwise sinks each read to
       // just in front of its MFMA and exposes the LDS latency 108 times per chunk).
       constexpr int PD = 1;  // prefetch distance in taps (PD + 1 operand sets in registers); 2 measured no faster (+20 VGPRs)
-      bf16x8 wa[PD + 1], xb[PD + 1][NTW];
+      eltx8 wa[PD + 1], xb[PD + 1][NTW];
       auto tap_off = [&](int t1) { return ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3; };
 #pragma unroll
       for (int p = 0; p < PD; ++p) {
-        wa[p] = __builtin_bit_cast(bf16x8, w_lds[(p * 2 + h) * 32 + r]);
+        wa[p] = __builtin_bit_cast(eltx8, w_lds[(p * 2 + h) * 32 + r]);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) xb[p][t] = __builtin_bit_cast(bf16x8, in_lds[lbase[t] + tap_off(p)]);
+        for (int t = 0; t < NTW; ++t) xb[p][t] = __builtin_bit_cast(eltx8, in_lds[lbase[t] + tap_off(p)]);
       }
       static_assert(IN_ROUNDS + W_ROUNDS <= 27, "one staging load per tap");
 #pragma unroll
@@ -349,9 +373,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
         if (tap + PD < 27) {
           const int t1 = tap + PD;
           const int toff = tap_off(t1);
-          wa[nxt] = __builtin_bit_cast(bf16x8, w_lds[(t1 * 2 + h) * 32 + r]);
+          wa[nxt] = __builtin_bit_cast(eltx8, w_lds[(t1 * 2 + h) * 32 + r]);
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) xb[nxt][t] = __builtin_bit_cast(bf16x8, in_lds[lbase[t] + toff]);
+          for (int t = 0; t < NTW; ++t) xb[nxt][t] = __builtin_bit_cast(eltx8, in_lds[lbase[t] + toff]);
         }
         if (tap < IN_ROUNDS)
           in_reg[tap] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, goff[tap] | kill, pf_kc * 32, 0);
@@ -371,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     // brick's output is assembled in LDS (8-byte chunks XOR-swizzled by voxel so both the ds_write_b64 and the
     // ds_read_b128 are conflict-free) and written out as whole rows: 4 lanes per voxel, 16 voxels = 1 KB contiguous per
     // wave instruction when Cout = 32.  The GroupNorm partial sums come from the same LDS image (8 channels per lane).
-    bf16* out_lds = reinterpret_cast<bf16*>(smem);  // [TZ*TY*TX voxels][32 co], reuses the input image
+    elt* out_lds = reinterpret_cast<elt*>(smem);  // [TZ*TY*TX voxels][32 co], reuses the input image
     __syncthreads();                                // every wave is done with the MFMA reads of the last chunk
     STAMP(11);
     // (an opaque copy of the thread id: without it the compiler hoists the epilogue's ~30 addresses, which are the same
@@ -388,15 +412,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       const int sw = (vl >> 1) & 7;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        bf16x4 o;
+        eltx4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)act_apply(acc[t][q * 4 + j], a.act);  // co = 8q + 4h + j
-        *reinterpret_cast<bf16x4*>(out_lds + vl * 32 + ((2 * q + e_h) ^ sw) * 4) = o;
+        for (int j = 0; j < 4; ++j) o[j] = (elt)act_apply(acc[t][q * 4 + j], a.act);  // co = 8q + 4h + j
+        *reinterpret_cast<eltx4*>(out_lds + vl * 32 + ((2 * q + e_h) ^ sw) * 4) = o;
       }
     }
     __syncthreads();
     STAMP(12);
-    // GroupNorm partials are kept per channel PAIR (v_dot2c_f32_bf16: two exact bf16 products + fp32 add per
+    // GroupNorm partials are kept per channel PAIR (v_dot2c_f32_bf16: two exact elt products + fp32 add per
     // instruction, 8 instructions per 8-channel piece instead of 24): entry 2j of the partial row gets the sums of
     // channels 2j and 2j+1, entry 2j+1 is zero.  GroupNorm only ever adds the channels of a group, so this is exact
     // whenever the channels per group are even (the host asks for fused partials only then).
@@ -418,14 +442,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
     const auto rsrc_add = __builtin_amdgcn_make_buffer_rsrc((void*)((a.add ? a.add : a.y) + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
     const int swl = (et >> 1) & 7;  // (vl >> 1) & 7 does not depend on the round: 64 voxels per round
-    const bf16* rd = out_lds + et * 32 + (pj ^ (swl >> 1)) * 8;
+    const elt* rd = out_lds + et * 32 + (pj ^ (swl >> 1)) * 8;
     constexpr int ROUNDS = (TZ * TY * TX * 4) / 256;
-    bf16x8 rows[ROUNDS];  // all LDS reads first (the accumulators' registers are free now), then the stores back to back:
+    eltx8 rows[ROUNDS];  // all LDS reads first (the accumulators' registers are free now), then the stores back to back:
 #pragma unroll            // read -> wait -> store per round exposed the LDS latency eight times
-    for (int it = 0; it < ROUNDS; ++it) rows[it] = *reinterpret_cast<const bf16x8*>(rd + it * 64 * 32);
+    for (int it = 0; it < ROUNDS; ++it) rows[it] = *reinterpret_cast<const eltx8*>(rd + it * 64 * 32);
     // GNB: the rows of y at the positions this lane stores, and the GroupNorm affine of its 8 channels (both through
     // buffer resources: positions / channels outside the tensor read zeros), all in flight before the first use
-    bf16x8 yrow[GNB ? ROUNDS : 1];
+    eltx8 yrow[GNB ? ROUNDS : 1];
     float ca[GNB ? 8 : 1], cbf[GNB ? 8 : 1];
     if constexpr (GNB) {
       const auto rsrc_gy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_y + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
@@ -434,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
         const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
         const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
         const unsigned soff = (unsigned)(((oz * a.oh + oyb) * a.ow + tx0) * a.cout + cb * 32) * 2u;
-        yrow[it] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_gy, ok ? vbase : OOB, soff, 0));
+        yrow[it] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_gy, ok ? vbase : OOB, soff, 0));
       }
       const auto rsrc_cf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_coef + (size_t)n * a.cout * 2), 0, (unsigned)a.cout * 8u, 0x00020000);
       const unsigned coff = (unsigned)(cb * 32 + pj * 8) * 8u;
@@ -449,15 +473,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     }
 #pragma unroll
     for (int it = 0; it < ROUNDS; ++it) {
-      bf16x8 v = rows[it];
+      eltx8 v = rows[it];
       if (swl & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
       const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
       const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
       const unsigned soff = (unsigned)(((oz * a.oh + oyb) * a.ow + tx0) * a.cout + cb * 32) * 2u;
       if (a.add) {  // (wave-uniform) y += add: 16-byte row pieces at the same offsets, out-of-range lanes read zeros
-        const bf16x8 ad = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_add, ok ? vbase : OOB, soff, 0));
+        const eltx8 ad = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_add, ok ? vbase : OOB, soff, 0));
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)ad[k]);
+        for (int k = 0; k < 8; ++k) v[k] = (elt)((float)v[k] + (float)ad[k]);
       }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_y, ok ? vbase : OOB, soff, 2);  // aux 2 = nt: streamed output must not push the input rows (read again by the next K chunk) out of L2
       if constexpr (GNB) {
@@ -479,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       } else if (ok && a.gn_partial) {  // statistics of what is stored (the rounded values), exactly like the stand-alone pass
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const bf16x2 pr = {v[2 * k], v[2 * k + 1]};
+          const eltx2 pr = {v[2 * k], v[2 * k + 1]};
           gs[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, gs[k], false);
           gq[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, gq[k], false);
         }
@@ -516,11 +540,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 // weight slice are used by all 27 taps exactly as in the forward convolution.  Bias and the decoder's skip tensor
 // (`x += encoder_features`, components.py:283-284) are added in the epilogue.
 struct CtArgs {
-  const bf16* x;
-  const bf16* wpk;
+  const elt* x;
+  const elt* wpk;
   const float* bias;
-  const bf16* skip;
-  bf16* y;
+  const elt* skip;
+  elt* y;
   int n, id, ih, iw;  // input grid (output is 2x)
   int cin, cout;
   int tiles_z, tiles_y, tiles_x, ntiles;
@@ -535,8 +559,8 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
   constexpr int W_CHUNKS = 27 * 2 * 32;
   constexpr int W_ROUNDS = (W_CHUNKS + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16x8* in_lds = reinterpret_cast<bf16x8*>(smem);
-  bf16x8* w_lds = reinterpret_cast<bf16x8*>(smem) + 2 * NV;
+  eltx8* in_lds = reinterpret_cast<eltx8*>(smem);
+  eltx8* w_lds = reinterpret_cast<eltx8*>(smem) + 2 * NV;
 
   const int bid = blockIdx.x;
   const int xcd = bid & 7, local = bid >> 3;
@@ -568,23 +592,23 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
     }
     goff[it] = off;
   }
-  const bf16* wsrc = a.wpk + (size_t)cb * a.nkc * (W_CHUNKS * 8);
-  bf16x8 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
+  const elt* wsrc = a.wpk + (size_t)cb * a.nkc * (W_CHUNKS * 8);
+  eltx8 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
   // Branch-free: every lane always loads (padding / out-of-image lanes read a valid dummy address); what is invalid
   // is replaced by zeros when the registers are committed to LDS, so the 16 loads issue back to back with no waits.
   auto prefetch = [&](int kc) {
 #pragma unroll
     for (int it = 0; it < IN_ROUNDS; ++it)
-      in_reg[it] = *reinterpret_cast<const bf16x8*>(a.x + (goff[it] >= 0 ? goff[it] : 0) + kc * 16);
-    const bf16* ws = wsrc + (size_t)kc * (W_CHUNKS * 8);
+      in_reg[it] = *reinterpret_cast<const eltx8*>(a.x + (goff[it] >= 0 ? goff[it] : 0) + kc * 16);
+    const elt* ws = wsrc + (size_t)kc * (W_CHUNKS * 8);
 #pragma unroll
     for (int it = 0; it < W_ROUNDS; ++it) {
       const int c = it * 256 + tid;
-      w_reg[it] = *reinterpret_cast<const bf16x8*>(ws + (size_t)(c < W_CHUNKS ? c : W_CHUNKS - 1) * 8);
+      w_reg[it] = *reinterpret_cast<const eltx8*>(ws + (size_t)(c < W_CHUNKS ? c : W_CHUNKS - 1) * 8);
     }
   };
   auto commit = [&]() {
-    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const eltx8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int it = 0; it < IN_ROUNDS; ++it) {
       const int p = it * 256 + tid;
@@ -614,10 +638,10 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
     commit();
     __syncthreads();
     if (kc + 1 < a.nkc) prefetch(kc + 1);
-    bf16x8 xb[8];
+    eltx8 xb[8];
 #pragma unroll
     for (int dl = 0; dl < 8; ++dl) xb[dl] = in_lds[lbase + (((dl >> 2) & 1) * HY + ((dl >> 1) & 1)) * HX + (dl & 1)];
-    bf16x8 wa[2];
+    eltx8 wa[2];
     wa[0] = w_lds[h * 32 + r];
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
@@ -673,15 +697,15 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
       const int oz = 2 * (tz0 + lz2) + pz, oy = 2 * ty0 + oy_l, ox = 2 * tx0 + ox_l;
       if (oz < od && oy < oh && ox < ow) {
         const size_t o = ((((size_t)n * od + oz) * oh + oy) * ow + ox) * a.cout + cb * 32 + piece * 8;
-        bf16x8 sk = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (a.skip) sk = *reinterpret_cast<const bf16x8*>(a.skip + o);
-        bf16x8 ov;
+        eltx8 sk = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (a.skip) sk = *reinterpret_cast<const eltx8*>(a.skip + o);
+        eltx8 ov;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          ov[j] = (bf16)(lo[j] + (float)sk[j]);
-          ov[4 + j] = (bf16)(hi[j] + (float)sk[4 + j]);
+          ov[j] = (elt)(lo[j] + (float)sk[j]);
+          ov[4 + j] = (elt)(hi[j] + (float)sk[4 + j]);
         }
-        *reinterpret_cast<bf16x8*>(a.y + o) = ov;
+        *reinterpret_cast<eltx8*>(a.y + o) = ov;
       }
     }
   }
@@ -692,11 +716,11 @@ int launch_convt_fwd_mfma(const void* x, const void* sec, const float* bias, con
   constexpr size_t lds = 512 * 32 * 4;  // the epilogue's fp32 half-block (64 KB) > staging images (36 KB); 2 workgroups per CU
   static_assert(lds >= ((size_t)2 * 3 * 5 * 17 + 27 * 2 * 32) * 16 && lds <= 80 * 1024, "LDS plan of convt_fwd");
   CtArgs a;
-  a.x = (const bf16*)x;
-  a.wpk = (const bf16*)sec;
+  a.x = (const elt*)x;
+  a.wpk = (const elt*)sec;
   a.bias = bias;
-  a.skip = (const bf16*)skip;
-  a.y = (bf16*)y;
+  a.skip = (const elt*)skip;
+  a.y = (elt*)y;
   a.n = n; a.id = d; a.ih = h; a.iw = w; a.cin = cin; a.cout = cout;
   a.tiles_z = (d + 1) / 2;
   a.tiles_y = (h + 3) / 4;
@@ -718,13 +742,13 @@ int launch_convt_fwd_mfma(const void* x, const void* sec, const float* bias, con
 // ================================================================================================== first layer (Cin = 1)
 // y[vox][co] = sum_tap W[co][tap] * x[vox + tap - 1]: with one input channel the contraction index is the TAP (27, padded
 // to 32 = two MFMA k-steps).  The B operand (k = tap, n = voxel) is gathered from an fp32 halo brick of x in LDS -- 8
-// scalar LDS reads per fragment -- and split into bf16 hi + lo parts (x = hi + lo to ~2^-17), so the network input keeps
-// fp32-level precision at 4 MFMAs per 32 voxels; the weights (32 x 32 bf16) live in registers for the kernel's lifetime.
+// scalar LDS reads per fragment -- and split into elt hi + lo parts (x = hi + lo to ~2^-17), so the network input keeps
+// fp32-level precision at 4 MFMAs per 32 voxels; the weights (32 x 32 elt) live in registers for the kernel's lifetime.
 // The kernel is bound by writing its output (32 channels per input voxel); the VALU formulation it replaces was 4x slower.
 struct C1Args {
   const float* x;    // N x D x H x W (one channel)
   const float* w;    // packed forward image Pf[tap][co] (fp32)
-  bf16* y;           // NDHWC
+  elt* y;           // NDHWC
   float* gn_partial; // nullable: [n][4 * bricks per sample][cout][2] per-wave {sum y, sum y^2} of the stored values
   int n, d, h, w_, cout;
   int tiles_z, tiles_y, tiles_x, ntiles, ncb;
@@ -743,13 +767,13 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
   const int tz0 = (tt % a.tiles_z) * TZ;
   const int n = tt / a.tiles_z;
   // weights: A operand, lane (co = r, h) holds taps 8h..8h+7 (k-step 0) and 16+8h..16+8h+7 (k-step 1); taps >= 27 are 0
-  bf16x8 wa[2];
+  eltx8 wa[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int tap = ks * 16 + 8 * h + j;
-      wa[ks][j] = (bf16)(tap < 27 ? a.w[(size_t)tap * a.cout + cb * 32 + r] : 0.f);
+      wa[ks][j] = (elt)(tap < 27 ? a.w[(size_t)tap * a.cout + cb * 32 + r] : 0.f);
     }
   // LDS offsets of this lane's 8 taps per k-step
   int toff[2][8];
@@ -782,30 +806,30 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 hi, lo;
+      eltx8 hi, lo;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float v = xs[base + toff[ks][j]];
-        hi[j] = (bf16)v;
-        lo[j] = (bf16)(v - (float)hi[j]);
+        hi[j] = (elt)v;
+        lo[j] = (elt)(v - (float)hi[j]);
       }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], hi, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], lo, acc, 0, 0, 0);
     }
     const int oz = tz0 + lz, oy = ty0 + ly, ox = tx0 + lx;
     if (oz < a.d && oy < a.h && ox < a.w_) {
-      bf16* yp = a.y + ((size_t)n * vol + ((size_t)oz * a.h + oy) * a.w_ + ox) * a.cout + cb * 32 + 4 * h;
+      elt* yp = a.y + ((size_t)n * vol + ((size_t)oz * a.h + oy) * a.w_ + ox) * a.cout + cb * 32 + 4 * h;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        bf16x4 o;
+        eltx4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          o[j] = (bf16)acc[q * 4 + j];
+          o[j] = (elt)acc[q * 4 + j];
           const float f = (float)o[j];  // statistics of what is stored
           ssum[q * 4 + j] += f;
           ssq[q * 4 + j] = fmaf(f, f, ssq[q * 4 + j]);
         }
-        *reinterpret_cast<bf16x4*>(yp + 8 * q) = o;
+        *reinterpret_cast<eltx4*>(yp + 8 * q) = o;
       }
     }
   }
@@ -832,7 +856,7 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
 }
 
 bool conv_c1_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int y_layout, bool bias) {
-  return cin == 1 && ksize == 3 && cout % 32 == 0 && x_dtype == MEDNET_F32 && y_dtype == MEDNET_BF16 &&
+  return cin == 1 && ksize == 3 && cout % 32 == 0 && x_dtype == MEDNET_F32 && y_dtype == ELT_DTYPE &&
          y_layout == MEDNET_NDHWC && !bias;
 }
 int conv_c1_stats_chunks(int d, int h, int w) { return 4 * ((d + 3) / 4) * ((h + 7) / 8) * ((w + 15) / 16); }
@@ -842,7 +866,7 @@ int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d,
   a.gn_partial = gn_partial;
   a.x = (const float*)x;
   a.w = w_pf;
-  a.y = (bf16*)y;
+  a.y = (elt*)y;
   a.n = n; a.d = d; a.h = h; a.w_ = w; a.cout = cout;
   a.tiles_z = (d + 3) / 4;
   a.tiles_y = (h + 7) / 8;
@@ -859,8 +883,8 @@ int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d,
 // mode 1: conv dgrad    Weff[m][k][t] = W[k][m][26-t]                           M=Cin  K=Cout
 // mode 2: convT fwd     Weff[m][k][t] = Wt[k][m][t]           (Wt: Cin,Cout,27) M=Cout K=Cin
 // mode 3: convT dgrad   Weff[m][k][t] = Wt[m][k][t]                             M=Cin  K=Cout
-__global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict__ w, bf16* __restrict__ out0,
-                                                        bf16* __restrict__ out1, int M0, int K0, int mode0, int mode1,
+__global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict__ w, elt* __restrict__ out0,
+                                                        elt* __restrict__ out1, int M0, int K0, int mode0, int mode1,
                                                         float* __restrict__ Pf, float* __restrict__ Pb, int transposed_src) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.y == 2) {  // the fp32 tap-major images of the direct kernels ride along in the same launch
@@ -880,7 +904,7 @@ __global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict_
   }
   // blockIdx.y = 0: forward image (M0 x K0), 1: data-gradient image (K0 x M0): one launch for both
   const int M = blockIdx.y ? K0 : M0, K = blockIdx.y ? M0 : K0, mode = blockIdx.y ? mode1 : mode0;
-  bf16* out = blockIdx.y ? out1 : out0;
+  elt* out = blockIdx.y ? out1 : out0;
   const size_t total = (size_t)((M + 31) / 32 * 32) * K * 27;  // rows beyond M (a 16-channel side) are zero padding
   if (e >= total) return;
   size_t q = e;
@@ -902,7 +926,7 @@ __global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict_
   else if (mode == 1) v = w[((size_t)k * M + m) * 27 + (26 - tap)];
   else if (mode == 2) v = w[((size_t)k * M + m) * 27 + tap];
   else v = w[((size_t)m * K + k) * 27 + tap];
-  out[e] = (bf16)v;
+  out[e] = (elt)v;
 }
 
 PackLayout pack_layout(int cin, int cout, int ksize) {
@@ -913,8 +937,8 @@ PackLayout pack_layout(int cin, int cout, int ksize) {
   L.f32_bwd = f32;
   // the contraction side of an image needs a multiple of 16 (one MFMA k-step), its M side is padded to 32 rows
   const bool mfma = ksize == 3 && cin % 16 == 0 && cout % 16 == 0;
-  const size_t fwd_bytes = mfma ? align_up((size_t)27 * ((cout + 31) / 32 * 32) * cin * sizeof(bf16), 256) : 0;
-  const size_t bwd_bytes = mfma ? align_up((size_t)27 * ((cin + 31) / 32 * 32) * cout * sizeof(bf16), 256) : 0;
+  const size_t fwd_bytes = mfma ? align_up((size_t)27 * ((cout + 31) / 32 * 32) * cin * sizeof(elt), 256) : 0;
+  const size_t bwd_bytes = mfma ? align_up((size_t)27 * ((cin + 31) / 32 * 32) * cout * sizeof(elt), 256) : 0;
   L.mfma_bytes = fwd_bytes > bwd_bytes ? fwd_bytes : bwd_bytes;
   L.mfma_fwd = 2 * f32;
   L.mfma_bwd = 2 * f32 + fwd_bytes;
@@ -927,9 +951,9 @@ int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, float* Pf, fl
   if (T != 27) return MEDNET_OK;
   const int cmax = cin > cout ? cin : cout, cmin = cin > cout ? cout : cin;
   const size_t total = (size_t)((cmax + 31) / 32 * 32) * ((cmin + 31) / 32 * 32) * 27;  // covers both padded images
-  const dim3 grid((unsigned)((total + 255) / 256), 3);  // y = 0/1: the two bf16 fragment images, 2: the fp32 images
+  const dim3 grid((unsigned)((total + 255) / 256), 3);  // y = 0/1: the two elt fragment images, 2: the fp32 images
   // forward image: M = cout, K = cin; backward (data-gradient) image: M = cin, K = cout
-  hipLaunchKernelGGL(pack_mfma_kernel, grid, dim3(256), 0, s, w, (bf16*)sec_fwd, (bf16*)sec_bwd, cout, cin,
+  hipLaunchKernelGGL(pack_mfma_kernel, grid, dim3(256), 0, s, w, (elt*)sec_fwd, (elt*)sec_bwd, cout, cin,
                      transposed_src ? 2 : 0, transposed_src ? 3 : 1, Pf, Pb, transposed_src);
   return check_launch("pack_mfma");
 }
@@ -940,7 +964,7 @@ bool conv_mfma_fits(int n, int d, int h, int w, int c) {
   return (double)d * h * w * c * 2.0 < 4294960000.0;
 }
 bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int x_layout, int y_layout, bool bias) {
-  return ksize == 3 && cin % 16 == 0 && cout % 16 == 0 && x_dtype == MEDNET_BF16 && y_dtype == MEDNET_BF16 &&
+  return ksize == 3 && cin % 16 == 0 && cout % 16 == 0 && x_dtype == ELT_DTYPE && y_dtype == ELT_DTYPE &&
          x_layout == MEDNET_NDHWC && y_layout == MEDNET_NDHWC && !bias;
 }
 
@@ -975,8 +999,8 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   FwdArgs a;
   a.gn_partial = gn_partial;
   a.act = act;
-  a.add = (const bf16*)add;
-  a.gnb_y = (const bf16*)gnb.y;
+  a.add = (const elt*)add;
+  a.gnb_y = (const elt*)gnb.y;
   a.gnb_coef = gnb.coef;
   a.gnb_act = gnb.act;
   const bool use_gnb = gnb.y != nullptr;
@@ -985,9 +1009,9 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
 #ifdef MEDNET_CONV_TIMING
   a.dbg = (long long*)(((unsigned long long)(unsigned)tuning_option("conv_dbg_hi", 0) << 32) | (unsigned)tuning_option("conv_dbg_lo", 0));
 #endif
-  a.x = (const bf16*)x;
-  a.wpk = (const bf16*)sec;
-  a.y = (bf16*)y;
+  a.x = (const elt*)x;
+  a.wpk = (const elt*)sec;
+  a.y = (elt*)y;
   a.n = n; a.od = od; a.oh = oh; a.ow = ow; a.id = id; a.ih = ih; a.iw = iw;
   a.cin = cin; a.cout = cout;
   a.tiles_z = (od + G::TZ - 1) / G::TZ;
@@ -1071,8 +1095,8 @@ struct WgTile<2> {
 };
 
 struct WgArgs {
-  const bf16* A;  // loop grid tensor (ad,ah,aw; ka channels)
-  const bf16* B;  // shifted tensor   (bd,bh,bw; kb channels)
+  const elt* A;  // loop grid tensor (ad,ah,aw; ka channels)
+  const elt* B;  // shifted tensor   (bd,bh,bw; kb channels)
   float* part;    // [wg][27][32][32]
   int n, ad, ah, aw, bd, bh, bw, ka, kb;
   int tiles_z, tiles_y, tiles_x, ntiles;
@@ -1090,8 +1114,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
   constexpr int A_ROUNDS = (NA * 4 + 255) / 256, B_ROUNDS = (NB * 4 + 255) / 256;
   constexpr int KSTEPS = NA / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* A_lds = reinterpret_cast<bf16*>(smem);            // [NA][32]
-  bf16* B_lds = reinterpret_cast<bf16*>(smem) + NA * 32;  // [NB][32]
+  elt* A_lds = reinterpret_cast<elt*>(smem);            // [NA][32]
+  elt* B_lds = reinterpret_cast<elt*>(smem) + NA * 32;  // [NB][32]
 
   const int pair = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
   const int ab = pair / a.nbb, bb = pair % a.nbb;
@@ -1123,10 +1147,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
         const int v = c >> 2, part = c & 3;
         const int lx = v % TX, ly = (v / TX) % TY, lz = v / (TX * TY);
         const int gz = tz0 + lz, gy = ty0 + ly, gx = tx0 + lx;
-        bf16x8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+        eltx8 val = {0, 0, 0, 0, 0, 0, 0, 0};
         if (gz < a.ad && gy < a.ah && gx < a.aw)
-          val = *reinterpret_cast<const bf16x8*>(a.A + ((((size_t)n * a.ad + gz) * a.ah + gy) * a.aw + gx) * a.ka + ab * 32 + part * 8);
-        *reinterpret_cast<bf16x8*>(A_lds + v * 32 + part * 8) = val;
+          val = *reinterpret_cast<const eltx8*>(a.A + ((((size_t)n * a.ad + gz) * a.ah + gy) * a.aw + gx) * a.ka + ab * 32 + part * 8);
+        *reinterpret_cast<eltx8*>(A_lds + v * 32 + part * 8) = val;
       }
     }
 #pragma unroll 4
@@ -1136,10 +1160,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
         const int v = c >> 2, part = c & 3;
         const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
         const int gz = STRIDE * tz0 - 1 + hz, gy = STRIDE * ty0 - 1 + hy, gx = STRIDE * tx0 - 1 + hx;
-        bf16x8 val = {0, 0, 0, 0, 0, 0, 0, 0};
+        eltx8 val = {0, 0, 0, 0, 0, 0, 0, 0};
         if (gz >= 0 && gz < a.bd && gy >= 0 && gy < a.bh && gx >= 0 && gx < a.bw)
-          val = *reinterpret_cast<const bf16x8*>(a.B + ((((size_t)n * a.bd + gz) * a.bh + gy) * a.bw + gx) * a.kb + bb * 32 + part * 8);
-        *reinterpret_cast<bf16x8*>(B_lds + v * 32 + part * 8) = val;
+          val = *reinterpret_cast<const eltx8*>(a.B + ((((size_t)n * a.bd + gz) * a.bh + gy) * a.bw + gx) * a.kb + bb * 32 + part * 8);
+        *reinterpret_cast<eltx8*>(B_lds + v * 32 + part * 8) = val;
       }
     }
     __syncthreads();
@@ -1154,13 +1178,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
       const int tap = wv + 4 * i < 27 ? wv + 4 * i : 26;
       toff[i] = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 64;
     }
-    auto load_set = [&](int ks, bf16x8& fa, bf16x8 (&fb)[7]) {
+    auto load_set = [&](int ks, eltx8& fa, eltx8 (&fb)[7]) {
       fa = tr_operand(Ab + (ks * TX + 8 * hk + q) * 64, 4 * 64);
       const char* brow = Bb + (((STRIDE * (ks / TY)) * HY + STRIDE * (ks % TY)) * HX + STRIDE * (8 * hk + q)) * 64;
 #pragma unroll
       for (int i = 0; i < 7; ++i) fb[i] = tr_operand(brow + toff[i], 4 * STRIDE * 64);
     };
-    bf16x8 fa0, fa1, fb0[7], fb1[7];
+    eltx8 fa0, fa1, fb0[7], fb1[7];
     load_set(0, fa0, fb0);
     static_assert(KSTEPS % 2 == 0, "k-steps are consumed in pairs");
     for (int ks = 0; ks < KSTEPS; ks += 2) {
@@ -1199,8 +1223,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
 // groups' partial sums are separate slabs for the reduce kernel), and with 512 threads the next brick fits in 13 staging
 // registers per lane, fetched with buffer loads (hardware zero padding) while the current brick is on the matrix cores.
 struct Wg2Args {
-  const bf16* A;
-  const bf16* B;
+  const elt* A;
+  const elt* B;
   float* part;  // [wg][27][32][32]
   int n, d, h, w, ka, kb;
   int tiles_z, tiles_y, tiles_x, ntiles;
@@ -1216,8 +1240,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
   constexpr int KSTEPS = NA / 16;
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* A_lds = reinterpret_cast<bf16*>(smem);
-  bf16* B_lds = reinterpret_cast<bf16*>(smem) + NA * 32;
+  elt* A_lds = reinterpret_cast<elt*>(smem);
+  elt* B_lds = reinterpret_cast<elt*>(smem) + NA * 32;
 
   const int pair = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
   const int ab = pair / a.nbb, bb = pair % a.nbb;
@@ -1315,9 +1339,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
 #pragma unroll
     for (int k2 = 0; k2 < KSTEPS / 2; ++k2) {
       const int ks = 2 * k2 + kgrp;  // the two wave groups interleave the brick's k-steps
-      const bf16x8 fa = tr_operand(Ab + (ks * TX + 8 * hk + q) * 64, 4 * 64);
+      const eltx8 fa = tr_operand(Ab + (ks * TX + 8 * hk + q) * 64, 4 * 64);
       const char* brow = Bb + (((ks / TY) * HY + ks % TY) * HX + 8 * hk + q) * 64;
-      bf16x8 fb[7];
+      eltx8 fb[7];
 #pragma unroll
       for (int i = 0; i < 7; ++i) fb[i] = tr_operand(brow + toff[i], 4 * 64);
       if (k2 < A_ROUNDS + B_ROUNDS) fetch_one(k2, nx);
@@ -1406,7 +1430,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_reduce_kernel(const float* __r
 }
 
 bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtype, int x_layout, int dy_layout) {
-  return ksize == 3 && cin % 16 == 0 && cout % 16 == 0 && x_dtype == MEDNET_BF16 && dy_dtype == MEDNET_BF16 &&
+  return ksize == 3 && cin % 16 == 0 && cout % 16 == 0 && x_dtype == ELT_DTYPE && dy_dtype == ELT_DTYPE &&
          x_layout == MEDNET_NDHWC && dy_layout == MEDNET_NDHWC;
 }
 // the kernel addresses its operands through buffer resources with 32-bit byte offsets
@@ -1451,8 +1475,8 @@ static int launch_wg(const void* A, const void* B, float* dw, int n, int ad, int
   constexpr size_t lds = ((size_t)G::TZ * G::TY * G::TX + (size_t)HZ * HY * HX) * 64;
   static_assert(lds <= 80 * 1024, "two workgroups must fit one CU");
   WgArgs a;
-  a.A = (const bf16*)A;
-  a.B = (const bf16*)B;
+  a.A = (const elt*)A;
+  a.B = (const elt*)B;
   a.part = (float*)ws;
   a.n = n; a.ad = ad; a.ah = ah; a.aw = aw; a.bd = bd; a.bh = bh; a.bw = bw; a.ka = ka; a.kb = kb;
   wgrad_plan<STRIDE>(n, ad, ah, aw, ka, kb, a);
@@ -1485,8 +1509,8 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
     return launch_wg<1>(dy, x, dw, n, d, h, w, d, h, w, cout, cin, ws, ws_bytes, s);
   constexpr size_t lds = ((size_t)4 * 8 * 16 + 6 * 10 * 18) * 64;
   Wg2Args a;
-  a.A = (const bf16*)dy;
-  a.B = (const bf16*)x;
+  a.A = (const elt*)dy;
+  a.B = (const elt*)x;
   a.part = (float*)ws;
   a.n = n; a.d = d; a.h = h; a.w = w; a.ka = cout; a.kb = cin;
   wgrad2_plan(n, d, h, w, cout, cin, a);
@@ -1512,12 +1536,12 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
 // ---- first-layer weight gradient (Cin = 1) on the matrix cores -----------------------------------------------------
 //   dW[co][tap] = sum_v x[v + tap - 1] * dy[v][co]:  D[tap (27 of 32 rows)][co] += A[tap][k = voxel] * B[k = voxel][co].
 // B comes from the dy brick in LDS through the transposing read (as in wgrad_mfma2); A is gathered from an fp32 halo brick
-// of x (lane = tap row: 8 consecutive x-values of its shifted row) and split into bf16 hi + lo parts (two MFMAs), so the
+// of x (lane = tap row: 8 consecutive x-values of its shifted row) and split into elt hi + lo parts (two MFMAs), so the
 // network input keeps fp32-level precision.  The kernel reads dy once and is bound by that (537 MB at config 2); the VALU
 // kernel it replaces (27 FMAs per voxel and channel) took 0.65 ms.
 struct Wc1Args {
   const float* x;  // N x D x H x W
-  const bf16* dy;  // N x D x H x W x cout
+  const elt* dy;  // N x D x H x W x cout
   float* part;     // [workgroup][cout][27]
   int n, d, h, w, cout;
   int tiles_z, tiles_y, tiles_x, ntiles;
@@ -1606,17 +1630,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_mfma_kernel(Wc1Args a) {
     for (int s8 = 0; s8 < 8; ++s8) {
       const int row = wv * 8 + s8;  // (lz, ly) = (row / TY, row % TY): 16 x-consecutive voxels = one MFMA k-step
       const float* px = xh + abase + ((row / TY) * HY + row % TY) * HX;
-      bf16x8 hi, lo;
+      eltx8 hi, lo;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float xv = px[j];
-        hi[j] = (bf16)xv;
-        lo[j] = (bf16)(xv - (float)hi[j]);
+        hi[j] = (elt)xv;
+        lo[j] = (elt)(xv - (float)hi[j]);
       }
       const char* brow = dyl + (row * TX + 8 * hk + q) * ROWB + coloff;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const bf16x8 fb = tr_operand(brow + b * 64, 4 * ROWB);
+        const eltx8 fb = tr_operand(brow + b * 64, 4 * ROWB);
         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, fb, acc[b], 0, 0, 0);
         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, fb, acc[b], 0, 0, 0);
       }
@@ -1644,7 +1668,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_mfma_kernel(Wc1Args a) {
 }
 
 bool wgrad_c1_mfma_supported(int cout, int x_dtype, int dy_dtype) {
-  return (cout == 32 || cout == 64) && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_BF16;
+  return (cout == 32 || cout == 64) && x_dtype == MEDNET_F32 && dy_dtype == ELT_DTYPE;
 }
 int wgrad_c1_mfma_blocks(int n, int d, int h, int w) {
   const int nt = n * ((d + 3) / 4) * ((h + 7) / 8) * ((w + 15) / 16);
@@ -1653,7 +1677,7 @@ int wgrad_c1_mfma_blocks(int n, int d, int h, int w) {
 int launch_wgrad_c1_mfma(const void* x, const void* dy, float* part, int n, int d, int h, int w, int cout, hipStream_t s) {
   Wc1Args a;
   a.x = (const float*)x;
-  a.dy = (const bf16*)dy;
+  a.dy = (const elt*)dy;
   a.part = part;
   a.n = n; a.d = d; a.h = h; a.w = w; a.cout = cout;
   a.tiles_z = (d + 3) / 4; a.tiles_y = (h + 7) / 8; a.tiles_x = (w + 15) / 16;
@@ -1694,8 +1718,8 @@ int launch_wgrad_c1_mfma(const void* x, const void* dy, float* part, int n, int 
 //   wave 2: 10 11 19 20 |  3  6 | 26     (shifts 010, 101, 000)
 //   wave 3:  4  5  7  8 |  9 18 | (18)   (shifts 100, 011; the 7th slot is a discarded duplicate)
 struct Ct2Args {
-  const bf16* A;  // x  (n, d, h, w, ka)
-  const bf16* B;  // dy (n, 2d, 2h, 2w, kb)
+  const elt* A;  // x  (n, d, h, w, ka)
+  const elt* B;  // dy (n, 2d, 2h, 2w, kb)
   float* part;    // [wg][27][32][32]
   int n, d, h, w, ka, kb;
   int tiles_z, tiles_y, tiles_x, ntiles;
@@ -1827,7 +1851,7 @@ __global__ __launch_bounds__(512, 2) void convt_wgrad_mfma2_kernel(Ct2Args a) {
       const int ks = 2 * k2 + kgrp;  // the two wave groups interleave the brick's k-steps (rows of 16 x-voxels)
       const char* arow = Ab + (((ks / TY) * HY + ks % TY) * HX) * 64;
       const char* brow = Bb + (ks * TX) * 64;
-      bf16x8 fa[3], fb[7];
+      eltx8 fa[3], fb[7];
 #pragma unroll
       for (int i = 0; i < 3; ++i) fa[i] = tr_operand(arow + aoff[i], 4 * 64);
 #pragma unroll
@@ -1904,8 +1928,8 @@ int launch_convt_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int
     return launch_wg<2>(x, dy, dw, n, d, h, w, 2 * d, 2 * h, 2 * w, cin, cout, ws, ws_bytes, s);
   constexpr size_t lds = 16384 + 8 * 128 * 64;
   Ct2Args a;
-  a.A = (const bf16*)x;
-  a.B = (const bf16*)dy;
+  a.A = (const elt*)x;
+  a.B = (const elt*)dy;
   a.part = (float*)ws;
   a.n = n; a.d = d; a.h = h; a.w = w; a.ka = cin; a.kb = cout;
   ct2_plan(n, d, h, w, cin, cout, a);

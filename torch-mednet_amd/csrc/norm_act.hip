@@ -732,6 +732,57 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// ---- fp16 storage: dynamic loss scaling without a host synchronisation (torch.cuda.amp.GradScaler's rule) ---------------
+// state[4] (device, fp32): {scale, good steps since the last change, optimizer steps taken, found_inf}.  The loss is
+// multiplied by state[0] on the device, so every gradient arrives times `scale`; grad_check raises found_inf if any
+// gradient is not finite, adam_scaled divides by the scale and SKIPS the update when found_inf is set (bias correction
+// uses the device-side step count, which a skipped step does not advance), scaler_update then halves the scale or
+// counts a good step and doubles it every `growth_interval` of them.
+__global__ __launch_bounds__(256) void grad_check_kernel(const float* __restrict__ g, size_t count, float* __restrict__ state) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+    const float v = g[i];
+    bad |= !(fabsf(v) <= 3.0e38f);  // NaN or +-inf
+  }
+  if (bad) state[3] = 1.f;  // (every writer stores the same value)
+}
+__global__ __launch_bounds__(256) void adam_scaled_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, size_t count, float lr,
+                                                          float b1, float b2, float eps, float wd, float inv_world,
+                                                          const float* __restrict__ state) {
+  if (state[3] != 0.f) return;  // overflow somewhere in this step's gradients: no update
+  const float t = state[2] + 1.f;
+  const float bc1 = 1.f - powf(b1, t), bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  const float gscale = inv_world / state[0];
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+    float gr = g[i] * gscale;
+    if (wd != 0.f) gr = fmaf(wd, p[i], gr);
+    const float mi = b1 * m[i] + (1.f - b1) * gr;
+    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+__global__ void scaler_update_kernel(float* __restrict__ state, float growth, float backoff, float interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (state[3] != 0.f) {
+    state[0] *= backoff;
+    state[1] = 0.f;
+  } else {
+    state[2] += 1.f;
+    state[1] += 1.f;
+    if (state[1] >= interval) {
+      state[0] *= growth;
+      state[1] = 0.f;
+    }
+  }
+  state[3] = 0.f;
+}
+
 }  // namespace mednet
 
 // =================================================================================================== C ABI
@@ -775,7 +826,8 @@ extern "C" int mednet_gn_stats(const void* x, const float* gamma, const float* b
   const dim3 grid(chunks, n);
 #define GO(T, V) hipLaunchKernelGGL((gn_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, partial, spatial, c, cv)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
-  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
   int rc = check_launch("gn_partial");
   if (rc) return rc;
@@ -809,7 +861,8 @@ extern "C" int mednet_gn_act_fwd(const void* x, const float* coef, const void* r
   const dim3 grid(chunks, n);
 #define GO(T, V) hipLaunchKernelGGL((gn_act_fwd_kernel<T, T, V>), grid, dim3(256), 0, s, (const T*)x, coef, (const T*)residual, (T*)z, spatial, c, act, cv)
   if (x_dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
-  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else if (x_dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
   return check_launch("gn_act_fwd");
 }
@@ -837,7 +890,8 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
   const int rpw = tuning_option("gn_lds_free", 1) ? lds_free_rows_per_wg(c / vec) : 0;
 #define GO(T, V) hipLaunchKernelGGL((gn_bwd_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, coef, stats, partial, spatial, c, groups, act, cv, rpw)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
-  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
   int rc = check_launch("gn_bwd_partial");
   if (rc) return rc;
@@ -853,7 +907,8 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
   }
 #define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
-  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
   return check_launch("gn_bwd_apply");
 }
@@ -890,7 +945,8 @@ extern "C" int mednet_gn_act_bwd_fused(const void* dz, const void* x, const floa
   const dim3 grid(chunks, n);
 #define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)nullptr, (const T*)x, (const T*)nullptr, coef, bcoef, (T*)dx, (T*)nullptr, spatial, c, act, cv)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
-  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
   return check_launch("gn_bwd_apply");
 }
@@ -900,7 +956,8 @@ extern "C" int mednet_act_fwd(const void* x, void* z, size_t count, int act, int
   hipStream_t s = (hipStream_t)stream;
   const unsigned g = flat_grid(count, 2048);
   if (dtype == MEDNET_F32) hipLaunchKernelGGL(act_fwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, (float*)z, count, act);
-  else hipLaunchKernelGGL(act_fwd_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)x, (bf16*)z, count, act);
+  else if (dtype == MEDNET_BF16) hipLaunchKernelGGL(act_fwd_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)x, (bf16*)z, count, act);
+  else hipLaunchKernelGGL(act_fwd_kernel<f16>, dim3(g), dim3(256), 0, s, (const f16*)x, (f16*)z, count, act);
   return check_launch("act_fwd");
 }
 extern "C" int mednet_act_bwd(const void* dz, const void* z, void* dx, size_t count, int act, int dtype,
@@ -909,7 +966,8 @@ extern "C" int mednet_act_bwd(const void* dz, const void* z, void* dx, size_t co
   hipStream_t s = (hipStream_t)stream;
   const unsigned g = flat_grid(count, 2048);
   if (dtype == MEDNET_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)dz, (const float*)z, (float*)dx, count, act);
-  else hipLaunchKernelGGL(act_bwd_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)dz, (const bf16*)z, (bf16*)dx, count, act);
+  else if (dtype == MEDNET_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)dz, (const bf16*)z, (bf16*)dx, count, act);
+  else hipLaunchKernelGGL(act_bwd_kernel<f16>, dim3(g), dim3(256), 0, s, (const f16*)dz, (const f16*)z, (f16*)dx, count, act);
   return check_launch("act_bwd");
 }
 extern "C" int mednet_add(const void* a, const void* b, void* out, size_t count, int dtype, mednet_stream stream) {
@@ -917,7 +975,8 @@ extern "C" int mednet_add(const void* a, const void* b, void* out, size_t count,
   hipStream_t s = (hipStream_t)stream;
   const unsigned g = flat_grid(count, 2048);
   if (dtype == MEDNET_F32) hipLaunchKernelGGL(add_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)out, count);
-  else hipLaunchKernelGGL(add_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, (bf16*)out, count);
+  else if (dtype == MEDNET_BF16) hipLaunchKernelGGL(add_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, (bf16*)out, count);
+  else hipLaunchKernelGGL(add_kernel<f16>, dim3(g), dim3(256), 0, s, (const f16*)a, (const f16*)b, (f16*)out, count);
   return check_launch("add");
 }
 
@@ -931,7 +990,8 @@ extern "C" int mednet_pool2_fwd(const void* x, void* y, int n, int d, int h, int
   const dim3 grid((unsigned)((total + 255) / 256));
 #define GO(T, V) hipLaunchKernelGGL((pool2_fwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, (T*)y, n, d, h, w, c, mode)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
-  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
   return check_launch("pool2_fwd");
 }
@@ -949,7 +1009,8 @@ extern "C" int mednet_pool2_bwd(const void* dy, const void* x, const void* add, 
   const dim3 grid((unsigned)((total + 255) / 256));
 #define GO(T, V) hipLaunchKernelGGL((pool2_bwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, n, d, h, w, c, mode)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
-  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
   return check_launch("pool2_bwd");
 }
@@ -963,7 +1024,8 @@ extern "C" int mednet_upcat_fwd(const void* enc, const void* x, void* out, int n
   const dim3 grid((unsigned)((total + 255) / 256));
 #define GO(T, V) hipLaunchKernelGGL((upcat_fwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)enc, (const T*)x, (T*)out, n, d, h, w, c_enc, xd, xh, xw, c_x)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
-  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
   return check_launch("upcat_fwd");
 }
@@ -984,9 +1046,23 @@ extern "C" int mednet_upcat_bwd(const void* dout, void* denc, void* dx, int n, i
                        xh, xw, c_x);                                                                                    \
   } while (0)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
-  else { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
+  else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
   return check_launch("upcat_bwd");
+}
+
+extern "C" int mednet_adam_step_scaled(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
+                                       float beta2, float eps, float weight_decay, float inv_world, float* scaler_state,
+                                       float growth_factor, float backoff_factor, int growth_interval, mednet_stream stream) {
+  MEDNET_REQUIRE(scaler_state != nullptr && growth_interval >= 1, MEDNET_E_SHAPE, "adam_step_scaled: scaler state required");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(grad_check_kernel, dim3(flat_grid(count, 1024)), dim3(256), 0, s, g, count, scaler_state);
+  hipLaunchKernelGGL(adam_scaled_kernel, dim3(flat_grid(count, 1024)), dim3(256), 0, s, p, g, m, v, count, lr, beta1, beta2, eps,
+                     weight_decay, inv_world, scaler_state);
+  hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, s, scaler_state, growth_factor, backoff_factor,
+                     (float)growth_interval);
+  return check_launch("adam_step_scaled");
 }
 
 extern "C" int mednet_adam_step(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,

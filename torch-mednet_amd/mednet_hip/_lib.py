@@ -34,14 +34,15 @@ SIGNATURES = {
     "mednet_set_option": (_i, [C.c_char_p, _i]),
     "mednet_conv3d_pack_bytes": (_sz, [_i, _i, _i]),
     "mednet_conv3d_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "mednet_conv3d_pack_elt": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mednet_conv3d_fused_stats_chunks": (_i, [_i] * 10),
     "mednet_conv3d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp]),
     "mednet_gn_finalize": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _f, _vp, _sz, _vp]),
     "mednet_conv3d_act_supported": (_i, [_i] * 7),
-    "mednet_conv3d_act_fwd": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp, _vp]),
-    "mednet_conv3d_dgrad_add": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
+    "mednet_conv3d_act_fwd": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp, _i, _vp]),
+    "mednet_conv3d_dgrad_add": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "mednet_conv3d_dgrad_gn_rows": (_i, [_i] * 7),
-    "mednet_conv3d_dgrad_gn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 7 + [_vp]),
+    "mednet_conv3d_dgrad_gn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 8 + [_vp]),
     "mednet_gn_act_bwd_fused": (_i, [_vp] * 6 + [_i, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mednet_conv3d_wgrad_ws_bytes": (_sz, [_i] * 7),
     "mednet_conv3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp, _sz, _vp]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "mednet_heatmap_loss_fwd": (_i, [_vp] * 4 + [_i, _i, _sz, _i64, _i64, _i, _i, _vp, _sz, _vp]),
     "mednet_heatmap_loss_bwd": (_i, [_vp] * 5 + [_i, _i, _sz, _i64, _i64, _i, _i, _vp]),
     "mednet_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    "mednet_adam_step_scaled": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _vp, _f, _f, _i, _vp]),
     "mednet_grid_gather": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "mednet_predict_assemble": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "mednet_crop_patches": (_i, [_vp, _i, _vp, _vp, _i, _vp] + [_i] * 10 + [_vp]),
@@ -108,7 +110,13 @@ def dt(t: torch.Tensor) -> int:
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
-    raise RuntimeError(f"mednet_hip: unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+    if t.dtype == torch.float16:
+        return F16
+    raise RuntimeError(f"mednet_hip: unsupported dtype {t.dtype} (float32 / bfloat16 / float16 only)")
+
+
+def dt_of(dtype: torch.dtype) -> int:
+    return {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}[dtype]
 
 
 def ptr(t):

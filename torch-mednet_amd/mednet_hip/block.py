@@ -103,20 +103,20 @@ def _conv_bwd(x, dy, packed, weight_p, need_dx, add=None, gnb=None):
     def dgrad():
         nonlocal dx, partial
         if need_dx:
-            dx = ops.empty_cl(n, cin, d, h, w, x.dtype if x.dtype in (torch.float32, torch.bfloat16) else config.act_dtype(), dy.device)
+            dx = ops.empty_cl(n, cin, d, h, w, x.dtype if x.dtype in (torch.float32, config.act_dtype()) else config.act_dtype(), dy.device)
             rows = 0
-            if gnb is not None and FUSE_GNB and dy.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16 \
-                    and (add is None or add.dtype == torch.bfloat16):
+            if gnb is not None and FUSE_GNB and dy.dtype in config.HALF_TYPES and dx.dtype == dy.dtype \
+                    and (add is None or add.dtype == dy.dtype):
                 rows = lib.mednet_conv3d_dgrad_gn_rows(n, d, h, w, cin, cout, config.conv_algo())
             if rows > 0:
                 y_prev, coef_prev, act_prev = gnb
                 partial = torch.empty((n, rows, cin, 2), dtype=torch.float32, device=dy.device)
                 L.check(lib.mednet_conv3d_dgrad_gn(dy.data_ptr(), packed.data_ptr(), L.ptr(add), dx.data_ptr(), y_prev.data_ptr(),
                                                    coef_prev.data_ptr(), act_prev, partial.data_ptr(), n, d, h, w, cin, cout,
-                                                   config.conv_algo(), L.stream()), "conv3d_dgrad_gn")
+                                                   config.conv_algo(), L.dt(dy), L.stream()), "conv3d_dgrad_gn")
             elif add is not None:
                 L.check(lib.mednet_conv3d_dgrad_add(dy.data_ptr(), packed.data_ptr(), add.data_ptr(), dx.data_ptr(), n, d, h, w,
-                                                    cin, cout, config.conv_algo(), L.stream()), "conv3d_dgrad_add")
+                                                    cin, cout, config.conv_algo(), L.dt(dy), L.stream()), "conv3d_dgrad_add")
             else:
                 L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin, 3,
                                               L.dt(dy), L.NDHWC, L.dt(dx), L.NDHWC, 1, config.conv_algo(), None, L.stream()),
@@ -167,7 +167,7 @@ class ResBlockFn(Function):
         # z1 feeds conv2 AND the residual add: the two gradients are summed in the epilogue of conv2's data gradient (bf16
         # matrix-core path), otherwise inside GroupNorm-1's backward (two more tensor reads)
         n_, c_, d_, h_, w_ = z1.shape
-        fuse = FUSE_DRES and dy2.dtype == torch.bfloat16 and dres.dtype == torch.bfloat16 and bool(
+        fuse = FUSE_DRES and dy2.dtype in config.HALF_TYPES and dres.dtype == dy2.dtype and bool(
             L.lib().mednet_conv3d_act_supported(n_, d_, h_, w_, c_, c_, config.conv_algo()))
         dz1, dw2, part1 = _conv_bwd(z1, dy2, pk2, w2, True, add=dres if fuse else None, gnb=(y1, c1, act) if fuse else None)
         dy1, _, dg1, db1 = _gn_bwd(dz1, None if fuse else dres, y1, None, c1, s1, g1, b1, groups, act, False, partial=part1)

@@ -113,8 +113,9 @@ def _storage_dtype(x: torch.Tensor) -> torch.dtype:
 
 
 def _as_act(x: torch.Tensor) -> torch.Tensor:
-    """Inputs that are neither fp32 nor bf16 (e.g. fp16/fp64 user tensors) are brought to the activation dtype."""
-    if x.dtype in (torch.float32, torch.bfloat16):
+    """Inputs that are neither fp32 nor the mode's 16-bit storage type (e.g. fp64 user tensors, bf16 in fp16 mode) are
+    brought to the activation dtype."""
+    if x.dtype == torch.float32 or x.dtype == config.act_dtype():
         return x
     return x.to(config.act_dtype())
 
@@ -129,7 +130,8 @@ def pack_conv_weight(weight: torch.Tensor, ksize: int, transposed: bool) -> torc
     cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
     nbytes = L.lib().mednet_conv3d_pack_bytes(cin, cout, ksize)
     buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    L.check(L.lib().mednet_conv3d_pack(w.data_ptr(), buf.data_ptr(), cin, cout, ksize, int(transposed), L.stream()),
+    elt = L.F16 if config.act_dtype() == torch.float16 else L.BF16  # element type of the matrix-core fragment images
+    L.check(L.lib().mednet_conv3d_pack_elt(w.data_ptr(), buf.data_ptr(), cin, cout, ksize, int(transposed), elt, L.stream()),
             "conv3d_pack")
     return buf
 
@@ -230,7 +232,7 @@ class ConvActFn(Function):
                 partial = torch.empty((n, chunks, cout, 2), dtype=torch.float32, device=x.device)
         with profiled_conv(3, cin, cout, n, d, h, w):
             L.check(lib.mednet_conv3d_act_fwd(xin.data_ptr(), packed.data_ptr(), z.data_ptr(), n, d, h, w, cin, cout, act,
-                                              config.conv_algo(), L.ptr(partial), L.stream()), "conv3d_act_fwd")
+                                              config.conv_algo(), L.ptr(partial), L.dt(z), L.stream()), "conv3d_act_fwd")
         ctx.save_for_backward(xin, packed, z)
         ctx.act = act
         ctx.weight = weight
@@ -252,9 +254,9 @@ class ConvActFn(Function):
 
 
 def conv3d_act_supported(x, cin, cout):
-    # mednet_conv3d_act_fwd has no dtype argument: it reads bf16.  An fp32 tensor handed to a bf16-mode layer (a block
+    # mednet_conv3d_act_fwd reads and writes ONE 16-bit type.  An fp32 tensor handed to a bf16-mode layer (a block
     # called stand-alone, a 16/32-channel network input) takes the unfused conv, which passes its dtypes.
-    if not (x.is_cuda and config.act_dtype() == torch.bfloat16 and x.dtype == torch.bfloat16 and x.dim() == 5):
+    if not (x.is_cuda and config.is_half_mode() and x.dtype == config.act_dtype() and x.dim() == 5):
         return False
     n, _, d, h, w = x.shape
     return bool(L.lib().mednet_conv3d_act_supported(n, d, h, w, cin, cout, config.conv_algo()))

@@ -64,11 +64,45 @@ class FlatAdam:
                        self.wd, self.t, grad_scale)
         self._bump()
 
+    def step_scaled(self, scaler: "LossScaler", inv_world=1.0):
+        """The same update behind the loss scaler: unscale, skip on overflow, adjust the scale -- all on the device."""
+        from . import _lib as L
+        self.t += 1
+        f = self.flat
+        L.check(L.lib().mednet_adam_step_scaled(f.flat.data_ptr(), f.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                                f.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                                inv_world, scaler.state.data_ptr(), scaler.growth_factor,
+                                                scaler.backoff_factor, scaler.growth_interval, L.stream()), "adam_step_scaled")
+        self._bump()
+
     def _bump(self):
         # torch's version counter only moves on torch in-place ops; a no-op in-place op on the flat buffer does not
         # reach the views' counters, so packed-weight caches are keyed on this step counter as well.
         for p in self.flat.params:
             p._mednet_step = self.t
+
+
+class LossScaler:
+    """Dynamic loss scaling for fp16 storage (BASELINE config 5; the reference's hint is the commented-out `precision=16` of
+    examples/train_seg.py:127).  torch.cuda.amp.GradScaler's rule -- scale 2^16, halve on overflow, double after 2000 clean
+    steps -- with the whole state on the device: the loss is multiplied by a device scalar, the overflow test, the decision
+    to skip the update and the scale update are kernels (mednet_adam_step_scaled), so a step never waits for the host."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.state = torch.tensor([init_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+
+    def scale_loss(self, loss):
+        return loss * self.state[0]
+
+    def snapshot(self):
+        """(scale, good steps, optimizer steps taken, found_inf) -- synchronises; for tests and logging only."""
+        return tuple(float(v) for v in self.state.tolist())
+
+
+def make_scaler(device):
+    from . import config
+    return LossScaler(device) if config.act_dtype() == torch.float16 else None
 
 
 def finish_backward():
@@ -200,6 +234,7 @@ class SegmentationStep(_GraphedStep):
         self.opt = FlatAdam(self.flat, lr=lr)
         self.world = world_size
         ops.SIDE["enabled"] = os.environ.get("MEDNET_SIDE_STREAM", "1") == "1"
+        self.scaler = make_scaler(dev)  # fp16 storage only
         self._init_graph(graph)
         self._exchange = None
 
@@ -208,7 +243,7 @@ class SegmentationStep(_GraphedStep):
         labels = batch["label"][:, -1, ...].long()
         outputs = self.model(inputs)
         loss = self.loss(outputs, labels)
-        loss.backward()
+        (loss if self.scaler is None else self.scaler.scale_loss(loss)).backward()
         finish_backward()
         return (loss.detach(),)
 
@@ -219,7 +254,10 @@ class SegmentationStep(_GraphedStep):
             self._exchange.force = force
         (loss,) = self._run(batch)
         scale = self._exchange.finish()  # 1/world is folded into Adam
-        self.opt.step(grad_scale=scale)
+        if self.scaler is None:
+            self.opt.step(grad_scale=scale)
+        else:
+            self.opt.step_scaled(self.scaler, inv_world=scale)
         return loss
 
 
@@ -267,6 +305,7 @@ class LandmarkStep(_GraphedStep):
         self.flat = FlatParams(model)
         self.opt = FlatAdam(self.flat, lr=lr)
         self.world = world_size
+        self.scaler = make_scaler(dev)
         self._init_graph(graph)
         self._exchange = BucketedExchange(model, self.flat, world_size)
 
@@ -280,12 +319,15 @@ class LandmarkStep(_GraphedStep):
         class_loss = self.loss_class(out_cls, labels)
         regression_loss = self.loss_reg(out_hm, heatmaps)
         loss = regression_loss + class_loss
-        loss.backward()
+        (loss if self.scaler is None else self.scaler.scale_loss(loss)).backward()
         finish_backward()
         return loss.detach(), class_loss.detach(), regression_loss.detach()
 
     def __call__(self, batch):
         out = self._run(batch)
         scale = self._exchange.finish()
-        self.opt.step(grad_scale=scale)
+        if self.scaler is None:
+            self.opt.step(grad_scale=scale)
+        else:
+            self.opt.step_scaled(self.scaler, inv_world=scale)
         return out
