@@ -268,10 +268,11 @@ def test_cfg4_128_bf16_timed_path_against_reference_golden(golden_dir):
     step.flat.release()
 
 
-# fp16 storage (BASELINE config 5).  Measured on MI355X (round 2): see the printed line; bounds are those times two.
-FP16_LOGITS = 4e-3
-FP16_GRAD_NORM = 2e-2
-FP16_GRAD_PROJ = 4e-2
+# fp16 storage (BASELINE config 5).  Measured on MI355X (round 2): strided logits 7.0e-4, gradient norms 4.1e-4, projections
+# 6.3e-3; the bounds are those times two.
+FP16_LOGITS = 1.5e-3
+FP16_GRAD_NORM = 1e-3
+FP16_GRAD_PROJ = 1.3e-2
 
 
 def test_cfg5_fp16_with_loss_scaling_against_reference_golden(golden_dir):
@@ -312,11 +313,11 @@ def test_cfg5_fp16_with_loss_scaling_against_reference_golden(golden_dir):
         for name, p in net.named_parameters():
             g = p.grad.detach().double().cpu().numpy().reshape(-1)
             norm = float(rec[f"grad.{name}.norm"])
-            if abs(np.sqrt((g * g).sum()) - norm) > 5 * FP16_GRAD_NORM * norm:
+            if abs(np.sqrt((g * g).sum()) - norm) > 0.1 * norm:
                 lost += 1
         step.flat.release()
     print(f"[fp16 cfg5 small] strided logits {rl:.2e}  worst grad-norm diff {wn:.2e}  worst projection diff {wp:.2e}; "
-          f"without loss scaling {lost} of {len(list(net.parameters()))} gradient tensors are off by more than {5 * FP16_GRAD_NORM:.0e}")
+          f"without loss scaling {lost} of {len(list(net.parameters()))} gradient tensors are off by more than 10 %")
     assert lost > 0
 
 

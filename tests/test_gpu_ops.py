@@ -224,6 +224,54 @@ def test_upsample_concat(mode, ce, cx, eshape, xshape):
     assert_close(xg.grad, xr.grad, 1e-6 if mode == "fp32" else 1e-2, "dx")
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (32, 64), (16, 48)])
+def test_matrix_core_conv_family_in_both_16bit_storage_types(mode, cin, cout):
+    """The 16-bit matrix-core kernels (conv forward / data gradient / weight gradient, ConvTranspose3d forward with bias /
+    data gradient / weight gradient) with activations ALREADY in the mode's storage type, so the MFMA paths run (an fp32
+    input takes the direct kernels): conv_mfma.hip is compiled once per element type (bf16: v_mfma_f32_32x32x16_bf16, fp16:
+    v_mfma_f32_32x32x16_f16, BASELINE config 5)."""
+    tol = TOL[mode]
+    dt = torch.bfloat16 if mode == "bf16" else torch.float16
+    x = half_round(rnd(f"mc{cin}{cout}x", 1, cin, 6, 10, 16), mode)
+    w = rnd(f"mc{cin}{cout}w", cout, cin, 3, 3, 3, scale=0.2)
+    g = rnd(f"mc{cin}{cout}g", 1, cout, 6, 10, 16)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    (F.conv3d(xr, wr, None, padding=1) * g).sum().backward()
+    with mednet_hip.precision(mode):
+        cv = hnn.Conv3d(cin, cout, 3, bias=False).to(DEV)
+        with torch.no_grad():
+            cv.weight.copy_(w)
+        xg = x.to(DEV).to(dt).requires_grad_(True)
+        y = cv(xg)
+        assert y.dtype == dt
+        (y.float() * g.to(DEV)).sum().backward()
+    assert_close(y, F.conv3d(x, w, None, padding=1), tol, "conv y")
+    assert_close(xg.grad, xr.grad, tol, "conv dx")
+    assert_close(cv.weight.grad, wr.grad, tol, "conv dw")
+    if cin % 32 or cout % 32:
+        return  # (the ConvTranspose3d matrix-core kernels take multiples of 32)
+    xt = half_round(rnd(f"mt{cin}{cout}x", 1, cin, 3, 5, 8), mode)
+    wt = rnd(f"mt{cin}{cout}w", cin, cout, 3, 3, 3, scale=0.2)
+    b = rnd(f"mt{cin}{cout}b", cout)
+    gt = rnd(f"mt{cin}{cout}g", 1, cout, 6, 10, 16)
+    xr, wr, br = xt.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv_transpose3d(xr, wr, br, stride=2, padding=1, output_padding=1)
+    (yr * gt).sum().backward()
+    with mednet_hip.precision(mode):
+        up = hnn.ConvTranspose3d(cin, cout).to(DEV)
+        with torch.no_grad():
+            up.weight.copy_(wt)
+            up.bias.copy_(b)
+        xg = xt.to(DEV).to(dt).requires_grad_(True)
+        y = up(xg)
+        (y.float() * gt.to(DEV)).sum().backward()
+    assert_close(y, yr, tol, "convT y")
+    assert_close(xg.grad, xr.grad, tol, "convT dx")
+    assert_close(up.weight.grad, wr.grad, tol, "convT dw")
+    assert_close(up.bias.grad, br.grad, 1e-3, "convT db")
+
+
 # ----------------------------------------------------------------------------------------------------- losses
 @pytest.mark.parametrize("kw", [dict(), dict(weight=[0.05, 1, 1, 1]), dict(weight=[0.05, 1, 1, 1], sigmoid_normalization=True),
                                 dict(weight=[0.05, 1, 1, 1], ignore_index=1), dict(ignore_index=0), dict(epsilon=1e-2)])

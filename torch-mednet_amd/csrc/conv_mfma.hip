@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
         else if (tap < IN_ROUNDS + W_ROUNDS)
           w_reg[tap - IN_ROUNDS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(tid * 16 + (tap - IN_ROUNDS) * 4096) | kill, 0, 0);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur], xb[cur][t], acc[t], 0, 0, 0);
+        for (int t = 0; t < NTW; ++t) acc[t] = MEDNET_MFMA_32x32x16(wa[cur], xb[cur][t], acc[t], 0, 0, 0);
         if (tap + PD < 27) __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);  // DS reads of tap+PD first ...
         if (tap < IN_ROUNDS + W_ROUNDS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // ... one staging load ...
         __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                          // ... then the MFMAs of tap
@@ -504,8 +504,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const eltx2 pr = {v[2 * k], v[2 * k + 1]};
-          gs[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, gs[k], false);
-          gq[k] = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, gq[k], false);
+          gs[k] = MEDNET_FDOT2(pr, ones, gs[k], false);
+          gq[k] = MEDNET_FDOT2(pr, pr, gq[k], false);
         }
       }
     }
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
       const int pz = kz != 1, py = ky != 1, px = kx != 1;      // output parity of this tap
       const int dz = kz == 0, dy = ky == 0, dx = kx == 0;      // input offset of this tap
       if (tap + 1 < 27) wa[(tap + 1) & 1] = w_lds[((tap + 1) * 2 + h) * 32 + r];  // next weight fragment in flight
-      acc[pz * 4 + py * 2 + px] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[tap & 1], xb[dz * 4 + dy * 2 + dx],
+      acc[pz * 4 + py * 2 + px] = MEDNET_MFMA_32x32x16(wa[tap & 1], xb[dz * 4 + dy * 2 + dx],
                                                                           acc[pz * 4 + py * 2 + px], 0, 0, 0);
       if (tap + 1 < 27) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -813,8 +813,8 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
         hi[j] = (elt)v;
         lo[j] = (elt)(v - (float)hi[j]);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], hi, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], lo, acc, 0, 0, 0);
+      acc = MEDNET_MFMA_32x32x16(wa[ks], hi, acc, 0, 0, 0);
+      acc = MEDNET_MFMA_32x32x16(wa[ks], lo, acc, 0, 0, 0);
     }
     const int oz = tz0 + lz, oy = ty0 + ly, ox = tx0 + lx;
     if (oz < a.d && oy < a.h && ox < a.w_) {
@@ -1190,12 +1190,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
     for (int ks = 0; ks < KSTEPS; ks += 2) {
       load_set(ks + 1, fa1, fb1);
 #pragma unroll
-      for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0[i], acc[i], 0, 0, 0);
+      for (int i = 0; i < 7; ++i) acc[i] = MEDNET_MFMA_32x32x16(fa0, fb0[i], acc[i], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
       load_set(ks + 2 < KSTEPS ? ks + 2 : ks, fa0, fb0);  // (the last pair re-reads a valid step; result unused)
 #pragma unroll
-      for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1[i], acc[i], 0, 0, 0);
+      for (int i = 0; i < 7; ++i) acc[i] = MEDNET_MFMA_32x32x16(fa1, fb1[i], acc[i], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
     }
@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
       for (int i = 0; i < 7; ++i) fb[i] = tr_operand(brow + toff[i], 4 * 64);
       if (k2 < A_ROUNDS + B_ROUNDS) fetch_one(k2, nx);
 #pragma unroll
-      for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[i], acc[i], 0, 0, 0);
+      for (int i = 0; i < 7; ++i) acc[i] = MEDNET_MFMA_32x32x16(fa, fb[i], acc[i], 0, 0, 0);
     }
   }
   // The two k-groups merge their accumulators through LDS (k-group 1 parks them, k-group 0 adds in a fixed order), so a
@@ -1641,8 +1641,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_mfma_kernel(Wc1Args a) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const eltx8 fb = tr_operand(brow + b * 64, 4 * ROWB);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, fb, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, fb, acc[b], 0, 0, 0);
+        acc[b] = MEDNET_MFMA_32x32x16(hi, fb, acc[b], 0, 0, 0);
+        acc[b] = MEDNET_MFMA_32x32x16(lo, fb, acc[b], 0, 0, 0);
       }
     }
   }
@@ -1860,7 +1860,7 @@ __global__ __launch_bounds__(512, 2) void convt_wgrad_mfma2_kernel(Ct2Args a) {
       for (int l = 0; l < LOADS_PER_STEP; ++l)
         if (k2 * LOADS_PER_STEP + l < A_ROUNDS + B_ROUNDS) fetch_one(k2 * LOADS_PER_STEP + l, nx);
 #pragma unroll
-      for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i < 4 ? 0 : i < 6 ? 1 : 2], fb[i], acc[i], 0, 0, 0);
+      for (int i = 0; i < 7; ++i) acc[i] = MEDNET_MFMA_32x32x16(fa[i < 4 ? 0 : i < 6 ? 1 : 2], fb[i], acc[i], 0, 0, 0);
     }
   }
   // k-group merge through LDS and write-out: as in wgrad_mfma2
