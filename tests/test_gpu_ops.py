@@ -269,7 +269,7 @@ def test_matrix_core_conv_family_in_both_16bit_storage_types(mode, cin, cout):
     assert_close(y, yr, tol, "convT y")
     assert_close(xg.grad, xr.grad, tol, "convT dx")
     assert_close(up.weight.grad, wr.grad, tol, "convT dw")
-    assert_close(up.bias.grad, br.grad, 1e-3, "convT db")
+    assert_close(up.bias.grad, br.grad, 5e-3 if mode == "bf16" else 1e-3, "convT db")
 
 
 # ----------------------------------------------------------------------------------------------------- losses

@@ -13,7 +13,8 @@ dev = torch.device("cuda", 0)
 mednet_hip.set_precision("bf16")
 
 
-def run(name, make_step, batch, steps=5, warmup=2):
+def run(name, make_step, batch, steps=5, warmup=2, precision="bf16"):
+    mednet_hip.set_precision(precision)
     step = make_step()
     for _ in range(warmup):
         out = step(batch)
@@ -25,7 +26,12 @@ def run(name, make_step, batch, steps=5, warmup=2):
     dt = (time.perf_counter() - t0) / steps
     n = batch["data"].shape[0]
     loss = float(out[0] if isinstance(out, tuple) else out)
-    print(json.dumps({"config": name, "patches_per_s": round(n / dt, 3), "ms_per_step": round(dt * 1e3, 2), "loss": round(loss, 5),
+    extra = {}
+    if getattr(step, "scaler", None) is not None:
+        sc = step.scaler.snapshot()
+        extra = {"loss_scale": sc[0], "optimizer_steps_taken": int(sc[2]), "steps_run": steps + warmup}
+    print(json.dumps({"config": name, "dtype": precision, "patches_per_s": round(n / dt, 3), "ms_per_step": round(dt * 1e3, 2),
+                      "loss": round(loss, 5), **extra,
                       "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
     step.flat.release()
     del step
@@ -44,5 +50,8 @@ if "unet3d" in which:
         lambda: SegmentationStep(keyed_init_(UNet3D(1, 4, False, f_maps=[32, 64, 128, 256])).to(dev), [0.05, 1, 1, 1.0]), b)
 if "cfg5" in which:
     b = {k: v.to(dev) for k, v in synthetic_batch(2, 1, (160, 160, 96), 4, 0, seed=1234).items()}
-    run("cfg5: ResidualUNet3D [64,128,256,512,1024] 4-class, 160x160x96, batch 2, bf16 storage (BASELINE names fp16)",
-        lambda: SegmentationStep(keyed_init_(ResidualUNet3D(1, 4, False, f_maps=[64, 128, 256, 512, 1024])).to(dev), [0.05, 1, 1, 1.0]), b, steps=3, warmup=1)
+    for prec in ("fp16", "bf16"):
+        run(f"cfg5: ResidualUNet3D [64,128,256,512,1024] 4-class, 160x160x96, batch 2, {prec} storage"
+            + (" + dynamic loss scaling (the mode BASELINE names)" if prec == "fp16" else ""),
+            lambda: SegmentationStep(keyed_init_(ResidualUNet3D(1, 4, False, f_maps=[64, 128, 256, 512, 1024])).to(dev), [0.05, 1, 1, 1.0]),
+            b, steps=5, warmup=2, precision=prec)
