@@ -225,6 +225,15 @@ enum { MEDNET_F16 = 2, MEDNET_U8 = 3 }; /* F16: third activation storage type (f
  * Positions come from the host-side restatement of the reference's sampling (same numpy generator calls). */
 int mednet_crop_patches(const void* src, int src_dtype, const int* pos, const int* slot, int count, void* out, int dst_dtype,
                         int c, int d, int h, int w, int c_total, int c_off, int pd, int ph, int pw, mednet_stream stream);
+/* ---- intensity augmentation of a batch of cropped patches, in place: the Compose of examples/train_seg.py:82-86
+ * (batchgenerators BrightnessTransform -> GammaTransform -> ContrastAugmentationTransform, applied per sample at
+ * dataset.py:340-341).  data: batch x channels x spatial fp32; params[batch][channels][3] (device) = {additive brightness,
+ * gamma, contrast factor} drawn by the caller in batchgenerators' order (mednet_hip.sampler.draw_augmentation); the
+ * data-dependent parts (sample range for the gamma map, channel mean / range for the contrast step) are computed on the
+ * device: five launches, no synchronisation. */
+size_t mednet_augment_ws_bytes(int batch, int channels, size_t spatial);
+int mednet_augment_patches(float* data, const float* params, int batch, int channels, size_t spatial, void* ws,
+                           size_t ws_bytes, mednet_stream stream);
 
 #ifdef __cplusplus
 }

@@ -121,3 +121,54 @@ def test_device_patch_sampler_reproduces_reference_batches(case, golden_dir):
     for i, it in enumerate(items):
         assert np.array_equal(data[i], it["data"]) and np.array_equal(label[i], it["label"]), (tag, i)
     assert np.array_equal(data[0], rec[f"{tag}.first_data"]) and np.array_equal(label[0], rec[f"{tag}.first_label"])
+
+
+def test_device_augmentation_matches_the_numpy_restatement():
+    """Row N1, the reference's `transform` (examples/train_seg.py:82-86: batchgenerators brightness -> gamma -> contrast on
+    'data', dataset.py:340-341): mednet_augment_patches against oracle/ref_augment.py on the same parameters (parity of the
+    oracle itself is UNPINNED: batchgenerators is not available; see the oracle's header), plus the properties the
+    transforms guarantee: the contrast step keeps every channel inside its range, identity parameters leave the patch alone."""
+    from mednet_hip import sampler as HS
+    from oracle import ref_augment as A
+    g = np.random.Generator(np.random.PCG64(11))
+    data = (g.standard_normal((3, 2, 9, 17, 23)) * 40 + 100).astype(np.float32)
+    np.random.seed(5)
+    params = A.draw_parameters(3, 2)
+    want = A.apply(data, params)
+    got = HS.augment_(torch.from_numpy(data.copy()).to(DEV), params).cpu().numpy()
+    err = np.abs(got - want).max() / np.abs(want).max()
+    assert err <= 2e-5, err  # (powf against numpy's float32 power)
+    for b in range(3):
+        for c in range(2):
+            assert got[b, c].min() >= want[b, c].min() - 1e-3 and got[b, c].max() <= want[b, c].max() + 1e-3
+    ident = np.zeros((3, 2, 3), dtype=np.float32)
+    ident[..., 1:] = 1.0
+    same = HS.augment_(torch.from_numpy(data.copy()).to(DEV), ident).cpu().numpy()
+    assert np.abs(same - data).max() <= 1e-4 * np.abs(data).max()
+
+
+def test_device_patch_sampler_with_augmentation_follows_the_reference_call_order():
+    """DevicePatchSampler(augment=True): per sample the position draws come first, then the transform's draws (the order of
+    MedDataset.__getitem__, dataset.py:285-341), so the crop positions differ from an un-augmented run exactly as the
+    reference's would; the batch equals the oracle sampler's crop pushed through the augmentation oracle."""
+    from mednet_hip.sampler import DevicePatchSampler
+    from oracle import ref_augment as A
+    from oracle import ref_sampler as S
+    tag, shapes, c_img, n_hm, patch, probs, draws, seed = S.SAMPLER_CASES[0]
+    images, labels, heatmaps = S.sampler_volumes(tag, shapes, c_img, n_hm, len(probs) if probs else 3)
+    ora = S.PatchSampler(images, labels, patch, samples_per_subject=4, heatmaps=heatmaps, class_probabilities=probs)
+    dev = DevicePatchSampler(images, labels, patch, samples_per_subject=4, heatmaps=heatmaps, class_probabilities=probs,
+                             device=DEV, augment=True)
+    np.random.seed(seed)
+    want = []
+    for i in range(4):
+        item = ora[i]                                  # position draws + crop (the oracle sampler)
+        prm = A.draw_parameters(1, item["data"].shape[0])  # then the transform's draws for this sample
+        want.append((item, A.apply(item["data"][None], prm)[0]))
+    np.random.seed(seed)
+    got = dev.batch([0, 1, 2, 3])
+    for i, (item, aug) in enumerate(want):
+        assert np.array_equal(got["patch_position"][i], item["patch_position"])
+        assert np.array_equal(got["label"][i].cpu().numpy(), item["label"])
+        d = got["data"][i].cpu().numpy()
+        assert np.abs(d - aug).max() <= 2e-5 * max(1.0, np.abs(aug).max()), i

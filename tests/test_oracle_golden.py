@@ -184,3 +184,46 @@ def test_sampler_oracle_matches_reference_golden(golden_dir):
         assert np.allclose([float(a["data"].astype(np.float64).sum()) for a in items], rec[f"{tag}.data_sum"])
         assert np.array_equal([int(a["label"].astype(np.int64).sum()) for a in items], rec[f"{tag}.label_sum"])
         assert np.array_equal(items[0]["data"], rec[f"{tag}.first_data"]) and np.array_equal(items[0]["label"], rec[f"{tag}.first_label"])
+
+
+def test_augment_oracle_properties():
+    """oracle/ref_augment.py (batchgenerators' brightness / gamma / contrast as composed at examples/train_seg.py:82-86) is
+    PARITY UNPINNED -- the library is neither vendored nor installed.  What can be pinned: the documented properties of
+    the three transforms, and that the product's host-side draw routine consumes numpy's generator exactly like the oracle's."""
+    from oracle import ref_augment as A
+    from mednet_hip import sampler as HS
+    g = np.random.Generator(np.random.PCG64(3))
+    data = (g.standard_normal((2, 3, 6, 7, 8)) * 10 + 50).astype(np.float32)
+    np.random.seed(9)
+    prm = A.draw_parameters(2, 3)
+    assert np.all((prm[..., 1] >= 0.7) & (prm[..., 1] <= 1.3)) and np.all((prm[..., 2] >= 0.3) & (prm[..., 2] <= 1.7))
+    assert np.all(prm[:, :, 1] == prm[:, :1, 1])  # one gamma per sample
+    out = A.apply(data, prm)
+    # identity parameters: nothing changes (up to the 1e-7 epsilon of the gamma map)
+    ident = np.zeros_like(prm)
+    ident[..., 1:] = 1.0
+    assert np.abs(A.apply(data, ident) - data).max() <= 1e-4 * np.abs(data).max()
+    # brightness alone shifts a channel; gamma keeps the sample's range; contrast keeps each channel's range and (unclipped) mean
+    only_b = ident.copy()
+    only_b[..., 0] = prm[..., 0]
+    assert np.allclose(A.apply(data, only_b) - data, prm[..., 0][..., None, None, None], atol=2e-4)
+    only_g = ident.copy()
+    only_g[..., 1] = prm[..., 1]
+    og = A.apply(data, only_g)
+    for b in range(2):
+        assert abs(og[b].min() - data[b].min()) <= 1e-3 and abs(og[b].max() - data[b].max()) <= 1e-3
+    only_c = ident.copy()
+    only_c[..., 2] = np.minimum(prm[..., 2], 1.0)  # shrinking never clips: the mean survives exactly
+    oc = A.apply(data, only_c)
+    assert np.allclose(oc.mean(axis=(2, 3, 4)), data.mean(axis=(2, 3, 4)), rtol=1e-4)
+    for b in range(2):  # the full Compose: every channel stays inside the sample's range after the brightness shift
+        lo = (data[b] + prm[b, :, 0][:, None, None, None]).min()
+        hi = (data[b] + prm[b, :, 0][:, None, None, None]).max()
+        assert out[b].min() >= lo - 1e-3 and out[b].max() <= hi + 1e-3
+    # same consumption of numpy's generator as the product's per-sample routine
+    np.random.seed(21)
+    a = A.draw_parameters(3, 2)
+    np.random.seed(21)
+    b_ = np.stack([HS.draw_augmentation(2) for _ in range(3)])
+    assert np.array_equal(a, b_)
+    assert (HS.AUG_BRIGHTNESS, HS.AUG_GAMMA_RANGE, HS.AUG_CONTRAST_RANGE) == ((A.BRIGHTNESS["mu"], A.BRIGHTNESS["sigma"]), A.GAMMA_RANGE, A.CONTRAST_RANGE)

@@ -73,6 +73,8 @@ SIGNATURES = {
     "mednet_grid_gather": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "mednet_predict_assemble": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "mednet_crop_patches": (_i, [_vp, _i, _vp, _vp, _i, _vp] + [_i] * 10 + [_vp]),
+    "mednet_augment_ws_bytes": (_sz, [_i, _i, _sz]),
+    "mednet_augment_patches": (_i, [_vp, _vp, _i, _i, _sz, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -7,7 +7,11 @@ get_random_patch_indices (:55-88), drawing from numpy's global generator in the 
 the same patches as the reference -- and the crop + cast (:313-331) of a whole batch is a few launches of
 mednet_crop_patches writing straight into the batch tensors the training step consumes
 ({'data': fp32 B x C x pD x pH x pW, 'label': uint8 B x (heat maps + 1) x ...}, segmentation.py:58-61).
-The optional batchgenerators `transform` of the reference is not part of this module."""
+The optional `transform` of the reference -- the batchgenerators Compose of examples/train_seg.py:82-86 (additive brightness,
+gamma, contrast on `data`), applied per sample at dataset.py:340-341 -- is `augment=True`: its random numbers are drawn on
+the host right after the sample's position (the reference's order of calls into numpy's global generator), the arithmetic
+runs on the device (mednet_augment_patches).  batchgenerators itself is not available here: see oracle/ref_augment.py
+("parity unpinned")."""
 from __future__ import annotations
 
 import numpy as np
@@ -42,6 +46,48 @@ def get_random_patch_indices(patch_size, img_shape, pos=None):
     return index_ini, index_ini + patch_size
 
 
+# examples/train_seg.py:84-86
+AUG_BRIGHTNESS = (0.0, 0.3)      # BrightnessTransform(mu, sigma)
+AUG_GAMMA_RANGE = (0.7, 1.3)     # GammaTransform(gamma_range)
+AUG_CONTRAST_RANGE = (0.3, 1.7)  # ContrastAugmentationTransform(contrast_range)
+
+
+def _range_draw(lo_hi):
+    if np.random.random() < 0.5 and lo_hi[0] < 1:
+        return np.random.uniform(lo_hi[0], 1)
+    return np.random.uniform(max(lo_hi[0], 1), lo_hi[1])
+
+
+def draw_augmentation(channels):
+    """The draws of one Compose call on ONE sample, in batchgenerators' order (per-sample and per-channel probability
+    draws included, all probabilities 1) -> (C, 3) float32: additive brightness, gamma (one per sample), contrast factor."""
+    out = np.zeros((channels, 3), dtype=np.float32)
+    np.random.uniform()
+    for c in range(channels):
+        np.random.uniform()
+        out[c, 0] = np.random.normal(*AUG_BRIGHTNESS)
+    np.random.uniform()
+    out[:, 1] = _range_draw(AUG_GAMMA_RANGE)
+    np.random.uniform()
+    for c in range(channels):
+        out[c, 2] = _range_draw(AUG_CONTRAST_RANGE)
+    return out
+
+
+def augment_(data, params):
+    """In place on a B x C x ... fp32 device tensor; params: (B, C, 3) array / tensor as from draw_augmentation."""
+    L.require_gpu(data, "augment")
+    assert data.dtype == torch.float32 and data.is_contiguous()
+    b, c = data.shape[:2]
+    spatial = data[0, 0].numel()
+    prm = torch.as_tensor(np.asarray(params, dtype=np.float32)).reshape(b, c, 3).to(data.device).contiguous()
+    lib = L.lib()
+    ws = L.workspace(lib.mednet_augment_ws_bytes(b, c, spatial), data.device)
+    L.check(lib.mednet_augment_patches(data.data_ptr(), prm.data_ptr(), b, c, spatial, ws.data_ptr(), ws.numel(), L.stream()),
+            "augment_patches")
+    return data
+
+
 _DT = {torch.float16: L.F16, torch.float32: L.F32, torch.uint8: L.U8}
 
 
@@ -50,8 +96,10 @@ class DevicePatchSampler:
     (numpy arrays or tensors).  `batch(indices)` -> the collated batch dict on the device."""
 
     def __init__(self, images, labels, patch_size, samples_per_subject=1, heatmaps=None, class_probabilities=None,
-                 subject_keys=None, device="cuda:0"):
+                 subject_keys=None, device="cuda:0", augment=False):
         self.device = torch.device(device)
+        self.augment = augment  # the reference's `transform` (train_seg.py:82-86) on 'data'
+        self.last_augmentation = None
         self.patch_size = np.array(patch_size, dtype=int)
         self.samples_per_subject = samples_per_subject
         self.subject_keys = subject_keys if subject_keys is not None else [str(i) for i in range(len(images))]
@@ -84,7 +132,11 @@ class DevicePatchSampler:
 
     def batch(self, indices):
         L.require_gpu(self.images[0], "patch sampler")
-        plan = [self.position(i) for i in indices]
+        plan, aug = [], []
+        for i in indices:  # per sample: position draws, then (optionally) the transform's draws -- the reference's order
+            plan.append(self.position(i))
+            if self.augment:
+                aug.append(draw_augmentation(self.images[0].shape[0]))
         b = len(plan)
         pd, ph, pw = (int(v) for v in self.patch_size)
         c_img = self.images[0].shape[0]
@@ -106,6 +158,9 @@ class DevicePatchSampler:
                 L.check(lib.mednet_crop_patches(vol.data_ptr(), _DT[vol.dtype], pos.data_ptr(), slot.data_ptr(), len(slots),
                                                 out.data_ptr(), dst, c, d, h, w, c_total, c_off, pd, ph, pw, L.stream()),
                         "crop_patches")
+        if self.augment:
+            self.last_augmentation = np.stack(aug)
+            augment_(data, self.last_augmentation)
         return {"subject_key": [self.subject_keys[p[0]] for p in plan],
                 "patch_position": np.stack([p[1] for p in plan]), "selected_class": np.array([int(p[2]) for p in plan]),
                 "data": data, "label": label}
