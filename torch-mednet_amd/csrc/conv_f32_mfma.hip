@@ -56,15 +56,23 @@ __device__ __forceinline__ f4 load_piece(const float* row, int c0, int K, bool i
   return v;
 }
 
-// weight slice of one chunk: w_lds[tap][h][co 32][4] <- P[tap][kc*8 + 4h + j][cb*32 + co]
-__device__ __forceinline__ void stage_weights(const float* P, float* w_lds, int kc, int cb, int K, int M, int tid) {
-#pragma unroll 9
+// weight slice of one chunk: w_lds[tap][h][co 32][4] <- P[tap][kc*8 + 4h + j][cb*32 + co]; thread `tid` moves elements
+// it * 256 + tid.  Split into fetch (global -> registers, in flight during the previous chunk's MFMAs) and commit.
+__device__ __forceinline__ void fetch_weights(const float* P, float (&w_reg)[27], int kc, int cb, int K, int M, int tid) {
+#pragma unroll
   for (int it = 0; it < 27; ++it) {
     const int idx = it * 256 + tid;
     const int co = idx & 31, i = (idx >> 5) & 7, t = idx >> 8;
     const int ci = kc * 8 + i, m = cb * 32 + co;
-    const float v = (ci < K && m < M) ? P[((size_t)t * K + ci) * M + m] : 0.f;
-    w_lds[((t * 2 + (i >> 2)) * 32 + co) * 4 + (i & 3)] = v;
+    w_reg[it] = (ci < K && m < M) ? P[((size_t)t * K + ci) * M + m] : 0.f;
+  }
+}
+__device__ __forceinline__ void commit_weights(float* w_lds, const float (&w_reg)[27], int tid) {
+#pragma unroll
+  for (int it = 0; it < 27; ++it) {
+    const int idx = it * 256 + tid;
+    const int co = idx & 31, i = (idx >> 5) & 7, t = idx >> 8;
+    w_lds[((t * 2 + (i >> 2)) * 32 + co) * 4 + (i & 3)] = w_reg[it];
   }
 }
 
@@ -125,15 +133,28 @@ __global__ __launch_bounds__(256, 2) void conv_f32_mfma_kernel(F32Args a) {
         acc[t][q * 4 + j] = (a.bias && co < a.m) ? a.bias[co] : 0.f;
       }
 
+  // staging is software-pipelined through registers: chunk kc + 1 is in flight while chunk kc is on the matrix cores
+  f4 in_reg[IN_ROUNDS];
+  float w_reg[27];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) {
+      const int p = it * 256 + tid;
+      in_reg[it] = load_piece(xs + (goff[it] >= 0 ? goff[it] : 0), kc * 8 + (p & 1) * 4, a.k, goff[it] >= 0);
+    }
+    fetch_weights(a.P, w_reg, kc, cb, a.k, a.m, tid);
+  };
+  fetch(0);
   for (int kc = 0; kc < a.nkc; ++kc) {
     __syncthreads();  // the previous chunk's operand reads are done
 #pragma unroll
     for (int it = 0; it < IN_ROUNDS; ++it) {
       const int p = it * 256 + tid;
-      if (goff[it] != -2) in_lds[(p & 1) * NV + (p >> 1)] = load_piece(xs + (goff[it] >= 0 ? goff[it] : 0), kc * 8 + (p & 1) * 4, a.k, goff[it] >= 0);
+      if (goff[it] != -2) in_lds[(p & 1) * NV + (p >> 1)] = in_reg[it];
     }
-    stage_weights(a.P, reinterpret_cast<float*>(w_lds), kc, cb, a.k, a.m, tid);
+    commit_weights(reinterpret_cast<float*>(w_lds), w_reg, tid);
     __syncthreads();
+    if (kc + 1 < a.nkc) fetch(kc + 1);
 #pragma unroll 3
     for (int tap = 0; tap < 27; ++tap) {
       const int toff = ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
@@ -262,15 +283,27 @@ __global__ __launch_bounds__(256, 2) void convt_f32_mfma_kernel(CtF32Args a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
 
+  f4 in_reg[IN_ROUNDS];
+  float w_reg[27];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) {
+      const int p = it * 256 + tid;
+      in_reg[it] = load_piece(xs + (goff[it] >= 0 ? goff[it] : 0), kc * 8 + (p & 1) * 4, a.k, goff[it] >= 0);
+    }
+    fetch_weights(a.P, w_reg, kc, cb, a.k, a.m, tid);
+  };
+  fetch(0);
   for (int kc = 0; kc < a.nkc; ++kc) {
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < IN_ROUNDS; ++it) {
       const int p = it * 256 + tid;
-      if (goff[it] != -2) in_lds[(p & 1) * NV + (p >> 1)] = load_piece(xs + (goff[it] >= 0 ? goff[it] : 0), kc * 8 + (p & 1) * 4, a.k, goff[it] >= 0);
+      if (goff[it] != -2) in_lds[(p & 1) * NV + (p >> 1)] = in_reg[it];
     }
-    stage_weights(a.P, reinterpret_cast<float*>(w_lds), kc, cb, a.k, a.m, tid);
+    commit_weights(reinterpret_cast<float*>(w_lds), w_reg, tid);
     __syncthreads();
+    if (kc + 1 < a.nkc) fetch(kc + 1);
     f4 xb[8];
 #pragma unroll
     for (int dl = 0; dl < 8; ++dl) xb[dl] = in_lds[lbase + (((dl >> 2) & 1) * HY + ((dl >> 1) & 1)) * HX + (dl & 1)];
