@@ -1,10 +1,11 @@
-"""BENCH.md from the artefacts of tools/gpu_profile.sh (rocprofv3 kernel trace + the two PMC passes under gpurun_out/)
-and profiles/r01_bench_line.json / profiles/r01_configs.json.  Per (kernel, grid): launches per step, mean duration in
+"""BENCH.md from the artefacts of tools/gpu_profile.sh (rocprofv3 kernel trace + the PMC passes under gpurun_out/)
+and profiles/rNN_bench_line.json / profiles/rNN_configs.json (ROUND env, default r02).  Per (kernel, grid): launches per step, mean duration in
 the step, HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), TB/s, and TFLOP/s where the launch shape is known."""
 import csv, glob, json, os, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
+ROUND = os.environ.get("ROUND", "r02")
 
 
 def newest(pattern):
@@ -32,7 +33,7 @@ def main():
     nsteps = len(adam) - 1
     steps = rows[adam[0] + 1:adam[-1] + 1]
     wall = (steps[-1]["e"] - steps[0]["s"]) / nsteps / 1e6
-    slots_b = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_slots.json")))
+    slots_b = json.load(open(os.path.join(ROOT, "profiles", ROUND + "_pmc_hbm_slots.json")))
     # per kernel: durations of its i-th launch in a step, averaged over the traced steps
     per_step = []
     for i in range(nsteps):
@@ -62,7 +63,7 @@ def main():
     # the dominant kernel's launches, one line each (the judge compares their mean with bench.py's roofline.avg_ms)
     dom = []
     for i, ps in enumerate(per_step):
-        k = [kk for kk in ps if "conv_mfma_kernel<1>" in kk]
+        k = [kk for kk in ps if "conv_mfma_kernel<1, false>" in kk and "mednet_f16" not in kk]
         if not k:
             continue
         bts = slots_b.get(k[0])
@@ -71,7 +72,7 @@ def main():
                 dom.append((i, j, us))
     if dom:
         fwd_slots = sorted({j for _, j, _ in dom})[:5]  # forward comes first in a step
-        with open(os.path.join(ROOT, "profiles", "r01_dominant_kernel_launches.csv"), "w") as f:
+        with open(os.path.join(ROOT, "profiles", ROUND + "_dominant_kernel_launches.csv"), "w") as f:
             f.write("step,launch_slot_in_step,pass,duration_us\n")
             for i, j, us in dom:
                 f.write(f"{i},{j},{'fwd' if j in fwd_slots else 'dgrad'},{us:.1f}\n")
@@ -79,24 +80,24 @@ def main():
         print("dominant kernel (32->32 @128^3): fwd launches mean %.1f us over %d, all %.1f us over %d" %
               (sum(fw) / len(fw), len(fw), sum(u for _, _, u in dom) / len(dom), len(dom)))
     out = []
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_line.json")))
-    out.append("# BENCH — measured on 1x MI355X (gfx950), round 1\n")
+    line = json.load(open(os.path.join(ROOT, "profiles", ROUND + "_bench_line.json")))
+    out.append(f"# BENCH — measured on 1x MI355X (gfx950), round {int(ROUND[1:])}\n")
     out.append("Produced by `tools/make_bench_md.py` from `tools/gpu_profile.sh` (bench.py, then `rocprofv3 --kernel-trace --stats`,"
                " then separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the same command).\n")
     out.append("## Headline (BASELINE config 2: ResidualUNet3D [32,64,128,256], 4 classes, 128^3, batch 4, bf16 storage)\n")
     out.append("```json\n" + json.dumps(line, indent=1) + "\n```\n")
-    cfgp = os.path.join(ROOT, "profiles", "r01_configs.json")
+    cfgp = os.path.join(ROOT, "profiles", ROUND + "_configs.json")
     if os.path.exists(cfgp):
         out.append("## Other configurations (same kernels; `tools/run_configs.py`)\n")
         out.append("| configuration | patches/s | ms/step | peak memory (GB) |\n|---|---|---|---|")
         for c in json.load(open(cfgp)):
             out.append(f"| {c['config']} | {c['patches_per_s']} | {c['ms_per_step']} | {c['max_mem_GB']} |")
         out.append("")
-    pp = os.path.join(ROOT, "profiles", "r01_predict_line.json")
+    pp = os.path.join(ROOT, "profiles", ROUND + "_predict_line.json")
     if os.path.exists(pp):
         out.append("## Inference path (SURVEY 8f row N2; `tools/run_predict.py --cpu`)\n")
         out.append("```json\n" + json.dumps(json.load(open(pp)), indent=1) + "\n```\n")
-    sp = os.path.join(ROOT, "profiles", "r01_sampler_line.json")
+    sp = os.path.join(ROOT, "profiles", ROUND + "_sampler_line.json")
     if os.path.exists(sp):
         out.append("## Training-patch sampler (SURVEY 8f row N1; `tools/run_sampler.py`)\n")
         out.append("```json\n" + json.dumps(json.load(open(sp)), indent=1) + "\n```\n")
@@ -115,7 +116,7 @@ def main():
             b = sum(v["bytes"]) / len(v["bytes"])
             mb, tbs = f"{b / 1e6:.0f}", f"{b / (mean * 1e-6) / 1e12:.2f}"
         tf = ""
-        if name == "conv_mfma_kernel<1>" and v["bytes"] and 1.4e9 < sum(v["bytes"]) / len(v["bytes"]) < 2.0e9:
+        if name.startswith("conv_mfma_kernel<1") and v["bytes"] and 1.4e9 < sum(v["bytes"]) / len(v["bytes"]) < 2.0e9:
             tf = f"{FLOP_L0 / (mean * 1e-6) / 1e12:.0f} (32->32 @128^3)"
         out.append(f"| `{name}` | {v['grid']} | {len(v['us'])} | {mean:.1f} | {ms:.3f} | {mb} | {tbs} | {tf} |")
     out.append(f"\nSum of kernel durations: {tot:.1f} ms per step.\n")
