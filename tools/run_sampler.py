@@ -36,7 +36,25 @@ for i in range(nb):
     b = ds.batch(range(i * B, i * B + B))
 torch.cuda.synchronize()
 dt_dev = (time.perf_counter() - t0) / nb
+# with the reference's intensity augmentation (train_seg.py:82-86) on the device
+dsa = DevicePatchSampler(images, labels, patch, samples_per_subject=16, class_probabilities=probs, device=dev, augment=True)
+for _ in range(3):
+    dsa.batch(range(B))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(nb):
+    b = dsa.batch(range(i * B, i * B + B))
+torch.cuda.synchronize()
+dt_aug = (time.perf_counter() - t0) / nb
+from oracle import ref_augment as A
 ora = S.PatchSampler(images, labels, patch, samples_per_subject=16, class_probabilities=probs)
+np.random.seed(1)
+t0 = time.perf_counter()
+for i in range(2):
+    items = [ora[j] for j in range(i * B, i * B + B)]
+    d = np.stack([a["data"] for a in items])
+    A.apply(d, A.draw_parameters(B, d.shape[1]))
+dt_cpu_aug = (time.perf_counter() - t0) / 2
 np.random.seed(1)
 t0 = time.perf_counter()
 nc = 6
@@ -61,5 +79,9 @@ print(json.dumps({"metric": "128^3 training patches/sec sampled (position + crop
                   "value": round(B / dt_dev, 1), "unit": "patches/s", "ms_per_batch_of_4": round(dt_dev * 1e3, 3),
                   "cpu_baseline": {"value": round(B / dt_cpu, 2), "unit": "patches/s", "kind": "port",
                                    "sample": f"oracle PatchSampler (numpy crop + stack), {nc} batches of 4, 1 process"},
+                  "with_augmentation": {"value": round(B / dt_aug, 1), "unit": "patches/s", "ms_per_batch_of_4": round(dt_aug * 1e3, 3),
+                                        "what": "+ brightness / gamma / contrast of train_seg.py:82-86 (mednet_augment_patches)",
+                                        "cpu_baseline": {"value": round(B / dt_cpu_aug, 2), "unit": "patches/s", "kind": "port",
+                                                         "sample": "oracle sampler + oracle/ref_augment.py (numpy), 2 batches of 4, 1 process"}},
                   "sampler_plus_training_step": {"value": round(B / dt_train, 2), "unit": "patches/s",
                                                  "ms_per_step": round(dt_train * 1e3, 2)}}))
