@@ -557,6 +557,114 @@ def test_conv3d_mfma_random_shapes_against_direct_kernels(n, cin, cout, shape):
     assert torch.all((tot[:, 0::2, 1] - q_ref).abs() <= 1e-4 * q_ref + 1e-6)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("n,shape", [(1, (66, 60, 50)),    # 544 bricks (a multiple of 8: one slab per XCD), ragged in z, y and x
+                                     (1, (76, 56, 64)),    # 532 bricks: interleaved brick order
+                                     (3, (32, 64, 48)),    # 576 bricks, the sample changes inside a workgroup's brick list
+                                     (2, (32, 60, 62))])   # 512 bricks, 2 z-layers of bricks per XCD: the x-z-y slab walk
+def test_conv32_specialisation_is_bit_identical_to_the_general_kernel(mode, n, shape):
+    """32 -> 32 channels on >= 512 bricks runs conv32_mfma_kernel (weights in registers, whole-row double-buffered bricks).
+    It accumulates in the general kernel's order (K chunk outer, tap inner, one fp32 accumulator per output), so outputs and
+    data gradients must be IDENTICAL bit for bit to the general kernel's (option conv32=0), and the fused GroupNorm partials
+    must add up to the same totals (their row layout differs)."""
+    tag = f"c32{n}{shape}"
+    x, w, cot = _conv_case(n, 32, 32, shape, tag)
+    x, w, cot = (half_round(t, mode) for t in (x, w, cot))
+    dt = torch.bfloat16 if mode == "bf16" else torch.float16
+    res = {}
+    mednet_hip.set_conv_algo("mfma")
+    try:
+        for special in (1, 0):
+            assert L.lib().mednet_set_option(b"conv32", special) == 0
+            with mednet_hip.precision(mode):
+                conv = hnn.Conv3d(32, 32, 3, bias=False).to(DEV)
+                with torch.no_grad():
+                    conv.weight.copy_(w)
+                xg = x.to(DEV).to(dt).requires_grad_(True)
+                y, partial = conv.forward_with_stats(xg)
+                y.backward(cot.to(DEV).to(dt))
+                res[special] = (y.detach().clone(), xg.grad.clone(), partial.double().sum(dim=1))
+    finally:
+        L.lib().mednet_set_option(b"conv32", 1)
+        mednet_hip.set_conv_algo("auto")
+    assert res[1][2].shape == res[0][2].shape
+    assert torch.equal(res[1][0], res[0][0]), "y differs from the general kernel"
+    assert torch.equal(res[1][1], res[0][1]), "dx differs from the general kernel"
+    tot1, tot0 = res[1][2], res[0][2]
+    nv = float(np.prod(shape))
+    q = tot0[:, 0::2, 1]
+    assert torch.all((tot1[:, 0::2, 0] - tot0[:, 0::2, 0]).abs() <= 2e-5 * (q * nv).sqrt() + 1e-3)
+    assert torch.all((tot1[:, 0::2, 1] - q).abs() <= 2e-5 * q)
+    assert torch.all(tot1[:, 1::2] == 0)
+    # ... and the general kernel is itself checked against the oracle; one direct comparison here as well
+    yr = F.conv3d(x, w, None, padding=1)
+    assert_close(res[1][0], yr, 6e-3 if mode == "bf16" else 1e-3, "y vs oracle")
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("n,shape", [(2, (32, 60, 62)), (1, (76, 56, 64))])
+def test_conv32_epilogue_variants_match_the_general_kernel(mode, n, shape):
+    """The specialised kernel's epilogue comes in compile-time variants (activation, summed second gradient, fused GroupNorm
+    statistics, fused first pass of a GroupNorm backward, with ragged rows / planes / x ends): each through its C-ABI entry
+    point against the general kernel (option conv32=0) -- tensors bit for bit, partial sums up to fp32 summation order."""
+    lib = L.lib()
+    dt = torch.bfloat16 if mode == "bf16" else torch.float16
+    dcode = L.dt(torch.empty(0, dtype=dt))
+    CL = torch.channels_last_3d
+    g = torch.Generator(device=DEV).manual_seed(11)
+    def rand(*sh, scale=1.0):
+        return (torch.randn(*sh, device=DEV, generator=g) * scale).to(dt).contiguous(memory_format=CL)
+    x, add, gy = rand(n, 32, *shape), rand(n, 32, *shape), rand(n, 32, *shape)
+    w = torch.randn(32, 32, 3, 3, 3, device=DEV, generator=g) * 0.05
+    coef = torch.randn(n, 32, 2, device=DEV, generator=g).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    ALGO_MFMA = 2
+    with mednet_hip.precision(mode):
+        pk = ops.pack_conv_weight(w, 3, False)
+    d, h, wd = shape
+
+    def run(special):
+        assert lib.mednet_set_option(b"conv32", special) == 0
+        out = {}
+        for act in (1, 3):   # ReLU, ELU; with and without the statistics
+            for stats in (False, True):
+                y = torch.empty_like(x)
+                rows = lib.mednet_conv3d_fused_stats_chunks(n, d, h, wd, 32, 32, 3, dcode, dcode, ALGO_MFMA)
+                part = torch.zeros(n, rows, 32, 2, device=DEV) if stats else None
+                L.check(lib.mednet_conv3d_act_fwd(x.data_ptr(), pk.data_ptr(), y.data_ptr(), n, d, h, wd, 32, 32, act, ALGO_MFMA,
+                                                  part.data_ptr() if stats else None, dcode, st), "act_fwd")
+                out[f"act{act}{stats}"] = (y, part.double().sum(1) if stats else None)
+        dx = torch.empty_like(x)
+        L.check(lib.mednet_conv3d_dgrad_add(x.data_ptr(), pk.data_ptr(), add.data_ptr(), dx.data_ptr(), n, d, h, wd, 32, 32,
+                                            ALGO_MFMA, dcode, st), "dgrad_add")
+        out["dgrad_add"] = (dx, None)
+        rows = lib.mednet_conv3d_dgrad_gn_rows(n, d, h, wd, 32, 32, ALGO_MFMA)
+        assert rows > 0
+        for gact in (0, 1, 2, 3):
+            for with_add in (False, True):
+                dx = torch.empty_like(x)
+                part = torch.zeros(n, rows, 32, 2, device=DEV)
+                L.check(lib.mednet_conv3d_dgrad_gn(x.data_ptr(), pk.data_ptr(), add.data_ptr() if with_add else None, dx.data_ptr(),
+                                                   gy.data_ptr(), coef.data_ptr(), gact, part.data_ptr(), n, d, h, wd, 32, 32,
+                                                   ALGO_MFMA, dcode, st), "dgrad_gn")
+                out[f"gn{gact}{with_add}"] = (dx, part.double().sum(1))
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        a, b = run(1), run(0)
+    finally:
+        lib.mednet_set_option(b"conv32", 1)
+    nv = float(np.prod(shape))
+    for k in a:
+        assert torch.equal(a[k][0], b[k][0]), f"{k}: tensor differs from the general kernel"
+        if a[k][1] is not None:
+            ta, tb = a[k][1], b[k][1]
+            assert ta.shape == tb.shape
+            scale = tb.abs().amax(dim=(1,), keepdim=True) + 1e-3
+            assert torch.all((ta - tb).abs() <= 5e-5 * scale + 2e-5 * tb.abs() + 1e-3 * nv ** 0.5 * 1e-2), f"{k}: partial sums differ"
+
+
 def test_conv3d_mfma_batch_larger_than_4GB():
     """A batch whose activation tensor exceeds 4 GB (34 x 128^3 x 32 ch bf16 = 4.6 GB): the MFMA kernels address one
     SAMPLE per buffer resource, so the last sample must come out bit-identical to the same sample run alone, and the

@@ -100,7 +100,7 @@ extern "C" int mednet_conv3d_fused_stats_chunks(int n, int d, int h, int w, int 
   if (algo == MEDNET_ALGO_DIRECT || !tuning_option("conv_fuse_stats", 1)) return 0;
   if (ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, false)) return conv_c1_stats_chunks(d, h, w);
   if (!ELT_CALL(y_dtype, conv_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, MEDNET_NDHWC, false)) return 0;
-  return conv_mfma_stats_chunks(n, d, h, w, cout);
+  return conv_mfma_stats_chunks(n, d, h, w, cin, cout);
 }
 
 extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void* y, int n, int d, int h,
@@ -229,7 +229,7 @@ extern "C" int mednet_conv3d_dgrad_add(const void* dy, const void* packed, const
 
 extern "C" int mednet_conv3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int algo) {
   if (!tuning_option("conv_fuse_gnb", 1) || !mednet_conv3d_act_supported(n, d, h, w, cout, cin, algo)) return 0;
-  return conv_mfma_stats_chunks(n, d, h, w, cin);  // (the kernel's output channels are the layer's Cin)
+  return conv_mfma_stats_chunks(n, d, h, w, cout, cin);  // (the kernel reads the layer's Cout channels, writes its Cin)
 }
 extern "C" int mednet_conv3d_dgrad_gn(const void* dy, const void* packed, const void* add, void* dx, const void* gn_y,
                                       const float* gn_coef, int gn_act, float* gn_partial, int n, int d, int h, int w,

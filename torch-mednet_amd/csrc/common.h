@@ -143,6 +143,22 @@ __device__ __forceinline__ float act_grad_from_out(float z, int act) {
   }
 }
 
+// MFMA accumulator form: ONE (wave-uniform) branch per 16 values; nothing at all for MEDNET_ACT_NONE (a switch per
+// element costs a conv epilogue thousands of cycles in scalar branches)
+typedef __attribute__((ext_vector_type(16))) float act_f32x16;
+__device__ __forceinline__ void act_apply_v16(act_f32x16& u, int act) {
+  if (act == MEDNET_ACT_NONE) return;
+  if (act == MEDNET_ACT_RELU) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) u[k] = u[k] > 0.f ? u[k] : 0.f;
+  } else if (act == MEDNET_ACT_LEAKY) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) u[k] = u[k] > 0.f ? u[k] : 0.1f * u[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) u[k] = u[k] > 0.f ? u[k] : __expf(u[k]) - 1.f;
+  }
+}
 // N-wide forms: ONE (wave-uniform) switch per vector instead of one per element
 template <int N>
 __device__ __forceinline__ void act_apply_n(float* u, int act) {

@@ -18,6 +18,7 @@
 // are read with the hardware transposing LDS read (ds_read_b64_tr_b16): no transposed copy is ever materialised.
 // A wave keeps 7 of the 27 taps (7 x 16 accumulator registers) and walks its workgroup's bricks; per-workgroup
 // partials are summed in a fixed order by a second kernel (deterministic, no atomics).
+#include <type_traits>
 #include "conv.h"
 
 // The 16-bit element type of this translation unit.  The file is compiled twice: as it stands for bf16 storage, and with
@@ -103,6 +104,10 @@ struct FwdArgs {
   const elt* gnb_y;      // conv output y of the layer in front (shape of this kernel's output)
   const float* gnb_coef;  // [n][cout][2] = {ca, cb}: its GroupNorm's forward affine, pre-activation = ca * y + cb
   int gnb_act;            // MEDNET_ACT_*
+  int xcd_chunk;          // conv32_mfma_kernel: bricks per XCD when the brick count divides by 8 (each XCD then works through a
+                          // CONTIGUOUS part of the volume, so neighbouring bricks' halos meet in its L2), else 0
+  int zslab;              // conv32_mfma_kernel: z-layers of bricks per XCD (> 0: the x-z-y walk of origin(); implies xcd_chunk)
+  unsigned rcp_zslab;
 #ifdef MEDNET_CONV_TIMING
   long long* dbg;  // [workgroup][16] s_memtime stamps of wave 0 (tools/probes/conv_timing.py)
 #endif
@@ -409,6 +414,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     asm volatile("" : "+v"(etid));
     const int e_lane = etid & 63, e_wv = etid >> 6, e_r = e_lane & 31, e_h = e_lane >> 5;
 #pragma unroll
+    for (int t = 0; t < NTW; ++t) act_apply_v16(acc[t], a.act);
+#pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int g = e_wv * NTW + t;
       const int lz = g / (TY / 2), ly = (g % (TY / 2)) * 2 + (e_r >> 4);
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       for (int q = 0; q < 4; ++q) {
         eltx4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (elt)act_apply(acc[t][q * 4 + j], a.act);  // co = 8q + 4h + j
+        for (int j = 0; j < 4; ++j) o[j] = (elt)acc[t][q * 4 + j];  // co = 8q + 4h + j
         *reinterpret_cast<eltx4*>(out_lds + vl * 32 + ((2 * q + e_h) ^ sw) * 4) = o;
       }
     }
@@ -536,6 +543,430 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   __builtin_amdgcn_s_waitcnt(0);  // all stores of this wave acknowledged
   STAMP(15);
 #endif
+}
+
+// ================================================================================================== 32 -> 32 channels
+// The layers that hold half of the network's FLOPs (conv2 / conv3 of the two full-resolution ExtResNetBlocks and their
+// data gradients, components.py:168-180) have Cin = Cout = 32: ONE channel block and two K chunks, i.e. every work item
+// uses the same 55 KB of weights.  The general kernel above re-stages them per item (14 of its 32 staging loads and LDS
+// writes per thread and item, 900 MB of L2 -> LDS traffic per launch) and reads every 64-byte voxel row twice, 32 bytes per
+// K chunk, one item period apart (1.57x the algorithmic HBM bytes: the second half often comes back from beyond L2).
+// This kernel is the specialisation: ONE workgroup of 4 waves per CU, one wave per SIMD with the whole 512-register file;
+//   * the weights live in REGISTERS for the workgroup's lifetime (54 A fragments x 4 = 216 registers per lane);
+//   * LDS holds only input bricks, whole 64-byte rows (both K chunks), DOUBLE buffered (2 x 69 KB): the next brick's 17
+//     pieces per thread are fetched during the tap loop (one load every third tap) and committed to the other buffer, so
+//     one barrier per item is all the synchronisation there is;
+//   * the epilogue goes through a 4 KB LDS area that is PRIVATE to the wave (a wave owns one z-plane of the brick = whole
+//     64-byte rows of 128 voxels), two halves of 64 voxels: no barrier, and the row stores are the same 1 KB-per-instruction
+//     stores as above.
+// B operand reads are the only LDS traffic of the tap loop: 1 KB per MFMA instead of 1.25 KB.
+// Variant bits of the specialisation: what the epilogue does is known at compile time (one wave per SIMD: a runtime
+// branch per row or value costs its full latency, nobody else is there to hide it)
+enum : int { C32_GNB = 1, C32_ADD = 2, C32_STATS = 4, C32_ACT = 8 };
+template <int V>
+__global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
+  constexpr bool GNB = (V & C32_GNB) != 0, ADD = (V & C32_ADD) != 0, STATS = (V & C32_STATS) != 0, ACT = (V & C32_ACT) != 0;
+  static_assert(!(GNB && (STATS || ACT)), "the data-gradient variant has its own sums and no activation");
+  constexpr int TZ = 4, TY = 8, TX = 16, HZ = 6, HY = 10, HX = 18, NV = HZ * HY * HX, NTW = 4;
+  constexpr int PIECES = 4 * NV, IN_ROUNDS = (PIECES + 255) / 256;  // 4320 16-byte pieces of a brick: 17 per thread
+  constexpr int NVP = NV + 4, BUF_PIECES = 4 * NVP;                 // plane pitch (in pieces) = 12 mod 16
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  typedef __attribute__((ext_vector_type(2))) elt eltx2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* in_lds = reinterpret_cast<u32x4*>(smem);                           // [2 buffers][4 pieces][NVP]
+  elt* wlds = reinterpret_cast<elt*>(smem + (size_t)2 * BUF_PIECES * 16) + (threadIdx.x >> 6) * 2048;  // 4 KB per wave
+#ifdef MEDNET_CONV_TIMING
+  bool stamp_item = false;
+  int item_no = 0;
+#endif
+  STAMP(0);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+  // brick of sequence number q of this workgroup's XCD (workgroup ids 8 apart share an XCD and its L2).  With zslab > 0 the
+  // XCD owns zslab consecutive z-layers of bricks of one sample and walks them x fastest, then z, then y: the 32 bricks its
+  // CUs work on together are one y-row of the slab, whose halos overlap in x and z, and the next y-row finds the shared two
+  // voxel rows still in L2 -- 1.17x the input bytes instead of the 2.1x of isolated bricks.  Otherwise bricks are dealt in
+  // linear order (x, y, z, sample), a contiguous run per XCD when the count divides by 8, else interleaved.
+  const int xcd = (int)(blockIdx.x & 7);
+  auto origin = [&](int q, int& n, int& tz0, int& ty0, int& tx0) {
+    if (a.zslab) {
+      int qd = fastdiv(q, a.tiles_x, a.rcp_tiles_x);
+      tx0 = (q - qd * a.tiles_x) * TX;
+      const int yy = fastdiv(qd, a.zslab, a.rcp_zslab);
+      const int zz = xcd * a.zslab + (qd - yy * a.zslab);
+      ty0 = yy * TY;
+      n = fastdiv(zz, a.tiles_z, a.rcp_tiles_z);
+      tz0 = (zz - n * a.tiles_z) * TZ;
+    } else {
+      int tt = a.xcd_chunk ? xcd * a.xcd_chunk + q : q;
+      int qd = fastdiv(tt, a.tiles_x, a.rcp_tiles_x);
+      tx0 = (tt - qd * a.tiles_x) * TX;
+      tt = qd;
+      qd = fastdiv(tt, a.tiles_y, a.rcp_tiles_y);
+      ty0 = (tt - qd * a.tiles_y) * TY;
+      tt = qd;
+      qd = fastdiv(tt, a.tiles_z, a.rcp_tiles_z);
+      tz0 = (tt - qd * a.tiles_z) * TZ;
+      n = qd;
+    }
+  };
+  // fused statistics, kept over the wave's items of a sample (row = 4 * workgroup + wave); workgroups beyond the item
+  // count still owe their (zero) rows
+  float gs[4], gq[4], bs[GNB ? 8 : 1], bq[GNB ? 8 : 1];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) gs[k] = gq[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < (GNB ? 8 : 1); ++k) bs[k] = bq[k] = 0.f;
+  int acc_n = 0;
+  const int acc_row = (int)blockIdx.x * 4 + wv;
+  auto flush = [&](int nn) {
+    const int pjl = lane & 3;
+    float* dst = a.gn_partial + (((size_t)nn * a.stats_rows + acc_row) * 32 + pjl * 8) * 2;
+    if constexpr (GNB) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        bs[k] = lane_class_sum<4>(bs[k]);
+        bq[k] = lane_class_sum<4>(bq[k]);
+      }
+      if (lane < 4) {
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          const f32x4 o = {bs[k], bq[k], bs[k + 1], bq[k + 1]};
+          *reinterpret_cast<f32x4*>(dst + k * 2) = o;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) bs[k] = bq[k] = 0.f;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        gs[k] = lane_class_sum<4>(gs[k]);
+        gq[k] = lane_class_sum<4>(gq[k]);
+      }
+      if (lane < 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f32x4 o = {gs[k], gq[k], 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(dst + k * 4) = o;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gs[k] = gq[k] = 0.f;
+    }
+  };
+  // brick sequence of this workgroup: seq, seq + step, ... < end (see origin())
+  const int seq_step = a.xcd_chunk ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int seq_end = a.xcd_chunk ? a.xcd_chunk : a.ntiles;
+  int seq = a.xcd_chunk ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (seq >= seq_end) {  // (workgroup-uniform) nothing to do but the statistics rows
+    if constexpr (GNB || STATS)
+      for (int nn = 0; nn < a.n; ++nn) flush(nn);
+    return;
+  }
+
+  // ---- the weights: A fragment of (chunk kc, tap) = piece ((kc*27 + tap)*2 + h)*32 + r of the packed image
+  //      The fragments of the last WT steps are not kept over the epilogue (which needs the registers): they are fetched
+  //      again (from L2) in the first steps of every tap loop, 40 steps before their use.
+  constexpr int WT = GNB && ADD ? 14 : 8;
+  eltx8 wreg[54];
+  const u32x4* wp = reinterpret_cast<const u32x4*>(a.wpk) + h * 32 + r;
+#pragma unroll
+  for (int i = 0; i < 54 - WT; ++i) wreg[i] = __builtin_bit_cast(eltx8, wp[i * 64]);
+
+  // ---- staging plan of a brick (halo 6 x 10 x 18 voxels = 60 x-rows of 72 16-byte pieces).  One wave per SIMD means
+  //      that whatever runs outside the tap loop is exposed in full and that vector work inside it must stay small, so the
+  //      plan is made of SCALARS: in the 15 main rounds wave w loads pieces 0..63 (voxels hx = 0..15) of row 4 * round + w
+  //      -- row validity is a scalar (an invalid row gets a resource of 0 bytes: the hardware range check returns zeros),
+  //      the row's byte offset goes into the load's scalar offset, and the per-lane part (x position, validity in x) is ONE
+  //      register per brick.  Two tail rounds fetch the rows' last 8 pieces (hx = 16, 17), a row per 8 threads.
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  constexpr int MAIN_ROUNDS = HZ * HY / 4, TAIL_ROUNDS = 2;
+  static_assert(MAIN_ROUNDS * 4 == HZ * HY && MAIN_ROUNDS + TAIL_ROUNDS == IN_ROUNDS && TAIL_ROUNDS * 32 >= HZ * HY, "round layout");
+  const int q4 = lane & 3, hx_main = lane >> 2;
+  int tail_pos[TAIL_ROUNDS];  // hz << 8 | hy of the thread's tail row; rows past the halo fail every range check
+#pragma unroll
+  for (int k = 0; k < TAIL_ROUNDS; ++k) {
+    const int row = 32 * k + (tid >> 3);
+    tail_pos[k] = row < HZ * HY ? ((row / HY) << 8) | (row % HY) : 0x7F00;
+  }
+  const int tail_hx = 16 + ((tid >> 2) & 1);
+  u32x4 in_reg[IN_ROUNDS];
+  // (mask arithmetic, not a select: a scalar branch would split the tap loop's basic block)
+  auto rsrc_of = [&](int n, bool ok) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)n * a.id * a.ih * a.iw * 32), 0, a.bytes_x & (0u - (unsigned)ok), 0x00020000);
+  };
+  unsigned voff_main = 0;
+  auto plan_main = [&](int tx0) {  // the per-lane part of a brick's main rounds
+    const int gx = tx0 - 1 + hx_main;
+    voff_main = (unsigned)gx < (unsigned)a.iw ? (unsigned)gx * 64u + (unsigned)q4 * 16u : OOB;
+  };
+  auto tail_voff = [&](int k, int tz0, int ty0, int tx0) {
+    const int gz = tz0 - 1 + (tail_pos[k] >> 8), gy = ty0 - 1 + (tail_pos[k] & 255), gxt = tx0 - 1 + tail_hx;
+    const bool ok = ((unsigned)gz < (unsigned)a.id) & ((unsigned)gy < (unsigned)a.ih) & ((unsigned)gxt < (unsigned)a.iw);
+    return ok ? (unsigned)((gz * a.ih + gy) * a.iw + gxt) * 64u + (unsigned)q4 * 16u : OOB;
+  };
+  // (a main round's scalar part comes in phases so that the tap loop can put a few scalar instructions into each MFMA gap
+  //  instead of all of them into one; phase < 0: everything at once)
+  int lr_gz = 0, lr_gy = 0;
+  unsigned lr_soff = 0, lr_num = 0;
+  auto load_round = [&](int it, int phase, int n, int tz0, int ty0, int tx0, bool valid) {
+    if (it < MAIN_ROUNDS) {
+      if (phase == 0 || phase < 0) {
+        const int row = it * 4 + wv_s;
+        const int hz = (row * 205) >> 11, hy = row - hz * HY;  // (row / 10 for row < 1029)
+        lr_gz = tz0 - 1 + hz;
+        lr_gy = ty0 - 1 + hy;
+      }
+      if (phase == 1 || phase < 0) {
+        const bool ok = valid & ((unsigned)lr_gz < (unsigned)a.id) & ((unsigned)lr_gy < (unsigned)a.ih);
+        lr_num = a.bytes_x & (0u - (unsigned)ok);
+      }
+      if (phase == 2 || phase < 0) lr_soff = (unsigned)((lr_gz * a.ih + lr_gy) * a.iw) * 64u;  // (anything for an invalid row)
+      if (phase == 3 || phase < 0)
+        in_reg[it] = __builtin_amdgcn_raw_buffer_load_b128(
+            __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)n * a.id * a.ih * a.iw * 32), 0, lr_num, 0x00020000), voff_main, lr_soff, 0);
+    } else if (phase == 3 || phase < 0) {
+      in_reg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_of(n, valid), tail_voff(it - MAIN_ROUNDS, tz0, ty0, tx0), 0, 0);
+    }
+  };
+  // LDS slot of a piece: plane q (planes NVP pieces apart: the four planes of a voxel on different banks), voxel row * 18 +
+  // hx; tail threads without a row write the zeros their out-of-range load returned to a spare slot (a select, not a
+  // branch: the tap loop stays one basic block)
+  const int slot_main = q4 * NVP + hx_main;
+  int slot_tail[TAIL_ROUNDS];
+#pragma unroll
+  for (int k = 0; k < TAIL_ROUNDS; ++k) {
+    const int row = 32 * k + (tid >> 3);
+    slot_tail[k] = row < HZ * HY ? q4 * NVP + row * HX + tail_hx : -1;
+  }
+  const int spare_slot = (2 * BUF_PIECES * 16 + 4 * 4096) / 16 + tid;
+  auto commit_one = [&](int b, int it) {
+    if (it < MAIN_ROUNDS) {
+      in_lds[b * BUF_PIECES + (it * 4 + wv_s) * HX + slot_main] = in_reg[it];
+    } else {
+      const int sl = slot_tail[it - MAIN_ROUNDS];
+      in_lds[sl >= 0 ? b * BUF_PIECES + sl : spare_slot] = in_reg[it];
+    }
+  };
+  int lbase[NTW];  // LDS piece index of tap (0,0,0) for this lane in plane 0 (row-rotated: conflict-free ds_read_b128)
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int ly = 2 * t + (r >> 4), lx = ((r & 15) - (r >> 4) * HX) & 15;
+    lbase[t] = (wv * HY + ly) * HX + lx;
+  }
+  [[maybe_unused]] const eltx2 ones = {(elt)1.0f, (elt)1.0f};
+  const size_t ovol = (size_t)a.od * a.oh * a.ow;
+
+  // ---- the first two bricks: loads in bursts.  From then on brick j + 2 is fetched during brick j's tap loop, a round
+  //      every third step, into the registers that brick j + 1's round has just left for LDS: a load has a whole brick
+  //      period (> 4 us) to arrive, and the memory system sees an even stream instead of 256 CUs bursting in step
+  {
+    int n0, tz0, ty0, tx0;
+    origin(seq, n0, tz0, ty0, tx0);
+    plan_main(tx0);
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) load_round(it, -1, n0, tz0, ty0, tx0, true);
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) commit_one(0, it);
+    const bool valid1 = seq + seq_step < seq_end;
+    origin(valid1 ? seq + seq_step : 0, n0, tz0, ty0, tx0);
+    plan_main(tx0);
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) load_round(it, -1, n0, tz0, ty0, tx0, valid1);
+  }
+  STAMP(1);
+  int buf = 0;
+  while (true) {
+    int n, tz0, ty0, tx0;
+    origin(seq, n, tz0, ty0, tx0);
+    const bool has_next = seq + seq_step < seq_end;
+    const bool has_next2 = seq + 2 * seq_step < seq_end;
+#ifdef MEDNET_CONV_TIMING
+    stamp_item = item_no == 4;
+    ++item_no;
+#endif
+    if constexpr (GNB || STATS) {  // a new sample: the sums so far go out (here, where no accumulator is alive)
+      while (acc_n < n) {
+        flush(acc_n);
+        ++acc_n;
+      }
+    }
+    int n2, tz2, ty2, tx2;  // brick j + 2
+    origin(has_next2 ? seq + 2 * seq_step : 0, n2, tz2, ty2, tx2);
+    __syncthreads();  // the brick is complete, and every wave is done reading the other buffer (the previous brick)
+    STAMP(3);
+
+    // ---- 54 steps (K chunk, tap) of 4 MFMAs; B operands are read TWO steps ahead (nobody else hides the LDS latency).
+    //      Step 3k: round k of brick j + 1 goes from its registers to the other LDS buffer, then round k of brick j + 2 is
+    //      requested into them.
+    f32x16 acc[NTW];
+    const u32x4* img = in_lds + (size_t)buf * BUF_PIECES;
+    auto b_operand = [&](int s1, int t) {
+      const int kc1 = s1 / 27, t1 = s1 % 27;
+      return __builtin_bit_cast(eltx8, img[(2 * kc1 + h) * NVP + lbase[t] + ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3]);
+    };
+    eltx8 xb[3][NTW];
+#pragma unroll
+    for (int s1 = 0; s1 < 2; ++s1) {
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) xb[s1][t] = b_operand(s1, t);
+    }
+    // issue order written out and fenced (sched_barrier): one MFMA, then the few other instructions of its gap -- a gap
+    // hides ~5 issue slots; the scheduler left to itself packs a step's reads and scalar work into one gap and the
+    // matrix pipe idles for the rest
+#pragma unroll
+    for (int s54 = 0; s54 < 54; ++s54) {
+      const int cur = s54 % 3, pre = (s54 + 2) % 3;
+      const int round = s54 / 3;
+      const bool staging = s54 % 3 == 0 && round < IN_ROUNDS;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (s54 == 0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[t] = MEDNET_MFMA_32x32x16(wreg[0], xb[cur][t], zero, 0, 0, 0);
+        } else {
+          acc[t] = MEDNET_MFMA_32x32x16(wreg[s54], xb[cur][t], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s54 + 2 < 54) xb[pre][t] = b_operand(s54 + 2, t);
+        if (s54 == 0 && t == 1) plan_main(tx2);
+        if (t == 2 && s54 % 3 != 0 && s54 / 3 * 2 + s54 % 3 - 1 < WT) {  // steps 1, 2, 4, 5, ...: transient weight fragments
+          const int wi = 54 - WT + s54 / 3 * 2 + s54 % 3 - 1;
+          wreg[wi] = __builtin_bit_cast(eltx8, __builtin_nontemporal_load(wp + wi * 64));
+        }
+        if (staging) {
+          if (t == 0) commit_one(buf ^ 1, round);
+          load_round(round, t, n2, tz2, ty2, tx2, has_next2);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(5);
+
+    // ---- epilogue: two halves of 64 voxels (4 x-rows) through the wave's private 4 KB of LDS -- no barrier
+    const int pj = lane & 3, ev = lane >> 2;  // row reads: voxel ev of 16 in an x-row, 16-byte piece pj
+    // rows outside the volume get resources of 0 bytes (loads return zeros, stores are dropped): validity in y and z is
+    // scalar, validity in x is the lane's offset
+    const bool plane_ok = tz0 + wv_s < a.od;
+    const bool lane_ok = tx0 + ev < a.ow;
+    const unsigned vb = lane_ok ? (unsigned)(ev * 32 + pj * 8) * 2u : OOB;
+    auto row_rsrc = [&](const elt* base, int j) {
+      const bool ok = plane_ok & (ty0 + j < a.oh);
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)n * ovol * 32), 0, a.bytes_y & (0u - (unsigned)ok), 0x00020000);
+    };
+    auto row_soff = [&](int j) { return (unsigned)((((tz0 + wv_s) * a.oh + ty0 + j) * a.ow + tx0) * 32) * 2u; };
+    // second operands in flight first: of all eight rows, or -- in the GroupNorm-backward variants, whose register file is
+    // full while the accumulators live -- of the first four, the others once the accumulators have gone to LDS
+    eltx8 adr[ADD ? 8 : 1], yrw[GNB ? 8 : 1];
+    auto second_operands = [&](int j0, int j1) {
+#pragma unroll
+      for (int j = j0; j < j1; ++j) {
+        if constexpr (ADD) adr[j] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(a.add, j), vb, row_soff(j), 0));
+        if constexpr (GNB) yrw[j] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(a.gnb_y, j), vb, row_soff(j), 0));
+      }
+    };
+    second_operands(0, GNB ? 4 : 8);
+    if constexpr (ACT) {
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) act_apply_v16(acc[t], a.act);
+    }
+    const int e_lx = ((r & 15) - (r >> 4) * HX) & 15;
+    const int e_sw = (e_lx >> 1) & 7;
+    eltx8 rows[8];
+    // LDS operations of a wave execute in order: half 1's writes may follow half 0's reads directly
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * half + tt;
+        const int vl = (2 * tt + (r >> 4)) * 16 + e_lx;  // voxel of the half: row (0..3) * 16 + x
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          eltx4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (elt)acc[t][q * 4 + j];  // co = 8q + 4h + j
+          *reinterpret_cast<eltx4*>(wlds + vl * 32 + ((2 * q + h) ^ e_sw) * 4) = o;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int vox = j * 16 + ev, swl = (vox >> 1) & 7;
+        rows[4 * half + j] = *reinterpret_cast<const eltx8*>(wlds + vox * 32 + (pj ^ (swl >> 1)) * 8);
+      }
+    }
+    float ca[GNB ? 8 : 1], cbf[GNB ? 8 : 1];
+    if constexpr (GNB) {  // (after the accumulators are gone: the register file is full until then)
+      second_operands(4, 8);
+      const auto rsrc_cf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_coef + (size_t)n * 64), 0, 256u, 0x00020000);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 c4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_cf, (unsigned)(pj * 64 + q * 16), 0, 0));
+        ca[2 * q] = c4[0];
+        cbf[2 * q] = c4[1];
+        ca[2 * q + 1] = c4[2];
+        cbf[2 * q + 1] = c4[3];
+      }
+    }
+    const bool swap_halves = (ev >> 1) & 1;  // (= bit 0 of the row swizzle (vox >> 1) & 7, the same for the eight rows)
+    [[maybe_unused]] const bool gnb_elu = a.gnb_act == MEDNET_ACT_ELU;
+    [[maybe_unused]] const float gnb_neg = a.gnb_act == MEDNET_ACT_LEAKY ? 0.1f : (a.gnb_act == MEDNET_ACT_RELU ? 0.f : 1.f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      eltx8 v = rows[j];
+      const eltx8 vs = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
+      v = swap_halves ? vs : v;
+      if constexpr (ADD) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (elt)((float)v[k] + (float)adr[j][k]);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), row_rsrc(a.y, j), vb, row_soff(j), 2);
+      [[maybe_unused]] const bool ok = lane_ok & plane_ok & (ty0 + j < a.oh);
+      if constexpr (GNB) {
+        float g[8], u[8], yy[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          yy[k] = (float)yrw[j][k];
+          g[k] = ok ? (float)v[k] : 0.f;
+          u[k] = fmaf(ca[k], yy[k], cbf[k]);
+        }
+        // du = dz * act'(u), branch-free for a runtime activation (control flow inside the row loop makes the compiler hoist
+        // all eight rows' conversions above it, which does not fit): the factor for u <= 0 is exp(u) (ELU), 0.1, 0 or 1
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float neg = gnb_elu ? __expf(u[k]) : gnb_neg;
+          g[k] = u[k] > 0.f ? g[k] : g[k] * neg;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          bs[k] += g[k];
+          bq[k] = fmaf(g[k], yy[k], bq[k]);
+        }
+      } else if constexpr (STATS) {
+        const eltx8 vz = ok ? v : eltx8{};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const eltx2 pr = {vz[2 * k], vz[2 * k + 1]};
+          gs[k] = MEDNET_FDOT2(pr, ones, gs[k], false);
+          gq[k] = MEDNET_FDOT2(pr, pr, gq[k], false);
+        }
+      }
+    }
+    STAMP(6);
+    if (!has_next) {
+      if constexpr (GNB || STATS) {
+        while (acc_n < a.n) {
+          flush(acc_n);
+          ++acc_n;
+        }
+      }
+      break;
+    }
+    seq += seq_step;
+    buf ^= 1;
+  }
+  STAMP(15);
 }
 
 // ================================================================================================== ConvTranspose3d forward
@@ -977,10 +1408,19 @@ bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype,
 // Accumulate mode needs: the persistent launch form (more items than the 512 resident workgroups, with margin so that every
 // workgroup starts on a valid item), brick count a multiple of 8 (no padding items), and ncb | 64 (a workgroup's channel
 // block never changes).
-static void conv_stats_plan(int n, int d, int h, int w, int cout, int& rows, int& accum) {
+// The 32 -> 32 specialisation (conv32_mfma_kernel): one workgroup per CU, at least two bricks each.
+static bool conv32_applies(int ntiles, int cin, int cout) {
+  return cin == 32 && cout == 32 && ntiles >= 512 && tuning_option("conv32", 1);
+}
+static void conv_stats_plan(int n, int d, int h, int w, int cin, int cout, int& rows, int& accum) {
   using G = FwdTile<1>;
   const int tps = ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
   const int ncb = (cout + 31) / 32, ntiles = n * tps;
+  if (conv32_applies(ntiles, cin, cout)) {  // always accumulating: one row per wave of the 256 workgroups
+    accum = 1;
+    rows = 256 * 4;
+    return;
+  }
   const int nitems = ((ntiles + 7) / 8) * 8 * ncb;
   accum = tuning_option("conv_persist", 1) && tuning_option("conv_stats_accum", 1) && nitems >= 1024 && ntiles % 8 == 0 &&
           64 % ncb == 0;
@@ -1037,7 +1477,49 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   if (tuning_option("conv_persist", 1) && grid > 512u) grid = 512u;
   a.stats_accum = 0;
   a.stats_rows = 4 * a.tiles_z * a.tiles_y * a.tiles_x;
-  if (gn_partial && STRIDE == 1) conv_stats_plan(n, od, oh, ow, cout, a.stats_rows, a.stats_accum);
+  if (gn_partial && STRIDE == 1) conv_stats_plan(n, od, oh, ow, cin, cout, a.stats_rows, a.stats_accum);
+  a.xcd_chunk = 0;
+  if constexpr (STRIDE == 1) {
+    if (conv32_applies(a.ntiles, cin, cout)) {
+      constexpr size_t lds32 = (size_t)2 * 4 * (HZ * HY * HX + 4) * 16 + 4 * 4096 + 256 * 16;
+      static_assert(lds32 <= 160 * 1024, "two bricks of whole rows + the waves' epilogue areas + spare slots");
+      a.xcd_chunk = a.ntiles % 8 == 0 ? a.ntiles / 8 : 0;
+      a.zslab = 0;
+      a.rcp_zslab = 0;
+      if ((n * a.tiles_z) % 8 == 0 && a.tiles_z % (n * a.tiles_z / 8) == 0 && tuning_option("conv32_zslab", 1)) {
+        a.zslab = n * a.tiles_z / 8;  // (a slab lies inside ONE sample: the statistics rows of a workgroup need that)
+        a.rcp_zslab = rcp(a.zslab);
+      }
+      const int variant = use_gnb ? (C32_GNB | (add ? C32_ADD : 0))
+                                  : ((add ? C32_ADD : 0) | (gn_partial ? C32_STATS : 0) | (act != MEDNET_ACT_NONE ? C32_ACT : 0));
+      MEDNET_REQUIRE(!use_gnb || act == MEDNET_ACT_NONE, MEDNET_E_UNSUPPORTED, "conv32_mfma: no activation in the data-gradient form");
+      static bool attr32[16] = {};
+      auto go = [&](auto kernel) -> int {
+        if (!attr32[variant]) {
+          if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32) != hipSuccess)
+            return fail(MEDNET_E_HIP, "conv32_mfma: cannot raise dynamic LDS to %zu", lds32);
+          attr32[variant] = true;
+        }
+        hipLaunchKernelGGL(kernel, dim3(256), dim3(256), lds32, s, a);
+        return MEDNET_OK;
+      };
+      int rc32 = MEDNET_OK;
+      switch (variant) {
+        case 0: rc32 = go(conv32_mfma_kernel<0>); break;
+        case C32_ADD: rc32 = go(conv32_mfma_kernel<C32_ADD>); break;
+        case C32_STATS: rc32 = go(conv32_mfma_kernel<C32_STATS>); break;
+        case C32_STATS | C32_ADD: rc32 = go(conv32_mfma_kernel<C32_STATS | C32_ADD>); break;
+        case C32_ACT: rc32 = go(conv32_mfma_kernel<C32_ACT>); break;
+        case C32_ACT | C32_ADD: rc32 = go(conv32_mfma_kernel<C32_ACT | C32_ADD>); break;
+        case C32_ACT | C32_STATS: rc32 = go(conv32_mfma_kernel<C32_ACT | C32_STATS>); break;
+        case C32_ACT | C32_STATS | C32_ADD: rc32 = go(conv32_mfma_kernel<C32_ACT | C32_STATS | C32_ADD>); break;
+        case C32_GNB: rc32 = go(conv32_mfma_kernel<C32_GNB>); break;
+        default: rc32 = go(conv32_mfma_kernel<C32_GNB | C32_ADD>); break;
+      }
+      if (rc32) return rc32;
+      return check_launch("conv32_mfma");
+    }
+  }
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[STRIDE]) {
     if (hipFuncSetAttribute((const void*)conv_mfma_kernel<STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1075,9 +1557,9 @@ int launch_conv_mfma_gnb(const void* dy, const void* packed_section, void* dx, i
   g.act = gn_act;
   return launch_fwd<1>(dy, packed_section, dx, n, d, h, w, d, h, w, cin, cout, gn_partial, s, MEDNET_ACT_NONE, add, g);
 }
-int conv_mfma_stats_chunks(int n, int d, int h, int w, int cout) {
+int conv_mfma_stats_chunks(int n, int d, int h, int w, int cin, int cout) {
   int rows, accum;
-  conv_stats_plan(n, d, h, w, cout, rows, accum);
+  conv_stats_plan(n, d, h, w, cin, cout, rows, accum);
   return rows;
 }
 
