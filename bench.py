@@ -82,7 +82,7 @@ def cpu_baseline(steps: int):
                       f"1 warm-up + {steps} timed steps (median {med:.2f} s/step)"}
 
 
-DOMINANT_KEY = "mednet::conv_mfma_kernel<1> 32->32@128^3 (persistent grid=131072, longest launches)"
+DOMINANT_KEY = "mednet::conv32_mfma_kernel<4> conv3d 32->32@128^3 (forward launches with fused GroupNorm statistics, grid=65536)"
 KERNEL_SOURCE = os.path.join(ROOT, "torch-mednet_amd", "csrc", "conv_mfma.hip")
 
 
@@ -262,7 +262,7 @@ def main():
             peak = MFMA_PEAK_TFLOPS[a.precision]
             ach = flops / (avg * 1e-3) / 1e12
             traffic, traffic_source = pmc_traffic(a.batch, P)
-            out["roofline"] = {"kernel": "conv_mfma_kernel<1>: conv3d 3x3x3 32->32 @128^3 (fwd launches)", "bound": "mfma",
+            out["roofline"] = {"kernel": "conv32_mfma_kernel<4>: conv3d 3x3x3 32->32 @128^3 (fwd launches)", "bound": "mfma",
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "traffic_source": traffic_source, "launches": len(ms),
                                "avg_ms": round(avg, 4), "flop_per_launch": flops}

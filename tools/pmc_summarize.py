@@ -6,14 +6,14 @@
                                       taken from (bench.py reports `traffic` only while that sha matches the source):
                                       separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, FETCH_SIZE doubled on gfx950 as
                                       MI355X_MICROARCH.md prescribes.
-The persistent conv kernel launches every large layer with the same grid (2 workgroups per CU), so its launches are split
-by duration: the 32->32 @128^3 layers (the dominant kernel bench.py reports) are the ones within 40 % of the longest."""
+The dominant kernel bench.py reports is the 32 -> 32 channel specialisation in its forward variant (conv32_mfma_kernel<4>:
+fused GroupNorm statistics); in the bf16 step of bench.py all its launches are the 32->32 @128^3 layers."""
 import csv, glob, hashlib, json, os, shutil, subprocess, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 ROUND = os.environ.get("ROUND", "r02")
-DOM = "mednet::conv_mfma_kernel<1> 32->32@128^3 (persistent grid=131072, longest launches)"
+DOM = "mednet::conv32_mfma_kernel<4> conv3d 32->32@128^3 (forward launches with fused GroupNorm statistics, grid=65536)"
 
 
 def newest(pattern):
@@ -21,14 +21,14 @@ def newest(pattern):
     return max(fs, key=os.path.getmtime) if fs else None
 
 
+def is_dominant(r):
+    return "conv32_mfma_kernel<4>" in r["Kernel_Name"] and "mednet_f16" not in r["Kernel_Name"]
+
+
 def per_kernel(path):
     agg = collections.defaultdict(list)
     rows = list(csv.DictReader(open(path)))
-    # the persistent conv kernel launches every large layer with the same grid; the 32->32 @128^3 launches are the ones that
-    # move the most bytes (537 MB in, 537 MB out; the next largest layer moves a quarter of that)
-    conv = [r for r in rows if "conv_mfma_kernel<1, false>" in r["Kernel_Name"] and "mednet_f16" not in r["Kernel_Name"] and r["Grid_Size"] == "131072"]
-    vmax = max((float(r["Counter_Value"]) for r in conv), default=0.0)
-    big = {id(r) for r in conv if float(r["Counter_Value"]) >= 0.5 * vmax}
+    big = {id(r) for r in rows if is_dominant(r)}
     for r in rows:
         name = r["Kernel_Name"].split("(")[0]
         key = f"{name} grid={r['Grid_Size']}"
@@ -76,9 +76,9 @@ def main():
                     "note": "hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE counts half of a wide coalesced read on gfx950"}
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{ROUND}_pmc_hbm_traffic.json"), "w"), indent=1)
     sq = newest("pmc_sq/*/*counter_collection.csv")
-    if sq:  # SQ counters of the dominant kernel's launches (same selection: the longest conv_mfma_kernel<1> launches)
+    if sq:  # SQ counters of the dominant kernel's launches
         rows = list(csv.DictReader(open(sq)))
-        conv = [r for r in rows if "conv_mfma_kernel<1, false>" in r["Kernel_Name"] and "mednet_f16" not in r["Kernel_Name"] and r["Grid_Size"] == "131072"]
+        conv = [r for r in rows if is_dominant(r)]
         byd = collections.defaultdict(dict)
         for r in conv:
             byd[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])

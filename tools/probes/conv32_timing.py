@@ -40,6 +40,33 @@ for special in (1, 0):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
         print(f"conv32={special} stats={with_stats}: {ms * 1e3:7.1f} us  {2.0 * N * s ** 3 * 32 * 32 * 27 / ms / 1e9:7.1f} TFLOP/s")
+# the data-gradient variants: + summed second gradient, + first pass of a GroupNorm backward (ELU), both
+add = torch.randn_like(x)
+gy = torch.randn_like(x)
+coef = torch.randn(N, 32, 2, device=dev)
+dx = torch.empty_like(x)
+for special in (1, 0):
+    lib.mednet_set_option(b"conv32", special)
+    rows = lib.mednet_conv3d_dgrad_gn_rows(N, s, s, s, 32, 32, 2)
+    part = torch.empty(N, rows, 32, 2, device=dev)
+    cases = {
+        "dgrad_add": lambda: lib.mednet_conv3d_dgrad_add(x.data_ptr(), pk.data_ptr(), add.data_ptr(), dx.data_ptr(), N, s, s, s, 32, 32, 2, 1, st),
+        "dgrad_gn": lambda: lib.mednet_conv3d_dgrad_gn(x.data_ptr(), pk.data_ptr(), None, dx.data_ptr(), gy.data_ptr(), coef.data_ptr(), 3,
+                                                       part.data_ptr(), N, s, s, s, 32, 32, 2, 1, st),
+        "dgrad_gn+add": lambda: lib.mednet_conv3d_dgrad_gn(x.data_ptr(), pk.data_ptr(), add.data_ptr(), dx.data_ptr(), gy.data_ptr(),
+                                                           coef.data_ptr(), 3, part.data_ptr(), N, s, s, s, 32, 32, 2, 1, st),
+    }
+    for name, fn in cases.items():
+        for _ in range(3):
+            L.check(fn(), name)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"conv32={special} {name:14s}: {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us")
 lib.mednet_set_option(b"conv32", 1)
 if "timing" in os.environ.get("MEDNET_LIB_PATH", ""):
     dbg = torch.zeros(256, 16, dtype=torch.int64, device=dev)

@@ -666,13 +666,17 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
   }
 
   // ---- the weights: A fragment of (chunk kc, tap) = piece ((kc*27 + tap)*2 + h)*32 + r of the packed image
-  //      The fragments of the last WT steps are not kept over the epilogue (which needs the registers): they are fetched
-  //      again (from L2) in the first steps of every tap loop, 40 steps before their use.
-  constexpr int WT = GNB && ADD ? 14 : 8;
+  //      Variants whose epilogue has second operands (the summed gradient, the GroupNorm input) want those rows in flight
+  //      BEFORE the tap loop ends -- their latency is otherwise exposed, 2 us per brick -- and have no registers for them:
+  //      there the fragments of steps [TW0, TW1) are transient, fetched again (from L2) 30+ steps before their use in every
+  //      tap loop, and the second operands take over their registers for the last 8 steps.
+  constexpr int NSEC = (ADD ? 8 : 0) + (GNB ? 8 : 0);  // second-operand rows (4 registers each, as a fragment)
+  constexpr int SEC0 = 54 - 8, WT = NSEC, TW1 = SEC0, TW0 = TW1 - WT;
   eltx8 wreg[54];
   const u32x4* wp = reinterpret_cast<const u32x4*>(a.wpk) + h * 32 + r;
 #pragma unroll
-  for (int i = 0; i < 54 - WT; ++i) wreg[i] = __builtin_bit_cast(eltx8, wp[i * 64]);
+  for (int i = 0; i < 54; ++i)
+    if (i < TW0 || i >= TW1) wreg[i] = __builtin_bit_cast(eltx8, wp[i * 64]);
 
   // ---- staging plan of a brick (halo 6 x 10 x 18 voxels = 60 x-rows of 72 16-byte pieces).  One wave per SIMD means
   //      that whatever runs outside the tap loop is exposed in full and that vector work inside it must stay small, so the
@@ -797,6 +801,20 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
     __syncthreads();  // the brick is complete, and every wave is done reading the other buffer (the previous brick)
     STAMP(3);
 
+    // ---- output rows of this wave (its z-plane of the brick, 8 x-rows of 16 voxels)
+    const int pj = lane & 3, ev = lane >> 2;  // row reads: voxel ev of 16 in an x-row, 16-byte piece pj
+    // rows outside the volume get resources of 0 bytes (loads return zeros, stores are dropped): validity in y and z is
+    // scalar, validity in x is the lane's offset
+    const bool plane_ok = tz0 + wv_s < a.od;
+    const bool lane_ok = tx0 + ev < a.ow;
+    const unsigned vb = lane_ok ? (unsigned)(ev * 32 + pj * 8) * 2u : OOB;
+    auto row_rsrc = [&](const elt* base, int j) {
+      const bool ok = plane_ok & (ty0 + j < a.oh);
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)n * ovol * 32), 0, a.bytes_y & (0u - (unsigned)ok), 0x00020000);
+    };
+    auto row_soff = [&](int j) { return (unsigned)((((tz0 + wv_s) * a.oh + ty0 + j) * a.ow + tx0) * 32) * 2u; };
+    [[maybe_unused]] eltx8 adr[ADD ? 8 : 1], yrw[GNB ? 8 : 1];  // second operands: requested in the last 8 steps below
+
     // ---- 54 steps (K chunk, tap) of 4 MFMAs; B operands are read TWO steps ahead (nobody else hides the LDS latency).
     //      Step 3k: round k of brick j + 1 goes from its registers to the other LDS buffer, then round k of brick j + 2 is
     //      requested into them.
@@ -832,9 +850,11 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (s54 + 2 < 54) xb[pre][t] = b_operand(s54 + 2, t);
         if (s54 == 0 && t == 1) plan_main(tx2);
-        if (t == 2 && s54 % 3 != 0 && s54 / 3 * 2 + s54 % 3 - 1 < WT) {  // steps 1, 2, 4, 5, ...: transient weight fragments
-          const int wi = 54 - WT + s54 / 3 * 2 + s54 % 3 - 1;
-          wreg[wi] = __builtin_bit_cast(eltx8, __builtin_nontemporal_load(wp + wi * 64));
+        if (t == 2 && s54 < WT) wreg[TW0 + s54] = __builtin_bit_cast(eltx8, __builtin_nontemporal_load(wp + (TW0 + s54) * 64));
+        if (t == 2 && s54 >= SEC0) {  // second operands of row s54 - SEC0
+          const int j = s54 - SEC0;
+          if constexpr (ADD) adr[j] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(a.add, j), vb, row_soff(j), 0));
+          if constexpr (GNB) yrw[j] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(a.gnb_y, j), vb, row_soff(j), 0));
         }
         if (staging) {
           if (t == 0) commit_one(buf ^ 1, round);
@@ -846,28 +866,6 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
     STAMP(5);
 
     // ---- epilogue: two halves of 64 voxels (4 x-rows) through the wave's private 4 KB of LDS -- no barrier
-    const int pj = lane & 3, ev = lane >> 2;  // row reads: voxel ev of 16 in an x-row, 16-byte piece pj
-    // rows outside the volume get resources of 0 bytes (loads return zeros, stores are dropped): validity in y and z is
-    // scalar, validity in x is the lane's offset
-    const bool plane_ok = tz0 + wv_s < a.od;
-    const bool lane_ok = tx0 + ev < a.ow;
-    const unsigned vb = lane_ok ? (unsigned)(ev * 32 + pj * 8) * 2u : OOB;
-    auto row_rsrc = [&](const elt* base, int j) {
-      const bool ok = plane_ok & (ty0 + j < a.oh);
-      return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)n * ovol * 32), 0, a.bytes_y & (0u - (unsigned)ok), 0x00020000);
-    };
-    auto row_soff = [&](int j) { return (unsigned)((((tz0 + wv_s) * a.oh + ty0 + j) * a.ow + tx0) * 32) * 2u; };
-    // second operands in flight first: of all eight rows, or -- in the GroupNorm-backward variants, whose register file is
-    // full while the accumulators live -- of the first four, the others once the accumulators have gone to LDS
-    eltx8 adr[ADD ? 8 : 1], yrw[GNB ? 8 : 1];
-    auto second_operands = [&](int j0, int j1) {
-#pragma unroll
-      for (int j = j0; j < j1; ++j) {
-        if constexpr (ADD) adr[j] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(a.add, j), vb, row_soff(j), 0));
-        if constexpr (GNB) yrw[j] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(a.gnb_y, j), vb, row_soff(j), 0));
-      }
-    };
-    second_operands(0, GNB ? 4 : 8);
     if constexpr (ACT) {
 #pragma unroll
       for (int t = 0; t < NTW; ++t) act_apply_v16(acc[t], a.act);
@@ -898,7 +896,6 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
     }
     float ca[GNB ? 8 : 1], cbf[GNB ? 8 : 1];
     if constexpr (GNB) {  // (after the accumulators are gone: the register file is full until then)
-      second_operands(4, 8);
       const auto rsrc_cf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_coef + (size_t)n * 64), 0, 256u, 0x00020000);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
