@@ -1,0 +1,111 @@
+// Which bf16 MFMA shape does the chip clock higher under load?  Two bare loops with the operand traffic of the 32 -> 32
+// convolution (A = weights in registers, B = one ds_read_b128 per 32 KFLOP... per 1 KB of B), one wave per SIMD, random data:
+//   shape 0: v_mfma_f32_32x32x16_bf16, 4 MFMAs + 4 ds_read_b128 per step
+//   shape 1: v_mfma_f32_16x16x32_bf16, 16 MFMAs + 8 ds_read_b128 per step (each B fragment feeds two MFMAs)
+// Shape 1 does twice the FLOPs per step (16 x 16384 against 4 x 32768) and runs half as many steps: the same LDS bytes per
+// FLOP and the same total FLOPs; prints wall time and TFLOP/s of both.  Measured on two boxes of the round-2 pool (profiles/
+// r02_mfma_shape_probe.log): 1.17-1.32 PFLOP/s, the two shapes within 2 % of each other -- the clock the chip holds under this
+// load, not the issue stream, bounds a bf16 MFMA loop fed from LDS at about half of the 2.5 PFLOP/s nominal peak, and the
+// shape does not move it here.
+// build: hipcc -O3 --offload-arch=gfx950 mfma_shape_probe.hip -o mfma_shape_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <int SHAPE>
+__global__ __launch_bounds__(256, 1) void probe(const u32x4* src, float* out, int steps) {
+  extern __shared__ u32x4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 8192; i += 256) lds[i] = src[i + (blockIdx.x & 7) * 8192];  // 128 KB of random bf16
+  __syncthreads();
+  bf16x8 w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = __builtin_bit_cast(bf16x8, src[tid + 256 * i]);
+  const u32x4* p = lds + (tid >> 6) * 1024 + lane;
+  if constexpr (SHAPE == 0) {
+    f32x16 acc[4] = {};
+    bf16x8 b[2][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[0][t] = __builtin_bit_cast(bf16x8, p[t * 64]);
+    for (int s = 0; s < steps; s += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          b[u ^ 1][t] = __builtin_bit_cast(bf16x8, p[((s + u + 1) & 3) * 256 + t * 64]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[(u * 4 + t) & 7], b[u][t], acc[t], 0, 0, 0);
+        }
+      }
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r += acc[t][i];
+    out[blockIdx.x * 256 + tid] = r;
+  } else {
+    f32x4 acc[16] = {};
+    bf16x8 b[2][8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) b[0][t] = __builtin_bit_cast(bf16x8, p[t * 64]);
+    for (int s = 0; s < steps; s += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          b[u ^ 1][t] = __builtin_bit_cast(bf16x8, p[((s + u + 1) & 1) * 512 + t * 64]);
+          acc[2 * t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[(2 * t) & 7], b[u][t], acc[2 * t], 0, 0, 0);
+          acc[2 * t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[(2 * t + 1) & 7], b[u][t], acc[2 * t + 1], 0, 0, 0);
+        }
+      }
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r += acc[t][i];
+    out[blockIdx.x * 256 + tid] = r;
+  }
+}
+
+int main() {
+  const size_t n = 8 * 8192;
+  std::vector<unsigned> h(n * 4);
+  srand(1);
+  for (auto& v : h) {  // random bf16 pairs in [-2, 2): random mantissas and signs, exponents near 0
+    unsigned a = (rand() & 0x807F) | (((rand() % 3) + 126) << 7), b = (rand() & 0x807F) | (((rand() % 3) + 126) << 7);
+    v = a | (b << 16);
+  }
+  u32x4* d;
+  float* o;
+  hipMalloc(&d, n * 16);
+  hipMalloc(&o, 256 * 256 * 4);
+  hipMemcpy(d, h.data(), n * 16, hipMemcpyHostToDevice);
+  hipFuncSetAttribute((const void*)probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute((const void*)probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int steps0 = 40000;  // shape 0 steps; shape 1 runs half as many of twice the FLOPs
+  for (int rep = 0; rep < 3; ++rep)
+    for (int shape = 0; shape < 2; ++shape) {
+      for (int warm = 0; warm < 2; ++warm) {
+        hipEventRecord(e0);
+        if (shape == 0) hipLaunchKernelGGL(probe<0>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
+        else hipLaunchKernelGGL(probe<1>, dim3(256), dim3(256), 131072, 0, d, o, steps0 / 2);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+      }
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      const double flop = 256.0 * 4 * steps0 * 4 * 2.0 * 32 * 32 * 16;  // the same for both shapes
+      printf("shape %s: %8.3f ms  %7.1f TFLOP/s  (%.1f cycles per 32768 FLOP per SIMD at 2.4 GHz; 32 = nominal peak)\n",
+             shape == 0 ? "32x32x16" : "16x16x32", ms, flop / ms / 1e9, ms * 1e-3 * 2.4e9 / (steps0 * 4.0));
+    }
+  return 0;
+}
