@@ -808,11 +808,19 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
     const bool plane_ok = tz0 + wv_s < a.od;
     const bool lane_ok = tx0 + ev < a.ow;
     const unsigned vb = lane_ok ? (unsigned)(ev * 32 + pj * 8) * 2u : OOB;
-    auto row_rsrc = [&](const elt* base, int j) {
+    // per row: bytes of its resources (0 = outside) and its scalar offset; made one row per step in the MIDDLE of the tap
+    // loop (pinned there: left alone, the ~100 scalar instructions end up in one MFMA gap or behind the loop)
+    unsigned row_num[8], row_off[8];
+    auto plan_row = [&](int j) {
       const bool ok = plane_ok & (ty0 + j < a.oh);
-      return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)n * ovol * 32), 0, a.bytes_y & (0u - (unsigned)ok), 0x00020000);
+      row_num[j] = a.bytes_y & (0u - (unsigned)ok);
+      row_off[j] = (unsigned)((((tz0 + wv_s) * a.oh + ty0 + j) * a.ow + tx0) * 32) * 2u;
+      asm volatile("" : "+s"(row_num[j]), "+s"(row_off[j]));
     };
-    auto row_soff = [&](int j) { return (unsigned)((((tz0 + wv_s) * a.oh + ty0 + j) * a.ow + tx0) * 32) * 2u; };
+    auto row_rsrc = [&](const elt* base, int j) {
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)n * ovol * 32), 0, row_num[j], 0x00020000);
+    };
+    auto row_soff = [&](int j) { return row_off[j]; };
     [[maybe_unused]] eltx8 adr[ADD ? 8 : 1], yrw[GNB ? 8 : 1];  // second operands: requested in the last 8 steps below
 
     // ---- 54 steps (K chunk, tap) of 4 MFMAs; B operands are read TWO steps ahead (nobody else hides the LDS latency).
@@ -850,6 +858,7 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (s54 + 2 < 54) xb[pre][t] = b_operand(s54 + 2, t);
         if (s54 == 0 && t == 1) plan_main(tx2);
+        if (t == 3 && s54 >= 24 && s54 < 32) plan_row(s54 - 24);
         if (t == 2 && s54 < WT) wreg[TW0 + s54] = __builtin_bit_cast(eltx8, __builtin_nontemporal_load(wp + (TW0 + s54) * 64));
         if (t == 2 && s54 >= SEC0) {  // second operands of row s54 - SEC0
           const int j = s54 - SEC0;
@@ -919,7 +928,7 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
         for (int k = 0; k < 8; ++k) v[k] = (elt)((float)v[k] + (float)adr[j][k]);
       }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), row_rsrc(a.y, j), vb, row_soff(j), 2);
-      [[maybe_unused]] const bool ok = lane_ok & plane_ok & (ty0 + j < a.oh);
+      [[maybe_unused]] const bool ok = lane_ok & (row_num[j] != 0u);
       if constexpr (GNB) {
         float g[8], u[8], yy[8];
 #pragma unroll
