@@ -90,6 +90,19 @@ int mednet_conv3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, i
 int mednet_conv3d_dgrad_gn(const void* dy, const void* packed, const void* add, void* dx, const void* gn_y,
                            const float* gn_coef, int gn_act, float* gn_partial, int n, int d, int h, int w, int cin,
                            int cout, int algo, int dtype, mednet_stream stream);
+/* GroupNorm-3 of an ExtResNetBlock (out = act(GroupNorm(conv3(z2)) + z1), components.py:170-178): its backward's first
+ * pass -- du = dout * act'(out), per-channel {sum du, sum du * y3} -- taken by the kernel that PRODUCES dout, from the
+ * stored (rounded) dout rows: the data gradient of the 1x1x1 head (model.py:204-207; dy = planar fp32 logit gradients,
+ * dx / gn_y = y3 / gn_z = out channels-last 16-bit, cin = block channels, cout = classes) for the last decoder block, and
+ * the pooling backward + skip-gradient join (mednet_pool2_bwd; model.py:194-205; x = the block output) for the encoder
+ * blocks.  gn_partial[n][rows][C][2] with rows from the *_rows call (0 = not supported for this shape / dtype; even
+ * d, h, w for the pooling form); mednet_gn_act_bwd_fused_res consumes it and also writes the residual-branch gradient. */
+int mednet_head_dgrad_gn_rows(int n, int d, int h, int w, int cin, int dtype);
+int mednet_head_dgrad_gn(const void* dy, const void* packed, void* dx, const void* gn_y, const void* gn_z, int gn_act,
+                         float* gn_partial, int n, int d, int h, int w, int cin, int cout, int dtype, mednet_stream stream);
+int mednet_pool2_bwd_gn_rows(int n, int d, int h, int w, int c, int dtype);
+int mednet_pool2_bwd_gn(const void* dy, const void* x, const void* add, void* dx, const void* gn_y, int gn_act,
+                        float* gn_partial, int n, int d, int h, int w, int c, int mode, int dtype, mednet_stream stream);
 size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
 /* dw[co,ci,tap] = sum_{n,v} dy[n,v,co] * x[n,v+tap,ci]; dbias[co] = sum dy (nullable). */
 int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
@@ -136,6 +149,10 @@ int mednet_gn_act_bwd_fused(const void* dz, const void* x, const float* coef, co
                             const float* partial, int rows, void* dx, float* dgamma, float* dbeta, int n,
                             size_t spatial, int c, int groups, int act, int dtype, void* ws, size_t ws_bytes,
                             mednet_stream stream);
+int mednet_gn_act_bwd_fused_res(const void* dz, const void* x, const void* z, const float* coef, const float* stats,
+                                const float* gamma, const float* fused_partial, int rows, void* dx, void* dres,
+                                float* dgamma, float* dbeta, int n, size_t spatial, int c, int groups, int act, int dtype,
+                                void* ws, size_t ws_bytes, mednet_stream stream);
 /* stand-alone activation (orders such as 'cr', 'crg'); in-place allowed (x == z). */
 int mednet_act_fwd(const void* x, void* z, size_t count, int act, int dtype, mednet_stream stream);
 int mednet_act_bwd(const void* dz, const void* z, void* dx, size_t count, int act, int dtype,

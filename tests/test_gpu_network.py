@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 import mednet_hip
+from mednet_hip import nn as hnn
 from mednet_hip.unet import components as HC
 from mednet_hip.unet import loss as HL
 from mednet_hip.unet import model as HM
@@ -629,6 +630,75 @@ def test_groupnorm_backward_sums_from_the_data_gradient_epilogue(n, c, shape):
     if c >= 32:  # the fused path really ran (otherwise both runs are the same code)
         from mednet_hip import _lib as L, config
         assert L.lib().mednet_conv3d_dgrad_gn_rows(n, *shape, c, c, config.conv_algo()) > 0
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("consumer,shape", [("head", (16, 24, 32)), ("head", (9, 11, 21)), ("pool", (16, 24, 32)), ("pool", (8, 8, 16))])
+def test_groupnorm3_backward_sums_from_the_producer_of_the_block_gradient(mode, consumer, shape):
+    """ExtResNetBlock backward (components.py:170-178) in the 16-bit modes: the first pass of GroupNorm-3's backward taken
+    by the op that produces the block's output gradient -- the 1x1x1 head's data gradient (model.py:204-207) or the pooling
+    backward + skip-gradient join (model.py:194-205) -- against the stand-alone pass (MEDNET_FUSE_GN3 off) on the same
+    tensors: same gradients up to fp32 summation order; and the sums are really used (ops.GN3_COUNT)."""
+    from mednet_hip import ops as hops
+    c = 32
+    x = torch.from_numpy(O._rng(f"gn3{consumer}{shape}").standard_normal((2, c) + shape).astype(np.float32))
+    res = {}
+    for fused in (True, False):
+        old = hops.FUSE_GN3
+        hops.FUSE_GN3 = fused
+        before = dict(hops.GN3_COUNT)
+        try:
+            with mednet_hip.precision(mode):
+                blk = O.keyed_init_(HC.ExtResNetBlock(c, c, order="cge", num_groups=8)).to(DEV)
+                xg = x.to(DEV).to(torch.bfloat16 if mode == "bf16" else torch.float16).requires_grad_(True)
+                out = blk(xg)
+                if consumer == "head":
+                    head = hnn.Conv3d(c, 4, 1, planar_output=True).to(DEV)
+                    with torch.no_grad():
+                        head.weight.copy_(torch.from_numpy(O._rng("gn3hw").standard_normal((4, c, 1, 1, 1)).astype(np.float32)) * 0.2)
+                        head.bias.zero_()
+                    y = head(out)
+                    cot = torch.from_numpy(O._rng("gn3hc").standard_normal(tuple(y.shape)).astype(np.float32)).to(DEV)
+                    (y * cot).sum().backward()
+                else:
+                    skip, pooled = hops.skip_pool2(out)
+                    c1 = torch.from_numpy(O._rng("gn3pc1").standard_normal(tuple(skip.shape)).astype(np.float32)).to(DEV)
+                    c2 = torch.from_numpy(O._rng("gn3pc2").standard_normal(tuple(pooled.shape)).astype(np.float32)).to(DEV)
+                    ((skip.float() * c1).sum() + (pooled.float() * c2).sum()).backward()
+                res[fused] = [xg.grad.float().clone()] + [p.grad.clone() for p in blk.parameters()]
+        finally:
+            hops.FUSE_GN3 = old
+        taken = hops.GN3_COUNT["taken"] - before["taken"]
+        assert taken == (1 if fused else 0), f"fused={fused}: the block's backward took the producer's sums {taken} times"
+    names = ["dx"] + [k for k, _ in blk.named_parameters()]
+    for k, a, b in zip(names, res[True], res[False]):
+        assert_close(a, b, 2e-3, f"fused vs stand-alone {k}")
+
+
+def test_groupnorm3_sums_are_declined_when_the_block_output_has_a_second_consumer():
+    """ops.GN3Hook: if autograd accumulates another gradient into the block's output gradient, the producer's sums no longer
+    describe it; the block must notice (object identity + version counter) and run its stand-alone pass."""
+    from mednet_hip import ops as hops
+    c, shape = 32, (8, 8, 16)
+    x = torch.from_numpy(O._rng("gn3two").standard_normal((1, c) + shape).astype(np.float32))
+    res = {}
+    for fused in (True, False):
+        old = hops.FUSE_GN3
+        hops.FUSE_GN3 = fused
+        before = dict(hops.GN3_COUNT)
+        try:
+            with mednet_hip.precision("bf16"):
+                blk = O.keyed_init_(HC.ExtResNetBlock(c, c, order="cge", num_groups=8)).to(DEV)
+                xg = x.to(DEV).bfloat16().requires_grad_(True)
+                out = blk(xg)
+                skip, pooled = hops.skip_pool2(out)
+                (skip.float().sum() + 2.0 * pooled.float().sum() + 3.0 * (out.float() ** 2).sum()).backward()  # `out` used twice
+                res[fused] = [xg.grad.float().clone()] + [p.grad.clone() for p in blk.parameters()]
+        finally:
+            hops.FUSE_GN3 = old
+        assert hops.GN3_COUNT["taken"] == before["taken"], "stale sums were used"
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
 
 
 def test_fp32_tensor_into_a_bf16_mode_conv_act_layer():

@@ -227,6 +227,24 @@ extern "C" int mednet_conv3d_dgrad_add(const void* dy, const void* packed, const
                   (hipStream_t)stream, MEDNET_ACT_NONE, add);
 }
 
+// data gradient of the 1x1x1 head + the first pass of the GroupNorm-3 backward of the ExtResNetBlock whose output it is
+extern "C" int mednet_head_dgrad_gn_rows(int n, int d, int h, int w, int cin, int dtype) {
+  (void)n;
+  if (!tuning_option("gn3_fuse", 1)) return 0;
+  return head_dgrad_gn_rows((size_t)d * h * w, cin, dtype);
+}
+extern "C" int mednet_head_dgrad_gn(const void* dy, const void* packed, void* dx, const void* gn_y, const void* gn_z, int gn_act,
+                                    float* gn_partial, int n, int d, int h, int w, int cin, int cout, int dtype,
+                                    mednet_stream stream) {
+  MEDNET_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && dy && packed && dx && gn_y && gn_z && gn_partial,
+                 MEDNET_E_SHAPE, "head_dgrad_gn: bad arguments");
+  MEDNET_REQUIRE(mednet_head_dgrad_gn_rows(n, d, h, w, cin, dtype) > 0, MEDNET_E_UNSUPPORTED,
+                 "head_dgrad_gn: cin=%d dtype=%d not supported", cin, dtype);
+  const PackLayout L = pack_layout(cin, cout, 1);
+  return launch_head_dgrad_gn(dy, (const float*)((const char*)packed + L.f32_bwd), dx, gn_y, gn_z, gn_act, gn_partial, n,
+                              (size_t)d * h * w, cout, cin, dtype, (hipStream_t)stream);
+}
+
 extern "C" int mednet_conv3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int algo) {
   if (!tuning_option("conv_fuse_gnb", 1) || !mednet_conv3d_act_supported(n, d, h, w, cout, cin, algo)) return 0;
   return conv_mfma_stats_chunks(n, d, h, w, cout, cin);  // (the kernel reads the layer's Cout channels, writes its Cin)

@@ -35,6 +35,9 @@ int launch_channel_sum(const void* x, float* out, int n, size_t spatial, int c, 
 bool head_dgrad_supported(int cin, int cout, int ksize, int x_dtype, int x_layout, int y_layout);
 int launch_head_dgrad(const void* dy, const float* Pb, void* dz, int n, size_t spatial, int m, int k, int out_dtype,
                       hipStream_t s);
+int head_dgrad_gn_rows(size_t spatial, int k, int dtype);
+int launch_head_dgrad_gn(const void* dy, const float* Pb, void* dz, const void* gy, const void* gz, int act, float* partial,
+                         int n, size_t spatial, int m, int k, int dtype, hipStream_t s);
 bool head_vox_supported(int k);
 int launch_head_fwd_vox(const void* z, const float* Pb, const float* bias, float* y, int n, size_t spatial, int k, int m,
                         int z_dtype, hipStream_t s);

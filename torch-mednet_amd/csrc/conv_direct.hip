@@ -552,6 +552,76 @@ __global__ __launch_bounds__(256) void head_dgrad_vox_kernel(const float* __rest
     st8(dz, ((size_t)n * spatial + v) * K + q * 8, t);
   }
 }
+// The same data gradient when its output dz is the gradient of an ExtResNetBlock's output (the last decoder block feeds
+// the head, model.py:204-207): the block's backward starts with GroupNorm-3's first pass over (dz, out, y3)
+// (components.py:170-178) -- du = dz * act'(out), sums of du and du * y3 per channel -- which is taken here from the STORED
+// (rounded) dz instead of a stand-alone pass that reads dz again.  A thread walks VPT voxels 256 apart, keeps 2K sums, and a
+// wave writes one partial row (LDS-free wave sums): partial[n][4 * chunk + wave][K][2] = {sum du, sum du * y3}.
+constexpr int HEAD_GN_VPT = 32;
+template <typename TO, int K>
+__global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restrict__ dy, const float* __restrict__ Pb /*[m][K]*/,
+                                                            TO* __restrict__ dz, const TO* __restrict__ gy,
+                                                            const TO* __restrict__ gz, float* __restrict__ partial,
+                                                            size_t spatial, int m, int act) {
+  const int n = blockIdx.y;
+  float ss[K], sq[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) ss[j] = sq[j] = 0.f;
+  const size_t v0 = (size_t)blockIdx.x * (256 * HEAD_GN_VPT) + threadIdx.x;
+  for (int it = 0; it < HEAD_GN_VPT; ++it) {
+    const size_t v = v0 + (size_t)it * 256;
+    if (v >= spatial) break;
+    float o[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) o[j] = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < m; ++i) {
+      const float d = dy[((size_t)n * m + i) * spatial + v];
+#pragma unroll
+      for (int j = 0; j < K; ++j) o[j] = fmaf(d, Pb[(size_t)i * K + j], o[j]);
+    }
+    const size_t row = ((size_t)n * spatial + v) * K;
+#pragma unroll
+    for (int q = 0; q < K / 8; ++q) {
+      F8 t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t.v[j] = (float)(TO)o[q * 8 + j];  // the stored value is what GroupNorm-3's second pass reads
+      st8(dz, row + q * 8, t);
+      const F8 zv = ld8(gz, row + q * 8), yv = ld8(gy, row + q * 8);
+      act_grad_n<8>(t.v, zv.v, act);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ss[q * 8 + j] += t.v[j];
+        sq[q * 8 + j] = fmaf(t.v[j], yv.v[j], sq[q * 8 + j]);
+      }
+    }
+  }
+  float* out = partial + (((size_t)n * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * K * 2;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const float a = wave_sum(ss[j]), b = wave_sum(sq[j]);
+    if ((threadIdx.x & 63) == 0) {
+      out[2 * j] = a;
+      out[2 * j + 1] = b;
+    }
+  }
+}
+int head_dgrad_gn_rows(size_t spatial, int k, int dtype) {
+  if (!(k == 16 || k == 32 || k == 64) || !(dtype == MEDNET_BF16 || dtype == MEDNET_F16)) return 0;
+  return 4 * (int)((spatial + 256 * HEAD_GN_VPT - 1) / (256 * HEAD_GN_VPT));
+}
+int launch_head_dgrad_gn(const void* dy, const float* Pb, void* dz, const void* gy, const void* gz, int act, float* partial,
+                         int n, size_t spatial, int m, int k, int dtype, hipStream_t s) {
+  MEDNET_REQUIRE(head_dgrad_gn_rows(spatial, k, dtype) > 0, MEDNET_E_UNSUPPORTED, "head_dgrad_gn: K=%d dtype=%d", k, dtype);
+  const dim3 grid((unsigned)((spatial + 256 * HEAD_GN_VPT - 1) / (256 * HEAD_GN_VPT)), n);
+#define HG_GO(TO_, K_) hipLaunchKernelGGL((head_dgrad_gn_kernel<TO_, K_>), grid, dim3(256), 0, s, (const float*)dy, Pb, (TO_*)dz, (const TO_*)gy, (const TO_*)gz, partial, spatial, m, act)
+#define HG_K(TO_) do { if (k == 16) HG_GO(TO_, 16); else if (k == 32) HG_GO(TO_, 32); else HG_GO(TO_, 64); } while (0)
+  if (dtype == MEDNET_BF16) HG_K(bf16);
+  else HG_K(f16);
+#undef HG_K
+#undef HG_GO
+  return check_launch("head_dgrad_gn");
+}
 bool head_vox_supported(int k) { return k == 16 || k == 32 || k == 64; }
 int launch_head_fwd_vox(const void* z, const float* Pb, const float* bias, float* y, int n, size_t spatial, int k, int m,
                         int z_dtype, hipStream_t s) {

@@ -631,6 +631,83 @@ __global__ __launch_bounds__(256) void pool2_bwd_kernel(const T* __restrict__ dy
   }
 }
 
+// The same join when x is the output of an ExtResNetBlock (an encoder level feeds the next level's pooling and the
+// decoder's skip join, model.py:194-205): dx is then the gradient that block's backward starts from, and the first pass
+// of its GroupNorm-3 backward -- du = dx * act'(x), per-channel sums of du and du * y3 (components.py:170-178) -- is taken
+// here from the STORED dx, with x already in registers for the arg-max.  A thread walks PV pooled voxels; LDS-free column
+// reduction, 4 partial rows per workgroup: partial[n][4 * workgroup + wave][c][2].  Even d, h, w only.
+constexpr int POOL_GN_PV = 4;
+template <typename T>
+__global__ __launch_bounds__(256) void pool2_bwd_gn_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ add, T* __restrict__ dx,
+                                                           const T* __restrict__ gy, float* __restrict__ partial, int d,
+                                                           int h, int w, int c, int mode, int act) {
+  constexpr int VEC = 8;
+  const int od = d / 2, oh = h / 2, ow = w / 2, cv = c / VEC;
+  const size_t per = (size_t)od * oh * ow * cv;
+  const int nn = blockIdx.y;
+  const int cc = (int)(threadIdx.x % cv);  // (256 % cv == 0: a thread keeps its channels)
+  float acc[2 * VEC];
+#pragma unroll
+  for (int k = 0; k < 2 * VEC; ++k) acc[k] = 0.f;
+  for (int it = 0; it < POOL_GN_PV; ++it) {
+    const size_t i = ((size_t)blockIdx.x * POOL_GN_PV + it) * 256 + threadIdx.x;
+    if (i >= per) break;
+    size_t v = i / cv;
+    const int ox = (int)(v % ow);
+    v /= ow;
+    const int oy = (int)(v % oh);
+    const int oz = (int)(v / oh);
+    const F8 g = VecIO<T, VEC>::load(dy, ((size_t)nn * per + i) * VEC);
+    F8 xv[8];
+    int arg[VEC];
+    float best[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      best[k] = -INFINITY;
+      arg[k] = 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int iz = 2 * oz + (t >> 2), iy = 2 * oy + ((t >> 1) & 1), ix = 2 * ox + (t & 1);
+      const size_t src = ((((size_t)nn * d + iz) * h + iy) * w + ix) * c + (size_t)cc * VEC;
+      xv[t] = VecIO<T, VEC>::load(x, src);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if (xv[t].v[k] > best[k] || xv[t].v[k] != xv[t].v[k]) {  // first maximum in scan order, NaN propagates (ATen)
+          best[k] = xv[t].v[k];
+          arg[k] = t;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int iz = 2 * oz + (t >> 2), iy = 2 * oy + ((t >> 1) & 1), ix = 2 * ox + (t & 1);
+      const size_t dst = ((((size_t)nn * d + iz) * h + iy) * w + ix) * c + (size_t)cc * VEC;
+      F8 o;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) o.v[k] = mode == MEDNET_POOL_MAX ? (arg[k] == t ? g.v[k] : 0.f) : 0.125f * g.v[k];
+      if (add) {
+        const F8 a = VecIO<T, VEC>::load(add, dst);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o.v[k] += a.v[k];
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) o.v[k] = (float)(T)o.v[k];  // the stored value is what GroupNorm-3's second pass reads
+      VecIO<T, VEC>::store(dx, dst, o);
+      const F8 yv = VecIO<T, VEC>::load(gy, dst);
+      act_grad_n<VEC>(o.v, xv[t].v, act);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        acc[2 * k] += o.v[k];
+        acc[2 * k + 1] = fmaf(o.v[k], yv.v[k], acc[2 * k + 1]);
+      }
+    }
+  }
+  float* out = partial + (((size_t)nn * gridDim.x + blockIdx.x) * 4) * c * 2;
+  column_reduce_lds_free<2 * VEC>(acc, cv, cc, true, out, c * 2);
+}
+
 // ---------------------------------------------------------------------------------------------- upsample + concat
 __device__ __forceinline__ int nearest_src(int dst, int in, int out) {
   const float scale = (float)in / (float)out;  // ATen: compute_scales_value when only `size` is given
@@ -913,10 +990,10 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
   return check_launch("gn_bwd_apply");
 }
 
-extern "C" int mednet_gn_act_bwd_fused(const void* dz, const void* x, const float* coef, const float* stats,
-                                       const float* gamma, const float* fused_partial, int rows, void* dx, float* dgamma,
-                                       float* dbeta, int n, size_t spatial, int c, int groups, int act, int dtype,
-                                       void* ws, size_t ws_bytes, mednet_stream stream) {
+static int gn_act_bwd_fused_impl(const void* dz, const void* x, const void* z, const float* coef, const float* stats,
+                                 const float* gamma, const float* fused_partial, int rows, void* dx, void* dres,
+                                 float* dgamma, float* dbeta, int n, size_t spatial, int c, int groups, int act, int dtype,
+                                 void* ws, size_t ws_bytes, mednet_stream stream) {
   MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "gn_act_bwd_fused: bad dtype");
   MEDNET_REQUIRE(c % groups == 0 && rows > 0 && fused_partial && coef, MEDNET_E_SHAPE, "gn_act_bwd_fused: bad arguments");
   const int vec = pick_vec(c);
@@ -943,12 +1020,30 @@ extern "C" int mednet_gn_act_bwd_fused(const void* dz, const void* x, const floa
     if (rc) return rc;
   }
   const dim3 grid(chunks, n);
-#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)nullptr, (const T*)x, (const T*)nullptr, coef, bcoef, (T*)dx, (T*)nullptr, spatial, c, act, cv)
+#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)nullptr, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
   return check_launch("gn_bwd_apply");
+}
+
+extern "C" int mednet_gn_act_bwd_fused(const void* dz, const void* x, const float* coef, const float* stats,
+                                       const float* gamma, const float* fused_partial, int rows, void* dx, float* dgamma,
+                                       float* dbeta, int n, size_t spatial, int c, int groups, int act, int dtype,
+                                       void* ws, size_t ws_bytes, mednet_stream stream) {
+  return gn_act_bwd_fused_impl(dz, x, nullptr, coef, stats, gamma, fused_partial, rows, dx, nullptr, dgamma, dbeta, n, spatial, c,
+                               groups, act, dtype, ws, ws_bytes, stream);
+}
+// ... for the residual layer of an ExtResNetBlock: the activation derivative comes from the block OUTPUT z, and du is also
+// the gradient of the residual branch (dres)
+extern "C" int mednet_gn_act_bwd_fused_res(const void* dz, const void* x, const void* z, const float* coef, const float* stats,
+                                           const float* gamma, const float* fused_partial, int rows, void* dx, void* dres,
+                                           float* dgamma, float* dbeta, int n, size_t spatial, int c, int groups, int act,
+                                           int dtype, void* ws, size_t ws_bytes, mednet_stream stream) {
+  MEDNET_REQUIRE(z && dres, MEDNET_E_SHAPE, "gn_act_bwd_fused_res: z and dres are required");
+  return gn_act_bwd_fused_impl(dz, x, z, coef, stats, gamma, fused_partial, rows, dx, dres, dgamma, dbeta, n, spatial, c, groups,
+                               act, dtype, ws, ws_bytes, stream);
 }
 
 extern "C" int mednet_act_fwd(const void* x, void* z, size_t count, int act, int dtype, mednet_stream stream) {
@@ -1013,6 +1108,33 @@ extern "C" int mednet_pool2_bwd(const void* dy, const void* x, const void* add, 
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
   return check_launch("pool2_bwd");
+}
+
+static bool pool2_gn_ok(int d, int h, int w, int c, int dtype) {
+  const int cv = c / 8;
+  return c % 8 == 0 && cv <= 64 && (cv & (cv - 1)) == 0 && !((d | h | w) & 1) && (dtype == MEDNET_BF16 || dtype == MEDNET_F16);
+}
+extern "C" int mednet_pool2_bwd_gn_rows(int n, int d, int h, int w, int c, int dtype) {
+  (void)n;
+  if (!pool2_gn_ok(d, h, w, c, dtype) || !tuning_option("gn3_fuse", 1)) return 0;
+  const size_t per = (size_t)(d / 2) * (h / 2) * (w / 2) * (c / 8);
+  return 4 * (int)((per + 256 * POOL_GN_PV - 1) / (256 * POOL_GN_PV));
+}
+extern "C" int mednet_pool2_bwd_gn(const void* dy, const void* x, const void* add, void* dx, const void* gn_y, int gn_act,
+                                   float* gn_partial, int n, int d, int h, int w, int c, int mode, int dtype,
+                                   mednet_stream stream) {
+  const int rows = mednet_pool2_bwd_gn_rows(n, d, h, w, c, dtype);
+  MEDNET_REQUIRE(rows > 0, MEDNET_E_UNSUPPORTED, "pool2_bwd_gn: shape %dx%dx%d c=%d dtype=%d not supported", d, h, w, c, dtype);
+  MEDNET_REQUIRE(gn_y && gn_partial, MEDNET_E_SHAPE, "pool2_bwd_gn: gn_y and gn_partial are required");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)(rows / 4), n);
+  if (dtype == MEDNET_BF16)
+    hipLaunchKernelGGL(pool2_bwd_gn_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)add, (bf16*)dx,
+                       (const bf16*)gn_y, gn_partial, d, h, w, c, mode, gn_act);
+  else
+    hipLaunchKernelGGL(pool2_bwd_gn_kernel<f16>, grid, dim3(256), 0, s, (const f16*)dy, (const f16*)x, (const f16*)add, (f16*)dx,
+                       (const f16*)gn_y, gn_partial, d, h, w, c, mode, gn_act);
+  return check_launch("pool2_bwd_gn");
 }
 
 extern "C" int mednet_upcat_fwd(const void* enc, const void* x, void* out, int n, int d, int h, int w, int c_enc,

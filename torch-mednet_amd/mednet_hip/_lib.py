@@ -44,6 +44,11 @@ SIGNATURES = {
     "mednet_conv3d_dgrad_gn_rows": (_i, [_i] * 7),
     "mednet_conv3d_dgrad_gn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 8 + [_vp]),
     "mednet_gn_act_bwd_fused": (_i, [_vp] * 6 + [_i, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mednet_gn_act_bwd_fused_res": (_i, [_vp] * 7 + [_i, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mednet_head_dgrad_gn_rows": (_i, [_i] * 6),
+    "mednet_head_dgrad_gn": (_i, [_vp] * 5 + [_i, _vp] + [_i] * 7 + [_vp]),
+    "mednet_pool2_bwd_gn_rows": (_i, [_i] * 6),
+    "mednet_pool2_bwd_gn": (_i, [_vp] * 5 + [_i, _vp] + [_i] * 7 + [_vp]),
     "mednet_conv3d_wgrad_ws_bytes": (_sz, [_i] * 7),
     "mednet_conv3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp, _sz, _vp]),
     "mednet_convt3d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),

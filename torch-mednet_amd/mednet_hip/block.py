@@ -68,6 +68,13 @@ def _gn_bwd(dz, dz2, y, z, coef, stats, gamma_p, beta_p, groups, act, want_dres,
     dgamma, dg_direct = ops._grad_target(gamma_p, (c,))
     dbeta, db_direct = ops._grad_target(beta_p, (c,))
     ws = L.workspace(lib.mednet_gn_ws_bytes(n, c, spatial), y.device)
+    if partial is not None and z is not None:  # residual layer: sums taken by the producer of dz (ops.GN3Hook)
+        assert dz2 is None and want_dres
+        L.check(lib.mednet_gn_act_bwd_fused_res(dz.data_ptr(), y.data_ptr(), z.data_ptr(), coef.data_ptr(), stats.data_ptr(),
+                                                gamma_p.data_ptr(), partial.data_ptr(), partial.shape[1], dy.data_ptr(),
+                                                dres.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), n, spatial, c, groups, act,
+                                                L.dt(y), ws.data_ptr(), ws.numel(), L.stream()), "gn_act_bwd_fused_res")
+        return dy, dres, (None if dg_direct else dgamma), (None if db_direct else dbeta)
     if partial is not None:
         assert dz2 is None and z is None and not want_dres
         L.check(lib.mednet_gn_act_bwd_fused(dz.data_ptr(), y.data_ptr(), coef.data_ptr(), stats.data_ptr(), gamma_p.data_ptr(),
@@ -137,7 +144,7 @@ def _conv_bwd(x, dy, packed, weight_p, need_dx, add=None, gnb=None):
 
 class ResBlockFn(Function):
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, pk1, pk2, pk3, groups, eps, act):
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, pk1, pk2, pk3, groups, eps, act, hook=None):
         L.require_gpu(x, "ExtResNetBlock")
         x = ops._as_act(x)
         xin = x.contiguous() if x.shape[1] == 1 else ops.to_cl(x)  # Cin == 1: NCDHW and NDHWC coincide
@@ -152,6 +159,9 @@ class ResBlockFn(Function):
         ctx.save_for_backward(xin, y1, z1, y2, z2, y3, out, s1, c1, s2, c2, s3, c3, pk1, pk2, pk3)
         ctx.params = (w1, g1, b1, w2, g2, b2, w3, g3, b3)
         ctx.meta = (groups, act)
+        ctx.gn3 = hook
+        if hook is not None:
+            hook.y3, hook.act = y3, act
         return out
 
     @staticmethod
@@ -159,9 +169,10 @@ class ResBlockFn(Function):
         xin, y1, z1, y2, z2, y3, out, s1, c1, s2, c2, s3, c3, pk1, pk2, pk3 = ctx.saved_tensors
         w1, g1, b1, w2, g2, b2, w3, g3, b3 = ctx.params
         groups, act = ctx.meta
+        part3 = ctx.gn3.take(dout) if ctx.gn3 is not None else None  # (before any conversion: identity matters)
         dout = ops.to_cl(dout.to(out.dtype))
         # GN3 + residual + activation: act' from the block output; dres = gradient of the residual branch (into z1)
-        dy3, dres, dg3, db3 = _gn_bwd(dout, None, y3, out, c3, s3, g3, b3, groups, act, True)
+        dy3, dres, dg3, db3 = _gn_bwd(dout, None, y3, out, c3, s3, g3, b3, groups, act, True, partial=part3)
         dz2, dw3, part2 = _conv_bwd(z2, dy3, pk3, w3, True, gnb=(y2, c2, act))
         dy2, _, dg2, db2 = _gn_bwd(dz2, None, y2, None, c2, s2, g2, b2, groups, act, False, partial=part2)
         # z1 feeds conv2 AND the residual add: the two gradients are summed in the epilogue of conv2's data gradient (bf16
@@ -172,11 +183,15 @@ class ResBlockFn(Function):
         dz1, dw2, part1 = _conv_bwd(z1, dy2, pk2, w2, True, add=dres if fuse else None, gnb=(y1, c1, act) if fuse else None)
         dy1, _, dg1, db1 = _gn_bwd(dz1, None if fuse else dres, y1, None, c1, s1, g1, b1, groups, act, False, partial=part1)
         dx, dw1, _ = _conv_bwd(xin, dy1, pk1, w1, ctx.needs_input_grad[0])
-        return (dx, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + (None,) * 6
+        return (dx, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + (None,) * 7
 
 
 def res_block(x, convs, norms, groups, eps, act):
     """convs / norms: the three mednet_hip.nn.Conv3d / GroupNorm modules of the block."""
     (k1, k2, k3), (n1, n2, n3) = convs, norms
-    return ResBlockFn.apply(x, k1.weight, n1.weight, n1.bias, k2.weight, n2.weight, n2.bias, k3.weight, n3.weight, n3.bias,
-                            k1._packed(), k2._packed(), k3._packed(), groups, eps, act)
+    hook = ops.GN3Hook() if (ops.FUSE_GN3 and config.is_half_mode()) else None
+    out = ResBlockFn.apply(x, k1.weight, n1.weight, n1.bias, k2.weight, n2.weight, n2.bias, k3.weight, n3.weight, n3.bias,
+                           k1._packed(), k2._packed(), k3._packed(), groups, eps, act, hook)
+    if hook is not None:
+        out._mednet_gn3 = hook  # see ops.GN3Hook: the consumer of `out` may take GroupNorm-3's first backward pass
+    return out

@@ -7,6 +7,8 @@ fragments; the network input (C=1) and the logits (written planar by the 1x1x1 h
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -137,6 +139,43 @@ def pack_conv_weight(weight: torch.Tensor, ksize: int, transposed: bool) -> torc
 
 
 # ------------------------------------------------------------------------------------------------- Conv3d
+class GN3Hook:
+    """Carried by the output tensor of an ExtResNetBlock (`out._mednet_gn3`): lets the op that consumes `out` -- the 1x1x1
+    head or the pooling + skip join -- take the first pass of the block's GroupNorm-3 backward while it produces the block's
+    output gradient (mednet_head_dgrad_gn / mednet_pool2_bwd_gn).  The block's backward uses the sums only if the gradient it
+    receives IS that tensor, untouched (same object, same version counter): any other consumer of `out` makes autograd
+    accumulate into / replace it, and the block falls back to its stand-alone pass."""
+    __slots__ = ("y3", "act", "partial", "dx", "version")
+
+    def __init__(self):
+        self.y3 = None
+        self.act = 0
+        self.partial = self.dx = None
+        self.version = -1
+
+    def offer(self, dx, partial):
+        self.dx, self.partial, self.version = dx, partial, dx._version
+
+    def take(self, dout):
+        """The sums, if `dout` is exactly the tensor they were taken from; releases the references either way."""
+        partial, dx, version = self.partial, self.dx, self.version
+        self.partial = self.dx = None
+        ok = partial is not None and dout is dx and dout._version == version
+        GN3_COUNT["taken" if ok else ("declined" if partial is not None else "absent")] += 1
+        return partial if ok else None
+
+
+FUSE_GN3 = os.environ.get("MEDNET_FUSE_GN3", "1") == "1"  # A/B knob
+GN3_COUNT = {"taken": 0, "declined": 0, "absent": 0}  # (tests: how the blocks' backward passes found their sums)
+
+
+def _gn3_hook_of(x, dtype):
+    h = getattr(x, "_mednet_gn3", None) if FUSE_GN3 else None
+    if h is None or h.y3 is None or h.y3.shape != x.shape or h.y3.dtype != dtype or dtype not in config.HALF_TYPES:
+        return None
+    return h
+
+
 class Conv3dFn(Function):
     """nn.Conv3d(k in {1,3}, stride 1, padding k//2)  -- components.py:8-9,44; model.py:77,179."""
 
@@ -165,6 +204,7 @@ class Conv3dFn(Function):
         ctx.save_for_backward(xin, packed)
         ctx.meta = (ksize, out_planar, cin, cout, bias is not None, x.dtype)
         ctx.params = (weight, bias)
+        ctx.gn3 = _gn3_hook_of(x, xin.dtype) if (ksize == 1 and out_planar and xin is x) else None
         if not want_stats:
             return y
         if partial is None:
@@ -182,9 +222,20 @@ class Conv3dFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = empty_cl(n, cin, d, h, w, x_dtype, dy.device)
-            L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin,
-                                          ksize, L.dt(dy), L.NCDHW if out_planar else L.NDHWC, L.dt(dx), L.NDHWC, 1,
-                                          config.conv_algo(), None, L.stream()), "conv3d_dgrad")
+            hook = ctx.gn3
+            rows = 0
+            if hook is not None and dy.dtype == torch.float32 and dx.dtype == xin.dtype and config.conv_algo() != L.ALGO_DIRECT:
+                rows = lib.mednet_head_dgrad_gn_rows(n, d, h, w, cin, L.dt(dx))
+            if rows > 0:  # + the first pass of the producing block's GroupNorm-3 backward (xin IS that block's output)
+                partial = torch.empty((n, rows, cin, 2), dtype=torch.float32, device=dy.device)
+                L.check(lib.mednet_head_dgrad_gn(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), hook.y3.data_ptr(),
+                                                 xin.data_ptr(), hook.act, partial.data_ptr(), n, d, h, w, cin, cout, L.dt(dx),
+                                                 L.stream()), "head_dgrad_gn")
+                hook.offer(dx, partial)
+            else:
+                L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin,
+                                              ksize, L.dt(dy), L.NCDHW if out_planar else L.NDHWC, L.dt(dx), L.NDHWC, 1,
+                                              config.conv_algo(), None, L.stream()), "conv3d_dgrad")
         direct_w = direct_b = False
         if ctx.needs_input_grad[1]:
             weight, bias = ctx.params
@@ -498,12 +549,14 @@ class SkipPool2Fn(Function):
     @staticmethod
     def forward(ctx, x, mode):
         L.require_gpu(x, "pool3d")
+        x0 = x
         x = to_cl(_as_act(x))
         n, c, d, h, w = x.shape
         y = empty_cl(n, c, d // 2, h // 2, w // 2, x.dtype, x.device)
         L.check(L.lib().mednet_pool2_fwd(x.data_ptr(), y.data_ptr(), n, d, h, w, c, mode, L.dt(x), L.stream()), "pool2_fwd")
         ctx.save_for_backward(x)
         ctx.mode = mode
+        ctx.gn3 = _gn3_hook_of(x0, x.dtype) if x is x0 else None
         return x.view_as(x), y
 
     @staticmethod
@@ -516,6 +569,15 @@ class SkipPool2Fn(Function):
         if dskip is not None:
             dskip = to_cl(dskip.to(x.dtype))
         dx = torch.empty_like(x, memory_format=CL)
+        hook = ctx.gn3
+        rows = L.lib().mednet_pool2_bwd_gn_rows(n, d, h, w, c, L.dt(x)) if hook is not None else 0
+        if rows > 0:  # + the first pass of the producing block's GroupNorm-3 backward (x IS that block's output)
+            partial = torch.empty((n, rows, c, 2), dtype=torch.float32, device=x.device)
+            L.check(L.lib().mednet_pool2_bwd_gn(dy.data_ptr(), x.data_ptr(), L.ptr(dskip), dx.data_ptr(), hook.y3.data_ptr(),
+                                                hook.act, partial.data_ptr(), n, d, h, w, c, ctx.mode, L.dt(x), L.stream()),
+                    "pool2_bwd_gn")
+            hook.offer(dx, partial)
+            return dx, None
         L.check(L.lib().mednet_pool2_bwd(dy.data_ptr(), x.data_ptr(), L.ptr(dskip), dx.data_ptr(), n, d, h, w, c, ctx.mode,
                                          L.dt(x), L.stream()), "pool2_bwd")
         return dx, None
