@@ -930,24 +930,30 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), row_rsrc(a.y, j), vb, row_soff(j), 2);
       [[maybe_unused]] const bool ok = lane_ok & (row_num[j] != 0u);
       if constexpr (GNB) {
-        float g[8], u[8], yy[8];
+        // du = dz * act'(u), u = ca * y + cb, branch-free for a runtime activation (control flow inside the row loop makes
+        // the compiler hoist all eight rows' conversions above it, which does not fit): the factor for u <= 0 is exp(u)
+        // (ELU), 0.1, 0 or 1.  Two channels per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): the epilogue of a
+        // one-wave-per-SIMD kernel is exposed, instruction for instruction.
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        const eltx8 vz = ok ? v : eltx8{};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          yy[k] = (float)yrw[j][k];
-          g[k] = ok ? (float)v[k] : 0.f;
-          u[k] = fmaf(ca[k], yy[k], cbf[k]);
-        }
-        // du = dz * act'(u), branch-free for a runtime activation (control flow inside the row loop makes the compiler hoist
-        // all eight rows' conversions above it, which does not fit): the factor for u <= 0 is exp(u) (ELU), 0.1, 0 or 1
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float neg = gnb_elu ? __expf(u[k]) : gnb_neg;
-          g[k] = u[k] > 0.f ? g[k] : g[k] * neg;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          bs[k] += g[k];
-          bq[k] = fmaf(g[k], yy[k], bq[k]);
+        for (int p2 = 0; p2 < 4; ++p2) {
+          const f32x2 yy = {(float)yrw[j][2 * p2], (float)yrw[j][2 * p2 + 1]};
+          const f32x2 g = {(float)vz[2 * p2], (float)vz[2 * p2 + 1]};
+          const f32x2 ca2 = {ca[2 * p2], ca[2 * p2 + 1]}, cb2 = {cbf[2 * p2], cbf[2 * p2 + 1]};
+          const f32x2 u = ca2 * yy + cb2;
+          const f32x2 ul = u * 1.44269504088896340736f;  // exp(u) = 2^(u * log2 e), as __expf
+          const f32x2 e = {__builtin_amdgcn_exp2f(ul[0]), __builtin_amdgcn_exp2f(ul[1])};
+          const f32x2 negc = {gnb_neg, gnb_neg};
+          const f32x2 gn = g * (gnb_elu ? e : negc);
+          const f32x2 du = {u[0] > 0.f ? g[0] : gn[0], u[1] > 0.f ? g[1] : gn[1]};
+          f32x2 s2 = {bs[2 * p2], bs[2 * p2 + 1]}, q2 = {bq[2 * p2], bq[2 * p2 + 1]};
+          s2 += du;
+          q2 = du * yy + q2;
+          bs[2 * p2] = s2[0];
+          bs[2 * p2 + 1] = s2[1];
+          bq[2 * p2] = q2[0];
+          bq[2 * p2 + 1] = q2[1];
         }
       } else if constexpr (STATS) {
         const eltx8 vz = ok ? v : eltx8{};
