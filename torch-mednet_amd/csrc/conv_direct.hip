@@ -555,52 +555,54 @@ __global__ __launch_bounds__(256) void head_dgrad_vox_kernel(const float* __rest
 // The same data gradient when its output dz is the gradient of an ExtResNetBlock's output (the last decoder block feeds
 // the head, model.py:204-207): the block's backward starts with GroupNorm-3's first pass over (dz, out, y3)
 // (components.py:170-178) -- du = dz * act'(out), sums of du and du * y3 per channel -- which is taken here from the STORED
-// (rounded) dz instead of a stand-alone pass that reads dz again.  A thread walks VPT voxels 256 apart, keeps 2K sums, and a
-// wave writes one partial row (LDS-free wave sums): partial[n][4 * chunk + wave][K][2] = {sum du, sum du * y3}.
-constexpr int HEAD_GN_VPT = 32;
+// (rounded) dz instead of a stand-alone pass that reads dz again: partial[n][4 * workgroup + wave][K][2] =
+// {sum du, sum du * y3}.
+// Lane mapping: K/8 lanes share a voxel, each owns 8 channels (one 16-byte piece of the voxel's row), so a wave's loads and
+// stores are whole contiguous rows (thread = voxel made every load touch 64 different cache lines: 534 us for 1.75 GB);
+// a lane keeps 16 sums, lanes of one channel group are summed with DPP (LDS-free) and every wave writes one partial row.
+constexpr int HEAD_GN_VPT = 32;  // voxels per lane group
 template <typename TO, int K>
 __global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restrict__ dy, const float* __restrict__ Pb /*[m][K]*/,
                                                             TO* __restrict__ dz, const TO* __restrict__ gy,
                                                             const TO* __restrict__ gz, float* __restrict__ partial,
                                                             size_t spatial, int m, int act) {
+  constexpr int CG = K / 8, VPW = 256 / CG;  // lanes per voxel, voxels per workgroup pass
   const int n = blockIdx.y;
-  float ss[K], sq[K];
+  const int cgi = threadIdx.x % CG, vi = threadIdx.x / CG;
+  float ss[8], sq[8];
 #pragma unroll
-  for (int j = 0; j < K; ++j) ss[j] = sq[j] = 0.f;
-  const size_t v0 = (size_t)blockIdx.x * (256 * HEAD_GN_VPT) + threadIdx.x;
+  for (int j = 0; j < 8; ++j) ss[j] = sq[j] = 0.f;
+  const size_t v0 = (size_t)blockIdx.x * (VPW * HEAD_GN_VPT) + vi;
   for (int it = 0; it < HEAD_GN_VPT; ++it) {
-    const size_t v = v0 + (size_t)it * 256;
+    const size_t v = v0 + (size_t)it * VPW;
     if (v >= spatial) break;
-    float o[K];
+    F8 t;
 #pragma unroll
-    for (int j = 0; j < K; ++j) o[j] = 0.f;
+    for (int j = 0; j < 8; ++j) t.v[j] = 0.f;
 #pragma unroll 4
     for (int i = 0; i < m; ++i) {
       const float d = dy[((size_t)n * m + i) * spatial + v];
+      const float* pw = Pb + (size_t)i * K + cgi * 8;
 #pragma unroll
-      for (int j = 0; j < K; ++j) o[j] = fmaf(d, Pb[(size_t)i * K + j], o[j]);
+      for (int j = 0; j < 8; ++j) t.v[j] = fmaf(d, pw[j], t.v[j]);
     }
-    const size_t row = ((size_t)n * spatial + v) * K;
+    const size_t row = ((size_t)n * spatial + v) * K + cgi * 8;
 #pragma unroll
-    for (int q = 0; q < K / 8; ++q) {
-      F8 t;
+    for (int j = 0; j < 8; ++j) t.v[j] = (float)(TO)t.v[j];  // the stored value is what GroupNorm-3's second pass reads
+    st8(dz, row, t);
+    const F8 zv = ld8(gz, row), yv = ld8(gy, row);
+    act_grad_n<8>(t.v, zv.v, act);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t.v[j] = (float)(TO)o[q * 8 + j];  // the stored value is what GroupNorm-3's second pass reads
-      st8(dz, row + q * 8, t);
-      const F8 zv = ld8(gz, row + q * 8), yv = ld8(gy, row + q * 8);
-      act_grad_n<8>(t.v, zv.v, act);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        ss[q * 8 + j] += t.v[j];
-        sq[q * 8 + j] = fmaf(t.v[j], yv.v[j], sq[q * 8 + j]);
-      }
+    for (int j = 0; j < 8; ++j) {
+      ss[j] += t.v[j];
+      sq[j] = fmaf(t.v[j], yv.v[j], sq[j]);
     }
   }
-  float* out = partial + (((size_t)n * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * K * 2;
+  float* out = partial + (((size_t)n * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * K * 2 + cgi * 16;
 #pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const float a = wave_sum(ss[j]), b = wave_sum(sq[j]);
-    if ((threadIdx.x & 63) == 0) {
+  for (int j = 0; j < 8; ++j) {
+    const float a = lane_class_sum<CG>(ss[j]), b = lane_class_sum<CG>(sq[j]);
+    if ((threadIdx.x & 63) < CG) {
       out[2 * j] = a;
       out[2 * j + 1] = b;
     }
@@ -608,12 +610,13 @@ __global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restr
 }
 int head_dgrad_gn_rows(size_t spatial, int k, int dtype) {
   if (!(k == 16 || k == 32 || k == 64) || !(dtype == MEDNET_BF16 || dtype == MEDNET_F16)) return 0;
-  return 4 * (int)((spatial + 256 * HEAD_GN_VPT - 1) / (256 * HEAD_GN_VPT));
+  const size_t per_wg = (size_t)(256 / (k / 8)) * HEAD_GN_VPT;
+  return 4 * (int)((spatial + per_wg - 1) / per_wg);
 }
 int launch_head_dgrad_gn(const void* dy, const float* Pb, void* dz, const void* gy, const void* gz, int act, float* partial,
                          int n, size_t spatial, int m, int k, int dtype, hipStream_t s) {
   MEDNET_REQUIRE(head_dgrad_gn_rows(spatial, k, dtype) > 0, MEDNET_E_UNSUPPORTED, "head_dgrad_gn: K=%d dtype=%d", k, dtype);
-  const dim3 grid((unsigned)((spatial + 256 * HEAD_GN_VPT - 1) / (256 * HEAD_GN_VPT)), n);
+  const dim3 grid((unsigned)(head_dgrad_gn_rows(spatial, k, dtype) / 4), n);
 #define HG_GO(TO_, K_) hipLaunchKernelGGL((head_dgrad_gn_kernel<TO_, K_>), grid, dim3(256), 0, s, (const float*)dy, Pb, (TO_*)dz, (const TO_*)gy, (const TO_*)gz, partial, spatial, m, act)
 #define HG_K(TO_) do { if (k == 16) HG_GO(TO_, 16); else if (k == 32) HG_GO(TO_, 32); else HG_GO(TO_, 64); } while (0)
   if (dtype == MEDNET_BF16) HG_K(bf16);
