@@ -95,11 +95,17 @@ int mednet_conv3d_dgrad_gn(const void* dy, const void* packed, const void* add, 
  * stored (rounded) dout rows: the data gradient of the 1x1x1 head (model.py:204-207; dy = planar fp32 logit gradients,
  * dx / gn_y = y3 / gn_z = out channels-last 16-bit, cin = block channels, cout = classes) for the last decoder block, and
  * the pooling backward + skip-gradient join (mednet_pool2_bwd; model.py:194-205; x = the block output) for the encoder
- * blocks.  gn_partial[n][rows][C][2] with rows from the *_rows call (0 = not supported for this shape / dtype; even
+ * blocks that feed a pooling.  gn_partial[n][rows][C][2] with rows from the *_rows call (0 = not supported for this shape / dtype; even
  * d, h, w for the pooling form); mednet_gn_act_bwd_fused_res consumes it and also writes the residual-branch gradient. */
 int mednet_head_dgrad_gn_rows(int n, int d, int h, int w, int cin, int dtype);
 int mednet_head_dgrad_gn(const void* dy, const void* packed, void* dx, const void* gn_y, const void* gn_z, int gn_act,
                          float* gn_partial, int n, int d, int h, int w, int cin, int cout, int dtype, mednet_stream stream);
+/* ... and the ConvTranspose3d data gradient (mednet_convt3d_dgrad: model.py:202-207, the decoder's upsampling consumes the
+ * output of the block below; (n,d,h,w) = dx dims, gn_y / gn_z = that block's y3 / output, Cin channels), matrix-core path. */
+int mednet_convt3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int dtype, int algo);
+int mednet_convt3d_dgrad_gn(const void* dy, const void* packed, void* dx, const void* gn_y, const void* gn_z, int gn_act,
+                            float* gn_partial, int n, int d, int h, int w, int cin, int cout, int dtype, int algo,
+                            mednet_stream stream);
 int mednet_pool2_bwd_gn_rows(int n, int d, int h, int w, int c, int dtype);
 int mednet_pool2_bwd_gn(const void* dy, const void* x, const void* add, void* dx, const void* gn_y, int gn_act,
                         float* gn_partial, int n, int d, int h, int w, int c, int mode, int dtype, mednet_stream stream);

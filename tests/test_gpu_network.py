@@ -633,11 +633,12 @@ def test_groupnorm_backward_sums_from_the_data_gradient_epilogue(n, c, shape):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
-@pytest.mark.parametrize("consumer,shape", [("head", (16, 24, 32)), ("head", (9, 11, 21)), ("pool", (16, 24, 32)), ("pool", (8, 8, 16))])
+@pytest.mark.parametrize("consumer,shape", [("head", (16, 24, 32)), ("head", (9, 11, 21)), ("pool", (16, 24, 32)), ("pool", (8, 8, 16)),
+                                            ("convt", (8, 12, 16)), ("convt", (3, 5, 9))])
 def test_groupnorm3_backward_sums_from_the_producer_of_the_block_gradient(mode, consumer, shape):
     """ExtResNetBlock backward (components.py:170-178) in the 16-bit modes: the first pass of GroupNorm-3's backward taken
-    by the op that produces the block's output gradient -- the 1x1x1 head's data gradient (model.py:204-207) or the pooling
-    backward + skip-gradient join (model.py:194-205) -- against the stand-alone pass (MEDNET_FUSE_GN3 off) on the same
+    by the op that produces the block's output gradient -- the 1x1x1 head's data gradient (model.py:204-207), the pooling
+    backward + skip-gradient join (model.py:194-205) or the decoder's ConvTranspose3d data gradient (model.py:202-203) -- against the stand-alone pass (MEDNET_FUSE_GN3 off) on the same
     tensors: same gradients up to fp32 summation order; and the sums are really used (ops.GN3_COUNT)."""
     from mednet_hip import ops as hops
     c = 32
@@ -660,6 +661,14 @@ def test_groupnorm3_backward_sums_from_the_producer_of_the_block_gradient(mode, 
                     y = head(out)
                     cot = torch.from_numpy(O._rng("gn3hc").standard_normal(tuple(y.shape)).astype(np.float32)).to(DEV)
                     (y * cot).sum().backward()
+                elif consumer == "convt":
+                    up = hnn.ConvTranspose3d(c, c).to(DEV)
+                    with torch.no_grad():
+                        up.weight.copy_(torch.from_numpy(O._rng("gn3cw").standard_normal((c, c, 3, 3, 3)).astype(np.float32)) * 0.05)
+                        up.bias.zero_()
+                    y = up(out)
+                    cot = torch.from_numpy(O._rng("gn3cc").standard_normal(tuple(y.shape)).astype(np.float32)).to(DEV)
+                    (y.float() * cot).sum().backward()
                 else:
                     skip, pooled = hops.skip_pool2(out)
                     c1 = torch.from_numpy(O._rng("gn3pc1").standard_normal(tuple(skip.shape)).astype(np.float32)).to(DEV)

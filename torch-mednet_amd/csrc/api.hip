@@ -309,6 +309,27 @@ extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx
                                   dx_dtype, (hipStream_t)stream);
 }
 
+static bool convt_dgrad_mfma_ok(int n, int d, int h, int w, int cin, int cout, int dtype) {
+  const PackLayout L = pack_layout(cin, cout, 3);
+  return L.mfma_bytes && cin % 32 == 0 && cout % 32 == 0 && is16(dtype) && conv_mfma_fits(n, 2 * d, 2 * h, 2 * w, cout);
+}
+extern "C" int mednet_convt3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int dtype, int algo) {
+  if (algo == MEDNET_ALGO_DIRECT || !tuning_option("gn3_fuse", 1) || !convt_dgrad_mfma_ok(n, d, h, w, cin, cout, dtype)) return 0;
+  return ELT_CALL(dtype, convt_dgrad_gn_rows, d, h, w);
+}
+extern "C" int mednet_convt3d_dgrad_gn(const void* dy, const void* packed, void* dx, const void* gn_y, const void* gn_z, int gn_act,
+                                       float* gn_partial, int n, int d, int h, int w, int cin, int cout, int dtype, int algo,
+                                       mednet_stream stream) {
+  int rc = conv_common_checks("convt3d_dgrad_gn", n, d, h, w, cin, cout, 3, dtype, dtype);
+  if (rc) return rc;
+  MEDNET_REQUIRE(gn_y && gn_z && gn_partial, MEDNET_E_SHAPE, "convt3d_dgrad_gn: gn_y, gn_z and gn_partial are required");
+  MEDNET_REQUIRE(mednet_convt3d_dgrad_gn_rows(n, d, h, w, cin, cout, dtype, algo) > 0, MEDNET_E_UNSUPPORTED,
+                 "convt3d_dgrad_gn: cin=%d cout=%d dtype=%d not on the matrix-core path", cin, cout, dtype);
+  const PackLayout L = pack_layout(cin, cout, 3);
+  return ELT_CALL(dtype, launch_convt_dgrad_gn_mfma, dy, (const char*)packed + L.mfma_bwd, dx, gn_y, gn_z, gn_act, gn_partial, n, d,
+                  h, w, cin, cout, (hipStream_t)stream);
+}
+
 extern "C" size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
   const size_t a = wgrad_direct_ws_bytes((size_t)n * d * h * w, cin, cout, 3);
   size_t b = convt_wgrad_mfma_ws_bytes(n, d, h, w, cin, cout);

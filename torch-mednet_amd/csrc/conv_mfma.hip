@@ -104,6 +104,9 @@ struct FwdArgs {
   const elt* gnb_y;      // conv output y of the layer in front (shape of this kernel's output)
   const float* gnb_coef;  // [n][cout][2] = {ca, cb}: its GroupNorm's forward affine, pre-activation = ca * y + cb
   int gnb_act;            // MEDNET_ACT_*
+  const elt* gnb_z;       // nullable: the layer in front is the RESIDUAL layer of an ExtResNetBlock (GroupNorm-3, components.py:
+                          // 170-178): this kernel's output is the block's output gradient, the activation derivative comes from
+                          // the block OUTPUT z (shape of this kernel's output) and gnb_coef is not used
   int xcd_chunk;          // conv32_mfma_kernel: bricks per XCD when the brick count divides by 8 (each XCD then works through a
                           // CONTIGUOUS part of the volume, so neighbouring bricks' halos meet in its L2), else 0
   int zslab;              // conv32_mfma_kernel: z-layers of bricks per XCD (> 0: the x-z-y walk of origin(); implies xcd_chunk)
@@ -461,26 +464,30 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     for (int it = 0; it < ROUNDS; ++it) rows[it] = *reinterpret_cast<const eltx8*>(rd + it * 64 * 32);
     // GNB: the rows of y at the positions this lane stores, and the GroupNorm affine of its 8 channels (both through
     // buffer resources: positions / channels outside the tensor read zeros), all in flight before the first use
-    eltx8 yrow[GNB ? ROUNDS : 1];
+    eltx8 yrow[GNB ? ROUNDS : 1], zrow[GNB ? ROUNDS : 1];
     float ca[GNB ? 8 : 1], cbf[GNB ? 8 : 1];
     if constexpr (GNB) {
       const auto rsrc_gy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_y + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
+      const auto rsrc_gz = __builtin_amdgcn_make_buffer_rsrc((void*)((a.gnb_z ? a.gnb_z : a.gnb_y) + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
 #pragma unroll
       for (int it = 0; it < ROUNDS; ++it) {
         const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
         const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
         const unsigned soff = (unsigned)(((oz * a.oh + oyb) * a.ow + tx0) * a.cout + cb * 32) * 2u;
         yrow[it] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_gy, ok ? vbase : OOB, soff, 0));
+        if (a.gnb_z) zrow[it] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_gz, ok ? vbase : OOB, soff, 0));
       }
-      const auto rsrc_cf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_coef + (size_t)n * a.cout * 2), 0, (unsigned)a.cout * 8u, 0x00020000);
-      const unsigned coff = (unsigned)(cb * 32 + pj * 8) * 8u;
+      if (!a.gnb_z) {
+        const auto rsrc_cf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_coef + (size_t)n * a.cout * 2), 0, (unsigned)a.cout * 8u, 0x00020000);
+        const unsigned coff = (unsigned)(cb * 32 + pj * 8) * 8u;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 c4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_cf, coff + q * 16, 0, 0));
-        ca[2 * q] = c4[0];
-        cbf[2 * q] = c4[1];
-        ca[2 * q + 1] = c4[2];
-        cbf[2 * q + 1] = c4[3];
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 c4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_cf, coff + q * 16, 0, 0));
+          ca[2 * q] = c4[0];
+          cbf[2 * q] = c4[1];
+          ca[2 * q + 1] = c4[2];
+          cbf[2 * q + 1] = c4[3];
+        }
       }
     }
 #pragma unroll
@@ -499,13 +506,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       if constexpr (GNB) {
         if (ok) {  // du = dz * act'(pre-activation) from the STORED dz, exactly what the apply pass recomputes
           float g[8], u[8], yy[8];
+          if (a.gnb_z) {  // (wave-uniform) residual layer: act' from the block output
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            yy[k] = (float)yrow[it][k];
-            g[k] = (float)v[k];
-            u[k] = fmaf(ca[k], yy[k], cbf[k]);
+            for (int k = 0; k < 8; ++k) {
+              yy[k] = (float)yrow[it][k];
+              g[k] = (float)v[k];
+              u[k] = (float)zrow[it][k];
+            }
+            act_grad_n<8>(g, u, a.gnb_act);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              yy[k] = (float)yrow[it][k];
+              g[k] = (float)v[k];
+              u[k] = fmaf(ca[k], yy[k], cbf[k]);
+            }
+            act_grad_pre_n<8>(g, u, a.gnb_act);
           }
-          act_grad_pre_n<8>(g, u, a.gnb_act);
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             bs[k] += g[k];
@@ -1443,6 +1460,7 @@ struct GnbSpec {  // fused first pass of a GroupNorm backward (see FwdArgs::gnb_
   const void* y = nullptr;
   const float* coef = nullptr;
   int act = MEDNET_ACT_NONE;
+  const void* z = nullptr;  // residual-layer form (FwdArgs::gnb_z)
 };
 
 template <int STRIDE>
@@ -1460,9 +1478,11 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   a.gnb_y = (const elt*)gnb.y;
   a.gnb_coef = gnb.coef;
   a.gnb_act = gnb.act;
+  a.gnb_z = (const elt*)gnb.z;
   const bool use_gnb = gnb.y != nullptr;
-  MEDNET_REQUIRE(!use_gnb || (STRIDE == 1 && gn_partial && gnb.coef), MEDNET_E_UNSUPPORTED,
-                 "conv_mfma: fused GroupNorm-backward sums need the stride-1 kernel, a partial buffer and the forward affine");
+  MEDNET_REQUIRE(!use_gnb || (gn_partial && (gnb.z ? STRIDE == 2 : (STRIDE == 1 && gnb.coef))), MEDNET_E_UNSUPPORTED,
+                 "conv_mfma: fused GroupNorm-backward sums need a partial buffer and the forward affine (stride 1) or the block "
+                 "output (stride 2)");
 #ifdef MEDNET_CONV_TIMING
   a.dbg = (long long*)(((unsigned long long)(unsigned)tuning_option("conv_dbg_hi", 0) << 32) | (unsigned)tuning_option("conv_dbg_lo", 0));
 #endif
@@ -1550,6 +1570,18 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
       return check_launch("conv_mfma(gnb)");
     }
   }
+  if constexpr (STRIDE == 2) {
+    if (use_gnb) {
+      static bool attr_gnb2 = false;
+      if (!attr_gnb2) {
+        if (hipFuncSetAttribute((const void*)conv_mfma_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+          return fail(MEDNET_E_HIP, "conv_mfma: cannot raise dynamic LDS to %zu", lds);
+        attr_gnb2 = true;
+      }
+      hipLaunchKernelGGL((conv_mfma_kernel<2, true>), dim3(grid), dim3(256), lds, s, a);
+      return check_launch("conv_mfma(gnb, stride 2)");
+    }
+  }
   hipLaunchKernelGGL((conv_mfma_kernel<STRIDE>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_mfma");
 }
@@ -1579,6 +1611,20 @@ int launch_convt_dgrad_mfma(const void* dy, const void* packed_section, void* dx
                             int cout, hipStream_t s) {
   // dx (d,h,w; Cin channels) <- dy (2d,2h,2w; Cout channels)
   return launch_fwd<2>(dy, packed_section, dx, n, d, h, w, 2 * d, 2 * h, 2 * w, cout, cin, nullptr, s);
+}
+// ... + the first pass of the GroupNorm-3 backward of the ExtResNetBlock whose output the ConvTranspose3d upsamples
+// (model.py:202-207): one partial row per wave and brick, gn_partial[n][rows][Cin][2]
+int convt_dgrad_gn_rows(int d, int h, int w) {
+  using G = FwdTile<2>;
+  return 4 * ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
+}
+int launch_convt_dgrad_gn_mfma(const void* dy, const void* packed_section, void* dx, const void* gn_y, const void* gn_z, int gn_act,
+                               float* gn_partial, int n, int d, int h, int w, int cin, int cout, hipStream_t s) {
+  GnbSpec g;
+  g.y = gn_y;
+  g.z = gn_z;
+  g.act = gn_act;
+  return launch_fwd<2>(dy, packed_section, dx, n, d, h, w, 2 * d, 2 * h, 2 * w, cout, cin, gn_partial, s, MEDNET_ACT_NONE, nullptr, g);
 }
 
 // ================================================================================================== weight gradient

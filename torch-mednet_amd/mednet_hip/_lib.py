@@ -48,6 +48,8 @@ SIGNATURES = {
     "mednet_head_dgrad_gn_rows": (_i, [_i] * 6),
     "mednet_head_dgrad_gn": (_i, [_vp] * 5 + [_i, _vp] + [_i] * 7 + [_vp]),
     "mednet_pool2_bwd_gn_rows": (_i, [_i] * 6),
+    "mednet_convt3d_dgrad_gn_rows": (_i, [_i] * 8),
+    "mednet_convt3d_dgrad_gn": (_i, [_vp] * 5 + [_i, _vp] + [_i] * 8 + [_vp]),
     "mednet_pool2_bwd_gn": (_i, [_vp] * 5 + [_i, _vp] + [_i] * 7 + [_vp]),
     "mednet_conv3d_wgrad_ws_bytes": (_sz, [_i] * 7),
     "mednet_conv3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp, _sz, _vp]),

@@ -327,7 +327,9 @@ class ConvT3dFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, skip, packed):
         L.require_gpu(x, "conv_transpose3d")
+        x0 = x
         x = to_cl(_as_act(x))
+        ctx.gn3 = _gn3_hook_of(x0, x.dtype) if x is x0 else None
         n, cin, d, h, w = x.shape
         cout = weight.shape[1]
         y = empty_cl(n, cout, 2 * d, 2 * h, 2 * w, config.act_dtype(), x.device)
@@ -353,8 +355,19 @@ class ConvT3dFn(Function):
         dx = dw = db = dskip = None
         if ctx.needs_input_grad[0]:
             dx = empty_cl(n, cin, d, h, w, x.dtype, dy.device)
-            L.check(lib.mednet_convt3d_dgrad(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), n, d, h, w, cin, cout,
-                                             L.dt(dy), L.dt(dx), config.conv_algo(), L.stream()), "convt3d_dgrad")
+            hook = ctx.gn3
+            rows = 0
+            if hook is not None and dy.dtype == dx.dtype:
+                rows = lib.mednet_convt3d_dgrad_gn_rows(n, d, h, w, cin, cout, L.dt(dx), config.conv_algo())
+            if rows > 0:  # + the first pass of the producing block's GroupNorm-3 backward (x IS that block's output)
+                partial = torch.empty((n, rows, cin, 2), dtype=torch.float32, device=dy.device)
+                L.check(lib.mednet_convt3d_dgrad_gn(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), hook.y3.data_ptr(),
+                                                    x.data_ptr(), hook.act, partial.data_ptr(), n, d, h, w, cin, cout, L.dt(dx),
+                                                    config.conv_algo(), L.stream()), "convt3d_dgrad_gn")
+                hook.offer(dx, partial)
+            else:
+                L.check(lib.mednet_convt3d_dgrad(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), n, d, h, w, cin, cout,
+                                                 L.dt(dy), L.dt(dx), config.conv_algo(), L.stream()), "convt3d_dgrad")
         direct_w = direct_b = False
         if ctx.needs_input_grad[1]:
             weight, bias = ctx.params
