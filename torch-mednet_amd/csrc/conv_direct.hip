@@ -561,6 +561,7 @@ __global__ __launch_bounds__(256) void head_dgrad_vox_kernel(const float* __rest
 // stores are whole contiguous rows (thread = voxel made every load touch 64 different cache lines: 534 us for 1.75 GB);
 // a lane keeps 16 sums, lanes of one channel group are summed with DPP (LDS-free) and every wave writes one partial row.
 constexpr int HEAD_GN_VPT = 32;  // voxels per lane group
+constexpr int HEAD_GN_MAXM = 64;  // classes (LDS image of the weights)
 template <typename TO, int K>
 __global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restrict__ dy, const float* __restrict__ Pb /*[m][K]*/,
                                                             TO* __restrict__ dz, const TO* __restrict__ gy,
@@ -569,6 +570,21 @@ __global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restr
   constexpr int CG = K / 8, VPW = 256 / CG;  // lanes per voxel, voxels per workgroup pass
   const int n = blockIdx.y;
   const int cgi = threadIdx.x % CG, vi = threadIdx.x / CG;
+  // the lane's slice of the weights (8 channels x m classes): in registers for up to 8 classes, else through LDS (per-lane
+  // global loads inside the class loop made the 18-class landmark head compute-bound: 986 us)
+  __shared__ float sPb[HEAD_GN_MAXM * K];
+  float wreg[8][8];
+  const bool in_regs = m <= 8;
+  if (in_regs) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wreg[i][j] = i < m ? Pb[(size_t)i * K + cgi * 8 + j] : 0.f;
+  } else if (m <= HEAD_GN_MAXM) {
+    for (int e = threadIdx.x; e < m * K; e += 256) sPb[e] = Pb[e];
+    __syncthreads();
+  }
+  const float* wsrc = m <= HEAD_GN_MAXM ? sPb : Pb;  // (more classes than the LDS image holds: straight from memory)
   float ss[8], sq[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) ss[j] = sq[j] = 0.f;
@@ -579,12 +595,26 @@ __global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restr
     F8 t;
 #pragma unroll
     for (int j = 0; j < 8; ++j) t.v[j] = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < m; ++i) {
-      const float d = dy[((size_t)n * m + i) * spatial + v];
-      const float* pw = Pb + (size_t)i * K + cgi * 8;
+    if (in_regs) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t.v[j] = fmaf(d, pw[j], t.v[j]);
+      for (int i = 0; i < 8; ++i) {
+        if (i < m) {
+          const float d = dy[((size_t)n * m + i) * spatial + v];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t.v[j] = fmaf(d, wreg[i][j], t.v[j]);
+        }
+      }
+    } else {
+#pragma unroll 2
+      for (int i = 0; i < m; ++i) {
+        const float d = dy[((size_t)n * m + i) * spatial + v];
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wsrc + i * K + cgi * 8), w1 = *reinterpret_cast<const f32x4*>(wsrc + i * K + cgi * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          t.v[j] = fmaf(d, w0[j], t.v[j]);
+          t.v[4 + j] = fmaf(d, w1[j], t.v[4 + j]);
+        }
+      }
     }
     const size_t row = ((size_t)n * spatial + v) * K + cgi * 8;
 #pragma unroll
