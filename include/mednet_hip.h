@@ -188,7 +188,9 @@ size_t mednet_loss_ws_bytes(int n, int c, size_t spatial);
 int mednet_dice_fwd(const float* logits, const int64_t* labels, const float* weight, float* loss, float* saved,
                     float* dice_out, int n, int c, size_t spatial, int64_t stride_n, int64_t stride_c, float eps,
                     int sigmoid, int ignore_index, void* ws, size_t ws_bytes, mednet_stream stream);
-/* dlogits is contiguous N x C x spatial; scaled by *dloss (device scalar). */
+/* dlogits has the layout of the logits view it belongs to (the same stride_n / stride_c; a contiguous N x C x spatial tensor
+ * for contiguous logits): a channel slice of the network output gets its gradient written into the matching slice of a
+ * full-size buffer (landmarks.py:71-72).  Scaled by *dloss (device scalar). */
 int mednet_dice_bwd(const float* logits, const int64_t* labels, const float* weight, const float* saved,
                     const float* dloss, float* dlogits, int n, int c, size_t spatial, int64_t stride_n,
                     int64_t stride_c, float eps, int sigmoid, int ignore_index, mednet_stream stream);
@@ -204,6 +206,7 @@ int mednet_ce_bwd(const float* logits, const int64_t* labels, const float* weigh
 int mednet_heatmap_loss_fwd(const float* out, const void* target, const float* cweight, float* loss, int n, int c,
                             size_t spatial, int64_t stride_n, int64_t stride_c, int kind, int tgt_u8, void* ws,
                             size_t ws_bytes, mednet_stream stream);
+/* (dout: the layout of `out`, as dlogits above) */
 int mednet_heatmap_loss_bwd(const float* out, const void* target, const float* cweight, const float* dloss,
                             float* dout, int n, int c, size_t spatial, int64_t stride_n, int64_t stride_c, int kind,
                             int tgt_u8, mednet_stream stream);

@@ -382,6 +382,34 @@ def test_landmark_loss_composition(kind, golden_dir):
     assert abs(float(rg2) - float(rg)) <= 1e-6 * abs(float(rg))
 
 
+@pytest.mark.parametrize("cls_loss", ["dice", "ce"])
+def test_channel_split_losses_write_one_gradient_buffer(cls_loss):
+    """LandmarkNet.training_step slices the network output into heat-map and class channels (landmarks.py:71-72).  The two
+    loss backward kernels write their slices of ONE full-size gradient (no concatenation): the gradient of the unsplit logits
+    must equal autograd's over plain slicing, bit for bit, and really be that shared buffer."""
+    from mednet_hip import ops as hops
+    n, nh, nc, sp = 2, 5, 3, (6, 10, 12)
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(n, nh + nc, *sp, generator=g)
+    hm = torch.randint(0, 256, (n, nh, *sp), generator=g, dtype=torch.uint8)
+    lab = torch.randint(0, nc, (n, *sp), generator=g)
+    wts = [0.3, 1.0, 0.7, 0.2, 1.5]
+    cw = torch.tensor([0.1, 1.0, 2.0])
+
+    def run(split):
+        x = logits.to(DEV).requires_grad_(True)
+        a, b = split(x)
+        reg = hops.heatmap_loss(a, hm.to(DEV), wts, "L2")
+        cl = hops.dice_loss(b, lab.to(DEV), cw.to(DEV)) if cls_loss == "dice" else hops.cross_entropy(b, lab.to(DEV), cw.to(DEV))
+        (reg + 2.0 * cl).backward()
+        return x.grad
+
+    g_fused = run(lambda x: hops.split_channels(x, nh))
+    g_plain = run(lambda x: (x[:, :nh], x[:, nh:]))
+    assert torch.equal(g_fused, g_plain)
+    assert g_fused.is_contiguous()
+
+
 def test_adam_step_matches_torch():
     g = np.random.Generator(np.random.PCG64(3))
     p0 = torch.from_numpy(g.standard_normal(10007).astype(np.float32))

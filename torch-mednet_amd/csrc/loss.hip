@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__
       for (int k = 0; k < MAXC; ++k)
         if (k < c) {
           const float dz = sigmoid ? g[k] * p[k] * (1.f - p[k]) : p[k] * (g[k] - dot);
-          dlg[((size_t)n * c + k) * spatial + v] = dz;
+          dlg[(size_t)n * sn + (size_t)k * sc + v] = dz;
         }
     }
   }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
       const float w = live ? (weight ? weight[y] : 1.f) * scale : 0.f;
 #pragma unroll
       for (int k = 0; k < MAXC; ++k)
-        if (k < c) dlg[((size_t)n * c + k) * spatial + v] = w * (p[k] - (k == y ? 1.f : 0.f));
+        if (k < c) dlg[(size_t)n * sn + (size_t)k * sc + v] = w * (p[k] - (k == y ? 1.f : 0.f));
     }
   }
 }
@@ -320,9 +320,9 @@ __global__ __launch_bounds__(256) void hm_bwd_kernel(const float* __restrict__ o
   for (int it = 0; it < 8; ++it) {
     const size_t v = v0 + (size_t)it * 256 + threadIdx.x;
     if (v < spatial) {
-      const size_t o = ((size_t)n * c + ch) * spatial + v;
-      const float d = out[(size_t)n * sn + (size_t)ch * sc + v] - ld(tgt, o);
-      dout[o] = kind == MEDNET_REG_L2 ? 2.f * d * scale : (d > 0.f ? scale : (d < 0.f ? -scale : 0.f));
+      const size_t o = ((size_t)n * c + ch) * spatial + v, os = (size_t)n * sn + (size_t)ch * sc + v;
+      const float d = out[os] - ld(tgt, o);
+      dout[os] = kind == MEDNET_REG_L2 ? 2.f * d * scale : (d > 0.f ? scale : (d < 0.f ? -scale : 0.f));
     }
   }
 }

@@ -499,29 +499,66 @@ class AddFn(Function):
 
 
 # ------------------------------------------------------------------------------------------------- channel split
+class _SplitGrad:
+    """Shared gradient buffer of a channel split: the loss backward kernels of the two halves write their slices of ONE
+    full-size tensor (they index the gradient with the strides of the logits slice they were given), so the split's backward
+    is that tensor, not a concatenation."""
+    __slots__ = ("shape", "base", "k")
+
+    def __init__(self, shape, k):
+        self.shape, self.k, self.base = tuple(shape), k, None
+
+
 class SplitChannelsFn(Function):
     """(x[:, :k], x[:, k:]) as ONE autograd node (landmarks.py:71-72 slices the network output into heat-map and class
-    channels): backward is a single concatenation of the two gradients instead of autograd's zero-fill + copy per slice
-    + add over the full logits tensor."""
+    channels): backward is the shared buffer both loss kernels wrote into (or, if the gradients came from somewhere else, a
+    single concatenation) instead of autograd's zero-fill + copy per slice + add over the full logits tensor."""
 
     @staticmethod
-    def forward(ctx, x, k):
-        ctx.k, ctx.shape = k, x.shape
+    def forward(ctx, x, k, holder):
+        ctx.k, ctx.shape, ctx.holder = k, x.shape, holder
         return x[:, :k], x[:, k:]
 
     @staticmethod
     def backward(ctx, d0, d1):
-        k, shape = ctx.k, ctx.shape
+        k, shape, holder = ctx.k, ctx.shape, ctx.holder
+        base = holder.base if holder is not None else None
+        if holder is not None:
+            holder.base = None
+        if (base is not None and d0 is not None and d1 is not None and d0.dtype == base.dtype == d1.dtype
+                and d0.data_ptr() == base.data_ptr() and d1.data_ptr() == base[:, k:].data_ptr()
+                and d0.stride() == base[:, :k].stride() and d1.stride() == base[:, k:].stride()):
+            return base, None, None
         ref = d0 if d0 is not None else d1
         if d0 is None:
             d0 = ref.new_zeros((shape[0], k) + tuple(shape[2:]))
         if d1 is None:
             d1 = ref.new_zeros((shape[0], shape[1] - k) + tuple(shape[2:]))
-        return torch.cat((d0, d1), dim=1), None
+        return torch.cat((d0, d1), dim=1), None, None
+
+
+SPLIT_SHARED = os.environ.get("MEDNET_SPLIT_SHARED", "1") == "1"  # A/B knob
 
 
 def split_channels(x, k):
-    return SplitChannelsFn.apply(x, k)
+    holder = _SplitGrad(x.shape, k) if (SPLIT_SHARED and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()) else None
+    a, b = SplitChannelsFn.apply(x, k, holder)
+    if holder is not None:
+        a._mednet_split, b._mednet_split = (holder, 0), (holder, k)
+    return a, b
+
+
+def _loss_grad_like(lg, split):
+    """fp32 gradient buffer with the STRIDES of the logits view `lg` (the loss backward kernels write with those strides):
+    a slice of the shared buffer of a channel split when there is one, else a fresh tensor of that layout."""
+    if split is not None:
+        holder, c0 = split
+        if holder.base is None:
+            holder.base = torch.empty(holder.shape, dtype=torch.float32, device=lg.device)
+        view = holder.base[:, c0:c0 + lg.shape[1]]
+        if tuple(view.shape) == tuple(lg.shape) and view.stride() == lg.stride():
+            return view
+    return torch.empty_strided(tuple(lg.shape), lg.stride(), dtype=torch.float32, device=lg.device)
 
 
 # ------------------------------------------------------------------------------------------------- pooling
@@ -676,6 +713,7 @@ class DiceLossFn(Function):
                 "dice_fwd")
         ctx.save_for_backward(lg, lab, wt, saved)
         ctx.meta = (eps, int(sigmoid), ii, sn, sc, logits.dtype)
+        ctx.split = getattr(logits, "_mednet_split", None) if lg is logits else None
         return loss
 
     @staticmethod
@@ -685,7 +723,7 @@ class DiceLossFn(Function):
         n, c = lg.shape[:2]
         spatial = lg[0, 0].numel()
         dl = dloss.to(torch.float32).contiguous()
-        dlogits = torch.empty(lg.shape, dtype=torch.float32, device=lg.device)
+        dlogits = _loss_grad_like(lg, ctx.split)
         L.check(L.lib().mednet_dice_bwd(lg.data_ptr(), lab.data_ptr(), L.ptr(wt), saved.data_ptr(), dl.data_ptr(),
                                         dlogits.data_ptr(), n, c, spatial, sn, sc, eps, sigmoid, ii, L.stream()),
                 "dice_bwd")
@@ -733,6 +771,7 @@ class CrossEntropyFn(Function):
                                   spatial, sn, sc, int(ignore_index), ws.data_ptr(), ws.numel(), L.stream()), "ce_fwd")
         ctx.save_for_backward(lg, lab, wt, saved)
         ctx.meta = (int(ignore_index), sn, sc, logits.dtype)
+        ctx.split = getattr(logits, "_mednet_split", None) if lg is logits else None
         return loss
 
     @staticmethod
@@ -742,7 +781,7 @@ class CrossEntropyFn(Function):
         n, c = lg.shape[:2]
         spatial = lg[0, 0].numel()
         dl = dloss.to(torch.float32).contiguous()
-        dlogits = torch.empty(lg.shape, dtype=torch.float32, device=lg.device)
+        dlogits = _loss_grad_like(lg, ctx.split)
         L.check(L.lib().mednet_ce_bwd(lg.data_ptr(), lab.data_ptr(), L.ptr(wt), saved.data_ptr(), dl.data_ptr(),
                                       dlogits.data_ptr(), n, c, spatial, sn, sc, ii, L.stream()), "ce_bwd")
         return dlogits.to(in_dtype), None, None, None
@@ -774,6 +813,7 @@ class HeatmapLossFn(Function):
                                             sc, kind, u8, ws.data_ptr(), ws.numel(), L.stream()), "heatmap_loss_fwd")
         ctx.save_for_backward(lg, tgt, wt)
         ctx.meta = (kind, u8, sn, sc, out.dtype)
+        ctx.split = getattr(out, "_mednet_split", None) if lg is out else None
         return loss
 
     @staticmethod
@@ -783,7 +823,7 @@ class HeatmapLossFn(Function):
         n, c = lg.shape[:2]
         spatial = lg[0, 0].numel()
         dl = dloss.to(torch.float32).contiguous()
-        dout = torch.empty(lg.shape, dtype=torch.float32, device=lg.device)
+        dout = _loss_grad_like(lg, ctx.split)
         L.check(L.lib().mednet_heatmap_loss_bwd(lg.data_ptr(), tgt.data_ptr(), L.ptr(wt), dl.data_ptr(), dout.data_ptr(),
                                                 n, c, spatial, sn, sc, kind, u8, L.stream()), "heatmap_loss_bwd")
         return dout.to(in_dtype), None, None, None
