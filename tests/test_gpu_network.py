@@ -684,6 +684,37 @@ def test_groupnorm3_backward_sums_from_the_producer_of_the_block_gradient(mode, 
         assert_close(a, b, 2e-3, f"fused vs stand-alone {k}")
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("order,cin,cout,shape", [("gcr", 32, 32, (16, 24, 32)), ("gcr", 96, 32, (9, 11, 21)), ("gcl", 32, 64, (8, 8, 16)),
+                                                  ("gce", 64, 64, (8, 16, 16))])
+def test_plain_groupnorm_backward_sums_from_the_following_conv(mode, order, cin, cout, shape):
+    """SingleConv in the 'g c .' orders (UNet3D's default 'gcr', components.py:12-67): GroupNorm -> conv -> activation.  The
+    first pass of that GroupNorm's backward is taken in the epilogue of the conv's data gradient (ops.GNBHook) against the
+    stand-alone pass: same gradients up to fp32 summation order, and the sums are really used."""
+    from mednet_hip import ops as hops
+    x = torch.from_numpy(O._rng(f"gnb2{order}{cin}{shape}").standard_normal((2, cin) + shape).astype(np.float32))
+    res = {}
+    for fused in (True, False):
+        old = hops.FUSE_GN3
+        hops.FUSE_GN3 = fused
+        before = dict(hops.GN3_COUNT)
+        try:
+            with mednet_hip.precision(mode):
+                net = nn.Sequential(O.keyed_init_(HC.SingleConv(cin, cout, 3, order, 8)), O.keyed_init_(HC.SingleConv(cout, cout, 3, order, 8))).to(DEV)
+                xg = x.to(DEV).to(torch.bfloat16 if mode == "bf16" else torch.float16).requires_grad_(True)
+                y = net(xg)
+                cot = torch.from_numpy(O._rng("gnb2c").standard_normal(tuple(y.shape)).astype(np.float32)).to(DEV)
+                (y.float() * cot).sum().backward()
+                res[fused] = [xg.grad.float().clone()] + [p.grad.clone() for p in net.parameters()]
+        finally:
+            hops.FUSE_GN3 = old
+        taken = hops.GN3_COUNT["taken"] - before["taken"]
+        assert taken == (2 if fused else 0), f"fused={fused}: {taken} GroupNorm backward passes took the conv's sums"
+    names = ["dx"] + [k for k, _ in net.named_parameters()]
+    for k, a, b in zip(names, res[True], res[False]):
+        assert_close(a, b, 2e-3, f"fused vs stand-alone {k}")
+
+
 def test_groupnorm3_sums_are_declined_when_the_block_output_has_a_second_consumer():
     """ops.GN3Hook: if autograd accumulates another gradient into the block's output gradient, the producer's sums no longer
     describe it; the block must notice (object identity + version counter) and run its stand-alone pass."""

@@ -166,6 +166,24 @@ class GN3Hook:
 
 
 FUSE_GN3 = os.environ.get("MEDNET_FUSE_GN3", "1") == "1"  # A/B knob
+
+
+class GNBHook(GN3Hook):
+    """The same contract for a plain GroupNorm (+ activation) whose output feeds a 3x3x3 convolution directly (the 'gcr'
+    orders of UNet3D, components.py:12-67): the conv's data gradient takes {sum du, sum du * x} of that GroupNorm's backward
+    in its epilogue (mednet_conv3d_dgrad_gn) and offers them with the gradient tensor it produced."""
+    __slots__ = ("coef",)
+
+    def __init__(self):
+        super().__init__()
+        self.coef = None
+
+
+def _gnb_hook_of(x, dtype):
+    h = getattr(x, "_mednet_gnb", None) if FUSE_GN3 else None
+    if h is None or h.y3 is None or h.y3.shape != x.shape or h.y3.dtype != dtype or dtype not in config.HALF_TYPES:
+        return None
+    return h
 GN3_COUNT = {"taken": 0, "declined": 0, "absent": 0}  # (tests: how the blocks' backward passes found their sums)
 
 
@@ -272,6 +290,7 @@ class ConvActFn(Function):
     def forward(ctx, x, weight, packed, act, want_stats):
         L.require_gpu(x, "conv3d+act")
         xin = to_cl(_as_act(x))
+        ctx.gnb = _gnb_hook_of(x, xin.dtype) if xin is x else None
         n, cin, d, h, w = xin.shape
         cout = weight.shape[0]
         lib = L.lib()
@@ -300,7 +319,11 @@ class ConvActFn(Function):
         du = torch.empty_like(z, memory_format=CL)
         L.check(L.lib().mednet_act_bwd(dz.data_ptr(), z.data_ptr(), du.data_ptr(), z.numel(), ctx.act, L.dt(z), L.stream()),
                 "act_bwd")
-        dx, dw, _ = block._conv_bwd(xin, du, packed, ctx.weight, ctx.needs_input_grad[0])
+        hook = ctx.gnb
+        dx, dw, partial = block._conv_bwd(xin, du, packed, ctx.weight, ctx.needs_input_grad[0],
+                                          gnb=None if hook is None else (hook.y3, hook.coef, hook.act))
+        if partial is not None:
+            hook.offer(dx, partial)
         return dx, dw, None, None, None
 
 
@@ -394,7 +417,7 @@ class GroupNormActFn(Function):
     """z = act(GroupNorm(x) [+ residual])  -- components.py:57, :36-40, :177-178."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, groups, eps, act, partial=None):
+    def forward(ctx, x, gamma, beta, residual, groups, eps, act, partial=None, hook=None):
         L.require_gpu(x, "group_norm_act")
         x = to_cl(_as_act(x))
         n, c, d, h, w = x.shape
@@ -424,6 +447,9 @@ class GroupNormActFn(Function):
         ctx.save_for_backward(x, z if keep_z else None, stats, gamma, coef)
         ctx.meta = (groups, act, residual is not None, gamma is not None, beta is not None)
         ctx.params = (gamma, beta)
+        ctx.gnb = hook
+        if hook is not None:
+            hook.y3, hook.coef, hook.act = x, coef, act
         return z
 
     @staticmethod
@@ -432,6 +458,7 @@ class GroupNormActFn(Function):
         groups, act, has_res, has_gamma, has_beta = ctx.meta
         n, c, d, h, w = x.shape
         spatial = d * h * w
+        fused = ctx.gnb.take(dz) if ctx.gnb is not None else None  # (before any conversion: identity matters)
         dz = to_cl(dz.to(x.dtype))
         lib = L.lib()
         dx = torch.empty_like(x, memory_format=CL)
@@ -440,14 +467,26 @@ class GroupNormActFn(Function):
         dgamma, direct_g = _grad_target(pg, (c,)) if has_gamma else (None, False)
         dbeta, direct_b = _grad_target(pb, (c,)) if has_beta else (None, False)
         ws = L.workspace(lib.mednet_gn_ws_bytes(n, c, spatial), x.device)
+        if fused is not None and not has_res:  # first pass taken by the conv data gradient that produced dz
+            L.check(lib.mednet_gn_act_bwd_fused(dz.data_ptr(), x.data_ptr(), coef.data_ptr(), stats.data_ptr(), L.ptr(gamma),
+                                                fused.data_ptr(), fused.shape[1], dx.data_ptr(), L.ptr(dgamma), L.ptr(dbeta), n,
+                                                spatial, c, groups, act, L.dt(x), ws.data_ptr(), ws.numel(), L.stream()),
+                    "gn_act_bwd_fused")
+            return dx, (None if direct_g else dgamma), (None if direct_b else dbeta), dres, None, None, None, None, None
         L.check(lib.mednet_gn_act_bwd(dz.data_ptr(), None, x.data_ptr(), L.ptr(z), coef.data_ptr(), stats.data_ptr(), L.ptr(gamma),
                                       dx.data_ptr(), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), n, spatial, c, groups, act,
                                       L.dt(x), ws.data_ptr(), ws.numel(), L.stream()), "gn_act_bwd")
-        return dx, (None if direct_g else dgamma), (None if direct_b else dbeta), dres, None, None, None, None
+        return dx, (None if direct_g else dgamma), (None if direct_b else dbeta), dres, None, None, None, None, None
 
 
 def group_norm_act(x, gamma, beta, groups, eps=1e-5, act=L.ACT_NONE, residual=None, partial=None):
-    return GroupNormActFn.apply(x, gamma, beta, residual, groups, eps, act, partial)
+    hook = None
+    if FUSE_GN3 and residual is None and config.is_half_mode() and torch.is_grad_enabled() and gamma is not None:
+        hook = GNBHook()  # the conv that consumes z may take this GroupNorm's first backward pass (see GNBHook)
+    z = GroupNormActFn.apply(x, gamma, beta, residual, groups, eps, act, partial, hook)
+    if hook is not None:
+        z._mednet_gnb = hook
+    return z
 
 
 # ------------------------------------------------------------------------------------------------- stand-alone activation
