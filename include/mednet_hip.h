@@ -145,15 +145,17 @@ int mednet_gn_act_fwd(const void* x, const float* coef, const void* residual, vo
 /* du = (dz [+ dz2]) * act';  dgamma/dbeta;  dx = GroupNorm backward of du;  dres (nullable) := du.
  * act' comes from the activated output z when given (ATen's in-place semantics), else -- no residual branch -- it is
  * recomputed from x and the forward coefficients `coef`, which saves reading z back (one tensor less per pass). */
+/* in_act (both forms below): MEDNET_ACT_* of the activation whose OUTPUT is x (conv -> ReLU -> this GroupNorm in the 'gcr'
+ * orders, components.py:36-40): dx is multiplied by its derivative here, sparing the conv layer's backward a pass. */
 int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x, const void* z, const float* coef,
                       const float* stats, const float* gamma, void* dx, void* dres, float* dgamma, float* dbeta, int n,
-                      size_t spatial, int c, int groups, int act, int dtype, void* ws, size_t ws_bytes,
+                      size_t spatial, int c, int groups, int act, int in_act, int dtype, void* ws, size_t ws_bytes,
                       mednet_stream stream);
 /* mednet_gn_act_bwd without its first pass: `partial` [n][rows][c][2] = per-channel {sum du, sum du * x} comes from the
  * kernel that produced dz (mednet_conv3d_dgrad_gn); act' is recomputed from x and `coef` (z is not read). */
 int mednet_gn_act_bwd_fused(const void* dz, const void* x, const float* coef, const float* stats, const float* gamma,
                             const float* partial, int rows, void* dx, float* dgamma, float* dbeta, int n,
-                            size_t spatial, int c, int groups, int act, int dtype, void* ws, size_t ws_bytes,
+                            size_t spatial, int c, int groups, int act, int in_act, int dtype, void* ws, size_t ws_bytes,
                             mednet_stream stream);
 int mednet_gn_act_bwd_fused_res(const void* dz, const void* x, const void* z, const float* coef, const float* stats,
                                 const float* gamma, const float* fused_partial, int rows, void* dx, void* dres,

@@ -710,9 +710,13 @@ def test_plain_groupnorm_backward_sums_from_the_following_conv(mode, order, cin,
             hops.FUSE_GN3 = old
         taken = hops.GN3_COUNT["taken"] - before["taken"]
         assert taken == (2 if fused else 0), f"fused={fused}: {taken} GroupNorm backward passes took the conv's sums"
+        masked = hops.GN3_COUNT["masked"] - before.get("masked", 0)  # the first layer's act' folded into the second GroupNorm's backward
+        assert masked == (1 if fused else 0), f"fused={fused}: {masked} activation-backward passes were folded away"
     names = ["dx"] + [k for k, _ in net.named_parameters()]
     for k, a, b in zip(names, res[True], res[False]):
-        assert_close(a, b, 2e-3, f"fused vs stand-alone {k}")
+        # (the folded activation derivative saves one rounding of the intermediate gradient to 16 bits: the two paths differ
+        #  by that rounding, 2^-9 relative per element in bf16)
+        assert_close(a, b, 4e-3 if mode == "bf16" else 1e-3, f"fused vs stand-alone {k}")
 
 
 def test_groupnorm3_sums_are_declined_when_the_block_output_has_a_second_consumer():

@@ -34,7 +34,7 @@ dbl = torch.ones(2048, device=dev, dtype=torch.float64)
 def gn_bwd_fused():
     L.check(lib.mednet_gn_act_bwd_fused(dx.data_ptr(), y_prev.data_ptr(), coef.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
                                         part.data_ptr(), rows, dyo.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), N, s ** 3, c, 8,
-                                        L.ACT_ELU, L.BF16, gws.data_ptr(), gws.numel(), main.cuda_stream), "gn_bwd_fused")
+                                        L.ACT_ELU, L.ACT_NONE, L.BF16, gws.data_ptr(), gws.numel(), main.cuda_stream), "gn_bwd_fused")
 
 
 def scenario(name, cand, wgrad_after_dgrad=False):

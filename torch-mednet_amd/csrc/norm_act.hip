@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256, GN_WAVES) void gn_bwd_apply_kernel(const T* __
                                                            const float* __restrict__ coef,
                                                            const float* __restrict__ bcoef, T* __restrict__ dx,
                                                            T* __restrict__ dres, size_t spatial, int c, int act,
-                                                           size_t chunk_vox) {
+                                                           size_t chunk_vox, int in_act) {
   const Cols<VEC> L(c);
   if (!L.active) return;
   const int n = blockIdx.y;
@@ -479,6 +479,9 @@ __global__ __launch_bounds__(256, GN_WAVES) void gn_bwd_apply_kernel(const T* __
     F8 o;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) o.v[k] = fmaf(k1[k], g1.v[k], fmaf(k2[k], xv.v[k], k3[k]));
+    // x is the OUTPUT of an activation (conv -> ReLU -> this GroupNorm in the 'gcr' orders): its derivative is folded in
+    // here, where x is in registers anyway, instead of a separate pass over (dx, x) in the conv layer's backward
+    if (in_act != MEDNET_ACT_NONE) act_grad_n<VEC>(o.v, xv.v, in_act);
     VecIO<T, VEC>::store(dx, i, o);
     if (dres) VecIO<T, VEC>::store(dres, i, g1);
   };
@@ -947,7 +950,7 @@ extern "C" int mednet_gn_act_fwd(const void* x, const float* coef, const void* r
 extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x, const void* z, const float* coef,
                                  const float* stats, const float* gamma, void* dx, void* dres, float* dgamma,
                                  float* dbeta, int n,
-                                 size_t spatial, int c, int groups, int act, int dtype, void* ws, size_t ws_bytes,
+                                 size_t spatial, int c, int groups, int act, int in_act, int dtype, void* ws, size_t ws_bytes,
                                  mednet_stream stream) {
   MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "gn_act_bwd: bad dtype");
   MEDNET_REQUIRE(c % groups == 0, MEDNET_E_SHAPE, "gn_act_bwd: C %% groups != 0");
@@ -982,7 +985,7 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
     rc = check_launch("gn_bwd_params");
     if (rc) return rc;
   }
-#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv)
+#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv, in_act)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
@@ -992,8 +995,8 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
 
 static int gn_act_bwd_fused_impl(const void* dz, const void* x, const void* z, const float* coef, const float* stats,
                                  const float* gamma, const float* fused_partial, int rows, void* dx, void* dres,
-                                 float* dgamma, float* dbeta, int n, size_t spatial, int c, int groups, int act, int dtype,
-                                 void* ws, size_t ws_bytes, mednet_stream stream) {
+                                 float* dgamma, float* dbeta, int n, size_t spatial, int c, int groups, int act, int in_act,
+                                 int dtype, void* ws, size_t ws_bytes, mednet_stream stream) {
   MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "gn_act_bwd_fused: bad dtype");
   MEDNET_REQUIRE(c % groups == 0 && rows > 0 && fused_partial && coef, MEDNET_E_SHAPE, "gn_act_bwd_fused: bad arguments");
   const int vec = pick_vec(c);
@@ -1020,7 +1023,7 @@ static int gn_act_bwd_fused_impl(const void* dz, const void* x, const void* z, c
     if (rc) return rc;
   }
   const dim3 grid(chunks, n);
-#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)nullptr, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv)
+#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)nullptr, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv, in_act)
   if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
@@ -1030,10 +1033,10 @@ static int gn_act_bwd_fused_impl(const void* dz, const void* x, const void* z, c
 
 extern "C" int mednet_gn_act_bwd_fused(const void* dz, const void* x, const float* coef, const float* stats,
                                        const float* gamma, const float* fused_partial, int rows, void* dx, float* dgamma,
-                                       float* dbeta, int n, size_t spatial, int c, int groups, int act, int dtype,
+                                       float* dbeta, int n, size_t spatial, int c, int groups, int act, int in_act, int dtype,
                                        void* ws, size_t ws_bytes, mednet_stream stream) {
   return gn_act_bwd_fused_impl(dz, x, nullptr, coef, stats, gamma, fused_partial, rows, dx, nullptr, dgamma, dbeta, n, spatial, c,
-                               groups, act, dtype, ws, ws_bytes, stream);
+                               groups, act, in_act, dtype, ws, ws_bytes, stream);
 }
 // ... for the residual layer of an ExtResNetBlock: the activation derivative comes from the block OUTPUT z, and du is also
 // the gradient of the residual branch (dres)
@@ -1043,7 +1046,7 @@ extern "C" int mednet_gn_act_bwd_fused_res(const void* dz, const void* x, const 
                                            int dtype, void* ws, size_t ws_bytes, mednet_stream stream) {
   MEDNET_REQUIRE(z && dres, MEDNET_E_SHAPE, "gn_act_bwd_fused_res: z and dres are required");
   return gn_act_bwd_fused_impl(dz, x, z, coef, stats, gamma, fused_partial, rows, dx, dres, dgamma, dbeta, n, spatial, c, groups,
-                               act, dtype, ws, ws_bytes, stream);
+                               act, MEDNET_ACT_NONE, dtype, ws, ws_bytes, stream);
 }
 
 extern "C" int mednet_act_fwd(const void* x, void* z, size_t count, int act, int dtype, mednet_stream stream) {

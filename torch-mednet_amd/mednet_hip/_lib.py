@@ -43,7 +43,7 @@ SIGNATURES = {
     "mednet_conv3d_dgrad_add": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "mednet_conv3d_dgrad_gn_rows": (_i, [_i] * 7),
     "mednet_conv3d_dgrad_gn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 8 + [_vp]),
-    "mednet_gn_act_bwd_fused": (_i, [_vp] * 6 + [_i, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mednet_gn_act_bwd_fused": (_i, [_vp] * 6 + [_i, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mednet_gn_act_bwd_fused_res": (_i, [_vp] * 7 + [_i, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mednet_head_dgrad_gn_rows": (_i, [_i] * 6),
     "mednet_head_dgrad_gn": (_i, [_vp] * 5 + [_i, _vp] + [_i] * 7 + [_vp]),
@@ -60,7 +60,7 @@ SIGNATURES = {
     "mednet_gn_ws_bytes": (_sz, [_i, _i, _sz]),
     "mednet_gn_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _f, _i, _vp, _sz, _vp]),
     "mednet_gn_act_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _vp]),
-    "mednet_gn_act_bwd": (_i, [_vp] * 11 + [_i, _sz, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mednet_gn_act_bwd": (_i, [_vp] * 11 + [_i, _sz, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mednet_act_fwd": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
     "mednet_act_bwd": (_i, [_vp, _vp, _vp, _sz, _i, _i, _vp]),
     "mednet_add": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),

@@ -79,12 +79,13 @@ def _gn_bwd(dz, dz2, y, z, coef, stats, gamma_p, beta_p, groups, act, want_dres,
         assert dz2 is None and z is None and not want_dres
         L.check(lib.mednet_gn_act_bwd_fused(dz.data_ptr(), y.data_ptr(), coef.data_ptr(), stats.data_ptr(), gamma_p.data_ptr(),
                                             partial.data_ptr(), partial.shape[1], dy.data_ptr(), dgamma.data_ptr(),
-                                            dbeta.data_ptr(), n, spatial, c, groups, act, L.dt(y), ws.data_ptr(), ws.numel(),
-                                            L.stream()), "gn_act_bwd_fused")
+                                            dbeta.data_ptr(), n, spatial, c, groups, act, L.ACT_NONE, L.dt(y), ws.data_ptr(),
+                                            ws.numel(), L.stream()), "gn_act_bwd_fused")
         return dy, None, (None if dg_direct else dgamma), (None if db_direct else dbeta)
     L.check(lib.mednet_gn_act_bwd(dz.data_ptr(), L.ptr(dz2), y.data_ptr(), L.ptr(z), coef.data_ptr(), stats.data_ptr(),
                                   gamma_p.data_ptr(), dy.data_ptr(), L.ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), n,
-                                  spatial, c, groups, act, L.dt(y), ws.data_ptr(), ws.numel(), L.stream()), "gn_act_bwd")
+                                  spatial, c, groups, act, L.ACT_NONE, L.dt(y), ws.data_ptr(), ws.numel(), L.stream()),
+            "gn_act_bwd")
     return dy, dres, (None if dg_direct else dgamma), (None if db_direct else dbeta)
 
 

@@ -179,12 +179,32 @@ class GNBHook(GN3Hook):
         self.coef = None
 
 
+class ActMaskHook:
+    """Carried by the output z of a fused conv -> activation layer: if z goes straight into a GroupNorm, that GroupNorm's
+    backward multiplies the gradient it produces by act'(z) (z is its own input, in registers anyway) and says so here; the
+    conv layer's backward then skips its activation-backward pass -- if the gradient it receives is that very tensor."""
+    __slots__ = ("act", "dx", "version")
+
+    def __init__(self, act):
+        self.act, self.dx, self.version = act, None, -1
+
+    def offer(self, dx):
+        self.dx, self.version = dx, dx._version
+
+    def take(self, dz):
+        dx, version = self.dx, self.version
+        self.dx = None
+        ok = dx is not None and dz is dx and dz._version == version
+        GN3_COUNT["masked"] += int(ok)
+        return ok
+
+
 def _gnb_hook_of(x, dtype):
     h = getattr(x, "_mednet_gnb", None) if FUSE_GN3 else None
     if h is None or h.y3 is None or h.y3.shape != x.shape or h.y3.dtype != dtype or dtype not in config.HALF_TYPES:
         return None
     return h
-GN3_COUNT = {"taken": 0, "declined": 0, "absent": 0}  # (tests: how the blocks' backward passes found their sums)
+GN3_COUNT = {"taken": 0, "declined": 0, "absent": 0, "masked": 0}  # (tests: how the blocks' backward passes found their sums)
 
 
 def _gn3_hook_of(x, dtype):
@@ -287,8 +307,9 @@ class ConvActFn(Function):
     that opens the next SingleConv.  Backward: activation' from the saved output, then the conv's two gradients."""
 
     @staticmethod
-    def forward(ctx, x, weight, packed, act, want_stats):
+    def forward(ctx, x, weight, packed, act, want_stats, mask=None):
         L.require_gpu(x, "conv3d+act")
+        ctx.mask = mask
         xin = to_cl(_as_act(x))
         ctx.gnb = _gnb_hook_of(x, xin.dtype) if xin is x else None
         n, cin, d, h, w = xin.shape
@@ -315,16 +336,20 @@ class ConvActFn(Function):
     def backward(ctx, dz, _dpartial=None):
         from . import block  # (block imports ops)
         xin, packed, z = ctx.saved_tensors
+        masked = ctx.mask is not None and ctx.mask.take(dz)  # (before any conversion: identity matters)
         dz = to_cl(dz.to(z.dtype))
-        du = torch.empty_like(z, memory_format=CL)
-        L.check(L.lib().mednet_act_bwd(dz.data_ptr(), z.data_ptr(), du.data_ptr(), z.numel(), ctx.act, L.dt(z), L.stream()),
-                "act_bwd")
+        if masked:  # the GroupNorm that consumed z already multiplied its input gradient by act'(z)
+            du = dz
+        else:
+            du = torch.empty_like(z, memory_format=CL)
+            L.check(L.lib().mednet_act_bwd(dz.data_ptr(), z.data_ptr(), du.data_ptr(), z.numel(), ctx.act, L.dt(z), L.stream()),
+                    "act_bwd")
         hook = ctx.gnb
         dx, dw, partial = block._conv_bwd(xin, du, packed, ctx.weight, ctx.needs_input_grad[0],
                                           gnb=None if hook is None else (hook.y3, hook.coef, hook.act))
         if partial is not None:
             hook.offer(dx, partial)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 def conv3d_act_supported(x, cin, cout):
@@ -338,7 +363,10 @@ def conv3d_act_supported(x, cin, cout):
 
 def conv3d_act(x, weight, packed, act, want_stats=False):
     """-> (activated output, GroupNorm partials of it or None)."""
-    z, partial = ConvActFn.apply(x, weight, packed, act, want_stats)
+    mask = ActMaskHook(act) if (FUSE_GN3 and torch.is_grad_enabled() and act != L.ACT_NONE) else None
+    z, partial = ConvActFn.apply(x, weight, packed, act, want_stats, mask)
+    if mask is not None:
+        z._mednet_actmask = mask
     return z, (partial if partial.numel() else None)
 
 
@@ -419,7 +447,9 @@ class GroupNormActFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, groups, eps, act, partial=None, hook=None):
         L.require_gpu(x, "group_norm_act")
+        x0 = x
         x = to_cl(_as_act(x))
+        ctx.inmask = getattr(x0, "_mednet_actmask", None) if (x is x0 and FUSE_GN3) else None
         n, c, d, h, w = x.shape
         if c % groups:
             raise RuntimeError(f"group_norm: C={c} not divisible by num_groups={groups}")
@@ -467,14 +497,18 @@ class GroupNormActFn(Function):
         dgamma, direct_g = _grad_target(pg, (c,)) if has_gamma else (None, False)
         dbeta, direct_b = _grad_target(pb, (c,)) if has_beta else (None, False)
         ws = L.workspace(lib.mednet_gn_ws_bytes(n, c, spatial), x.device)
+        inmask = ctx.inmask  # x is the output of a fused conv -> activation layer: fold act'(x) into dx (ActMaskHook)
+        in_act = inmask.act if inmask is not None else L.ACT_NONE
+        if inmask is not None:
+            inmask.offer(dx)
         if fused is not None and not has_res:  # first pass taken by the conv data gradient that produced dz
             L.check(lib.mednet_gn_act_bwd_fused(dz.data_ptr(), x.data_ptr(), coef.data_ptr(), stats.data_ptr(), L.ptr(gamma),
                                                 fused.data_ptr(), fused.shape[1], dx.data_ptr(), L.ptr(dgamma), L.ptr(dbeta), n,
-                                                spatial, c, groups, act, L.dt(x), ws.data_ptr(), ws.numel(), L.stream()),
+                                                spatial, c, groups, act, in_act, L.dt(x), ws.data_ptr(), ws.numel(), L.stream()),
                     "gn_act_bwd_fused")
             return dx, (None if direct_g else dgamma), (None if direct_b else dbeta), dres, None, None, None, None, None
         L.check(lib.mednet_gn_act_bwd(dz.data_ptr(), None, x.data_ptr(), L.ptr(z), coef.data_ptr(), stats.data_ptr(), L.ptr(gamma),
-                                      dx.data_ptr(), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), n, spatial, c, groups, act,
+                                      dx.data_ptr(), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), n, spatial, c, groups, act, in_act,
                                       L.dt(x), ws.data_ptr(), ws.numel(), L.stream()), "gn_act_bwd")
         return dx, (None if direct_g else dgamma), (None if direct_b else dbeta), dres, None, None, None, None, None
 
