@@ -757,6 +757,34 @@ def test_fp32_tensor_into_a_bf16_mode_conv_act_layer():
     assert_close(yg, yo, 2e-2, "crg with an fp32 input")
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_batched_repack_after_the_optimizer_step_equals_per_layer_packing(mode):
+    """train.BatchedRepack: after Adam, ONE launch rebuilds the packed images of all matrix-core conv layers in place; they
+    must be byte-identical to what the per-layer packing (nn._PackedWeightMixin._packed) would build from the new weights,
+    and the next forward must not repack them."""
+    from mednet_hip import ops as hops, train as T
+    from mednet_hip.synth import synthetic_batch
+    with mednet_hip.precision(mode):
+        net = O.keyed_init_(HM.ResidualUNet3D(1, 3, False, f_maps=[16, 32, 64])).to(DEV)
+        step = T.SegmentationStep(net, loss_weight=[0.2, 1.0, 1.0], lr=1e-2)
+        batch = {k: v.to(DEV) for k, v in synthetic_batch(2, 1, (16, 16, 32), 3, 0, seed=3).items()}
+        step(batch)   # first step packs layer by layer; its optimizer step is followed by the batched repack
+        step(batch)
+        assert step.repack.table is not None and len(step.repack.mods) >= 10
+        up = lambda v, a: (v + a - 1) // a * a
+        for m in step.repack.mods:
+            fresh = hops.pack_conv_weight(m.weight, 3, m._transposed)
+            w = m.weight
+            cin, cout = (w.shape[0], w.shape[1]) if m._transposed else (w.shape[1], w.shape[0])
+            # the four sections of a pack buffer (include/mednet_hip.h; the gaps between them are never written)
+            f32 = up(27 * cin * cout * 4, 256)
+            fwd, bwd = 27 * up(cout, 32) * cin * 2, 27 * up(cin, 32) * cout * 2
+            for lo, size in ((0, 27 * cin * cout * 4), (f32, 27 * cin * cout * 4), (2 * f32, fwd), (2 * f32 + up(fwd, 256), bwd)):
+                assert torch.equal(fresh[lo:lo + size], m._pack_buf[lo:lo + size]), "batched repack differs from the per-layer pack"
+            assert m._packed() is m._pack_buf, "the next forward would repack this layer"
+        step.flat.release()
+
+
 def test_bitwise_reproducible_step():
     """No float atomics anywhere: two runs of the same step give identical bits (race screen)."""
     ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64])

@@ -87,6 +87,42 @@ extern "C" int mednet_conv3d_pack_elt(const float* w, void* packed, int cin, int
   return launch_pack_f32(w, (float*)(base + L.f32_fwd), (float*)(base + L.f32_bwd), cin, cout, L.taps, transposed_src, s);
 }
 
+// ---- all layers at once: the table is built once per model (pointers of parameters and pack buffers do not move), the launch
+//      is repeated after every optimizer step
+extern "C" size_t mednet_conv3d_pack_table_bytes(int njobs) { return (size_t)njobs * sizeof(PackJobDev); }
+extern "C" int mednet_conv3d_pack_table(const mednet_pack_job* jobs, int njobs, void* table_host, unsigned* max_blocks) {
+  MEDNET_REQUIRE(jobs && table_host && max_blocks && njobs > 0, MEDNET_E_SHAPE, "conv3d_pack_table: bad arguments");
+  PackJobDev* t = (PackJobDev*)table_host;
+  unsigned mb = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const mednet_pack_job& j = jobs[i];
+    const PackLayout L = pack_layout(j.cin, j.cout, j.ksize);
+    MEDNET_REQUIRE(j.ksize == 3 && L.mfma_bytes, MEDNET_E_UNSUPPORTED,
+                   "conv3d_pack_table: layer %d (%d -> %d, k=%d) has no matrix-core images; pack it with mednet_conv3d_pack", i, j.cin,
+                   j.cout, j.ksize);
+    char* base = (char*)j.packed;
+    t[i].w = j.w;
+    t[i].sec_fwd = base + L.mfma_fwd;
+    t[i].sec_bwd = base + L.mfma_bwd;
+    t[i].Pf = (float*)(base + L.f32_fwd);
+    t[i].Pb = (float*)(base + L.f32_bwd);
+    t[i].cin = j.cin;
+    t[i].cout = j.cout;
+    t[i].transposed = j.transposed_src;
+    t[i].nblocks = pack_mfma_blocks(j.cin, j.cout);
+    t[i].pad[0] = t[i].pad[1] = 0;
+    if (t[i].nblocks > mb) mb = t[i].nblocks;
+  }
+  *max_blocks = mb;
+  return MEDNET_OK;
+}
+extern "C" int mednet_conv3d_pack_many(const void* table_device, int njobs, unsigned max_blocks, int elt_dtype,
+                                       mednet_stream stream) {
+  MEDNET_REQUIRE(is16(elt_dtype), MEDNET_E_DTYPE, "conv3d_pack_many: the matrix-core images are bf16 or fp16 (got dtype %d)", elt_dtype);
+  MEDNET_REQUIRE(table_device && njobs > 0 && njobs <= 65535 && max_blocks > 0, MEDNET_E_SHAPE, "conv3d_pack_many: bad arguments");
+  return ELT_CALL(elt_dtype, launch_pack_mfma_many, table_device, njobs, max_blocks, (hipStream_t)stream);
+}
+
 static int conv_common_checks(const char* who, int n, int d, int h, int w, int cin, int cout, int ksize, int dt1, int dt2) {
   MEDNET_REQUIRE(dtype_ok(dt1) && dtype_ok(dt2), MEDNET_E_DTYPE, "%s: bad dtype", who);
   MEDNET_REQUIRE(ksize == 3 || ksize == 1, MEDNET_E_UNSUPPORTED, "%s: kernel size %d (supported: 1, 3)", who, ksize);

@@ -1348,9 +1348,9 @@ int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d,
 // mode 1: conv dgrad    Weff[m][k][t] = W[k][m][26-t]                           M=Cin  K=Cout
 // mode 2: convT fwd     Weff[m][k][t] = Wt[k][m][t]           (Wt: Cin,Cout,27) M=Cout K=Cin
 // mode 3: convT dgrad   Weff[m][k][t] = Wt[m][k][t]                             M=Cin  K=Cout
-__global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict__ w, elt* __restrict__ out0,
-                                                        elt* __restrict__ out1, int M0, int K0, int mode0, int mode1,
-                                                        float* __restrict__ Pf, float* __restrict__ Pb, int transposed_src) {
+__device__ __forceinline__ void pack_mfma_body(const float* __restrict__ w, elt* __restrict__ out0, elt* __restrict__ out1,
+                                               int M0, int K0, int mode0, int mode1, float* __restrict__ Pf,
+                                               float* __restrict__ Pb, int transposed_src) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.y == 2) {  // the fp32 tap-major images of the direct kernels ride along in the same launch
     const int cin = K0, cout = M0, T = 27;
@@ -1393,6 +1393,19 @@ __global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict_
   else v = w[((size_t)m * K + k) * 27 + tap];
   out[e] = (elt)v;
 }
+__global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict__ w, elt* __restrict__ out0,
+                                                        elt* __restrict__ out1, int M0, int K0, int mode0, int mode1,
+                                                        float* __restrict__ Pf, float* __restrict__ Pb, int transposed_src) {
+  pack_mfma_body(w, out0, out1, M0, K0, mode0, mode1, Pf, Pb, transposed_src);
+}
+// all 3x3x3 layers of a network in ONE launch (after the optimizer step every layer's weights have moved): blockIdx.z = layer,
+// its descriptor comes from a device table built once (mednet_conv3d_pack_table); blocks beyond a layer's size exit
+__global__ __launch_bounds__(256) void pack_mfma_many_kernel(const PackJobDev* __restrict__ jobs) {
+  const PackJobDev j = jobs[blockIdx.z];
+  if (blockIdx.x >= j.nblocks) return;
+  pack_mfma_body(j.w, (elt*)j.sec_fwd, (elt*)j.sec_bwd, j.cout, j.cin, j.transposed ? 2 : 0, j.transposed ? 3 : 1, j.Pf, j.Pb,
+                 j.transposed);
+}
 
 PackLayout pack_layout(int cin, int cout, int ksize) {
   PackLayout L;
@@ -1421,6 +1434,16 @@ int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, float* Pf, fl
   hipLaunchKernelGGL(pack_mfma_kernel, grid, dim3(256), 0, s, w, (elt*)sec_fwd, (elt*)sec_bwd, cout, cin,
                      transposed_src ? 2 : 0, transposed_src ? 3 : 1, Pf, Pb, transposed_src);
   return check_launch("pack_mfma");
+}
+
+unsigned pack_mfma_blocks(int cin, int cout) {
+  const int cmax = cin > cout ? cin : cout, cmin = cin > cout ? cout : cin;
+  const size_t total = (size_t)((cmax + 31) / 32 * 32) * ((cmin + 31) / 32 * 32) * 27;
+  return (unsigned)((total + 255) / 256);
+}
+int launch_pack_mfma_many(const void* table_device, int njobs, unsigned max_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(pack_mfma_many_kernel, dim3(max_blocks, 3, (unsigned)njobs), dim3(256), 0, s, (const PackJobDev*)table_device);
+  return check_launch("pack_mfma_many");
 }
 
 // the kernels address ONE SAMPLE of the activation tensor through a buffer resource with 32-bit byte offsets

@@ -35,6 +35,9 @@ SIGNATURES = {
     "mednet_conv3d_pack_bytes": (_sz, [_i, _i, _i]),
     "mednet_conv3d_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mednet_conv3d_pack_elt": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mednet_conv3d_pack_table_bytes": (_sz, [_i]),
+    "mednet_conv3d_pack_table": (_i, [_vp, _i, _vp, _vp]),
+    "mednet_conv3d_pack_many": (_i, [_vp, _i, C.c_uint, _i, _vp]),
     "mednet_conv3d_fused_stats_chunks": (_i, [_i] * 10),
     "mednet_conv3d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp]),
     "mednet_gn_finalize": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _f, _vp, _sz, _vp]),

@@ -82,6 +82,57 @@ class FlatAdam:
             p._mednet_step = self.t
 
 
+class BatchedRepack:
+    """After an optimizer step every conv layer's packed weight images are stale; instead of one small launch per layer at
+    its next forward (23 per step for cfg2) ONE launch rebuilds the matrix-core layers' images (mednet_conv3d_pack_many).
+    The device table of (parameter, pack buffer, shape) is built once: parameters live in the flat buffer and the pack
+    buffers are rewritten in place.  Layers without matrix-core images (first conv, 1x1x1 head) keep the per-layer path."""
+
+    ENABLED = os.environ.get("MEDNET_BATCHED_PACK", "1") == "1"  # A/B knob
+
+    def __init__(self, model):
+        from . import nn as hnn
+        self.mods = [m for m in model.modules() if isinstance(m, hnn._PackedWeightMixin) and m.kernel_size[0] == 3
+                     and m.weight.shape[0] % 16 == 0 and m.weight.shape[1] % 16 == 0]
+        self.sig = None
+        self.table = None
+        self.max_blocks = 0
+
+    def _signature(self):
+        from . import config
+        return tuple((m.weight.data_ptr(), m._pack_buf.data_ptr()) for m in self.mods) + (config.act_dtype(),)
+
+    def run(self):
+        """Call right after the parameters changed (same stream).  No-op until every layer has been packed once."""
+        import ctypes as C
+        from . import _lib as L, config
+        if not self.ENABLED or not self.mods or any(getattr(m, "_pack_buf", None) is None for m in self.mods):
+            return
+        if not config.is_half_mode():
+            return
+        lib = L.lib()
+        sig = self._signature()
+        if sig != self.sig:
+            class Job(C.Structure):
+                _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("cin", C.c_int), ("cout", C.c_int), ("ksize", C.c_int),
+                            ("transposed_src", C.c_int)]
+            jobs = (Job * len(self.mods))()
+            for j, m in zip(jobs, self.mods):
+                w = m.weight
+                cin, cout = (w.shape[0], w.shape[1]) if m._transposed else (w.shape[1], w.shape[0])
+                j.w, j.packed, j.cin, j.cout, j.ksize, j.transposed_src = w.data_ptr(), m._pack_buf.data_ptr(), cin, cout, 3, int(m._transposed)
+            host = torch.empty(lib.mednet_conv3d_pack_table_bytes(len(self.mods)), dtype=torch.uint8)
+            mb = C.c_uint(0)
+            L.check(lib.mednet_conv3d_pack_table(C.addressof(jobs), len(self.mods), host.data_ptr(), C.addressof(mb)), "pack_table")
+            self.table = host.to(self.mods[0].weight.device)
+            self.max_blocks, self.sig = mb.value, sig
+        elt = L.F16 if config.act_dtype() == torch.float16 else L.BF16
+        L.check(lib.mednet_conv3d_pack_many(self.table.data_ptr(), len(self.mods), self.max_blocks, elt, L.stream()), "pack_many")
+        for m in self.mods:  # what _PackedWeightMixin._packed() will compute at the next forward
+            w = m.weight
+            m._pack_key = (w.data_ptr(), w._version, getattr(w, "_mednet_step", 0), str(w.device), config.act_dtype())
+
+
 class LossScaler:
     """Dynamic loss scaling for fp16 storage (BASELINE config 5; the reference's hint is the commented-out `precision=16` of
     examples/train_seg.py:127).  torch.cuda.amp.GradScaler's rule -- scale 2^16, halve on overflow, double after 2000 clean
@@ -232,6 +283,7 @@ class SegmentationStep(_GraphedStep):
         self.loss = (HL.DiceLoss(weight=w) if loss == "DICE" else HL.CrossEntropyLoss(weight=w)).to(dev)
         self.flat = FlatParams(model)
         self.opt = FlatAdam(self.flat, lr=lr)
+        self.repack = BatchedRepack(model)
         self.world = world_size
         ops.SIDE["enabled"] = os.environ.get("MEDNET_SIDE_STREAM", "1") == "1"
         self.scaler = make_scaler(dev)  # fp16 storage only
@@ -258,6 +310,7 @@ class SegmentationStep(_GraphedStep):
             self.opt.step(grad_scale=scale)
         else:
             self.opt.step_scaled(self.scaler, inv_world=scale)
+        self.repack.run()
         return loss
 
 
@@ -304,6 +357,7 @@ class LandmarkStep(_GraphedStep):
         self.loss_reg = HL.HeatmapRegressionLoss(regression_weight, regression).to(dev)
         self.flat = FlatParams(model)
         self.opt = FlatAdam(self.flat, lr=lr)
+        self.repack = BatchedRepack(model)
         self.world = world_size
         self.scaler = make_scaler(dev)
         self._init_graph(graph)
@@ -330,4 +384,5 @@ class LandmarkStep(_GraphedStep):
             self.opt.step(grad_scale=scale)
         else:
             self.opt.step_scaled(self.scaler, inv_world=scale)
+        self.repack.run()
         return out
