@@ -159,7 +159,7 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
   // first layer (one input channel): contraction over the 27 taps on the matrix cores
   if (!dgrad && algo != MEDNET_ALGO_DIRECT && x_layout == MEDNET_NDHWC &&
       ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, y_layout, bias != nullptr))
-    return ELT_CALL(y_dtype, launch_conv_c1_mfma, x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, gn_partial, s);
+    return ELT_CALL(y_dtype, launch_conv_c1_mfma, x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, gn_partial, s, x_dtype);
   MEDNET_REQUIRE(gn_partial == nullptr, MEDNET_E_UNSUPPORTED,
                  "conv3d_fwd: fused GroupNorm partials are only produced by the MFMA paths (ask mednet_conv3d_fused_stats_chunks)");
   // fp32 storage (the 1e-3 parity mode): 3x3x3 forward / data gradient on the fp32 matrix-core instruction

@@ -829,8 +829,8 @@ int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int 
                                               : wgrad_c1_mfma_supported(cout, x_dtype, dy_dtype);
   if (tuning_option("wgrad_c1_mfma", 1) && c1_mfma) {  // matrix-core form (16-bit modes)
     blocks = wgrad_c1_mfma_blocks(n, d, h, w);
-    int rc = dy_dtype == MEDNET_F16 ? mednet_f16::launch_wgrad_c1_mfma(x, dy, part, n, d, h, w, cout, s)
-                                    : launch_wgrad_c1_mfma(x, dy, part, n, d, h, w, cout, s);
+    int rc = dy_dtype == MEDNET_F16 ? mednet_f16::launch_wgrad_c1_mfma(x, dy, part, n, d, h, w, cout, s, x_dtype)
+                                    : launch_wgrad_c1_mfma(x, dy, part, n, d, h, w, cout, s, x_dtype);
     if (rc) return rc;
     const size_t count = (size_t)27 * cout;
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, part, dw, count, blocks);

@@ -1217,6 +1217,7 @@ struct C1Args {
   float* gn_partial; // nullable: [n][4 * bricks per sample][cout][2] per-wave {sum y, sum y^2} of the stored values
   int n, d, h, w_, cout;
   int tiles_z, tiles_y, tiles_x, ntiles, ncb;
+  int x16;  // 1: x holds elt values (the 1-channel output of a GroupNorm in the 'gcr' orders), else fp32 (the network input)
 };
 
 __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
@@ -1252,8 +1253,9 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
   for (int i = tid; i < NV; i += 256) {
     const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
     const int gz = tz0 - 1 + hz, gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+    const size_t gi = (((size_t)n * a.d + gz) * a.h + gy) * a.w_ + gx;
     xs[i] = (gz >= 0 && gz < a.d && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_)
-                ? a.x[(((size_t)n * a.d + gz) * a.h + gy) * a.w_ + gx]
+                ? (a.x16 ? (float)reinterpret_cast<const elt*>(a.x)[gi] : a.x[gi])
                 : 0.f;
   }
   __syncthreads();
@@ -1321,15 +1323,16 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
 }
 
 bool conv_c1_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int y_layout, bool bias) {
-  return cin == 1 && ksize == 3 && cout % 32 == 0 && x_dtype == MEDNET_F32 && y_dtype == ELT_DTYPE &&
+  return cin == 1 && ksize == 3 && cout % 32 == 0 && (x_dtype == MEDNET_F32 || x_dtype == ELT_DTYPE) && y_dtype == ELT_DTYPE &&
          y_layout == MEDNET_NDHWC && !bias;
 }
 int conv_c1_stats_chunks(int d, int h, int w) { return 4 * ((d + 3) / 4) * ((h + 7) / 8) * ((w + 15) / 16); }
 int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d, int h, int w, int cout, float* gn_partial,
-                        hipStream_t s) {
+                        hipStream_t s, int x_dtype) {
   C1Args a;
   a.gn_partial = gn_partial;
   a.x = (const float*)x;
+  a.x16 = x_dtype != MEDNET_F32;
   a.w = w_pf;
   a.y = (elt*)y;
   a.n = n; a.d = d; a.h = h; a.w_ = w; a.cout = cout;
@@ -2115,6 +2118,7 @@ struct Wc1Args {
   int tiles_z, tiles_y, tiles_x, ntiles;
   unsigned rcp_tiles_x, rcp_tiles_y, rcp_tiles_z;
   unsigned bytes_x, bytes_dy;  // per sample
+  int x16;                     // 1: x holds elt values, else fp32
 };
 
 template <int NB>  // 32-channel blocks of dy
@@ -2153,6 +2157,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_mfma_kernel(Wc1Args a) {
     const size_t svox = (size_t)qd * a.d * a.h * a.w;
     const auto rD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + svox * a.cout), 0, a.bytes_dy, 0x00020000);
     const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + svox), 0, a.bytes_x, 0x00020000);
+    const auto rX16 = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const elt*>(a.x) + svox), 0, a.bytes_x, 0x00020000);
 #pragma unroll
     for (int it = 0; it < DY_ROUNDS; ++it) {
       const int c = it * 256 + tid;
@@ -2167,8 +2172,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_mfma_kernel(Wc1Args a) {
       const int v = it * 256 + tid;
       const int gz = tz0 - 1 + v / (HX * HY), gy = ty0 - 1 + (v / HX) % HY, gx = tx0 - 1 + v % HX;
       const bool in_vol = (v < NH) & ((unsigned)gz < (unsigned)a.d) & ((unsigned)gy < (unsigned)a.h) & ((unsigned)gx < (unsigned)a.w);
-      const unsigned off = (unsigned)((gz * a.h + gy) * a.w + gx) * 4u;
-      rx[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, in_vol ? off : OOB, 0, 0));
+      const unsigned vidx = (unsigned)((gz * a.h + gy) * a.w + gx);
+      if (a.x16) {  // (wave-uniform) 2-byte elements: a 16-bit buffer load of the element, widened
+        const unsigned short raw = __builtin_amdgcn_raw_buffer_load_b16(rX16, in_vol ? vidx * 2u : OOB, 0, 0);
+        rx[it] = (float)__builtin_bit_cast(elt, raw);
+      } else {
+        rx[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, in_vol ? vidx * 4u : OOB, 0, 0));
+      }
     }
   };
   auto commit = [&]() {
@@ -2236,15 +2246,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_mfma_kernel(Wc1Args a) {
 }
 
 bool wgrad_c1_mfma_supported(int cout, int x_dtype, int dy_dtype) {
-  return (cout == 32 || cout == 64) && x_dtype == MEDNET_F32 && dy_dtype == ELT_DTYPE;
+  return (cout == 32 || cout == 64) && (x_dtype == MEDNET_F32 || x_dtype == ELT_DTYPE) && dy_dtype == ELT_DTYPE;
 }
 int wgrad_c1_mfma_blocks(int n, int d, int h, int w) {
   const int nt = n * ((d + 3) / 4) * ((h + 7) / 8) * ((w + 15) / 16);
   return nt < 1024 ? nt : 1024;
 }
-int launch_wgrad_c1_mfma(const void* x, const void* dy, float* part, int n, int d, int h, int w, int cout, hipStream_t s) {
+int launch_wgrad_c1_mfma(const void* x, const void* dy, float* part, int n, int d, int h, int w, int cout, hipStream_t s,
+                         int x_dtype) {
   Wc1Args a;
   a.x = (const float*)x;
+  a.x16 = x_dtype != MEDNET_F32;
   a.dy = (const elt*)dy;
   a.part = part;
   a.n = n; a.d = d; a.h = h; a.w = w; a.cout = cout;
@@ -2253,7 +2265,7 @@ int launch_wgrad_c1_mfma(const void* x, const void* dy, float* part, int n, int 
   auto rcp = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
   a.rcp_tiles_x = rcp(a.tiles_x); a.rcp_tiles_y = rcp(a.tiles_y); a.rcp_tiles_z = rcp(a.tiles_z);
   MEDNET_REQUIRE((double)d * h * w * cout * 2.0 < 4294960000.0, MEDNET_E_UNSUPPORTED, "wgrad_c1_mfma: one sample must stay below 4 GB");
-  a.bytes_x = (unsigned)((size_t)d * h * w * 4);
+  a.bytes_x = (unsigned)((size_t)d * h * w * (a.x16 ? 2 : 4));
   a.bytes_dy = (unsigned)((size_t)d * h * w * cout * 2);
   const int blocks = wgrad_c1_mfma_blocks(n, d, h, w);
   const int nb = cout / 32;
