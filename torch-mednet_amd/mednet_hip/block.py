@@ -162,7 +162,7 @@ class ResBlockFn(Function):
         ctx.meta = (groups, act)
         ctx.gn3 = hook
         if hook is not None:
-            hook.y3, hook.act = y3, act
+            hook.gn_in, hook.act = y3, act
         return out
 
     @staticmethod

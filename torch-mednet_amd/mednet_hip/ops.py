@@ -145,10 +145,10 @@ class GN3Hook:
     output gradient (mednet_head_dgrad_gn / mednet_pool2_bwd_gn).  The block's backward uses the sums only if the gradient it
     receives IS that tensor, untouched (same object, same version counter): any other consumer of `out` makes autograd
     accumulate into / replace it, and the block falls back to its stand-alone pass."""
-    __slots__ = ("y3", "act", "partial", "dx", "version")
+    __slots__ = ("gn_in", "act", "partial", "dx", "version")
 
     def __init__(self):
-        self.y3 = None
+        self.gn_in = None  # the GroupNorm's input (y3 of an ExtResNetBlock; x of a plain GroupNorm)
         self.act = 0
         self.partial = self.dx = None
         self.version = -1
@@ -201,7 +201,7 @@ class ActMaskHook:
 
 def _gnb_hook_of(x, dtype):
     h = getattr(x, "_mednet_gnb", None) if FUSE_GN3 else None
-    if h is None or h.y3 is None or h.y3.shape != x.shape or h.y3.dtype != dtype or dtype not in config.HALF_TYPES:
+    if h is None or h.gn_in is None or h.gn_in.shape != x.shape or h.gn_in.dtype != dtype or dtype not in config.HALF_TYPES:
         return None
     return h
 GN3_COUNT = {"taken": 0, "declined": 0, "absent": 0, "masked": 0}  # (tests: how the blocks' backward passes found their sums)
@@ -209,7 +209,7 @@ GN3_COUNT = {"taken": 0, "declined": 0, "absent": 0, "masked": 0}  # (tests: how
 
 def _gn3_hook_of(x, dtype):
     h = getattr(x, "_mednet_gn3", None) if FUSE_GN3 else None
-    if h is None or h.y3 is None or h.y3.shape != x.shape or h.y3.dtype != dtype or dtype not in config.HALF_TYPES:
+    if h is None or h.gn_in is None or h.gn_in.shape != x.shape or h.gn_in.dtype != dtype or dtype not in config.HALF_TYPES:
         return None
     return h
 
@@ -266,7 +266,7 @@ class Conv3dFn(Function):
                 rows = lib.mednet_head_dgrad_gn_rows(n, d, h, w, cin, L.dt(dx))
             if rows > 0:  # + the first pass of the producing block's GroupNorm-3 backward (xin IS that block's output)
                 partial = torch.empty((n, rows, cin, 2), dtype=torch.float32, device=dy.device)
-                L.check(lib.mednet_head_dgrad_gn(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), hook.y3.data_ptr(),
+                L.check(lib.mednet_head_dgrad_gn(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), hook.gn_in.data_ptr(),
                                                  xin.data_ptr(), hook.act, partial.data_ptr(), n, d, h, w, cin, cout, L.dt(dx),
                                                  L.stream()), "head_dgrad_gn")
                 hook.offer(dx, partial)
@@ -346,7 +346,7 @@ class ConvActFn(Function):
                     "act_bwd")
         hook = ctx.gnb
         dx, dw, partial = block._conv_bwd(xin, du, packed, ctx.weight, ctx.needs_input_grad[0],
-                                          gnb=None if hook is None else (hook.y3, hook.coef, hook.act))
+                                          gnb=None if hook is None else (hook.gn_in, hook.coef, hook.act))
         if partial is not None:
             hook.offer(dx, partial)
         return dx, dw, None, None, None, None
@@ -412,7 +412,7 @@ class ConvT3dFn(Function):
                 rows = lib.mednet_convt3d_dgrad_gn_rows(n, d, h, w, cin, cout, L.dt(dx), config.conv_algo())
             if rows > 0:  # + the first pass of the producing block's GroupNorm-3 backward (x IS that block's output)
                 partial = torch.empty((n, rows, cin, 2), dtype=torch.float32, device=dy.device)
-                L.check(lib.mednet_convt3d_dgrad_gn(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), hook.y3.data_ptr(),
+                L.check(lib.mednet_convt3d_dgrad_gn(dy.data_ptr(), packed.data_ptr(), dx.data_ptr(), hook.gn_in.data_ptr(),
                                                     x.data_ptr(), hook.act, partial.data_ptr(), n, d, h, w, cin, cout, L.dt(dx),
                                                     config.conv_algo(), L.stream()), "convt3d_dgrad_gn")
                 hook.offer(dx, partial)
@@ -479,7 +479,7 @@ class GroupNormActFn(Function):
         ctx.params = (gamma, beta)
         ctx.gnb = hook
         if hook is not None:
-            hook.y3, hook.coef, hook.act = x, coef, act
+            hook.gn_in, hook.coef, hook.act = x, coef, act
         return z
 
     @staticmethod
@@ -696,7 +696,7 @@ class SkipPool2Fn(Function):
         rows = L.lib().mednet_pool2_bwd_gn_rows(n, d, h, w, c, L.dt(x)) if hook is not None else 0
         if rows > 0:  # + the first pass of the producing block's GroupNorm-3 backward (x IS that block's output)
             partial = torch.empty((n, rows, c, 2), dtype=torch.float32, device=x.device)
-            L.check(L.lib().mednet_pool2_bwd_gn(dy.data_ptr(), x.data_ptr(), L.ptr(dskip), dx.data_ptr(), hook.y3.data_ptr(),
+            L.check(L.lib().mednet_pool2_bwd_gn(dy.data_ptr(), x.data_ptr(), L.ptr(dskip), dx.data_ptr(), hook.gn_in.data_ptr(),
                                                 hook.act, partial.data_ptr(), n, d, h, w, c, ctx.mode, L.dt(x), L.stream()),
                     "pool2_bwd_gn")
             hook.offer(dx, partial)
