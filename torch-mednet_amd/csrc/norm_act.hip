@@ -186,14 +186,29 @@ __global__ __launch_bounds__(64) void reduce_partials_dux_kernel(const float* __
                                                                  const float* __restrict__ stats, float* __restrict__ csum,
                                                                  int c, int groups, int chunks) {
   const int n = blockIdx.x / c, cc = blockIdx.x % c;
-  double a = 0.0, b = 0.0;
-  for (int ch = threadIdx.x; ch < chunks; ch += 64) {
-    const float* p = partial + (((size_t)n * chunks + ch) * c + cc) * 2;
-    a += (double)p[0];
-    b += (double)p[1];
+  double a = 0.0, b = 0.0, a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;  // four row loads in flight
+  const float* base = partial + ((size_t)n * chunks * c + cc) * 2;
+  const size_t rs = (size_t)c * 2;
+  int ch = threadIdx.x;
+  for (; ch + 192 < chunks; ch += 256) {
+    const float2 p0 = *reinterpret_cast<const float2*>(base + ch * rs), p1 = *reinterpret_cast<const float2*>(base + (ch + 64) * rs);
+    const float2 p2 = *reinterpret_cast<const float2*>(base + (ch + 128) * rs), p3 = *reinterpret_cast<const float2*>(base + (ch + 192) * rs);
+    a += (double)p0.x;
+    b += (double)p0.y;
+    a1 += (double)p1.x;
+    b1 += (double)p1.y;
+    a2 += (double)p2.x;
+    b2 += (double)p2.y;
+    a3 += (double)p3.x;
+    b3 += (double)p3.y;
   }
-  a = wave_sum(a);
-  b = wave_sum(b);
+  for (; ch < chunks; ch += 64) {
+    const float2 p0 = *reinterpret_cast<const float2*>(base + ch * rs);
+    a += (double)p0.x;
+    b += (double)p0.y;
+  }
+  a = wave_sum((a + a1) + (a2 + a3));
+  b = wave_sum((b + b1) + (b2 + b3));
   if (threadIdx.x == 0) {
     const int g = cc / (c / groups);
     const double mean = stats[((size_t)n * groups + g) * 2], rstd = stats[((size_t)n * groups + g) * 2 + 1];
