@@ -162,6 +162,26 @@ def fp32_parity_mode(dev, batch: int, patch: int, steps: int):
     return rec
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, RCCL over xGMI) as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
+    arguments>` -- the command line the driver itself uses -- as a child process and return its exit code."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,14 +196,28 @@ def main():
                     help="timed steps of the fp32 (1e-3 parity) mode for the fp32_parity_mode sub-record (0 = skip)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("MEDNET_GRAPH", "0")),
                     help="1: replay forward+loss+backward as one captured hipGraph per step (train._GraphedStep)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="every rank prints its RANK/LOCAL_RANK/WORLD_SIZE as one JSON line and exits (no GPU call): "
+                         "checks the launcher on a box without GPUs")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Bare `python bench.py --gpus N`: this process becomes the launcher.  It has made no GPU call (importing torch
+        # does not initialise HIP) and never will: the N ranks are CHILD processes of torch.distributed.run, rank 0's
+        # JSON line passes through the inherited stdout, and the launcher exits with the children's return code.
+        raise SystemExit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: one rank per GPU, launch with "
+                         f"--nproc-per-node {a.gpus} (or run bare `python bench.py --gpus {a.gpus}`, which launches the ranks)")
+    if a.dry_launch:
+        print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world_size": world,
+                          "master": f"{os.environ.get('MASTER_ADDR', '')}:{os.environ.get('MASTER_PORT', '')}",
+                          "pid": os.getpid()}), flush=True)
+        return
+    assert torch.cuda.is_available(), (f"bench.py rank {rank}/{world} needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("MEDNET_FORCE_DIST") == "1"  # the latter: 1-rank RCCL rehearsal
@@ -249,7 +283,8 @@ def main():
             "config": {"workload": f"ResidualUNet3D f_maps={F_MAPS} 4-class, {P}^3 patches, batch {a.batch}/GPU, "
                                    f"fwd+DiceLoss+bwd+allreduce+Adam (BASELINE config {'2' if world == 1 else '3'})",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "loss": round(final_loss, 6),
-                       "graph_replay": bool(a.graph)},
+                       "graph_replay": bool(a.graph),
+                       "gradient_exchange": step._exchange.describe() if step._exchange is not None else "none"},
             "host_enqueue_ms_per_step": round(1e3 * t_issue / n_issue, 3),
         }
         if P == 128 and a.precision == "bf16":

@@ -148,3 +148,111 @@ def test_synth_generators_match_oracle():
     m2 = synth.keyed_init_(O.ResidualUNet3D(1, 4, False, f_maps=[8, 16]))
     for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.equal(p, q), k
+
+
+def _torch_adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """CPU stand-in for the fused Adam launch (ops.adam_step_ -> mednet_adam_step): torch.optim.Adam's update on the flat
+    buffers, with the gradient scale (1/world) the kernel folds in."""
+    g = g * grad_scale
+    if weight_decay:
+        g = g + weight_decay * p
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    denom = (v / (1 - beta2 ** step)).sqrt_().add_(eps)
+    p.addcdiv_(m / (1 - beta1 ** step), denom, value=-lr)
+
+
+def _step_worker(rank, world, port, out, buckets):
+    for p in (ROOT, os.path.join(ROOT, "torch-mednet_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MEDNET_BUCKETS=buckets)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle import ref_cpu as O
+    from mednet_hip import ops
+    from mednet_hip.train import SegmentationStep
+    ops.adam_step_ = _torch_adam_step_  # the one device launch of __call__ that has no CPU form
+    w = [0.05, 1.0]
+    model = _cpu_hybrid_of_product_model(O)
+    step = SegmentationStep(model, loss_weight=w, lr=1e-3, world_size=world)
+    step.loss = O.DiceLoss(weight=torch.tensor(w))  # (the product's DiceLoss is a HIP kernel)
+    step.flat.grads_as_attr()  # CPU leaves: autograd accumulates straight into the flat gradient slices
+    losses = []
+    for it in range(3):
+        step.flat.grad.zero_()
+        batch = O.synthetic_batch(1, 1, (16, 16, 16), 2, 0, seed=500 + 10 * it + rank)
+        losses.append(float(step(batch)))
+    assert step._exchange.enabled == (buckets == "1")
+    torch.save({"params": step.flat.flat.clone(), "losses": losses, "t": step.opt.t,
+                "exchange": step._exchange.describe()}, os.path.join(out, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("buckets", ["0", "1"])
+def test_segmentation_step_call_world2(tmp_path, buckets):
+    """SegmentationStep.__call__ end to end on two gloo ranks: forward/backward of the product's module skeleton, the
+    gradient exchange (single all-reduce, or the two-bucket overlapped form), 1/world folded into the Adam update, three
+    steps.  Both ranks must hold identical parameters, equal to a one-process run that averages the two ranks' gradients
+    (Dice over the LOCAL batch, then the mean of the gradients) and steps torch.optim.Adam."""
+    port = 33500 + (os.getpid() % 2000) + int(buckets)
+    mp.spawn(_step_worker, args=(2, port, str(tmp_path), buckets), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "s0.pt")
+    r1 = torch.load(tmp_path / "s1.pt")
+    assert r0["t"] == r1["t"] == 3
+    assert torch.equal(r0["params"], r1["params"])
+    assert ("2 buckets" in r0["exchange"]) == (buckets == "1")
+    from oracle import ref_cpu as O
+    from mednet_hip.train import FlatParams
+    ref = O.keyed_init_(O.ResidualUNet3D(1, 2, False, f_maps=[8, 16, 32]))
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    crit = O.DiceLoss(weight=torch.tensor([0.05, 1.0]))
+    for it in range(3):
+        grads = []
+        for rank in range(2):
+            opt.zero_grad()
+            O.seg_training_step(ref, crit, O.synthetic_batch(1, 1, (16, 16, 16), 2, 0, seed=500 + 10 * it + rank)).backward()
+            grads.append([p.grad.clone() for p in ref.parameters()])
+        for p, g0, g1 in zip(ref.parameters(), *grads):
+            p.grad = 0.5 * (g0 + g1)
+        opt.step()
+    flat = FlatParams(ref)  # same flat order as the ranks'
+    assert torch.allclose(r0["params"], flat.flat, rtol=2e-5, atol=2e-7)
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_gpus2_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher around it must BE the launcher: two child ranks, each with its own
+    RANK/LOCAL_RANK and WORLD_SIZE=2 (examples/train_seg.py:126 Trainer(gpus=N)).  --dry-launch stops before any GPU call."""
+    import json
+    r = _run_bench(["--gpus", "2", "--dry-launch"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert sorted(x["rank"] for x in recs) == [0, 1]
+    assert all(x["world_size"] == 2 and x["local_rank"] == x["rank"] and x["master"].startswith("127.0.0.1:") for x in recs)
+    assert len({x["pid"] for x in recs}) == 2
+
+
+def test_bench_world_size_mismatch_is_an_error():
+    r = _run_bench(["--gpus", "2", "--dry-launch"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
+    r = _run_bench(["--gpus", "1", "--dry-launch"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the loud failure on a box WITHOUT GPUs")
+def test_bench_gpus2_without_gpus_fails_inside_both_ranks():
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "rank 0/2 needs an MI355X" in r.stderr and "rank 1/2 needs an MI355X" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]  # no 1-GPU number under an N-GPU label

@@ -201,11 +201,34 @@ class BucketedExchange:
     def __init__(self, model, flat: FlatParams, world_size: int, force: bool = False, levels: int = 2):
         self.flat, self.world, self.work = flat, world_size, None
         self.split = late_bucket_split(model, flat, levels) if (world_size > 1 or force) else None
-        # Opt-in (MEDNET_BUCKETS=1): in the one-rank RCCL rehearsal on an MI355X the collective launched inside backward
-        # cost the compute stream 0.6 ms, four times what the single 35 MB all-reduce after backward costs (0.14 ms).
-        self.enabled = self.split is not None and os.environ.get("MEDNET_BUCKETS", "0") == "1"
+        # MEDNET_BUCKETS=1/0 forces the choice; unset it follows the size of the exchange: in the one-rank RCCL rehearsal on
+        # an MI355X the collective launched inside backward cost the compute stream 0.6 ms, four times what the single
+        # 35 MB all-reduce of cfg3 costs after backward (0.14 ms; its ring time over xGMI is ~0.4 ms of a 22 ms step), so
+        # small models keep ONE exchange; cfg5's 565 MB is ~6.5 ms single-ring against a 52 ms step and
+        # goes under the backward of the full-resolution encoders.
+        self.enabled = self.split is not None and self.overlap_selected(flat.total * 4)
         if self.enabled:
             list(model.encoders)[levels - 1].register_forward_hook(self._on_forward)
+
+    AUTO_OVERLAP_BYTES = 128 << 20
+
+    @classmethod
+    def overlap_selected(cls, grad_bytes: int) -> bool:
+        forced = os.environ.get("MEDNET_BUCKETS")
+        if forced in ("0", "1"):
+            return forced == "1"
+        return grad_bytes > cls.AUTO_OVERLAP_BYTES
+
+    def describe(self) -> str:
+        """For bench records: which exchange this step runs."""
+        if not (self.world > 1 or getattr(self, "force", False)):
+            return "none (1 rank)"
+        mb = self.flat.total * 4 / 1e6
+        if self.enabled:
+            early = (self.flat.total - self.split) * 4 / 1e6
+            return (f"2 buckets: {early:.1f} MB all-reduced under the backward of the full-resolution encoders, "
+                    f"{mb - early:.1f} MB after backward")
+        return f"one all-reduce of the flat fp32 gradient buffer ({mb:.1f} MB) after backward"
 
     def _on_forward(self, module, inputs, output):
         if isinstance(output, tuple):  # Encoder(x, with_skip=True) -> (skip, out): the hook belongs on the level's output
