@@ -82,6 +82,56 @@ def cpu_baseline(steps: int):
                       f"1 warm-up + {steps} timed steps (median {med:.2f} s/step)"}
 
 
+def cfg1_plumbing(dev, steps: int = 20):
+    """BASELINE config 1 -- the call sequence of examples/train_seg.py: ResidualUNet3D f_maps=[8] (1 level), 2 classes, 32^3
+    patches, batch 2, fp32, SegmentationNet.training_step + Adam.  The reference runs it on PyTorch CPU: the oracle is timed
+    on the host cores, the same step through the HIP path (fp32 storage mode) beside it.  It is plumbing, not a benchmark
+    (1.5 GFLOP per batch: launch-bound on the GPU)."""
+    import mednet_hip
+    from oracle import ref_cpu as O
+    from mednet_hip.train import SegmentationStep
+    from mednet_hip.unet.model import ResidualUNet3D
+    from mednet_hip.synth import keyed_init_, synthetic_batch
+    w = [0.05, 1.0]
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    ora = O.keyed_init_(O.ResidualUNet3D(1, 2, False, f_maps=[8]))
+    opt = torch.optim.Adam(ora.parameters(), lr=1e-3)
+    crit = O.DiceLoss(weight=torch.tensor(w))
+    batch = O.synthetic_batch(2, 1, (32, 32, 32), 2, 0, seed=1234)
+    times, first_cpu = [], None
+    for _ in range(steps + 3):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        lo = O.seg_training_step(ora, crit, batch)
+        lo.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+        if first_cpu is None:
+            first_cpu = float(lo.detach())
+    cpu_s = sorted(times[3:])[len(times[3:]) // 2]
+    with mednet_hip.precision("fp32"):
+        model = keyed_init_(ResidualUNet3D(1, 2, False, f_maps=[8])).to(dev)
+        step = SegmentationStep(model, loss_weight=w, lr=1e-3)
+        b = {k: v.to(dev) for k, v in synthetic_batch(2, 1, (32, 32, 32), 2, 0, seed=1234).items()}
+        first_hip = float(step(b))
+        for _ in range(2):
+            step(b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(b)
+        torch.cuda.synchronize()
+        hip_s = (time.perf_counter() - t0) / steps
+        step.flat.release()
+    del model, step
+    return {"workload": "BASELINE config 1: ResidualUNet3D f_maps=[8] 2-class, 32^3 patches, batch 2, fp32, "
+                        "training_step + Adam (examples/train_seg.py call sequence)",
+            "cpu_oracle_patches_per_s": round(2 / cpu_s, 2), "cpu_cores": cores, "cpu_model": cpu_model(), "cpu_kind": "port",
+            "hip_fp32_patches_per_s": round(2 / hip_s, 1), "first_step_loss_cpu": round(first_cpu, 6),
+            "first_step_loss_hip": round(first_hip, 6), "steps": steps, "unit": "32^3 patches/s"}
+
+
 DOMINANT_KEY = "mednet::conv32_mfma_kernel<4> conv3d 32->32@128^3 (forward launches with fused GroupNorm statistics, grid=65536)"
 KERNEL_SOURCE = os.path.join(ROOT, "torch-mednet_amd", "csrc", "conv_mfma.hip")
 
@@ -307,6 +357,7 @@ def main():
             out["fp32_parity_mode"] = fp32_parity_mode(dev, a.batch, P, a.fp32_steps)
         if a.cpu_steps > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.cpu_steps)
+            out["cfg1_plumbing"] = cfg1_plumbing(dev)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -506,7 +506,7 @@ def test_blocks_against_reference_golden(golden_dir):
 
     E, D = HC.ExtResNetBlock, HC.DoubleConv
     cases = {f"single_{o}": (lambda o=o: HC.SingleConv(8, 16, 3, o, 8), [("single_" + o, (2, 8, 6, 10, 12))])
-             for o in ["cge", "gcr", "cg", "cr", "cl", "ce", "crg"]}
+             for o in ["cge", "gcr", "cg", "cr", "cl", "ce", "crg", "bcr", "cbe"]}  # b: stock nn.BatchNorm3d between HIP ops
     cases.update({
         "single_cge_c4": (lambda: HC.SingleConv(4, 4, 3, "cge", 8), [("single_cge_c4", (1, 4, 5, 6, 7))]),
         "double_enc_gcr": (lambda: D(8, 32, True, 3, "gcr", 8), [("double_enc", (1, 8, 8, 8, 8))]),
@@ -534,6 +534,34 @@ def test_blocks_against_reference_golden(golden_dir):
                 assert_close(t.grad, torch.from_numpy(rec[f"{tag}.dx{i}"]), 5e-4, f"{tag}.dx{i}")
             for k, p in m.named_parameters():
                 assert_close(p.grad, torch.from_numpy(rec[f"{tag}.dp.{k}"]), 5e-4, f"{tag}.dp.{k}")
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("order", ["bcr", "cbe"])
+def test_batchnorm_orders_in_the_16_bit_modes(mode, order):
+    """Order char 'b' (components.py:58-63): a stock nn.BatchNorm3d fed by / feeding the HIP conv in 16-bit channels-last
+    storage -- the place where a silent layout or dtype slip would hide.  Against the oracle on 16-bit-representable inputs."""
+    half = torch.bfloat16 if mode == "bf16" else torch.float16
+    x = torch.from_numpy(O._rng(f"bn16{order}").standard_normal((2, 16, 6, 10, 12)).astype(np.float32)).to(half).float()
+    ora = O.keyed_init_(O.SingleConv(16, 32, 3, order, 8))
+    xo = x.clone().requires_grad_(True)
+    yo = ora(xo)
+    g = torch.from_numpy(O._rng("bn16cot").standard_normal(tuple(yo.shape)).astype(np.float32))
+    (yo * g).sum().backward()
+    with mednet_hip.precision(mode):
+        net = O.keyed_init_(HC.SingleConv(16, 32, 3, order, 8)).to(DEV)
+        xg = x.to(DEV).requires_grad_(True)
+        yg = net(xg)
+        assert tuple(yg.shape) == tuple(yo.shape)
+        (yg.float() * g.to(DEV)).sum().backward()
+    tol_y, tol_g = (1.5e-2, 3e-2) if mode == "bf16" else (2e-3, 4e-3)
+    assert_close(yg, yo, tol_y, f"{order} y")
+    assert_close(xg.grad, xo.grad, tol_g, f"{order} dx")
+    for (k, a), (_, b) in zip(net.named_parameters(), ora.named_parameters()):
+        assert_close(a.grad, b.grad, tol_g, f"{order} d{k}")
+    for (k, a), (_, b) in zip(net.named_buffers(), ora.named_buffers()):  # running statistics moved the same way
+        if a.dtype.is_floating_point:
+            assert_close(a, b, tol_y, f"{order} buffer {k}")
 
 
 @pytest.mark.parametrize("groups", [8, 16, 32])
@@ -711,12 +739,41 @@ def test_plain_groupnorm_backward_sums_from_the_following_conv(mode, order, cin,
         taken = hops.GN3_COUNT["taken"] - before["taken"]
         assert taken == (2 if fused else 0), f"fused={fused}: {taken} GroupNorm backward passes took the conv's sums"
         masked = hops.GN3_COUNT["masked"] - before.get("masked", 0)  # the first layer's act' folded into the second GroupNorm's backward
-        assert masked == (1 if fused else 0), f"fused={fused}: {masked} activation-backward passes were folded away"
+        # (only ReLU layers are folded: applied twice -- when the conv layer has to decline -- a 0/1 mask stays a mask, ELU's or
+        #  LeakyReLU's derivative would not)
+        assert masked == (1 if fused and order == "gcr" else 0), f"fused={fused}: {masked} activation-backward passes were folded away"
     names = ["dx"] + [k for k, _ in net.named_parameters()]
     for k, a, b in zip(names, res[True], res[False]):
         # (the folded activation derivative saves one rounding of the intermediate gradient to 16 bits: the two paths differ
         #  by that rounding, 2^-9 relative per element in bf16)
         assert_close(a, b, 4e-3 if mode == "bf16" else 1e-3, f"fused vs stand-alone {k}")
+
+
+@pytest.mark.parametrize("order", ["gcr", "gcl", "gce"])
+def test_activation_fold_with_a_second_consumer_of_the_conv_layer_output(order):
+    """ops.ActMaskHook decline path: the output z of a fused conv -> activation layer feeds the next layer's GroupNorm AND a
+    second consumer, so autograd sums two gradients of z and the conv layer must run its own activation backward.  Whatever
+    the next GroupNorm folded into its dx must then not be applied a second time (ReLU: idempotent; LeakyReLU / ELU: the
+    fold is off).  Checked against the CPU oracle modules in fp64-free fp32 with bf16 tolerances."""
+    cin, shape = 32, (8, 8, 16)
+    x = torch.from_numpy(O._rng(f"fold2{order}").standard_normal((1, cin) + shape).astype(np.float32))
+    with mednet_hip.precision("bf16"):
+        l1, l2 = O.keyed_init_(HC.SingleConv(cin, cin, 3, order, 8)).to(DEV), O.keyed_init_(HC.SingleConv(cin, cin, 3, order, 8)).to(DEV)
+        xg = x.to(DEV).to(torch.bfloat16).requires_grad_(True)
+        z = l1(xg)
+        y = l2(z)
+        c1 = torch.from_numpy(O._rng("fold2c1").standard_normal(tuple(y.shape)).astype(np.float32)).to(DEV)
+        c2 = torch.from_numpy(O._rng("fold2c2").standard_normal(tuple(z.shape)).astype(np.float32)).to(DEV)
+        ((y.float() * c1).sum() + (z.float() * c2).sum()).backward()
+        got = [xg.grad.float().cpu()] + [p.grad.cpu() for p in list(l1.parameters()) + list(l2.parameters())]
+    o1, o2 = O.keyed_init_(O.SingleConv(cin, cin, 3, order, 8)), O.keyed_init_(O.SingleConv(cin, cin, 3, order, 8))
+    xo = x.to(torch.bfloat16).float().requires_grad_(True)
+    zo = o1(xo)
+    yo = o2(zo.clone())  # (the oracle's activations are in-place)
+    ((yo * c1.cpu()).sum() + (zo * c2.cpu()).sum()).backward()
+    want = [xo.grad] + [p.grad for p in list(o1.parameters()) + list(o2.parameters())]
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert_close(a, b, 3e-2, f"{order}: gradient {i} with a second consumer of the conv layer's output")
 
 
 def test_groupnorm3_sums_are_declined_when_the_block_output_has_a_second_consumer():

@@ -410,6 +410,44 @@ def test_channel_split_losses_write_one_gradient_buffer(cls_loss):
     assert g_fused.is_contiguous()
 
 
+def test_channel_split_with_two_losses_on_one_slice():
+    """Dice AND cross-entropy on the class slice (and the regression loss applied twice on the heat-map slice): only the
+    first backward of a slice may write the shared buffer; the others get tensors of their own and autograd sums them.
+    Must equal plain slicing."""
+    from mednet_hip import ops as hops
+    n, nh, nc, sp = 2, 3, 3, (4, 6, 8)
+    g = torch.Generator().manual_seed(9)
+    logits = torch.randn(n, nh + nc, *sp, generator=g)
+    hm = torch.randint(0, 256, (n, nh, *sp), generator=g, dtype=torch.uint8)
+    lab = torch.randint(0, nc, (n, *sp), generator=g)
+    cw = torch.tensor([0.1, 1.0, 2.0])
+
+    def run(split):
+        x = logits.to(DEV).requires_grad_(True)
+        a, b = split(x)
+        loss = hops.dice_loss(b, lab.to(DEV), cw.to(DEV)) + 3.0 * hops.cross_entropy(b, lab.to(DEV), cw.to(DEV)) \
+            + hops.heatmap_loss(a, hm.to(DEV), [0.3, 1.0, 0.7], "L2") + 0.5 * hops.heatmap_loss(a, hm.to(DEV), [1.0, 0.2, 0.4], "L1")
+        loss.backward()
+        return x.grad
+
+    g_fused = run(lambda x: hops.split_channels(x, nh))
+    g_plain = run(lambda x: (x[:, :nh], x[:, nh:]))
+    assert_close(g_fused, g_plain, 1e-6, "two losses per slice")
+    # and against ATen on the CPU
+    x = logits.clone().requires_grad_(True)
+    a, b = x[:, :nh], x[:, nh:]
+    p = torch.softmax(b, 1)
+    oh = torch.nn.functional.one_hot(lab, nc).permute(0, 4, 1, 2, 3).float()
+    inter = (p * oh).transpose(0, 1).flatten(1).sum(-1) * cw
+    den = (p + oh).transpose(0, 1).flatten(1).sum(-1)
+    dice = torch.mean(1 - 2 * inter / den.clamp(min=1e-5))
+    ce = torch.nn.functional.cross_entropy(b, lab, weight=cw)
+    l2 = sum(w * torch.nn.functional.mse_loss(a[:, c], hm[:, c].float()) for c, w in enumerate([0.3, 1.0, 0.7]))
+    l1 = sum(w * torch.nn.functional.l1_loss(a[:, c], hm[:, c].float()) for c, w in enumerate([1.0, 0.2, 0.4]))
+    (dice + 3.0 * ce + l2 + 0.5 * l1).backward()
+    assert_close(g_fused, x.grad, 1e-5, "two losses per slice vs ATen")
+
+
 def test_adam_step_matches_torch():
     g = np.random.Generator(np.random.PCG64(3))
     p0 = torch.from_numpy(g.standard_normal(10007).astype(np.float32))

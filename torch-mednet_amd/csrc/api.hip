@@ -31,6 +31,19 @@ int mednet_internal_tuning_option(const char* name, int default_value) {
   return default_value;
 }
 
+// CUs of the current device, asked once (the one-workgroup-per-CU kernels are laid out for the MI355X's 256)
+int mednet_internal_cu_count(void) {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+      cus = n;
+    else
+      (void)hipGetLastError();
+  }
+  return cus;
+}
+
 namespace mednet_f16 {  // conv_mfma.hip compiled with -DMEDNET_ELT_F16 -Dmednet=mednet_f16 (fp16 storage)
 #include "conv_mfma_decl.inc"
 }

@@ -10,6 +10,7 @@
 int mednet_internal_fail(int code, const char* fmt, ...);
 int mednet_internal_check_launch(const char* what);
 int mednet_internal_tuning_option(const char* name, int default_value);
+int mednet_internal_cu_count(void);
 
 namespace mednet {
 

@@ -1464,8 +1464,10 @@ bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype,
 // workgroup starts on a valid item), brick count a multiple of 8 (no padding items), and ncb | 64 (a workgroup's channel
 // block never changes).
 // The 32 -> 32 specialisation (conv32_mfma_kernel): one workgroup per CU, at least two bricks each.
+// Its grid is exactly 256 workgroups and conv_stats_plan hands out 256 * 4 statistics rows: that is the MI355X's CU count.
+// On a device with another count (a partitioned part) the general kernel takes the call.
 static bool conv32_applies(int ntiles, int cin, int cout) {
-  return cin == 32 && cout == 32 && ntiles >= 512 && tuning_option("conv32", 1);
+  return cin == 32 && cout == 32 && ntiles >= 512 && ::mednet_internal_cu_count() == 256 && tuning_option("conv32", 1);
 }
 static void conv_stats_plan(int n, int d, int h, int w, int cin, int cout, int& rows, int& accum) {
   using G = FwdTile<1>;

@@ -828,7 +828,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 // ---- fp16 storage: dynamic loss scaling without a host synchronisation (torch.cuda.amp.GradScaler's rule) ---------------
-// state[4] (device, fp32): {scale, good steps since the last change, optimizer steps taken, found_inf}.  The loss is
+// state[8] (device, fp32): {scale, good steps since the last change, optimizer steps taken, found_inf, steps skipped, -, -, -}.  The loss is
 // multiplied by state[0] on the device, so every gradient arrives times `scale`; grad_check raises found_inf if any
 // gradient is not finite, adam_scaled divides by the scale and SKIPS the update when found_inf is set (bias correction
 // uses the device-side step count, which a skipped step does not advance), scaler_update then halves the scale or
@@ -865,8 +865,9 @@ __global__ __launch_bounds__(256) void adam_scaled_kernel(float* __restrict__ p,
 __global__ void scaler_update_kernel(float* __restrict__ state, float growth, float backoff, float interval) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (state[3] != 0.f) {
-    state[0] *= backoff;
+    state[0] = fmaxf(state[0] * backoff, 1.f);  // never below 1: a persistent NaN (out-of-range labels) must not drive it to 0
     state[1] = 0.f;
+    state[4] += 1.f;  // skipped steps, for the host to surface
   } else {
     state[2] += 1.f;
     state[1] += 1.f;

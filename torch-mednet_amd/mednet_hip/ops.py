@@ -450,6 +450,12 @@ class GroupNormActFn(Function):
         x0 = x
         x = to_cl(_as_act(x))
         ctx.inmask = getattr(x0, "_mednet_actmask", None) if (x is x0 and FUSE_GN3) else None
+        # The fold multiplies dx by act'(x) HERE; the conv layer skips its own activation backward only if the gradient it
+        # receives is this very tensor (ActMaskHook.take).  If it declines (x has a second consumer, a tensor hook replaced
+        # the gradient) act' is applied twice to this contribution: idempotent for ReLU (a 0/1 mask), wrong for
+        # LeakyReLU / ELU -- so only ReLU layers are folded.
+        if ctx.inmask is not None and ctx.inmask.act != L.ACT_RELU:
+            ctx.inmask = None
         n, c, d, h, w = x.shape
         if c % groups:
             raise RuntimeError(f"group_norm: C={c} not divisible by num_groups={groups}")
@@ -576,10 +582,11 @@ class _SplitGrad:
     """Shared gradient buffer of a channel split: the loss backward kernels of the two halves write their slices of ONE
     full-size tensor (they index the gradient with the strides of the logits slice they were given), so the split's backward
     is that tensor, not a concatenation."""
-    __slots__ = ("shape", "base", "k")
+    __slots__ = ("shape", "base", "k", "claimed")
 
     def __init__(self, shape, k):
         self.shape, self.k, self.base = tuple(shape), k, None
+        self.claimed = set()  # slice offsets whose view has been handed to a loss backward (one writer per slice)
 
 
 class SplitChannelsFn(Function):
@@ -598,6 +605,7 @@ class SplitChannelsFn(Function):
         base = holder.base if holder is not None else None
         if holder is not None:
             holder.base = None
+            holder.claimed.clear()
         if (base is not None and d0 is not None and d1 is not None and d0.dtype == base.dtype == d1.dtype
                 and d0.data_ptr() == base.data_ptr() and d1.data_ptr() == base[:, k:].data_ptr()
                 and d0.stride() == base[:, :k].stride() and d1.stride() == base[:, k:].stride()):
@@ -626,11 +634,16 @@ def _loss_grad_like(lg, split):
     a slice of the shared buffer of a channel split when there is one, else a fresh tensor of that layout."""
     if split is not None:
         holder, c0 = split
-        if holder.base is None:
-            holder.base = torch.empty(holder.shape, dtype=torch.float32, device=lg.device)
-        view = holder.base[:, c0:c0 + lg.shape[1]]
-        if tuple(view.shape) == tuple(lg.shape) and view.stride() == lg.stride():
-            return view
+        # ONE writer per slice: a second loss on the same slice (Dice + CE on the class logits, a loss applied twice) gets a
+        # tensor of its own -- autograd then sums the two, and SplitChannelsFn.backward sees a gradient that is not the
+        # shared view and takes its concatenation path.  (Two kernels writing one view would leave 2*G2, not G1+G2.)
+        if c0 not in holder.claimed:
+            if holder.base is None:
+                holder.base = torch.empty(holder.shape, dtype=torch.float32, device=lg.device)
+            view = holder.base[:, c0:c0 + lg.shape[1]]
+            if tuple(view.shape) == tuple(lg.shape) and view.stride() == lg.stride():
+                holder.claimed.add(c0)
+                return view
     return torch.empty_strided(tuple(lg.shape), lg.stride(), dtype=torch.float32, device=lg.device)
 
 

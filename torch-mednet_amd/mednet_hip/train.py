@@ -56,9 +56,38 @@ class FlatAdam:
         self.flat, self.lr, self.betas, self.eps, self.wd = flat, lr, betas, eps, weight_decay
         self.m = torch.zeros_like(flat.flat)
         self.v = torch.zeros_like(flat.flat)
-        self.t = 0
+        self.t = 0  # calls so far.  Plain mode: = optimizer steps taken (bias correction uses it).  Behind a LossScaler the
+        #             bias correction uses the DEVICE count scaler.state[2], which a skipped step does not advance: there
+        #             `t` only versions the parameters (_bump) and steps_taken() reads the truth.
+        self._scaled = None  # which of the two update forms this optimizer runs (they keep different step counts)
+
+    def steps_taken(self, scaler: "LossScaler | None" = None) -> int:
+        """Optimizer steps actually applied (synchronises when a scaler holds the count)."""
+        return self.t if scaler is None else int(scaler.state[2].item())
+
+    def state_dict(self, scaler: "LossScaler | None" = None):
+        sd = {"m": self.m.detach().cpu().clone(), "v": self.v.detach().cpu().clone(), "t": self.steps_taken(scaler),
+              "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd}
+        if scaler is not None:
+            sd["scaler"] = scaler.state_dict()
+        return sd
+
+    def load_state_dict(self, sd, scaler: "LossScaler | None" = None):
+        self.m.copy_(sd["m"].to(self.m.device))
+        self.v.copy_(sd["v"].to(self.v.device))
+        self.t = int(sd["t"])
+        if scaler is not None and "scaler" in sd:
+            scaler.load_state_dict(sd["scaler"])
+
+    def _form(self, scaled: bool):
+        if self._scaled is None:
+            self._scaled = scaled
+        elif self._scaled != scaled:
+            raise RuntimeError("FlatAdam: step() and step_scaled() keep different step counts (host / device) and cannot "
+                               "be mixed on one optimizer")
 
     def step(self, grad_scale=1.0):
+        self._form(False)
         self.t += 1
         ops.adam_step_(self.flat.flat, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
                        self.wd, self.t, grad_scale)
@@ -67,6 +96,7 @@ class FlatAdam:
     def step_scaled(self, scaler: "LossScaler", inv_world=1.0):
         """The same update behind the loss scaler: unscale, skip on overflow, adjust the scale -- all on the device."""
         from . import _lib as L
+        self._form(True)
         self.t += 1
         f = self.flat
         L.check(L.lib().mednet_adam_step_scaled(f.flat.data_ptr(), f.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
@@ -140,15 +170,30 @@ class LossScaler:
     to skip the update and the scale update are kernels (mednet_adam_step_scaled), so a step never waits for the host."""
 
     def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
-        self.state = torch.tensor([init_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+        self.state = torch.tensor([init_scale, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
         self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+
+    def state_dict(self):
+        """Everything a resumed run needs (synchronises): the device state {scale, good steps, optimizer steps taken,
+        found_inf, skipped steps} and the rule's constants."""
+        return {"state": self.state.detach().cpu().clone(), "growth_factor": self.growth_factor,
+                "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval}
+
+    def load_state_dict(self, sd):
+        self.state.copy_(sd["state"].to(self.state.device))
+        self.growth_factor, self.backoff_factor = sd["growth_factor"], sd["backoff_factor"]
+        self.growth_interval = sd["growth_interval"]
+
+    def skipped_steps(self) -> int:
+        """Steps whose update was skipped for non-finite gradients (synchronises)."""
+        return int(self.state[4].item())
 
     def scale_loss(self, loss):
         return loss * self.state[0]
 
     def snapshot(self):
         """(scale, good steps, optimizer steps taken, found_inf) -- synchronises; for tests and logging only."""
-        return tuple(float(v) for v in self.state.tolist())
+        return tuple(float(v) for v in self.state[:4].tolist())
 
 
 def make_scaler(device):

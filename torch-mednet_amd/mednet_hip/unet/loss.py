@@ -150,7 +150,7 @@ class LandmarkLoss(nn.Module):
         self.ce_loss = WeightedCrossEntropyLoss(target_one_hot_encoded=False)
 
     def forward(self, logits, heatmaps):
-        return ops.heatmap_loss(logits, heatmaps, None, "L2") if logits.is_cuda else F.mse_loss(logits, heatmaps)
+        return ops.heatmap_loss(logits, heatmaps, None, "L2")  # (loss.py:251 F.mse_loss; raises on CPU tensors like every op)
 
 
 class CrossEntropyLoss(nn.Module):
