@@ -203,10 +203,14 @@ def fp32_parity_mode(dev, batch: int, patch: int, steps: int):
     pps = batch * steps / dt
     rec = {"value": round(pps, 3), "unit": "patches/s", "ms_per_step": round(1e3 * dt / steps, 2), "steps": steps,
            "dtype": "fp32", "loss": round(float(loss), 6),
-           "tolerance_met": "1e-3 rel-L2 on logits and every gradient vs the reference (fp32 storage, fp32 matrix-core "
-                            "contraction v_mfma_f32_32x32x2_f32)"}
-    if patch == 128:
-        rec["frac_of_fp32_mfma_peak"] = round(pps * FLOP_PER_PATCH / (MFMA_PEAK_TFLOPS["fp32"] * 1e12), 4)
+           "arithmetic": "fp32 storage of activations, gradients and parameters; 3x3x3 contractions as split-bf16 (hi*hi + "
+                         "hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation: ~2^-16 per product); first layer, "
+                         "ConvTranspose weight gradient on v_mfma_f32_32x32x2_f32; GroupNorm, head and losses fp32",
+           "tolerance_met": "1e-3 rel-L2 on logits and every gradient vs the reference "
+                            "(tests: test_cfg2_128_against_reference_golden, test_cfg4_128_landmark_...)"}
+    if patch == 128:  # three bf16 MFMAs per product
+        rec["frac_of_bf16_mfma_peak_counting_3_mfma_per_product"] = round(
+            3 * pps * FLOP_PER_PATCH / (MFMA_PEAK_TFLOPS["bf16"] * 1e12), 4)
     del model, step
     torch.cuda.empty_cache()
     return rec

@@ -48,8 +48,10 @@ int mednet_set_option(const char* name, int value);
 /* Weight packing: PyTorch (Cout,Cin,k,k,k) [or ConvTranspose3d's (Cin,Cout,k,k,k) when transposed_src=1] ->
  * opaque buffer holding the tap-major layouts the forward, data-gradient and MFMA kernels read. */
 size_t mednet_conv3d_pack_bytes(int cin, int cout, int ksize);
-/* mednet_conv3d_pack writes the matrix-core fragment images in bf16; _elt takes the 16-bit storage type of the activations
- * the layer will see (MEDNET_BF16 | MEDNET_F16: BASELINE config 5 stores fp16).  The buffer size is the same. */
+/* mednet_conv3d_pack writes the matrix-core fragment images in bf16; _elt takes the storage type of the activations the
+ * layer will see (MEDNET_BF16 | MEDNET_F16: BASELINE config 5 stores fp16).  MEDNET_F32 (the fp32 storage mode, the one that
+ * meets the reference within 1e-3): bf16 images of the HIGH halves bf16(w) plus images of the LOW halves
+ * bf16(w - bf16(w)) for the split-bf16 contraction (conv_x3_mfma.hip).  The buffer size is the same in every case. */
 int mednet_conv3d_pack_elt(const float* w, void* packed, int cin, int cout, int ksize, int transposed_src, int elt_dtype,
                            mednet_stream stream);
 int mednet_conv3d_pack(const float* w, void* packed, int cin, int cout, int ksize, int transposed_src,

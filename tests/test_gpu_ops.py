@@ -115,6 +115,104 @@ def test_conv_transpose3d_with_skip(mode, n, cin, cout, shape, skip):
         assert_close(skg.grad, skr.grad, tol, "dskip")
 
 
+def _set_option(name, value):
+    L.check(L.lib().mednet_set_option(name.encode(), int(value)), "set_option")
+
+
+@pytest.mark.parametrize("n,cin,cout,shape", [(2, 32, 32, (9, 11, 21)), (1, 48, 16, (5, 6, 7)), (3, 16, 48, (4, 9, 17)),
+                                              (1, 64, 96, (8, 8, 16))])
+def test_split_bf16_conv_family_in_the_fp32_mode(n, cin, cout, shape):
+    """fp32 storage mode, channel counts that are multiples of 16: forward, data gradient and weight gradient run as
+    split-bf16 contractions (csrc/conv_x3_mfma.hip: hi*hi + hi*lo + lo*hi on the bf16 matrix cores).  Against ATen in fp64
+    at 3e-5 (the mode's budget is 1e-3 after 21 layers), ragged bricks and several samples included, and against the exact
+    fp32 matrix-core kernels (option x3=0) to show that a different kernel really ran."""
+    tag = f"x3{n}{cin}{cout}{shape}"
+    x, w, cot = rnd(tag + "x", n, cin, *shape), rnd(tag + "w", cout, cin, 3, 3, 3, scale=0.1), rnd(tag + "g", n, cout, *shape)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, padding=1)
+    (yr * cot.double()).sum().backward()
+    res = {}
+    try:
+        for x3 in (1, 0):
+            _set_option("x3", x3)
+            with mednet_hip.precision("fp32"):
+                conv = hnn.Conv3d(cin, cout, 3, bias=False).to(DEV)
+                with torch.no_grad():
+                    conv.weight.copy_(w)
+                xg = x.to(DEV).requires_grad_(True)
+                y = conv(xg)
+                (y * cot.to(DEV)).sum().backward()
+                res[x3] = (y.detach().cpu(), xg.grad.cpu(), conv.weight.grad.cpu())
+    finally:
+        _set_option("x3", 1)
+    for name, a, b, ref in zip(("y", "dx", "dw"), res[1], res[0], (yr, xr.grad, wr.grad)):
+        assert_close(a.double(), ref, 3e-5, f"split-bf16 {name}")
+        assert_close(b.double(), ref, 3e-6, f"fp32 mfma {name}")
+        assert not torch.equal(a, b), f"{name}: option x3 selected no other kernel"
+
+
+@pytest.mark.parametrize("n,cin,cout,shape", [(2, 32, 16, (3, 5, 9)), (1, 64, 32, (4, 4, 8)), (1, 16, 48, (5, 3, 17))])
+def test_split_bf16_conv_transpose_in_the_fp32_mode(n, cin, cout, shape):
+    """ConvTranspose3d + bias + skip (components.py:259-264,283-284) in the fp32 mode: forward and data gradient on the
+    split-bf16 kernels (the weight gradient stays on the fp32 matrix-core kernel)."""
+    tag = f"x3ct{n}{cin}{cout}{shape}"
+    oshape = tuple(2 * s for s in shape)
+    x, w = rnd(tag + "x", n, cin, *shape), rnd(tag + "w", cin, cout, 3, 3, 3, scale=0.1)
+    b, sk, cot = rnd(tag + "b", cout), rnd(tag + "s", n, cout, *oshape), rnd(tag + "g", n, cout, *oshape)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.conv_transpose3d(xr, wr, br, stride=2, padding=1, output_padding=1) + sk.double()
+    (yr * cot.double()).sum().backward()
+    res = {}
+    try:
+        for x3 in (1, 0):
+            _set_option("x3", x3)
+            with mednet_hip.precision("fp32"):
+                up = hnn.ConvTranspose3d(cin, cout).to(DEV)
+                with torch.no_grad():
+                    up.weight.copy_(w)
+                    up.bias.copy_(b)
+                xg = x.to(DEV).requires_grad_(True)
+                y = up(xg, skip=sk.to(DEV))
+                (y * cot.to(DEV)).sum().backward()
+                res[x3] = (y.detach().cpu(), xg.grad.cpu(), up.weight.grad.cpu())
+    finally:
+        _set_option("x3", 1)
+    for name, a, b2, ref in zip(("y", "dx", "dw"), res[1], res[0], (yr, xr.grad, wr.grad)):
+        assert_close(a.double(), ref, 3e-5, f"split-bf16 {name}")
+        assert_close(b2.double(), ref, 3e-6, f"fp32 mfma {name}")
+    assert not torch.equal(res[1][0], res[0][0]) and not torch.equal(res[1][1], res[0][1])
+
+
+def test_split_bf16_forward_keeps_the_groupnorm_statistics():
+    """fp32 mode, Cout <= 32, at least 256 bricks: the split-bf16 forward kernel also writes the GroupNorm partial sums of what
+    it stores (no stand-alone statistics pass).  ExtResNetBlock 32 -> 32 against the oracle, with and without the fusion."""
+    from mednet_hip.unet import components as HC
+    shape = (32, 64, 64)
+    assert L.lib().mednet_conv3d_fused_stats_chunks(1, *shape, 32, 32, 3, L.F32, L.F32, L.ALGO_AUTO) > 0
+    x = rnd("x3stats", 1, 32, *shape)
+    ora = O.keyed_init_(O.ExtResNetBlock(32, 32, order="cge"))
+    xo = x.clone().requires_grad_(True)
+    yo = ora(xo)
+    g = rnd("x3statsg", *yo.shape)
+    (yo * g).sum().backward()
+    res = {}
+    try:
+        for fuse in (1, 0):
+            _set_option("x3_stats", fuse)
+            with mednet_hip.precision("fp32"):
+                blk = O.keyed_init_(HC.ExtResNetBlock(32, 32, order="cge")).to(DEV)
+                xg = x.to(DEV).requires_grad_(True)
+                y = blk(xg)
+                (y * g.to(DEV)).sum().backward()
+                res[fuse] = [y.detach().cpu(), xg.grad.cpu()] + [p.grad.cpu() for p in blk.parameters()]
+    finally:
+        _set_option("x3_stats", 1)
+    want = [yo, xo.grad] + [p.grad for p in ora.parameters()]
+    for i, (a, b, r) in enumerate(zip(res[1], res[0], want)):
+        assert_close(a, r, 1e-4, f"fused statistics, tensor {i}")
+        assert_close(b, r, 1e-4, f"stand-alone statistics, tensor {i}")
+
+
 _ACTS = {"none": (L.ACT_NONE, lambda u: u), "relu": (L.ACT_RELU, F.relu), "leaky": (L.ACT_LEAKY, lambda u: F.leaky_relu(u, 0.1)),
          "elu": (L.ACT_ELU, F.elu)}
 

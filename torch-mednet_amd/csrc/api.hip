@@ -88,6 +88,9 @@ extern "C" int mednet_conv3d_pack(const float* w, void* packed, int cin, int cou
 }
 extern "C" int mednet_conv3d_pack_elt(const float* w, void* packed, int cin, int cout, int ksize, int transposed_src,
                                       int elt_dtype, mednet_stream stream) {
+  // MEDNET_F32 = the fp32 storage mode: bf16 high images + the low images of the split-bf16 contraction (conv_x3_mfma.hip)
+  const bool with_low = elt_dtype == MEDNET_F32;
+  if (with_low) elt_dtype = MEDNET_BF16;
   MEDNET_REQUIRE(is16(elt_dtype), MEDNET_E_DTYPE, "conv3d_pack: the matrix-core images are bf16 or fp16 (got dtype %d)", elt_dtype);
   MEDNET_REQUIRE(ksize == 3 || ksize == 1, MEDNET_E_UNSUPPORTED, "conv3d_pack: kernel size %d (supported: 1, 3)", ksize);
   MEDNET_REQUIRE(cin > 0 && cout > 0, MEDNET_E_SHAPE, "conv3d_pack: bad channels %d -> %d", cin, cout);
@@ -96,7 +99,7 @@ extern "C" int mednet_conv3d_pack_elt(const float* w, void* packed, int cin, int
   hipStream_t s = (hipStream_t)stream;
   if (L.mfma_bytes)  // one launch writes the two bf16 fragment images and the two fp32 images
     return ELT_CALL(elt_dtype, launch_pack_mfma, w, base + L.mfma_fwd, base + L.mfma_bwd, (float*)(base + L.f32_fwd),
-                    (float*)(base + L.f32_bwd), cin, cout, L.taps, transposed_src, s);
+                    (float*)(base + L.f32_bwd), cin, cout, L.taps, transposed_src, s, with_low ? L.lo_delta : 0);
   return launch_pack_f32(w, (float*)(base + L.f32_fwd), (float*)(base + L.f32_bwd), cin, cout, L.taps, transposed_src, s);
 }
 
@@ -123,7 +126,9 @@ extern "C" int mednet_conv3d_pack_table(const mednet_pack_job* jobs, int njobs, 
     t[i].cout = j.cout;
     t[i].transposed = j.transposed_src;
     t[i].nblocks = pack_mfma_blocks(j.cin, j.cout);
-    t[i].pad[0] = t[i].pad[1] = 0;
+    MEDNET_REQUIRE(L.lo_delta < 0x7fffffffu, MEDNET_E_UNSUPPORTED, "conv3d_pack_table: layer %d too large", i);
+    t[i].lo_delta = (int)L.lo_delta;
+    t[i].pad = 0;
     if (t[i].nblocks > mb) mb = t[i].nblocks;
   }
   *max_blocks = mb;
@@ -131,9 +136,11 @@ extern "C" int mednet_conv3d_pack_table(const mednet_pack_job* jobs, int njobs, 
 }
 extern "C" int mednet_conv3d_pack_many(const void* table_device, int njobs, unsigned max_blocks, int elt_dtype,
                                        mednet_stream stream) {
+  const bool with_low = elt_dtype == MEDNET_F32;  // fp32 storage mode: bf16 high + low images (see mednet_conv3d_pack_elt)
+  if (with_low) elt_dtype = MEDNET_BF16;
   MEDNET_REQUIRE(is16(elt_dtype), MEDNET_E_DTYPE, "conv3d_pack_many: the matrix-core images are bf16 or fp16 (got dtype %d)", elt_dtype);
   MEDNET_REQUIRE(table_device && njobs > 0 && njobs <= 65535 && max_blocks > 0, MEDNET_E_SHAPE, "conv3d_pack_many: bad arguments");
-  return ELT_CALL(elt_dtype, launch_pack_mfma_many, table_device, njobs, max_blocks, (hipStream_t)stream);
+  return ELT_CALL(elt_dtype, launch_pack_mfma_many, table_device, njobs, max_blocks, (hipStream_t)stream, with_low ? 1 : 0);
 }
 
 static int conv_common_checks(const char* who, int n, int d, int h, int w, int cin, int cout, int ksize, int dt1, int dt2) {
@@ -147,6 +154,10 @@ static int conv_common_checks(const char* who, int n, int d, int h, int w, int c
 extern "C" int mednet_conv3d_fused_stats_chunks(int n, int d, int h, int w, int cin, int cout, int ksize, int x_dtype,
                                                 int y_dtype, int algo) {
   if (algo == MEDNET_ALGO_DIRECT || !tuning_option("conv_fuse_stats", 1)) return 0;
+  if (x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32)  // fp32 storage: the split-bf16 forward kernel keeps the sums per wave
+    return conv_f32_mfma_enabled() && conv_x3_enabled() && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin)
+               ? conv_x3_stats_rows(n, d, h, w, cout)
+               : 0;
   if (ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, false)) return conv_c1_stats_chunks(d, h, w);
   if (!ELT_CALL(y_dtype, conv_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, MEDNET_NDHWC, false)) return 0;
   return conv_mfma_stats_chunks(n, d, h, w, cin, cout);
@@ -173,11 +184,16 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
   if (!dgrad && algo != MEDNET_ALGO_DIRECT && x_layout == MEDNET_NDHWC &&
       ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, y_layout, bias != nullptr))
     return ELT_CALL(y_dtype, launch_conv_c1_mfma, x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, gn_partial, s, x_dtype);
+  // fp32 storage (the 1e-3 parity mode): 3x3x3 forward / data gradient as a split-bf16 contraction on the bf16 matrix cores
+  // (three MFMAs per product; the pack must hold the low images: mednet_conv3d_pack_elt(MEDNET_F32)) ...
+  const bool f32_mode = algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 &&
+                        y_dtype == MEDNET_F32 && (x_layout == MEDNET_NDHWC || cin == 1) && y_layout == MEDNET_NDHWC;
+  if (f32_mode && conv_x3_enabled() && L.mfma_bytes && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin))
+    return launch_conv_x3(x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), L.lo_delta, bias, y, n, d, h, w, cin, cout, gn_partial, s);
   MEDNET_REQUIRE(gn_partial == nullptr, MEDNET_E_UNSUPPORTED,
                  "conv3d_fwd: fused GroupNorm partials are only produced by the MFMA paths (ask mednet_conv3d_fused_stats_chunks)");
-  // fp32 storage (the 1e-3 parity mode): 3x3x3 forward / data gradient on the fp32 matrix-core instruction
-  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32 &&
-      (x_layout == MEDNET_NDHWC || cin == 1) && y_layout == MEDNET_NDHWC)
+  // ... or, for the shapes that kernel does not take (first layer, odd channel counts), on the fp32 matrix-core instruction
+  if (f32_mode)
     return launch_conv_f32_mfma(x, (const float*)(base + (dgrad ? L.f32_bwd : L.f32_fwd)), bias, y, n, d, h, w, cin, cout, s);
   // 1x1x1 head forward (channels-last features -> planar fp32 logits): the packed backward image Pb[t=0][co][ci] = W[m][k]
   if (!dgrad && algo != MEDNET_ALGO_DIRECT && ksize == 1 && x_layout == MEDNET_NDHWC && y_layout == MEDNET_NCDHW &&
@@ -200,8 +216,10 @@ extern "C" size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int c
   const size_t c1 = cin == 1 ? wgrad_c1_ws_bytes(n, d, h, w, cout) : 0;
   const size_t c2 = ksize == 1 ? wgrad_1x1_ws_bytes(n, (size_t)d * h * w, cin, cout) : 0;
   const size_t f = ksize == 3 ? wgrad_f32_mfma_ws_bytes(n, d, h, w, cout, cin, 0) : 0;
+  const size_t f3 = conv_x3_supported(cin, cout, ksize) ? wgrad_x3_ws_bytes(n, d, h, w, cin, cout) : 0;
   size_t m = a > b ? a : b;
   if (f > m) m = f;
+  if (f3 > m) m = f3;
   if (c1 > m) m = c1;
   if (c2 > m) m = c2;
   // the bias-gradient partials live behind the weight-gradient partials
@@ -227,8 +245,12 @@ extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, flo
   if (algo != MEDNET_ALGO_DIRECT && wgrad_1x1_supported(cin, cout, ksize, x_layout, dy_layout, dy_dtype))
     return launch_wgrad_1x1(x, dy, dw, n, (size_t)d * h * w, cin, cout, x_dtype, ws, ws_bytes, s);
   if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32 &&
-      (x_layout == MEDNET_NDHWC || cin == 1) && dy_layout == MEDNET_NDHWC)
+      (x_layout == MEDNET_NDHWC || cin == 1) && dy_layout == MEDNET_NDHWC) {
+    const int cmax = cin > cout ? cin : cout;
+    if (conv_x3_enabled() && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cmax))
+      return launch_wgrad_x3(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);  // split-bf16 contraction over the voxels
     return launch_wgrad_f32_mfma(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
+  }
   const bool mfma_ok = ELT_CALL(dy_dtype, wgrad_mfma_supported, cin, cout, ksize, x_dtype, dy_dtype, x_layout, dy_layout) &&
                        wgrad_mfma_fits(n, d, h, w, cin > cout ? cin : cout, 1);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
@@ -326,9 +348,13 @@ extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
     return ELT_CALL(x_dtype, launch_convt_fwd_mfma, x, (const char*)packed + L.mfma_fwd, bias, skip, y, n, d, h, w, cin, cout,
                     (hipStream_t)stream);
-  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32)
+  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32) {
+    if (conv_x3_enabled() && L.mfma_bytes && conv_x3_supported(cin, cout, 3))
+      return launch_convt_fwd_x3(x, (const char*)packed + L.mfma_fwd, L.lo_delta, bias, skip, y, n, d, h, w, cin, cout,
+                                 (hipStream_t)stream);
     return launch_convt_fwd_f32_mfma(x, (const float*)((const char*)packed + L.f32_fwd), bias, skip, y, n, d, h, w, cin, cout,
                                      (hipStream_t)stream);
+  }
   ConvGeom g;
   g.n = n; g.od = 2 * d; g.oh = 2 * h; g.ow = 2 * w; g.id = d; g.ih = h; g.iw = w;
   g.k = cin; g.m = cout; g.ks = 3; g.in_planar = 0; g.out_planar = 0;
@@ -348,9 +374,12 @@ extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx
   if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
     return ELT_CALL(dy_dtype, launch_convt_dgrad_mfma, dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cin, cout,
                     (hipStream_t)stream);
-  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && dy_dtype == MEDNET_F32 && dx_dtype == MEDNET_F32)
+  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && dy_dtype == MEDNET_F32 && dx_dtype == MEDNET_F32) {
+    if (conv_x3_enabled() && L.mfma_bytes && conv_x3_supported(cin, cout, 3) && conv_x3_fits(2 * d, 2 * h, 2 * w, cout))
+      return launch_convt_dgrad_x3(dy, (const char*)packed + L.mfma_bwd, L.lo_delta, dx, n, d, h, w, cin, cout, (hipStream_t)stream);
     return launch_convt_dgrad_f32_mfma(dy, (const float*)((const char*)packed + L.f32_bwd), dx, n, d, h, w, cin, cout,
                                        (hipStream_t)stream);
+  }
   ConvGeom g;
   g.n = n; g.od = d; g.oh = h; g.ow = w; g.id = 2 * d; g.ih = 2 * h; g.iw = 2 * w;
   g.k = cout; g.m = cin; g.ks = 3; g.in_planar = 0; g.out_planar = 0;

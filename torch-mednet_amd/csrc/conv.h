@@ -69,4 +69,21 @@ int launch_wgrad_f32_mfma(const void* x, const void* dy, float* dw, int n, int d
 int launch_convt_wgrad_f32_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, void* ws,
                                 size_t ws_bytes, hipStream_t s);
 
+// split-bf16 matrix-core kernels (three v_mfma_f32_32x32x16_bf16 per product on hi/lo halves), conv_x3_mfma.hip: the parity
+// mode's 3x3x3 family at bf16 matrix-core speed.  `sec_hi` = the layer's bf16 fragment image (PackLayout::mfma_fwd / mfma_bwd),
+// the low image sits PackLayout::lo_delta bytes behind it (mednet_conv3d_pack_elt(MEDNET_F32)).
+bool conv_x3_enabled();
+bool conv_x3_supported(int cin, int cout, int ksize);
+bool conv_x3_fits(int d, int h, int w, int c);
+int conv_x3_stats_rows(int n, int d, int h, int w, int cout);
+int launch_conv_x3(const void* x, const void* sec_hi, size_t lo_delta, const float* bias, void* y, int n, int d, int h, int w, int k,
+                   int m, float* stats, hipStream_t s);
+int launch_convt_dgrad_x3(const void* dy, const void* sec_hi, size_t lo_delta, void* dx, int n, int d, int h, int w, int cin,
+                          int cout, hipStream_t s);
+int launch_convt_fwd_x3(const void* x, const void* sec_hi, size_t lo_delta, const float* bias, const void* skip, void* y, int n,
+                        int d, int h, int w, int cin, int cout, hipStream_t s);
+size_t wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+int launch_wgrad_x3(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, void* ws,
+                    size_t ws_bytes, hipStream_t s);
+
 }  // namespace mednet

@@ -1353,7 +1353,7 @@ int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d,
 // mode 3: convT dgrad   Weff[m][k][t] = Wt[m][k][t]                             M=Cin  K=Cout
 __device__ __forceinline__ void pack_mfma_body(const float* __restrict__ w, elt* __restrict__ out0, elt* __restrict__ out1,
                                                int M0, int K0, int mode0, int mode1, float* __restrict__ Pf,
-                                               float* __restrict__ Pb, int transposed_src) {
+                                               float* __restrict__ Pb, int transposed_src, size_t lo_delta) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.y == 2) {  // the fp32 tap-major images of the direct kernels ride along in the same launch
     const int cin = K0, cout = M0, T = 27;
@@ -1370,9 +1370,14 @@ __device__ __forceinline__ void pack_mfma_body(const float* __restrict__ w, elt*
     }
     return;
   }
-  // blockIdx.y = 0: forward image (M0 x K0), 1: data-gradient image (K0 x M0): one launch for both
-  const int M = blockIdx.y ? K0 : M0, K = blockIdx.y ? M0 : K0, mode = blockIdx.y ? mode1 : mode0;
-  elt* out = blockIdx.y ? out1 : out0;
+  // blockIdx.y = 0: forward image (M0 x K0), 1: data-gradient image (K0 x M0): one launch for both.
+  // blockIdx.y = 3 / 4 (fp32 storage mode only, bf16 build): the LOW images of the split-bf16 contraction (conv_x3_mfma.hip):
+  // element = bf16(w - float(bf16(w))), same order, `lo_delta` bytes behind the high image.
+  const bool low = blockIdx.y >= 3;
+  const int img = low ? blockIdx.y - 3 : blockIdx.y;
+  const int M = img ? K0 : M0, K = img ? M0 : K0, mode = img ? mode1 : mode0;
+  elt* out = img ? out1 : out0;
+  if (low) out = reinterpret_cast<elt*>(reinterpret_cast<char*>(out) + lo_delta);
   const size_t total = (size_t)((M + 31) / 32 * 32) * K * 27;  // rows beyond M (a 16-channel side) are zero padding
   if (e >= total) return;
   size_t q = e;
@@ -1394,12 +1399,13 @@ __device__ __forceinline__ void pack_mfma_body(const float* __restrict__ w, elt*
   else if (mode == 1) v = w[((size_t)k * M + m) * 27 + (26 - tap)];
   else if (mode == 2) v = w[((size_t)k * M + m) * 27 + tap];
   else v = w[((size_t)m * K + k) * 27 + tap];
-  out[e] = (elt)v;
+  out[e] = low ? (elt)(v - (float)(elt)v) : (elt)v;
 }
 __global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict__ w, elt* __restrict__ out0,
                                                         elt* __restrict__ out1, int M0, int K0, int mode0, int mode1,
-                                                        float* __restrict__ Pf, float* __restrict__ Pb, int transposed_src) {
-  pack_mfma_body(w, out0, out1, M0, K0, mode0, mode1, Pf, Pb, transposed_src);
+                                                        float* __restrict__ Pf, float* __restrict__ Pb, int transposed_src,
+                                                        size_t lo_delta) {
+  pack_mfma_body(w, out0, out1, M0, K0, mode0, mode1, Pf, Pb, transposed_src, lo_delta);
 }
 // all 3x3x3 layers of a network in ONE launch (after the optimizer step every layer's weights have moved): blockIdx.z = layer,
 // its descriptor comes from a device table built once (mednet_conv3d_pack_table); blocks beyond a layer's size exit
@@ -1407,7 +1413,7 @@ __global__ __launch_bounds__(256) void pack_mfma_many_kernel(const PackJobDev* _
   const PackJobDev j = jobs[blockIdx.z];
   if (blockIdx.x >= j.nblocks) return;
   pack_mfma_body(j.w, (elt*)j.sec_fwd, (elt*)j.sec_bwd, j.cout, j.cin, j.transposed ? 2 : 0, j.transposed ? 3 : 1, j.Pf, j.Pb,
-                 j.transposed);
+                 j.transposed, (size_t)j.lo_delta);
 }
 
 PackLayout pack_layout(int cin, int cout, int ksize) {
@@ -1423,19 +1429,22 @@ PackLayout pack_layout(int cin, int cout, int ksize) {
   L.mfma_bytes = fwd_bytes > bwd_bytes ? fwd_bytes : bwd_bytes;
   L.mfma_fwd = 2 * f32;
   L.mfma_bwd = 2 * f32 + fwd_bytes;
-  L.total = 2 * f32 + fwd_bytes + bwd_bytes + 256;
+  // the low images of the split-bf16 contraction (written only when the pack is asked for them: fp32 storage mode)
+  L.lo_delta = fwd_bytes + bwd_bytes;
+  L.total = 2 * f32 + 2 * (fwd_bytes + bwd_bytes) + 256;
   return L;
 }
 
 int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, float* Pf, float* Pb, int cin, int cout, int T,
-                     int transposed_src, hipStream_t s) {
+                     int transposed_src, hipStream_t s, size_t lo_delta) {
   if (T != 27) return MEDNET_OK;
   const int cmax = cin > cout ? cin : cout, cmin = cin > cout ? cout : cin;
   const size_t total = (size_t)((cmax + 31) / 32 * 32) * ((cmin + 31) / 32 * 32) * 27;  // covers both padded images
-  const dim3 grid((unsigned)((total + 255) / 256), 3);  // y = 0/1: the two elt fragment images, 2: the fp32 images
+  // y = 0/1: the two elt fragment images, 2: the fp32 images, 3/4: the low images (lo_delta != 0)
+  const dim3 grid((unsigned)((total + 255) / 256), lo_delta ? 5 : 3);
   // forward image: M = cout, K = cin; backward (data-gradient) image: M = cin, K = cout
   hipLaunchKernelGGL(pack_mfma_kernel, grid, dim3(256), 0, s, w, (elt*)sec_fwd, (elt*)sec_bwd, cout, cin,
-                     transposed_src ? 2 : 0, transposed_src ? 3 : 1, Pf, Pb, transposed_src);
+                     transposed_src ? 2 : 0, transposed_src ? 3 : 1, Pf, Pb, transposed_src, lo_delta);
   return check_launch("pack_mfma");
 }
 
@@ -1444,8 +1453,9 @@ unsigned pack_mfma_blocks(int cin, int cout) {
   const size_t total = (size_t)((cmax + 31) / 32 * 32) * ((cmin + 31) / 32 * 32) * 27;
   return (unsigned)((total + 255) / 256);
 }
-int launch_pack_mfma_many(const void* table_device, int njobs, unsigned max_blocks, hipStream_t s) {
-  hipLaunchKernelGGL(pack_mfma_many_kernel, dim3(max_blocks, 3, (unsigned)njobs), dim3(256), 0, s, (const PackJobDev*)table_device);
+int launch_pack_mfma_many(const void* table_device, int njobs, unsigned max_blocks, hipStream_t s, int with_low) {
+  hipLaunchKernelGGL(pack_mfma_many_kernel, dim3(max_blocks, with_low ? 5 : 3, (unsigned)njobs), dim3(256), 0, s,
+                     (const PackJobDev*)table_device);
   return check_launch("pack_mfma_many");
 }
 

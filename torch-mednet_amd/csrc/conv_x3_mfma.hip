@@ -1,0 +1,786 @@
+// Split-bf16 matrix-core kernels for the 3x3x3 convolution family in the fp32 STORAGE mode (config.precision "fp32"): the
+// mode that meets the reference within 1e-3, at bf16 matrix-core speed instead of the fp32 MFMA's (1/16 of it).
+//
+// Every fp32 operand is split where it enters LDS:   v = hi + lo,  hi = bf16(v),  lo = bf16(v - hi)   (16 significant bits)
+// and a product is contracted as three bf16 MFMAs with fp32 accumulation,
+//        x * w  ~  x_hi * w_hi  +  x_hi * w_lo  +  x_lo * w_hi                 (the dropped x_lo * w_lo term is 2^-16 relative)
+// so the result differs from the exact fp32 fmaf chain of conv_f32_mfma.hip by ~2^-16 per product -- 256x below bf16 storage's
+// error, an order of magnitude inside the 1e-3 budget after 21 layers and their backward (measured: tests/test_gpu_network.py,
+// the cfg2 / cfg4 128^3 golden tests run in this mode).  Activations, gradients, GroupNorm and the losses stay fp32.
+// Caveat: an infinite input gives NaN, not +-inf (inf * w_lo with w_lo == 0); finite data is unaffected.
+//
+//   conv_x3_kernel<1>      nn.Conv3d 3^3 forward and data gradient (components.py:8-9,44), Cin and Cout multiples of 16
+//   conv_x3_kernel<2>      nn.ConvTranspose3d(k3,s2,p1,op1) data gradient (in = 2*out - 1 + tap)
+//   convt_x3_kernel        nn.ConvTranspose3d forward + bias + skip (components.py:259-264,283-284), output-parity classes
+//   wgrad_x3_kernel        conv weight gradient (contraction over voxels, both operands through ds_read_b64_tr_b16)
+//
+// Weights: the packed buffer's bf16 fragment images [cb][kc][tap][k-half][32 co][8 ci] (conv_mfma.hip, pack_mfma_body) hold the
+// high halves; mednet_conv3d_pack_elt(MEDNET_F32) also writes the low halves `lo_delta` bytes behind them, same order, so a
+// weight slice of one 16-channel chunk is two linear 27 KB copies.
+// Forward-type kernels are persistent (one workgroup per CU, each XCD walks a contiguous range of bricks); a step = one
+// 16-channel chunk of one brick: the chunk's input halo (fp32 rows -> hi / lo planes [hl][k-half][voxel] of 16-byte pieces)
+// and weight slice are committed to LDS, then 27 taps x N-tiles x 3 MFMAs run while the NEXT step's global loads -- dealt out
+// one per tap, the next brick's first chunk included -- are in flight into registers.
+#include "conv.h"
+
+namespace mednet {
+
+typedef __attribute__((ext_vector_type(4))) float f4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+#define X3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+struct HiLo {
+  bf16x8 hi, lo;
+};
+// 8 fp32 (two 16-byte loads) -> 8 high + 8 low bf16
+__device__ __forceinline__ HiLo split8(u32x4 ua, u32x4 ub) {
+  const f4 a = __builtin_bit_cast(f4, ua), b = __builtin_bit_cast(f4, ub);
+  HiLo r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bf16 ha = (bf16)a[j], hb = (bf16)b[j];
+    r.hi[j] = ha;
+    r.hi[j + 4] = hb;
+    r.lo[j] = (bf16)(a[j] - (float)ha);
+    r.lo[j + 4] = (bf16)(b[j] - (float)hb);
+  }
+  return r;
+}
+
+constexpr unsigned X3_OOB = 0xFFFFFF00u;  // a buffer-load offset past every resource: the hardware returns zeros
+
+// ================================================================================================== forward / data gradient
+template <int STRIDE>
+struct X3Tile;
+template <>
+struct X3Tile<1> {
+  static constexpr int TZ = 4, TY = 8, TX = 16, NWAVES = 8;
+};
+template <>
+struct X3Tile<2> {
+  static constexpr int TZ = 2, TY = 4, TX = 16, NWAVES = 4;
+};
+
+struct X3Args {
+  const float* x;     // N x (id,ih,iw) x K, channels last, fp32
+  const bf16* w_hi;   // image [ncb][nkc][27][2][32][8]; the low image lo_delta bytes behind it
+  unsigned lo_delta, w_bytes;  // w_bytes: lo_delta + bytes of one image (one buffer resource spans both)
+  const float* bias;  // nullable, M
+  float* y;           // N x (od,oh,ow) x M
+  float* stats;       // nullable: GroupNorm partials [n][rows][M][2] of the stored output (see conv_x3_stats_rows)
+  int n, od, oh, ow, id, ih, iw, k, m;
+  int tiles_z, tiles_y, tiles_x, tps, nkc, ncb, nitems, per_xcd, stats_rows, xps;  // xps: item ranges ("XCDs") per sample
+  unsigned bytes_in;  // bytes of ONE sample of x (buffer resources are per sample: 32-bit offsets)
+};
+
+template <int STRIDE>
+__global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3Args a) {
+  using G = X3Tile<STRIDE>;
+  constexpr int TZ = G::TZ, TY = G::TY, TX = G::TX, NWAVES = G::NWAVES, NTHR = NWAVES * 64;
+  constexpr int HZ = STRIDE * (TZ - 1) + 3, HY = STRIDE * (TY - 1) + 3, HX = STRIDE * (TX - 1) + 3;
+  constexpr int NV = HZ * HY * HX;
+  constexpr int NTW = TZ * TY * TX / 32 / NWAVES;
+  constexpr int IN_PIECES = 2 * NV, IN_ROUNDS = (IN_PIECES + NTHR - 1) / NTHR;
+  constexpr int W_SLICE = 27 * 2 * 32;  // 16-byte pieces of one image slice
+  constexpr int W_PIECES = 2 * W_SLICE, W_ROUNDS = (W_PIECES + NTHR - 1) / NTHR;
+  static_assert(IN_ROUNDS + W_ROUNDS <= 27, "one staging round per tap");
+  static_assert(NTW >= 1 && NTW * NWAVES * 32 == TZ * TY * TX, "whole N-tiles per wave");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16x8* in_lds = reinterpret_cast<bf16x8*>(smem);  // [hl][k-half][NV]
+  bf16x8* w_lds = in_lds + 4 * NV;                    // [hl][27][k-half][32 co]
+
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- staging plan of this thread (independent of the brick): halo piece p = it * NTHR + tid -> (voxel p >> 1, k-half p & 1)
+  int rel[IN_ROUNDS], hzyx[IN_ROUNDS];
+#pragma unroll
+  for (int it = 0; it < IN_ROUNDS; ++it) {
+    const int p = it * NTHR + tid;
+    const int v = p >> 1;
+    const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
+    rel[it] = ((hz * a.ih + hy) * a.iw + hx) * a.k * 4 + (p & 1) * 32;
+    hzyx[it] = p < IN_PIECES ? (hz << 16) | (hy << 8) | hx : (0x4000 << 16);  // (past the halo: never inside a volume)
+  }
+  int lv[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int g = wv * NTW + t;
+    const int lz = g / (TY / 2), ly = (g % (TY / 2)) * 2 + (r >> 4), lx = r & 15;
+    lv[t] = ((STRIDE * lz) * HY + STRIDE * ly) * HX + STRIDE * lx + h * NV;
+  }
+
+  struct Item {
+    int tz0, ty0, tx0, n, cb, base, valid;
+    __amdgpu_buffer_rsrc_t rs;
+  };
+  // the i-th item of this workgroup: XCD (blockIdx & 7 under round-robin placement) x walks items [x * per_xcd, (x+1) * per_xcd)
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slot_step = gridDim.x >> 3;
+  auto decode = [&](int i) {
+    Item it;
+    const int slot = slot0 + i * slot_step;
+    const int item = xcd * a.per_xcd + slot;
+    it.valid = slot < a.per_xcd && item < a.nitems;
+    const int iv = it.valid ? item : 0;
+    int tile = iv / a.ncb;
+    it.cb = iv - tile * a.ncb;
+    it.n = tile / a.tps;
+    tile -= it.n * a.tps;
+    it.tx0 = (tile % a.tiles_x) * TX;
+    tile /= a.tiles_x;
+    it.ty0 = (tile % a.tiles_y) * TY;
+    it.tz0 = (tile / a.tiles_y) * TZ;
+    it.base = (((STRIDE * it.tz0 - 1) * a.ih + (STRIDE * it.ty0 - 1)) * a.iw + (STRIDE * it.tx0 - 1)) * a.k * 4;
+    it.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)it.n * a.id * a.ih * a.iw * a.k), 0, a.bytes_in, 0x00020000);
+    return it;
+  };
+
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_hi, 0, a.w_bytes, 0x00020000);
+  u32x4 in_reg[IN_ROUNDS][2], w_reg[W_ROUNDS];
+  auto fetch_round = [&](int j, const Item& it, int kc) {
+    if (j < IN_ROUNDS) {
+      const int gz = STRIDE * it.tz0 - 1 + (hzyx[j] >> 16), gy = STRIDE * it.ty0 - 1 + ((hzyx[j] >> 8) & 255),
+                gx = STRIDE * it.tx0 - 1 + (hzyx[j] & 255);
+      const bool ok = ((unsigned)gz < (unsigned)a.id) & ((unsigned)gy < (unsigned)a.ih) & ((unsigned)gx < (unsigned)a.iw) & (it.valid != 0);
+      const unsigned off = ok ? (unsigned)(it.base + rel[j] + kc * 64) : X3_OOB;
+      in_reg[j][0] = __builtin_amdgcn_raw_buffer_load_b128(it.rs, off, 0, 0);
+      in_reg[j][1] = __builtin_amdgcn_raw_buffer_load_b128(it.rs, off + 16u, 0, 0);
+    } else if (j < IN_ROUNDS + W_ROUNDS) {  // (branch-free: one resource spans the high and the low image)
+      const int jw = j - IN_ROUNDS;
+      const int q = jw * NTHR + tid;
+      const int hl = q >= W_SLICE;
+      const unsigned off = (unsigned)((it.cb * a.nkc + kc) * W_SLICE + (q - hl * W_SLICE)) * 16u + (hl ? a.lo_delta : 0u);
+      w_reg[jw] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, ((q < W_PIECES) & (it.valid != 0)) ? off : X3_OOB, 0, 0);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) {
+      const int p = it * NTHR + tid;
+      if (p < IN_PIECES) {
+        const HiLo s = split8(in_reg[it][0], in_reg[it][1]);
+        in_lds[(p & 1) * NV + (p >> 1)] = s.hi;
+        in_lds[(2 + (p & 1)) * NV + (p >> 1)] = s.lo;
+      }
+    }
+#pragma unroll
+    for (int jw = 0; jw < W_ROUNDS; ++jw) {
+      const int q = jw * NTHR + tid;
+      if (q < W_PIECES) w_lds[q] = __builtin_bit_cast(bf16x8, w_reg[jw]);
+    }
+  };
+
+  f32x16 acc[NTW];
+  auto init_acc = [&]() {  // (the bias is added at the store)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  };
+  // per-wave GroupNorm partials of the stored output: this lane's channels are 8q + 4h + j (16 of the block's 32)
+  float ssum[16], ssq[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ssum[i] = ssq[i] = 0.f;
+  int stats_n = -1, stats_cb = 0;
+  auto flush_stats = [&]() {
+    // sum over the wave's 32 voxel lanes of each k-half (lanes with equal h), then one row per wave of the workgroups that
+    // work on this sample (conv_x3_stats_rows: a workgroup stays inside one sample): entries [n][row][co][2]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float s = ssum[i], q2 = ssq[i];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        s += __shfl_xor(s, o);
+        q2 += __shfl_xor(q2, o);
+      }
+      if (r == 0 && stats_n >= 0) {
+        const int co = stats_cb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+        if (co < a.m) {
+          const int row = ((xcd % a.xps) * slot_step + slot0) * NWAVES + wv;
+          float* dst = a.stats + (((size_t)stats_n * a.stats_rows + row) * a.m + co) * 2;
+          dst[0] = s;
+          dst[1] = q2;
+        }
+      }
+      ssum[i] = ssq[i] = 0.f;
+    }
+  };
+  auto store = [&](const Item& it) {
+    const size_t ovol = (size_t)a.od * a.oh * a.ow;
+    if (a.stats && (it.n != stats_n || it.cb != stats_cb)) {
+      if (stats_n >= 0) flush_stats();
+      stats_n = it.n;
+      stats_cb = it.cb;
+    }
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int g = wv * NTW + t;
+      const int oz = it.tz0 + g / (TY / 2), oy = it.ty0 + (g % (TY / 2)) * 2 + (r >> 4), ox = it.tx0 + (r & 15);
+      if (oz < a.od && oy < a.oh && ox < a.ow) {
+        float* yp = a.y + ((size_t)it.n * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.m;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co0 = it.cb * 32 + 8 * q + 4 * h;
+          if (co0 < a.m) {
+            f4 o = {acc[t][q * 4], acc[t][q * 4 + 1], acc[t][q * 4 + 2], acc[t][q * 4 + 3]};
+            if (a.bias) o += *reinterpret_cast<const f4*>(a.bias + co0);
+            __builtin_nontemporal_store(o, reinterpret_cast<f4*>(yp + co0));
+            if (a.stats) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                ssum[q * 4 + j] += o[j];
+                ssq[q * 4 + j] = fmaf(o[j], o[j], ssq[q * 4 + j]);
+              }
+            }
+          }
+        }
+      }
+    }
+  };
+
+  int idx = 0;
+  Item cur = decode(0);
+  if (!cur.valid) return;
+  int kc = 0;
+#pragma unroll
+  for (int j = 0; j < IN_ROUNDS + W_ROUNDS; ++j) fetch_round(j, cur, 0);
+  init_acc();
+  for (;;) {
+    const bool last_chunk = kc + 1 == a.nkc;
+    Item nxt = cur;
+    int nkc_ = kc + 1;
+    if (last_chunk) {
+      nxt = decode(++idx);
+      nkc_ = 0;
+    }
+    __syncthreads();  // the previous step's operand reads are done
+    commit();
+    __syncthreads();
+    // Two operand sets: the LDS reads of tap t+1 are in flight while the MFMAs of tap t run; the fence at the end of a tap keeps
+    // the compiler from hoisting later taps' reads as well (it then spills: 27 taps x 6 reads are all independent).
+    bf16x8 wa_hi[2], wa_lo[2], xh[2][NTW], xl[2][NTW];
+    auto load_tap = [&](int tap, int b) {
+      const int toff = ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
+      wa_hi[b] = w_lds[tap * 64 + h * 32 + r];
+      wa_lo[b] = w_lds[W_SLICE + tap * 64 + h * 32 + r];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        xh[b][t] = in_lds[lv[t] + toff];
+        xl[b][t] = in_lds[2 * NV + lv[t] + toff];
+      }
+    };
+    load_tap(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int b = tap & 1;
+      if (tap + 1 < 27) load_tap(tap + 1, b ^ 1);
+      fetch_round(tap, nxt, nkc_);  // (rounds past IN_ROUNDS + W_ROUNDS are empty)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        acc[t] = X3_MFMA(wa_lo[b], xh[b][t], acc[t]);
+        acc[t] = X3_MFMA(wa_hi[b], xl[b][t], acc[t]);
+        acc[t] = X3_MFMA(wa_hi[b], xh[b][t], acc[t]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (last_chunk) {
+      store(cur);
+      if (!nxt.valid) break;
+      init_acc();
+    }
+    cur = nxt;
+    kc = nkc_;
+  }
+  if (a.stats && stats_n >= 0) flush_stats();
+}
+
+static int x3_grid() {
+  int cus = ::mednet_internal_cu_count();
+  if (cus <= 0) cus = 256;
+  return (cus + 7) / 8 * 8;
+}
+
+bool conv_x3_enabled() { return tuning_option("x3", 1) != 0; }
+bool conv_x3_supported(int cin, int cout, int ksize) { return ksize == 3 && cin % 16 == 0 && cout % 16 == 0; }
+// the kernels address one sample through a buffer resource with 32-bit byte offsets
+bool conv_x3_fits(int d, int h, int w, int c) { return (double)d * h * w * c * 4.0 < 4294960000.0; }
+
+// GroupNorm partial rows per sample written by the forward kernel (0: no fused statistics for this shape).  Each wave keeps
+// {sum y, sum y^2} of everything it stores and writes ONE row at the end; that needs every workgroup to stay inside one sample
+// and one channel block and to have at least one brick: one channel block (Cout <= 32), the eight item ranges aligned with the
+// samples (n divides 8), at least one brick per workgroup.  Then rows = (ranges per sample) * (workgroups per range) * waves.
+int conv_x3_stats_rows(int n, int d, int h, int w, int cout) {
+  using G = X3Tile<1>;
+  if (!tuning_option("x3_stats", 1)) return 0;
+  if (cout > 32 || n > 8 || 8 % n != 0) return 0;
+  const int tps = ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
+  const int nitems = n * tps, grid = x3_grid();
+  if (nitems % 8 != 0 || nitems / 8 < grid / 8) return 0;
+  return (8 / n) * (grid / 8) * G::NWAVES;
+}
+
+template <int STRIDE>
+static int launch_x3(const void* x, const void* sec_hi, size_t lo_delta, const float* bias, void* y, int n, int od, int oh, int ow,
+                     int id, int ih, int iw, int k, int m, float* stats, hipStream_t s) {
+  using G = X3Tile<STRIDE>;
+  constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
+  constexpr size_t lds = ((size_t)4 * HZ * HY * HX + 2 * 27 * 2 * 32) * 16;
+  static_assert(lds <= 160 * 1024, "one workgroup per CU");
+  MEDNET_REQUIRE(k % 16 == 0 && m % 16 == 0 && lo_delta != 0, MEDNET_E_UNSUPPORTED, "conv_x3: channels %d -> %d", k, m);
+  X3Args a;
+  a.x = (const float*)x;
+  a.w_hi = (const bf16*)sec_hi;
+  const size_t img = (size_t)27 * ((m + 31) / 32 * 32) * k * 2;
+  MEDNET_REQUIRE(lo_delta + img < 4294960000.0, MEDNET_E_UNSUPPORTED, "conv_x3: weight images too large");
+  a.lo_delta = (unsigned)lo_delta;
+  a.w_bytes = (unsigned)(lo_delta + img);
+  a.bias = bias;
+  a.y = (float*)y;
+  a.stats = stats;
+  a.n = n; a.od = od; a.oh = oh; a.ow = ow; a.id = id; a.ih = ih; a.iw = iw; a.k = k; a.m = m;
+  a.tiles_z = (od + G::TZ - 1) / G::TZ;
+  a.tiles_y = (oh + G::TY - 1) / G::TY;
+  a.tiles_x = (ow + G::TX - 1) / G::TX;
+  a.tps = a.tiles_z * a.tiles_y * a.tiles_x;
+  a.nkc = k / 16;
+  a.ncb = (m + 31) / 32;
+  MEDNET_REQUIRE((double)n * a.tps * a.ncb < 2147483647.0, MEDNET_E_UNSUPPORTED, "conv_x3: too many bricks");
+  a.nitems = n * a.tps * a.ncb;
+  a.per_xcd = (a.nitems + 7) / 8;
+  a.stats_rows = stats ? conv_x3_stats_rows(n, od, oh, ow, m) : 0;
+  a.xps = n <= 8 && 8 % n == 0 ? 8 / n : 1;
+  MEDNET_REQUIRE(!stats || (STRIDE == 1 && a.stats_rows > 0), MEDNET_E_UNSUPPORTED, "conv_x3: no fused statistics for this shape");
+  a.bytes_in = (unsigned)((size_t)id * ih * iw * k * 4);
+  static bool attr_set[3] = {false, false, false};
+  if (!attr_set[STRIDE]) {
+    if (hipFuncSetAttribute((const void*)conv_x3_kernel<STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(MEDNET_E_HIP, "conv_x3: cannot raise dynamic LDS to %zu", lds);
+    attr_set[STRIDE] = true;
+  }
+  hipLaunchKernelGGL((conv_x3_kernel<STRIDE>), dim3(x3_grid()), dim3(G::NWAVES * 64), lds, s, a);
+  return check_launch("conv_x3");
+}
+
+int launch_conv_x3(const void* x, const void* sec_hi, size_t lo_delta, const float* bias, void* y, int n, int d, int h, int w, int k,
+                   int m, float* stats, hipStream_t s) {
+  return launch_x3<1>(x, sec_hi, lo_delta, bias, y, n, d, h, w, d, h, w, k, m, stats, s);
+}
+int launch_convt_dgrad_x3(const void* dy, const void* sec_hi, size_t lo_delta, void* dx, int n, int d, int h, int w, int cin,
+                          int cout, hipStream_t s) {
+  // dx (d,h,w; Cin) <- dy (2d,2h,2w; Cout): contraction over Cout
+  return launch_x3<2>(dy, sec_hi, lo_delta, nullptr, dx, n, d, h, w, 2 * d, 2 * h, 2 * w, cout, cin, nullptr, s);
+}
+
+// ================================================================================================== ConvTranspose3d forward
+// out[2j + p] = bias + skip + sum over the taps k of parity class p of W[k] * x[j + delta_k]   (per dim: k=1 -> p=0,d=0;
+// k=0 -> p=1,d=1; k=2 -> p=1,d=0).  A workgroup owns a 2x4x16 brick of INPUT voxels (4x8x32 outputs), a wave one N-tile of 32
+// input voxels with all 8 output parity classes in registers (8 x 16 accumulators), as convt_f32_mfma_kernel; operands split
+// as above.  Not persistent: the launch has thousands of short workgroups, two per CU.
+struct CtX3Args {
+  const float* x;
+  const bf16* w_hi;  // forward image of the layer (mode 2: Weff[co][ci][tap] = Wt[ci][co][tap]); low image lo_delta behind
+  unsigned lo_delta, w_bytes;
+  const float* bias;
+  const float* skip;
+  float* y;
+  int n, id, ih, iw, k, m;
+  int tiles_z, tiles_y, tiles_x, ntiles, nkc, ncb;
+};
+
+__global__ __launch_bounds__(256, 2) void convt_x3_kernel(CtX3Args a) {
+  constexpr int TZ = 2, TY = 4, TX = 16, HZ = TZ + 1, HY = TY + 1, HX = TX + 1, NV = HZ * HY * HX;
+  constexpr int IN_PIECES = 2 * NV, IN_ROUNDS = (IN_PIECES + 255) / 256;
+  constexpr int W_SLICE = 27 * 2 * 32, W_PIECES = 2 * W_SLICE, W_ROUNDS = (W_PIECES + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16x8* in_lds = reinterpret_cast<bf16x8*>(smem);  // [hl][k-half][NV]
+  bf16x8* w_lds = in_lds + 4 * NV;                    // [hl][27][k-half][32 co]
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x / a.ncb, cb = blockIdx.x % a.ncb;
+  int tt = tile;
+  const int tx0 = (tt % a.tiles_x) * TX;
+  tt /= a.tiles_x;
+  const int ty0 = (tt % a.tiles_y) * TY;
+  tt /= a.tiles_y;
+  const int tz0 = (tt % a.tiles_z) * TZ;
+  const int n = tt / a.tiles_z;
+  const float* xs = a.x + (size_t)n * a.id * a.ih * a.iw * a.k;
+  long long goff[IN_ROUNDS];  // element offset of the piece's 8 channels (chunk 0), -1 outside the volume / past the halo
+#pragma unroll
+  for (int it = 0; it < IN_ROUNDS; ++it) {
+    const int p = it * 256 + tid;
+    const int v = p >> 1;
+    long long off = -1;
+    if (p < IN_PIECES) {
+      const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
+      const int gz = tz0 + hz, gy = ty0 + hy, gx = tx0 + hx;
+      if (gz < a.id && gy < a.ih && gx < a.iw) off = (((long long)gz * a.ih + gy) * a.iw + gx) * a.k + (p & 1) * 8;
+    }
+    goff[it] = off;
+  }
+  const int lz = wv / (TY / 2), ly = (wv % (TY / 2)) * 2 + (r >> 4), lx = r & 15;
+  const int lbase = (lz * HY + ly) * HX + lx + h * NV;
+  f32x16 acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_hi, 0, a.w_bytes, 0x00020000);
+  u32x4 in_reg[IN_ROUNDS][2], w_reg[W_ROUNDS];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      in_reg[it][0] = in_reg[it][1] = z;
+      if (goff[it] >= 0) {
+        const float* src = xs + goff[it] + kc * 16;
+        in_reg[it][0] = *reinterpret_cast<const u32x4*>(src);
+        in_reg[it][1] = *reinterpret_cast<const u32x4*>(src + 4);
+      }
+    }
+  };
+  fetch(0);
+  for (int kc = 0; kc < a.nkc; ++kc) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IN_ROUNDS; ++it) {
+      const int p = it * 256 + tid;
+      if (p < IN_PIECES) {
+        const HiLo s = split8(in_reg[it][0], in_reg[it][1]);
+        in_lds[(p & 1) * NV + (p >> 1)] = s.hi;
+        in_lds[(2 + (p & 1)) * NV + (p >> 1)] = s.lo;
+      }
+    }
+    // the weight slice is copied here, not prefetched through registers (8 x 16 accumulators leave no room for it); the
+    // CU's second workgroup covers the latency
+#pragma unroll
+    for (int jw = 0; jw < W_ROUNDS; ++jw) {
+      const int q = jw * 256 + tid;
+      const int hl = q >= W_SLICE;
+      const unsigned off = (unsigned)((cb * a.nkc + kc) * W_SLICE + (q - hl * W_SLICE)) * 16u + (hl ? a.lo_delta : 0u);
+      w_reg[jw] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, q < W_PIECES ? off : X3_OOB, 0, 0);
+    }
+#pragma unroll
+    for (int jw = 0; jw < W_ROUNDS; ++jw) {
+      const int q = jw * 256 + tid;
+      if (q < W_PIECES) w_lds[q] = __builtin_bit_cast(bf16x8, w_reg[jw]);
+    }
+    __syncthreads();
+    if (kc + 1 < a.nkc) fetch(kc + 1);
+    bf16x8 xh[8], xl[8];
+#pragma unroll
+    for (int dl = 0; dl < 8; ++dl) {
+      const int o = lbase + (((dl >> 2) & 1) * HY + ((dl >> 1) & 1)) * HX + (dl & 1);
+      xh[dl] = in_lds[o];
+      xl[dl] = in_lds[2 * NV + o];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+      const int pc = (kz != 1) * 4 + (ky != 1) * 2 + (kx != 1);  // output parity class of this tap
+      const int dl = (kz == 0) * 4 + (ky == 0) * 2 + (kx == 0);  // input offset of this tap
+      const bf16x8 wa_hi = w_lds[tap * 64 + h * 32 + r];
+      const bf16x8 wa_lo = w_lds[W_SLICE + tap * 64 + h * 32 + r];
+      acc[pc] = X3_MFMA(wa_lo, xh[dl], acc[pc]);
+      acc[pc] = X3_MFMA(wa_hi, xl[dl], acc[pc]);
+      acc[pc] = X3_MFMA(wa_hi, xh[dl], acc[pc]);
+    }
+  }
+  const int od = 2 * a.id, oh = 2 * a.ih, ow = 2 * a.iw;
+  const int jz = tz0 + lz, jy = ty0 + ly, jx = tx0 + lx;
+  if (jz < a.id && jy < a.ih && jx < a.iw) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int oz = 2 * jz + (p >> 2), oy = 2 * jy + ((p >> 1) & 1), ox = 2 * jx + (p & 1);
+      const size_t o = ((((size_t)n * od + oz) * oh + oy) * ow + ox) * a.m;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co0 = cb * 32 + 8 * q + 4 * h;
+        if (co0 < a.m) {
+          f4 v = {acc[p][q * 4], acc[p][q * 4 + 1], acc[p][q * 4 + 2], acc[p][q * 4 + 3]};
+          if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + co0);
+          if (a.skip) v += *reinterpret_cast<const f4*>(a.skip + o + co0);
+          *reinterpret_cast<f4*>(a.y + o + co0) = v;
+        }
+      }
+    }
+  }
+}
+
+int launch_convt_fwd_x3(const void* x, const void* sec_hi, size_t lo_delta, const float* bias, const void* skip, void* y, int n,
+                        int d, int h, int w, int cin, int cout, hipStream_t s) {
+  constexpr size_t lds = ((size_t)4 * 3 * 5 * 17 + 2 * 27 * 2 * 32) * 16;
+  static_assert(lds <= 80 * 1024, "two workgroups per CU");
+  MEDNET_REQUIRE(cin % 16 == 0 && cout % 16 == 0 && lo_delta != 0, MEDNET_E_UNSUPPORTED, "convt_x3: channels %d -> %d", cin, cout);
+  CtX3Args a;
+  a.x = (const float*)x;
+  a.w_hi = (const bf16*)sec_hi;
+  const size_t img = (size_t)27 * ((cout + 31) / 32 * 32) * cin * 2;
+  MEDNET_REQUIRE(lo_delta + img < 4294960000.0, MEDNET_E_UNSUPPORTED, "convt_x3: weight images too large");
+  a.lo_delta = (unsigned)lo_delta;
+  a.w_bytes = (unsigned)(lo_delta + img);
+  a.bias = bias; a.skip = (const float*)skip; a.y = (float*)y;
+  a.n = n; a.id = d; a.ih = h; a.iw = w; a.k = cin; a.m = cout;
+  a.tiles_z = (d + 1) / 2; a.tiles_y = (h + 3) / 4; a.tiles_x = (w + 15) / 16;
+  a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
+  a.nkc = cin / 16;
+  a.ncb = (cout + 31) / 32;
+  MEDNET_REQUIRE((double)a.ntiles * a.ncb < 2147483647.0, MEDNET_E_UNSUPPORTED, "convt_x3: grid too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)convt_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(MEDNET_E_HIP, "convt_x3: cannot raise dynamic LDS to %zu", lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(convt_x3_kernel, dim3((unsigned)(a.ntiles * a.ncb)), dim3(256), lds, s, a);
+  return check_launch("convt_x3");
+}
+
+// ================================================================================================== weight gradient
+//   R[tap][a][b] = sum_v A[v][a] * B[v + tap - 1][b]      A = dy (Cout), B = x (Cin);   dw[(a*KB + b)*27 + tap]
+// Brick 4x4x16 (halo 6x6x18); LDS rows [voxel][32 channels] bf16, a high and a low plane per operand; a k-step = 16
+// x-consecutive voxels, both MFMA operands through the transposing LDS read (lane mapping: conv_mfma.hip tr_operand,
+// tools/probes/tr_probe.hip).  A wave owns 7 of the 27 taps (7 x 16 accumulators; the wave with 6 recomputes tap 26, discarded),
+// one wave per SIMD: two operand sets, the reads of k-step s+1 in flight while the 21 MFMAs of k-step s run; the next brick's
+// 15 staging rounds are dealt out one per k-step.  Per-workgroup slabs, fixed-order reduce (no atomics).
+struct WgX3Args {
+  const float* A;
+  const float* B;
+  float* part;  // [workgroup][27][32][32]
+  int n, d, h, w, ka, kb;
+  int tiles_z, tiles_y, tiles_x, tps, ntiles, nab, nbb, splits;
+  unsigned bytesA, bytesB;  // per sample
+};
+
+__device__ __forceinline__ bf16x8 x3_tr_operand(const char* base, int second) {
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + second));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256) void wgrad_x3_kernel(WgX3Args a) {
+  constexpr int TZ = 4, TY = 4, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+  constexpr int NA = TZ * TY * TX, NB = HZ * HY * HX;
+  constexpr int A_ROUNDS = NA * 4 / 256, B_ROUNDS = (NB * 4 + 255) / 256;
+  constexpr int KSTEPS = NA / 16;
+  static_assert(A_ROUNDS + B_ROUNDS <= KSTEPS, "one staging round per k-step");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // bytes: A_hi [NA][64] | A_lo | B_hi [NB][64] | B_lo
+  constexpr int A_LO = NA * 64, B_HI = 2 * NA * 64, B_LO = 2 * NA * 64 + NB * 64;
+
+  const int pair = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
+  const int ab = pair / a.nbb, bb = pair % a.nbb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int tw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, hk = lane >> 5;
+  const int coloff = (16 * (g & 1) + 4 * p) * 2;
+
+  u32x4 regA[A_ROUNDS][2], regB[B_ROUNDS][2];
+  struct Next {
+    int tz0, ty0, tx0;
+    bool valid;
+    __amdgpu_buffer_rsrc_t rA, rB;
+  };
+  auto plan = [&](int tile) {
+    Next nx;
+    nx.valid = tile < a.ntiles;
+    int tt = nx.valid ? tile : 0;
+    const int n = tt / a.tps;
+    tt -= n * a.tps;
+    nx.tx0 = (tt % a.tiles_x) * TX;
+    tt /= a.tiles_x;
+    nx.ty0 = (tt % a.tiles_y) * TY;
+    nx.tz0 = (tt / a.tiles_y) * TZ;
+    const size_t svox = (size_t)n * a.d * a.h * a.w;
+    nx.rA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + svox * a.ka), 0, a.bytesA, 0x00020000);
+    nx.rB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + svox * a.kb), 0, a.bytesB, 0x00020000);
+    return nx;
+  };
+  auto fetch_round = [&](int j, const Next& nx) {
+    if (j < A_ROUNDS) {
+      const int c = j * 256 + tid;
+      const int v = c >> 2, part = c & 3;
+      const int gz = nx.tz0 + v / (TX * TY), gy = nx.ty0 + (v / TX) % TY, gx = nx.tx0 + v % TX;
+      const bool ok = (gz < a.d) & (gy < a.h) & (gx < a.w) & (ab * 32 + part * 8 < a.ka) & nx.valid;
+      const unsigned off = ok ? ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.ka + ab * 32 + part * 8) * 4u : X3_OOB;
+      regA[j][0] = __builtin_amdgcn_raw_buffer_load_b128(nx.rA, off, 0, 0);
+      regA[j][1] = __builtin_amdgcn_raw_buffer_load_b128(nx.rA, off + 16u, 0, 0);
+    } else if (j < A_ROUNDS + B_ROUNDS) {
+      const int it = j - A_ROUNDS;
+      const int c = it * 256 + tid;
+      const int v = c >> 2, part = c & 3;
+      const int gz = nx.tz0 - 1 + v / (HX * HY), gy = nx.ty0 - 1 + (v / HX) % HY, gx = nx.tx0 - 1 + v % HX;
+      const bool ok = (c < NB * 4) & ((unsigned)gz < (unsigned)a.d) & ((unsigned)gy < (unsigned)a.h) &
+                      ((unsigned)gx < (unsigned)a.w) & (bb * 32 + part * 8 < a.kb) & nx.valid;
+      const unsigned off = ok ? ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.kb + bb * 32 + part * 8) * 4u : X3_OOB;
+      regB[it][0] = __builtin_amdgcn_raw_buffer_load_b128(nx.rB, off, 0, 0);
+      regB[it][1] = __builtin_amdgcn_raw_buffer_load_b128(nx.rB, off + 16u, 0, 0);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_ROUNDS; ++it) {
+      const int c = it * 256 + tid;
+      const HiLo s = split8(regA[it][0], regA[it][1]);
+      *reinterpret_cast<bf16x8*>(smem + c * 16) = s.hi;
+      *reinterpret_cast<bf16x8*>(smem + A_LO + c * 16) = s.lo;
+    }
+#pragma unroll
+    for (int it = 0; it < B_ROUNDS; ++it) {
+      const int c = it * 256 + tid;
+      if (c < NB * 4) {
+        const HiLo s = split8(regB[it][0], regB[it][1]);
+        *reinterpret_cast<bf16x8*>(smem + B_HI + c * 16) = s.hi;
+        *reinterpret_cast<bf16x8*>(smem + B_LO + c * 16) = s.lo;
+      }
+    }
+  };
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  int toff[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = tw + 4 * i < 27 ? tw + 4 * i : 26;
+    toff[i] = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 64;
+  }
+  const char* Ab = smem + coloff;
+  const char* Bb = smem + B_HI + coloff;
+  struct Set {
+    bf16x8 ah, al, bh[7], bl[7];
+  };
+  auto load_set = [&](int ks, Set& st) {
+    const char* arow = Ab + (ks * TX + 8 * hk + q) * 64;
+    st.ah = x3_tr_operand(arow, 4 * 64);
+    st.al = x3_tr_operand(arow + A_LO, 4 * 64);
+    const char* brow = Bb + (((ks / TY) * HY + ks % TY) * HX + 8 * hk + q) * 64;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      st.bh[i] = x3_tr_operand(brow + toff[i], 4 * 64);
+      st.bl[i] = x3_tr_operand(brow + (B_LO - B_HI) + toff[i], 4 * 64);
+    }
+  };
+  auto mfma_set = [&](const Set& st) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      acc[i] = X3_MFMA(st.al, st.bh[i], acc[i]);
+      acc[i] = X3_MFMA(st.ah, st.bl[i], acc[i]);
+      acc[i] = X3_MFMA(st.ah, st.bh[i], acc[i]);
+    }
+  };
+
+  int tile = split;
+  if (tile < a.ntiles) {
+    const Next first = plan(tile);
+#pragma unroll
+    for (int j = 0; j < A_ROUNDS + B_ROUNDS; ++j) fetch_round(j, first);
+  }
+  for (; tile < a.ntiles; tile += a.splits) {
+    __syncthreads();  // the previous brick is consumed
+    commit();
+    __syncthreads();
+    const Next nx = plan(tile + a.splits);
+    Set s0, s1;
+    load_set(0, s0);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks += 2) {
+      load_set(ks + 1, s1);
+      fetch_round(ks, nx);
+      mfma_set(s0);
+      if (ks + 2 < KSTEPS) load_set(ks + 2, s0);
+      fetch_round(ks + 1, nx);
+      mfma_set(s1);
+    }
+  }
+  float* out = a.part + (size_t)blockIdx.x * 27 * 1024;
+  const int col = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = tw + 4 * i;
+    if (tap < 27) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) out[((size_t)tap * 32 + (j & 3) + 8 * (j >> 2) + 4 * hk) * 32 + col] = acc[i][j];
+    }
+  }
+}
+
+// dw[(a*KB + b)*27 + tap] = sum over the splits of part[(pair*splits + split)][tap][a%32][b%32], fixed order
+__global__ __launch_bounds__(256) void wgrad_x3_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int ka, int kb,
+                                                              int nbb, int splits) {
+  const size_t total = (size_t)((ka + 31) / 32) * nbb * 1024 * 27;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int b32 = (int)(e % 32), a32 = (int)((e / 32) % 32), tap = (int)((e / 1024) % 27);
+  const int pair = (int)(e / (1024 * 27));
+  const int ab = pair / nbb, bb = pair % nbb;
+  const float* src = part + ((size_t)pair * splits) * 27 * 1024 + (size_t)tap * 1024 + a32 * 32 + b32;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 4 <= splits; k += 4) {
+    s0 += src[(size_t)k * 27 * 1024];
+    s1 += src[(size_t)(k + 1) * 27 * 1024];
+    s2 += src[(size_t)(k + 2) * 27 * 1024];
+    s3 += src[(size_t)(k + 3) * 27 * 1024];
+  }
+  for (; k < splits; ++k) s0 += src[(size_t)k * 27 * 1024];
+  if (ab * 32 + a32 < ka && bb * 32 + b32 < kb) dw[((size_t)(ab * 32 + a32) * kb + bb * 32 + b32) * 27 + tap] = (s0 + s1) + (s2 + s3);
+}
+
+static void wgx3_plan(int n, int d, int h, int w, int ka, int kb, WgX3Args& a) {
+  a.tiles_z = (d + 3) / 4;
+  a.tiles_y = (h + 3) / 4;
+  a.tiles_x = (w + 15) / 16;
+  a.tps = a.tiles_z * a.tiles_y * a.tiles_x;
+  a.ntiles = n * a.tps;
+  a.nab = (ka + 31) / 32;
+  a.nbb = (kb + 31) / 32;
+  const int pairs = a.nab * a.nbb;
+  int splits = (x3_grid() + pairs - 1) / pairs;  // about one workgroup per CU
+  if (splits > a.ntiles) splits = a.ntiles;
+  if (splits < 1) splits = 1;
+  a.splits = splits;
+}
+
+size_t wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  WgX3Args a;
+  wgx3_plan(n, d, h, w, cout, cin, a);
+  return (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+}
+
+int launch_wgrad_x3(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, void* ws,
+                    size_t ws_bytes, hipStream_t s) {
+  constexpr size_t lds = ((size_t)4 * 4 * 16 + 6 * 6 * 18) * 64 * 2;
+  static_assert(lds <= 160 * 1024, "one workgroup per CU");
+  MEDNET_REQUIRE(cin % 16 == 0 && cout % 16 == 0, MEDNET_E_UNSUPPORTED, "wgrad_x3: channels %d -> %d", cin, cout);
+  WgX3Args a;
+  a.A = (const float*)dy;  // A = dy (Cout rows), B = x (Cin cols)
+  a.B = (const float*)x;
+  a.part = (float*)ws;
+  a.n = n; a.d = d; a.h = h; a.w = w; a.ka = cout; a.kb = cin;
+  wgx3_plan(n, d, h, w, cout, cin, a);
+  a.bytesA = (unsigned)((size_t)d * h * w * cout * 4);
+  a.bytesB = (unsigned)((size_t)d * h * w * cin * 4);
+  const size_t need = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+  MEDNET_REQUIRE(ws_bytes >= need, MEDNET_E_WORKSPACE, "wgrad_x3: workspace %zu < %zu", ws_bytes, need);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wgrad_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(MEDNET_E_HIP, "wgrad_x3: cannot raise dynamic LDS to %zu", lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_x3_kernel, dim3(a.nab * a.nbb * a.splits), dim3(256), lds, s, a);
+  int rc = check_launch("wgrad_x3");
+  if (rc) return rc;
+  const size_t total = (size_t)a.nab * a.nbb * 1024 * 27;
+  hipLaunchKernelGGL(wgrad_x3_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, cout, cin, a.nbb,
+                     a.splits);
+  return check_launch("wgrad_x3_reduce");
+}
+
+}  // namespace mednet

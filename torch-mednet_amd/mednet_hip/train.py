@@ -138,8 +138,6 @@ class BatchedRepack:
         from . import _lib as L, config
         if not self.ENABLED or not self.mods or any(getattr(m, "_pack_buf", None) is None for m in self.mods):
             return
-        if not config.is_half_mode():
-            return
         lib = L.lib()
         sig = self._signature()
         if sig != self.sig:
@@ -156,7 +154,7 @@ class BatchedRepack:
             L.check(lib.mednet_conv3d_pack_table(C.addressof(jobs), len(self.mods), host.data_ptr(), C.addressof(mb)), "pack_table")
             self.table = host.to(self.mods[0].weight.device)
             self.max_blocks, self.sig = mb.value, sig
-        elt = L.F16 if config.act_dtype() == torch.float16 else L.BF16
+        elt = {torch.float16: L.F16, torch.bfloat16: L.BF16}.get(config.act_dtype(), L.F32)  # (F32: + the low images)
         L.check(lib.mednet_conv3d_pack_many(self.table.data_ptr(), len(self.mods), self.max_blocks, elt, L.stream()), "pack_many")
         for m in self.mods:  # what _PackedWeightMixin._packed() will compute at the next forward
             w = m.weight
