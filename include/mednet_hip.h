@@ -29,7 +29,10 @@ enum { MEDNET_F32 = 0, MEDNET_BF16 = 1 };
 enum { MEDNET_NDHWC = 0, MEDNET_NCDHW = 1 };
 enum { MEDNET_ACT_NONE = 0, MEDNET_ACT_RELU = 1, MEDNET_ACT_LEAKY = 2, MEDNET_ACT_ELU = 3 };
 enum { MEDNET_POOL_MAX = 0, MEDNET_POOL_AVG = 1 };
-enum { MEDNET_ALGO_AUTO = 0, MEDNET_ALGO_DIRECT = 1, MEDNET_ALGO_MFMA = 2 };
+/* ALGO_EXACT = ALGO_AUTO, except that fp32-storage contractions use exact fp32 products (v_mfma_f32_32x32x2_f32) instead of
+ * the split-bf16 contraction (three bf16 MFMAs per product, ~2^-16 relative): asked for by networks with ReLU / LeakyReLU,
+ * whose gradients are discontinuous in the pre-activations (mednet_hip/config.py exact_products). */
+enum { MEDNET_ALGO_AUTO = 0, MEDNET_ALGO_DIRECT = 1, MEDNET_ALGO_MFMA = 2, MEDNET_ALGO_EXACT = 3 };
 enum { MEDNET_REG_L2 = 0, MEDNET_REG_L1 = 1 };
 enum {
   MEDNET_OK = 0, MEDNET_E_SHAPE = -1, MEDNET_E_DTYPE = -2, MEDNET_E_WORKSPACE = -3, MEDNET_E_HIP = -4,

@@ -155,7 +155,7 @@ extern "C" int mednet_conv3d_fused_stats_chunks(int n, int d, int h, int w, int 
                                                 int y_dtype, int algo) {
   if (algo == MEDNET_ALGO_DIRECT || !tuning_option("conv_fuse_stats", 1)) return 0;
   if (x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32)  // fp32 storage: the split-bf16 forward kernel keeps the sums per wave
-    return conv_f32_mfma_enabled() && conv_x3_enabled() && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin)
+    return conv_f32_mfma_enabled() && (algo != MEDNET_ALGO_EXACT && conv_x3_enabled()) && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin)
                ? conv_x3_stats_rows(n, d, h, w, cout)
                : 0;
   if (ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, false)) return conv_c1_stats_chunks(d, h, w);
@@ -188,7 +188,7 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
   // (three MFMAs per product; the pack must hold the low images: mednet_conv3d_pack_elt(MEDNET_F32)) ...
   const bool f32_mode = algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 &&
                         y_dtype == MEDNET_F32 && (x_layout == MEDNET_NDHWC || cin == 1) && y_layout == MEDNET_NDHWC;
-  if (f32_mode && conv_x3_enabled() && L.mfma_bytes && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin))
+  if (f32_mode && (algo != MEDNET_ALGO_EXACT && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin))
     return launch_conv_x3(x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), L.lo_delta, bias, y, n, d, h, w, cin, cout, gn_partial, s);
   MEDNET_REQUIRE(gn_partial == nullptr, MEDNET_E_UNSUPPORTED,
                  "conv3d_fwd: fused GroupNorm partials are only produced by the MFMA paths (ask mednet_conv3d_fused_stats_chunks)");
@@ -247,7 +247,7 @@ extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, flo
   if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32 &&
       (x_layout == MEDNET_NDHWC || cin == 1) && dy_layout == MEDNET_NDHWC) {
     const int cmax = cin > cout ? cin : cout;
-    if (conv_x3_enabled() && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cmax))
+    if ((algo != MEDNET_ALGO_EXACT && conv_x3_enabled()) && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cmax))
       return launch_wgrad_x3(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);  // split-bf16 contraction over the voxels
     return launch_wgrad_f32_mfma(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
   }
@@ -349,7 +349,7 @@ extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float
     return ELT_CALL(x_dtype, launch_convt_fwd_mfma, x, (const char*)packed + L.mfma_fwd, bias, skip, y, n, d, h, w, cin, cout,
                     (hipStream_t)stream);
   if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32) {
-    if (conv_x3_enabled() && L.mfma_bytes && conv_x3_supported(cin, cout, 3))
+    if ((algo != MEDNET_ALGO_EXACT && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, 3))
       return launch_convt_fwd_x3(x, (const char*)packed + L.mfma_fwd, L.lo_delta, bias, skip, y, n, d, h, w, cin, cout,
                                  (hipStream_t)stream);
     return launch_convt_fwd_f32_mfma(x, (const float*)((const char*)packed + L.f32_fwd), bias, skip, y, n, d, h, w, cin, cout,
@@ -375,7 +375,7 @@ extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx
     return ELT_CALL(dy_dtype, launch_convt_dgrad_mfma, dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cin, cout,
                     (hipStream_t)stream);
   if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && dy_dtype == MEDNET_F32 && dx_dtype == MEDNET_F32) {
-    if (conv_x3_enabled() && L.mfma_bytes && conv_x3_supported(cin, cout, 3) && conv_x3_fits(2 * d, 2 * h, 2 * w, cout))
+    if ((algo != MEDNET_ALGO_EXACT && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, 3) && conv_x3_fits(2 * d, 2 * h, 2 * w, cout))
       return launch_convt_dgrad_x3(dy, (const char*)packed + L.mfma_bwd, L.lo_delta, dx, n, d, h, w, cin, cout, (hipStream_t)stream);
     return launch_convt_dgrad_f32_mfma(dy, (const float*)((const char*)packed + L.f32_bwd), dx, n, d, h, w, cin, cout,
                                        (hipStream_t)stream);

@@ -18,7 +18,7 @@ F32, BF16 = 0, 1
 NDHWC, NCDHW = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3
 POOL_MAX, POOL_AVG = 0, 1
-ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_EXACT = 0, 1, 2, 3
 REG_L2, REG_L1 = 0, 1
 PAD_CONSTANT, PAD_SYMMETRIC = 0, 1
 F16, U8 = 2, 3  # storage types of resident volumes (mednet_crop_patches only)

@@ -147,6 +147,7 @@ class ResBlockFn(Function):
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, pk1, pk2, pk3, groups, eps, act, hook=None):
         L.require_gpu(x, "ExtResNetBlock")
+        ctx.algo = config.conv_algo()
         x = ops._as_act(x)
         xin = x.contiguous() if x.shape[1] == 1 else ops.to_cl(x)  # Cin == 1: NCDHW and NDHWC coincide
         cout = w1.shape[0]
@@ -166,6 +167,7 @@ class ResBlockFn(Function):
         return out
 
     @staticmethod
+    @ops._with_algo
     def backward(ctx, dout):
         xin, y1, z1, y2, z2, y3, out, s1, c1, s2, c2, s3, c3, pk1, pk2, pk3 = ctx.saved_tensors
         w1, g1, b1, w2, g2, b2, w3, g3, b3 = ctx.params

@@ -47,7 +47,41 @@ def set_conv_algo(name: str):
 
 
 def conv_algo() -> int:
-    return _state["algo"]
+    """Algorithm argument of the conv-family C-ABI calls.  Inside an `exact_products` scope the automatic choice becomes
+    ALGO_EXACT: in the fp32 storage mode the contraction then runs on exact fp32 products (v_mfma_f32_32x32x2_f32) instead of
+    the split-bf16 contraction (~2^-16 per product); nothing changes for the 16-bit modes."""
+    a = _state["algo"]
+    return _lib.ALGO_EXACT if (a == _lib.ALGO_AUTO and _state.get("exact")) else a
+
+
+@contextlib.contextmanager
+def exact_products(on: bool = True):
+    """Networks with KINKED activations (ReLU 'r', LeakyReLU 'l' in the order string, components.py:36-38) are piecewise
+    linear: their gradient is a discontinuous function of every pre-activation, so a 2^-16 perturbation of a convolution
+    output flips a few activation masks and moves first-layer gradients by more than the 1e-3 budget (measured: UNet3D 'gcr'
+    at 32^3, 1.4e-3).  Such layers therefore ask for exact fp32 products; the smooth default order 'cge' (ELU) does not.
+    A scope only turns the request ON (an inner smooth layer inside a kinked network stays exact)."""
+    old = _state.get("exact", False)
+    if on:
+        _state["exact"] = True
+    try:
+        yield
+    finally:
+        _state["exact"] = old
+
+
+@contextlib.contextmanager
+def algo_scope(algo):
+    """Backward passes run outside the forward's scopes: replay the algorithm choice an op captured at forward."""
+    if algo is None:
+        yield
+        return
+    old = (_state["algo"], _state.get("exact", False))
+    _state["algo"], _state["exact"] = (_lib.ALGO_AUTO, True) if algo == _lib.ALGO_EXACT else (algo, False)
+    try:
+        yield
+    finally:
+        _state["algo"], _state["exact"] = old
 
 
 @contextlib.contextmanager

@@ -91,6 +91,14 @@ class profiled_conv:
         return False
 
 
+def _with_algo(backward):
+    """backward of a conv-family Function: replays the algorithm choice (config.conv_algo()) captured at forward."""
+    def wrapped(ctx, *grads):
+        with config.algo_scope(getattr(ctx, "algo", None)):
+            return backward(ctx, *grads)
+    return wrapped
+
+
 def _grad_target(param, shape):
     """Trainer hook (train.FlatParams): when a Parameter carries `_mednet_grad` (a contiguous fp32 view into the flat
     gradient buffer) the kernels write the gradient there and autograd gets None -> no copy / accumulate kernels."""
@@ -221,6 +229,7 @@ class Conv3dFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, packed, ksize, out_planar, out_dtype, want_stats=False):
         L.require_gpu(x, "conv3d")
+        ctx.algo = config.conv_algo()
         x = _as_act(x)
         n, cin, d, h, w = x.shape
         cout = weight.shape[0]
@@ -252,6 +261,7 @@ class Conv3dFn(Function):
         return y, partial
 
     @staticmethod
+    @_with_algo
     def backward(ctx, dy, _dpartial=None):
         xin, packed = ctx.saved_tensors
         ksize, out_planar, cin, cout, has_bias, x_dtype = ctx.meta
@@ -310,6 +320,7 @@ class ConvActFn(Function):
     @staticmethod
     def forward(ctx, x, weight, packed, act, want_stats, mask=None):
         L.require_gpu(x, "conv3d+act")
+        ctx.algo = config.conv_algo()
         ctx.mask = mask
         xin = to_cl(_as_act(x))
         ctx.gnb = _gnb_hook_of(x, xin.dtype) if xin is x else None
@@ -334,6 +345,7 @@ class ConvActFn(Function):
         return z, partial
 
     @staticmethod
+    @_with_algo
     def backward(ctx, dz, _dpartial=None):
         from . import block  # (block imports ops)
         xin, packed, z = ctx.saved_tensors
@@ -379,6 +391,7 @@ class ConvT3dFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, skip, packed):
         L.require_gpu(x, "conv_transpose3d")
+        ctx.algo = config.conv_algo()
         x0 = x
         x = to_cl(_as_act(x))
         ctx.gn3 = _gn3_hook_of(x0, x.dtype) if x is x0 else None
@@ -398,6 +411,7 @@ class ConvT3dFn(Function):
         return y
 
     @staticmethod
+    @_with_algo
     def backward(ctx, dy):
         x, packed = ctx.saved_tensors
         cin, cout, has_bias, has_skip, skip_dtype = ctx.meta

@@ -15,6 +15,7 @@ import os
 
 from .. import _lib as L
 from .. import block
+from .. import config
 from .. import nn as hnn
 from .. import ops
 
@@ -54,13 +55,24 @@ def create_conv(in_channels, out_channels, kernel_size, order, num_groups, paddi
     return modules
 
 
+def _kinked(order: str) -> bool:
+    """ReLU / LeakyReLU in the layer: the network is piecewise linear and asks for exact fp32 products in the fp32 storage
+    mode (config.exact_products says why)."""
+    return "r" in order or "l" in order
+
+
 class SingleConv(nn.Sequential):
     def __init__(self, in_channels, out_channels, kernel_size=3, order="crg", num_groups=8, padding=1):
         super().__init__()
         for name, module in create_conv(in_channels, out_channels, kernel_size, order, num_groups, padding=padding):
             self.add_module(name, module)
+        self._kinked = _kinked(order)
 
     def forward(self, x, residual=None, final_act=L.ACT_NONE, partial=None, stats_for=None):
+        with config.exact_products(self._kinked or final_act in (L.ACT_RELU, L.ACT_LEAKY)):
+            return self._forward(x, residual, final_act, partial, stats_for)
+
+    def _forward(self, x, residual=None, final_act=L.ACT_NONE, partial=None, stats_for=None):
         """`residual`/`final_act` let ExtResNetBlock fold `out += residual; act(out)` into the last GroupNorm.
         `partial`: GroupNorm partial sums of the INPUT x (from the kernel that produced it), used when this layer opens with
         a GroupNorm ('gcr').  `stats_for`: the GroupNorm module that will consume this layer's output (DoubleConv passes
@@ -146,6 +158,7 @@ class ExtResNetBlock(nn.Module):
                                 num_groups=num_groups)
         key = "l" if "l" in order else ("e" if "e" in order else "r")
         self.non_linearity = _ACT_MODULES[key][1](inplace=True)
+        self._kinked = key != "e"
 
     def _plain(self):
         """(convs, norms) when the block is 3 x [3^3 conv without bias -> GroupNorm (-> activation)] with one group count:
@@ -166,6 +179,10 @@ class ExtResNetBlock(nn.Module):
         return convs, norms
 
     def forward(self, x):
+        with config.exact_products(self._kinked):
+            return self._forward(x)
+
+    def _forward(self, x):
         plain = self._plain() if (x.is_cuda and block.ENABLED) else None
         if plain is not None:
             convs, norms = plain
@@ -173,6 +190,10 @@ class ExtResNetBlock(nn.Module):
         residual = self.conv1(x)
         out = self.conv2(residual)
         return self.conv3(out, residual=residual, final_act=self.non_linearity.code)
+
+
+def _module_kinked(module) -> bool:
+    return any(getattr(m, "_kinked", False) for m in module.modules())
 
 
 _FUSE_SKIP_POOL = os.environ.get("MEDNET_SKIP_POOL", "1") == "1"  # A/B knob
@@ -222,11 +243,12 @@ class Decoder(nn.Module):
                                          order=conv_layer_order, num_groups=num_groups)
 
     def forward(self, encoder_features, x):
-        if self.upsample is None:
-            x = ops.upsample_concat(encoder_features, x)
-        else:
-            x = self.upsample(x, skip=encoder_features)
-        return self.basic_module(x)
+        with config.exact_products(_module_kinked(self.basic_module)):  # (the upsampling follows its block)
+            if self.upsample is None:
+                x = ops.upsample_concat(encoder_features, x)
+            else:
+                x = self.upsample(x, skip=encoder_features)
+            return self.basic_module(x)
 
 
 class FinalConv(nn.Sequential):

@@ -9,6 +9,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from .. import config
 from .. import nn as hnn
 from .. import ops
 from .components import Decoder, DoubleConv, Encoder, ExtResNetBlock, SingleConv  # noqa: F401  (re-exported like the reference)
@@ -93,6 +94,13 @@ class _UNetCore(*((_Base,) if _Base is not nn.Module else (_CheckpointCompat, nn
         self.final_conv = hnn.Conv3d(f_maps[0], out_channels, 1, planar_output=True)
 
     def forward(self, x):
+        # ReLU / LeakyReLU anywhere in the order string: the whole network asks for exact fp32 products in the fp32 storage
+        # mode (config.exact_products); the default 'cge' runs the split-bf16 contraction
+        kinked = any(getattr(m, "_kinked", False) for m in self.modules())
+        with config.exact_products(kinked):
+            return self._forward(x)
+
+    def _forward(self, x):
         skips = []
         for i, enc in enumerate(self.encoders):
             if i == 0:
