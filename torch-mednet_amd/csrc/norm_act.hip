@@ -38,6 +38,29 @@ struct VecIO<T, 8> {
   static __device__ __forceinline__ F8 load_last(const T* p, size_t i) { return GN_NT ? ld8_nt(p, i) : ld8(p, i); }
   static __device__ __forceinline__ void store(T* p, size_t i, const F8& v) { st8(p, i, v); }
 };
+// fp32 storage: 4 channels = one 16-byte access per lane (8 columns per 32-channel row: a wave instruction covers whole
+// 128-byte rows); the 8-wide form needs two accesses per tensor and voxel and twice the registers (it spilled at 4 waves/SIMD)
+template <>
+struct VecIO<float, 4> {
+  static __device__ __forceinline__ F8 load(const float* p, size_t i) {
+    F8 r;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.v[k] = a[k];
+    return r;
+  }
+  static __device__ __forceinline__ F8 load_last(const float* p, size_t i) {
+    F8 r;
+    const f32x4 a = GN_NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i)) : *reinterpret_cast<const f32x4*>(p + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.v[k] = a[k];
+    return r;
+  }
+  static __device__ __forceinline__ void store(float* p, size_t i, const F8& v) {
+    const f32x4 a = {v.v[0], v.v[1], v.v[2], v.v[3]};
+    *reinterpret_cast<f32x4*>(p + i) = a;
+  }
+};
 template <typename T>
 struct VecIO<T, 1> {
   static __device__ __forceinline__ F8 load(const T* p, size_t i) {
@@ -890,12 +913,19 @@ static inline unsigned flat_grid(size_t count, size_t per_block) {
   if (b < 1) b = 1;
   return (unsigned)b;
 }
-static inline int pick_vec(int c) { return (c % 8 == 0 && c / 8 <= 256) ? 8 : 1; }
-// upper bound of the partial rows per sample any GroupNorm pass writes for C channels (chunks <= 1024)
+static inline int pick_vec(int c, int dtype = MEDNET_BF16) {
+  if (dtype == MEDNET_F32 && c % 4 == 0 && c / 4 <= 256 && tuning_option("gn_f32_vec4", 1)) return 4;
+  return (c % 8 == 0 && c / 8 <= 256) ? 8 : 1;
+}
+// upper bound of the partial rows per sample any GroupNorm pass writes for C channels (chunks <= 1024), over both vector widths
 static inline size_t gn_partial_rows_max(int c) {
-  const int vec = pick_vec(c), cols = c / vec;
-  const int rpw = cols <= 256 ? lds_free_rows_per_wg(cols) : 0;
-  return (size_t)1024 * (rpw > 1 ? rpw : 1);
+  int best = 1;
+  for (int dt = 0; dt < 2; ++dt) {
+    const int vec = pick_vec(c, dt ? MEDNET_BF16 : MEDNET_F32), cols = c / vec;
+    const int rpw = cols <= 256 ? lds_free_rows_per_wg(cols) : 0;
+    if (rpw > best) best = rpw;
+  }
+  return (size_t)1024 * best;
 }
 
 extern "C" size_t mednet_gn_ws_bytes(int n, int c, size_t spatial) {
@@ -911,7 +941,7 @@ extern "C" int mednet_gn_stats(const void* x, const float* gamma, const float* b
   MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "gn_stats: bad dtype %d", dtype);
   MEDNET_REQUIRE(n > 0 && c > 0 && groups > 0 && c % groups == 0 && spatial > 0, MEDNET_E_SHAPE,
                  "gn_stats: bad shape n=%d c=%d groups=%d", n, c, groups);
-  const int vec = pick_vec(c);
+  const int vec = pick_vec(c, dtype);
   MEDNET_REQUIRE(c / vec <= 256, MEDNET_E_UNSUPPORTED, "gn_stats: C=%d unsupported (need C%%8==0 or C<=256)", c);
   MEDNET_REQUIRE(ws_bytes >= mednet_gn_ws_bytes(n, c, spatial), MEDNET_E_WORKSPACE, "gn_stats: workspace too small");
   size_t cv;
@@ -921,7 +951,7 @@ extern "C" int mednet_gn_stats(const void* x, const float* gamma, const float* b
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(chunks, n);
 #define GO(T, V) hipLaunchKernelGGL((gn_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, partial, spatial, c, cv)
-  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  if (dtype == MEDNET_F32) { if (vec == 4) GO(float, 4); else if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
@@ -948,7 +978,7 @@ extern "C" int mednet_gn_act_fwd(const void* x, const float* coef, const void* r
                                  size_t spatial, int c, int act, int x_dtype, int z_dtype, mednet_stream stream) {
   MEDNET_REQUIRE(dtype_ok(x_dtype) && dtype_ok(z_dtype), MEDNET_E_DTYPE, "gn_act_fwd: bad dtype");
   MEDNET_REQUIRE(x_dtype == z_dtype, MEDNET_E_UNSUPPORTED, "gn_act_fwd: x and z must share a dtype");
-  const int vec = pick_vec(c);
+  const int vec = pick_vec(c, x_dtype);
   MEDNET_REQUIRE(c / vec <= 256, MEDNET_E_UNSUPPORTED, "gn_act_fwd: C=%d unsupported", c);
   size_t cv;
   unsigned chunks;
@@ -956,7 +986,7 @@ extern "C" int mednet_gn_act_fwd(const void* x, const float* coef, const void* r
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(chunks, n);
 #define GO(T, V) hipLaunchKernelGGL((gn_act_fwd_kernel<T, T, V>), grid, dim3(256), 0, s, (const T*)x, coef, (const T*)residual, (T*)z, spatial, c, act, cv)
-  if (x_dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  if (x_dtype == MEDNET_F32) { if (vec == 4) GO(float, 4); else if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (x_dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
@@ -972,7 +1002,7 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
   MEDNET_REQUIRE(c % groups == 0, MEDNET_E_SHAPE, "gn_act_bwd: C %% groups != 0");
   MEDNET_REQUIRE(act == MEDNET_ACT_NONE || z != nullptr || coef != nullptr, MEDNET_E_SHAPE,
                  "gn_act_bwd: act' needs the activated output z or the forward coefficients");
-  const int vec = pick_vec(c);
+  const int vec = pick_vec(c, dtype);
   MEDNET_REQUIRE(c / vec <= 256, MEDNET_E_UNSUPPORTED, "gn_act_bwd: C=%d unsupported", c);
   MEDNET_REQUIRE(ws_bytes >= mednet_gn_ws_bytes(n, c, spatial), MEDNET_E_WORKSPACE, "gn_act_bwd: workspace too small");
   size_t cv;
@@ -985,7 +1015,7 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
   const dim3 grid(chunks, n);
   const int rpw = tuning_option("gn_lds_free", 1) ? lds_free_rows_per_wg(c / vec) : 0;
 #define GO(T, V) hipLaunchKernelGGL((gn_bwd_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, coef, stats, partial, spatial, c, groups, act, cv, rpw)
-  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  if (dtype == MEDNET_F32) { if (vec == 4) GO(float, 4); else if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
@@ -1002,7 +1032,7 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
     if (rc) return rc;
   }
 #define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv, in_act)
-  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  if (dtype == MEDNET_F32) { if (vec == 4) GO(float, 4); else if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
@@ -1015,7 +1045,7 @@ static int gn_act_bwd_fused_impl(const void* dz, const void* x, const void* z, c
                                  int dtype, void* ws, size_t ws_bytes, mednet_stream stream) {
   MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "gn_act_bwd_fused: bad dtype");
   MEDNET_REQUIRE(c % groups == 0 && rows > 0 && fused_partial && coef, MEDNET_E_SHAPE, "gn_act_bwd_fused: bad arguments");
-  const int vec = pick_vec(c);
+  const int vec = pick_vec(c, dtype);
   MEDNET_REQUIRE(c / vec <= 256, MEDNET_E_UNSUPPORTED, "gn_act_bwd_fused: C=%d unsupported", c);
   MEDNET_REQUIRE(ws_bytes >= mednet_gn_ws_bytes(n, c, spatial), MEDNET_E_WORKSPACE, "gn_act_bwd_fused: workspace too small");
   size_t cv;
@@ -1040,7 +1070,7 @@ static int gn_act_bwd_fused_impl(const void* dz, const void* x, const void* z, c
   }
   const dim3 grid(chunks, n);
 #define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)nullptr, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv, in_act)
-  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  if (dtype == MEDNET_F32) { if (vec == 4) GO(float, 4); else if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
@@ -1103,7 +1133,7 @@ extern "C" int mednet_pool2_fwd(const void* x, void* y, int n, int d, int h, int
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)((total + 255) / 256));
 #define GO(T, V) hipLaunchKernelGGL((pool2_fwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, (T*)y, n, d, h, w, c, mode)
-  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  if (dtype == MEDNET_F32) { if (vec == 4) GO(float, 4); else if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
@@ -1122,7 +1152,7 @@ extern "C" int mednet_pool2_bwd(const void* dy, const void* x, const void* add, 
   const size_t total = (size_t)n * (d / 2) * (h / 2) * (w / 2) * (c / vec);
   const dim3 grid((unsigned)((total + 255) / 256));
 #define GO(T, V) hipLaunchKernelGGL((pool2_bwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, n, d, h, w, c, mode)
-  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  if (dtype == MEDNET_F32) { if (vec == 4) GO(float, 4); else if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
@@ -1164,7 +1194,7 @@ extern "C" int mednet_upcat_fwd(const void* enc, const void* x, void* out, int n
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)((total + 255) / 256));
 #define GO(T, V) hipLaunchKernelGGL((upcat_fwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)enc, (const T*)x, (T*)out, n, d, h, w, c_enc, xd, xh, xw, c_x)
-  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  if (dtype == MEDNET_F32) { if (vec == 4) GO(float, 4); else if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
@@ -1186,7 +1216,7 @@ extern "C" int mednet_upcat_bwd(const void* dout, void* denc, void* dx, int n, i
     hipLaunchKernelGGL((upcat_bwd_x_kernel<T, V>), g2, dim3(256), 0, s, (const T*)dout, (T*)dx, n, d, h, w, c_enc, xd,  \
                        xh, xw, c_x);                                                                                    \
   } while (0)
-  if (dtype == MEDNET_F32) { if (vec == 8) GO(float, 8); else GO(float, 1); }
+  if (dtype == MEDNET_F32) { if (vec == 4) GO(float, 4); else if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
