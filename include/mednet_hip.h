@@ -104,6 +104,11 @@ int mednet_conv3d_dgrad_add(const void* dy, const void* packed, const void* add,
  * gn_partial[n][rows][Cin][2] = per-channel {sum du, sum du * gn_y} (rows = mednet_conv3d_dgrad_gn_rows(...), 0 = not
  * supported for this shape).  mednet_gn_act_bwd_fused consumes it: no stand-alone pass re-reads dx and gn_y. */
 int mednet_conv3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int algo);
+/* ... by storage type: MEDNET_F32 = the fp32 storage mode, where the split-bf16 data-gradient kernel takes the sums (and the
+ * summed second gradient) the same way; 16-bit types answer as mednet_conv3d_dgrad_gn_rows.  mednet_conv3d_dgrad_add_supported:
+ * 1 if mednet_conv3d_dgrad_add takes this layer in this storage type. */
+int mednet_conv3d_dgrad_gn_rows_dt(int n, int d, int h, int w, int cin, int cout, int algo, int dtype);
+int mednet_conv3d_dgrad_add_supported(int n, int d, int h, int w, int cin, int cout, int algo, int dtype);
 int mednet_conv3d_dgrad_gn(const void* dy, const void* packed, const void* add, void* dx, const void* gn_y,
                            const float* gn_coef, int gn_act, float* gn_partial, int n, int d, int h, int w, int cin,
                            int cout, int algo, int dtype, mednet_stream stream);

@@ -183,14 +183,17 @@ def test_split_bf16_conv_transpose_in_the_fp32_mode(n, cin, cout, shape):
     assert not torch.equal(res[1][0], res[0][0]) and not torch.equal(res[1][1], res[0][1])
 
 
-def test_split_bf16_forward_keeps_the_groupnorm_statistics():
-    """fp32 mode, Cout <= 32, at least 256 bricks: the split-bf16 forward kernel also writes the GroupNorm partial sums of what
-    it stores (no stand-alone statistics pass).  ExtResNetBlock 32 -> 32 against the oracle, with and without the fusion."""
+@pytest.mark.parametrize("n,c,shape", [(1, 32, (32, 64, 64)), (2, 64, (16, 32, 64)), (2, 256, (16, 32, 32))])
+def test_split_bf16_kernels_keep_the_groupnorm_sums(n, c, shape):
+    """fp32 mode, enough bricks per workgroup: the split-bf16 forward kernel also writes the GroupNorm partial sums of what it
+    stores, and its data-gradient form sums the residual-branch gradient in and takes the first pass of the previous
+    GroupNorm's backward (no stand-alone statistics / partial passes).  One, two and eight channel blocks (the row plan differs:
+    a group of bricks per item range, or several); ExtResNetBlock against the oracle, with and without the fusions."""
     from mednet_hip.unet import components as HC
-    shape = (32, 64, 64)
-    assert L.lib().mednet_conv3d_fused_stats_chunks(1, *shape, 32, 32, 3, L.F32, L.F32, L.ALGO_AUTO) > 0
-    x = rnd("x3stats", 1, 32, *shape)
-    ora = O.keyed_init_(O.ExtResNetBlock(32, 32, order="cge"))
+    assert L.lib().mednet_conv3d_fused_stats_chunks(n, *shape, c, c, 3, L.F32, L.F32, L.ALGO_AUTO) > 0
+    assert L.lib().mednet_conv3d_dgrad_gn_rows_dt(n, *shape, c, c, L.ALGO_AUTO, L.F32) > 0
+    x = rnd(f"x3stats{c}", n, c, *shape)
+    ora = O.keyed_init_(O.ExtResNetBlock(c, c, order="cge"))
     xo = x.clone().requires_grad_(True)
     yo = ora(xo)
     g = rnd("x3statsg", *yo.shape)
@@ -199,18 +202,20 @@ def test_split_bf16_forward_keeps_the_groupnorm_statistics():
     try:
         for fuse in (1, 0):
             _set_option("x3_stats", fuse)
+            _set_option("conv_fuse_gnb", fuse)
             with mednet_hip.precision("fp32"):
-                blk = O.keyed_init_(HC.ExtResNetBlock(32, 32, order="cge")).to(DEV)
+                blk = O.keyed_init_(HC.ExtResNetBlock(c, c, order="cge")).to(DEV)
                 xg = x.to(DEV).requires_grad_(True)
                 y = blk(xg)
                 (y * g.to(DEV)).sum().backward()
                 res[fuse] = [y.detach().cpu(), xg.grad.cpu()] + [p.grad.cpu() for p in blk.parameters()]
     finally:
         _set_option("x3_stats", 1)
+        _set_option("conv_fuse_gnb", 1)
     want = [yo, xo.grad] + [p.grad for p in ora.parameters()]
     for i, (a, b, r) in enumerate(zip(res[1], res[0], want)):
-        assert_close(a, r, 1e-4, f"fused statistics, tensor {i}")
-        assert_close(b, r, 1e-4, f"stand-alone statistics, tensor {i}")
+        assert_close(a, r, 1e-4, f"fused sums, tensor {i}")
+        assert_close(b, r, 1e-4, f"stand-alone passes, tensor {i}")
 
 
 _ACTS = {"none": (L.ACT_NONE, lambda u: u), "relu": (L.ACT_RELU, F.relu), "leaky": (L.ACT_LEAKY, lambda u: F.leaky_relu(u, 0.1)),

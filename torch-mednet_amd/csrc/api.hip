@@ -285,8 +285,28 @@ extern "C" int mednet_conv3d_act_fwd(const void* x, const void* packed, void* y,
 }
 
 // data gradient of a 3x3x3 conv with a second gradient of the same tensor summed in the epilogue (matrix-core path only)
+// fp32 storage: is the split-bf16 data-gradient kernel (which can sum a second gradient and take GroupNorm-backward sums) taking
+// the layer Cin -> Cout?
+static bool x3_dgrad_ok(int n, int d, int h, int w, int cin, int cout, int algo) {
+  (void)n;
+  return algo != MEDNET_ALGO_DIRECT && algo != MEDNET_ALGO_EXACT && conv_f32_mfma_enabled() && conv_x3_enabled() &&
+         conv_x3_supported(cin, cout, 3) && conv_x3_fits(d, h, w, cout);
+}
+extern "C" int mednet_conv3d_dgrad_add_supported(int n, int d, int h, int w, int cin, int cout, int algo, int dtype) {
+  if (dtype == MEDNET_F32) return x3_dgrad_ok(n, d, h, w, cin, cout, algo) ? 1 : 0;
+  return is16(dtype) ? mednet_conv3d_act_supported(n, d, h, w, cout, cin, algo) : 0;
+}
 extern "C" int mednet_conv3d_dgrad_add(const void* dy, const void* packed, const void* add, void* dx, int n, int d, int h,
                                        int w, int cin, int cout, int algo, int dtype, mednet_stream stream) {
+  if (dtype == MEDNET_F32) {
+    int rc32 = conv_common_checks("conv3d_dgrad_add", n, d, h, w, cin, cout, 3, dtype, dtype);
+    if (rc32) return rc32;
+    MEDNET_REQUIRE(x3_dgrad_ok(n, d, h, w, cin, cout, algo), MEDNET_E_UNSUPPORTED,
+                   "conv3d_dgrad_add: fp32 storage fuses the add only on the split-bf16 path (cin=%d cout=%d)", cin, cout);
+    const PackLayout L32 = pack_layout(cin, cout, 3);
+    return launch_conv_x3_dgrad(dy, (const char*)packed + L32.mfma_bwd, L32.lo_delta, dx, n, d, h, w, cout, cin, add, nullptr, nullptr,
+                                MEDNET_ACT_NONE, nullptr, (hipStream_t)stream);
+  }
   MEDNET_REQUIRE(is16(dtype), MEDNET_E_DTYPE, "conv3d_dgrad_add: 16-bit storage only (dtype %d)", dtype);
   int rc = conv_common_checks("conv3d_dgrad_add", n, d, h, w, cin, cout, 3, dtype, dtype);
   if (rc) return rc;
@@ -320,9 +340,25 @@ extern "C" int mednet_conv3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, 
   if (!tuning_option("conv_fuse_gnb", 1) || !mednet_conv3d_act_supported(n, d, h, w, cout, cin, algo)) return 0;
   return conv_mfma_stats_chunks(n, d, h, w, cout, cin);  // (the kernel reads the layer's Cout channels, writes its Cin)
 }
+extern "C" int mednet_conv3d_dgrad_gn_rows_dt(int n, int d, int h, int w, int cin, int cout, int algo, int dtype) {
+  if (dtype == MEDNET_F32)  // (the kernel writes the layer's Cin channels: they are its "output" channel blocks)
+    return tuning_option("conv_fuse_gnb", 1) && x3_dgrad_ok(n, d, h, w, cin, cout, algo) ? conv_x3_stats_rows(n, d, h, w, cin) : 0;
+  return is16(dtype) ? mednet_conv3d_dgrad_gn_rows(n, d, h, w, cin, cout, algo) : 0;
+}
 extern "C" int mednet_conv3d_dgrad_gn(const void* dy, const void* packed, const void* add, void* dx, const void* gn_y,
                                       const float* gn_coef, int gn_act, float* gn_partial, int n, int d, int h, int w,
                                       int cin, int cout, int algo, int dtype, mednet_stream stream) {
+  if (dtype == MEDNET_F32) {
+    int rc32 = conv_common_checks("conv3d_dgrad_gn", n, d, h, w, cin, cout, 3, dtype, dtype);
+    if (rc32) return rc32;
+    MEDNET_REQUIRE(gn_y && gn_coef && gn_partial, MEDNET_E_SHAPE, "conv3d_dgrad_gn: gn_y, gn_coef and gn_partial are required");
+    MEDNET_REQUIRE(gn_act >= MEDNET_ACT_NONE && gn_act <= MEDNET_ACT_ELU, MEDNET_E_UNSUPPORTED, "conv3d_dgrad_gn: activation %d", gn_act);
+    MEDNET_REQUIRE(mednet_conv3d_dgrad_gn_rows_dt(n, d, h, w, cin, cout, algo, dtype) > 0, MEDNET_E_UNSUPPORTED,
+                   "conv3d_dgrad_gn: fp32 storage fuses the GroupNorm sums only on the split-bf16 path (cin=%d cout=%d)", cin, cout);
+    const PackLayout L32 = pack_layout(cin, cout, 3);
+    return launch_conv_x3_dgrad(dy, (const char*)packed + L32.mfma_bwd, L32.lo_delta, dx, n, d, h, w, cout, cin, add, gn_y, gn_coef,
+                                gn_act, gn_partial, (hipStream_t)stream);
+  }
   MEDNET_REQUIRE(is16(dtype), MEDNET_E_DTYPE, "conv3d_dgrad_gn: 16-bit storage only (dtype %d)", dtype);
   int rc = conv_common_checks("conv3d_dgrad_gn", n, d, h, w, cin, cout, 3, dtype, dtype);
   if (rc) return rc;

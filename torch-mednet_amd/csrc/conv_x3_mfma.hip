@@ -69,7 +69,13 @@ struct X3Args {
   unsigned lo_delta, w_bytes;  // w_bytes: lo_delta + bytes of one image (one buffer resource spans both)
   const float* bias;  // nullable, M
   float* y;           // N x (od,oh,ow) x M
-  float* stats;       // nullable: GroupNorm partials [n][rows][M][2] of the stored output (see conv_x3_stats_rows)
+  float* stats;       // nullable: partial rows [n][rows][M][2] (see conv_x3_stats_rows): GroupNorm statistics {sum y, sum y^2}
+                      // of the stored output, or -- with gn_y -- the first pass of a GroupNorm backward {sum du, sum du * gn_y}
+  const float* add;   // nullable: a second gradient of the output tensor, summed before the store (data-gradient form)
+  const float* gn_y;  // nullable (data-gradient form): the conv output the GroupNorm in FRONT of this layer normalised (shape of
+                      // y); du = y_stored * act'(ca * gn_y + cb) with gn_coef[n][M] = {ca, cb}
+  const float* gn_coef;
+  int gn_act;
   int n, od, oh, ow, id, ih, iw, k, m;
   int tiles_z, tiles_y, tiles_x, tps, nkc, ncb, nitems, per_xcd, stats_rows, xps;  // xps: item ranges ("XCDs") per sample
   unsigned bytes_in;  // bytes of ONE sample of x (buffer resources are per sample: 32-bit offsets)
@@ -123,11 +129,13 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
     const int slot = slot0 + i * slot_step;
     const int item = xcd * a.per_xcd + slot;
     it.valid = slot < a.per_xcd && item < a.nitems;
+    // items are ordered (sample, channel block, brick): a workgroup's consecutive items stay in one (sample, channel block)
+    // group as long as possible, which is what lets a wave keep per-channel sums in registers (conv_x3_stats_rows)
     const int iv = it.valid ? item : 0;
-    int tile = iv / a.ncb;
-    it.cb = iv - tile * a.ncb;
-    it.n = tile / a.tps;
-    tile -= it.n * a.tps;
+    const int grp = iv / a.tps;
+    int tile = iv - grp * a.tps;
+    it.n = grp / a.ncb;
+    it.cb = grp - it.n * a.ncb;
     it.tx0 = (tile % a.tiles_x) * TX;
     tile /= a.tiles_x;
     it.ty0 = (tile % a.tiles_y) * TY;
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
       if (r == 0 && stats_n >= 0) {
         const int co = stats_cb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
         if (co < a.m) {
-          const int row = ((xcd % a.xps) * slot_step + slot0) * NWAVES + wv;
+          const int row = ((xcd % (a.xps > 0 ? a.xps : 1)) * slot_step + slot0) * NWAVES + wv;
           float* dst = a.stats + (((size_t)stats_n * a.stats_rows + row) * a.m + co) * 2;
           dst[0] = s;
           dst[1] = q2;
@@ -226,8 +234,22 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
           if (co0 < a.m) {
             f4 o = {acc[t][q * 4], acc[t][q * 4 + 1], acc[t][q * 4 + 2], acc[t][q * 4 + 3]};
             if (a.bias) o += *reinterpret_cast<const f4*>(a.bias + co0);
+            if (a.add) o += __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.add + (yp - a.y) + co0));
             __builtin_nontemporal_store(o, reinterpret_cast<f4*>(yp + co0));
-            if (a.stats) {
+            if (a.gn_y) {  // first pass of the backward of the GroupNorm (+ activation) that produced this layer's input
+              const f4 gy = *reinterpret_cast<const f4*>(a.gn_y + (yp - a.y) + co0);
+              const float* cf = a.gn_coef + ((size_t)it.n * a.m + co0) * 2;
+              const f4 c01 = *reinterpret_cast<const f4*>(cf), c23 = *reinterpret_cast<const f4*>(cf + 4);
+              float u[4] = {fmaf(c01[0], gy[0], c01[1]), fmaf(c01[2], gy[1], c01[3]), fmaf(c23[0], gy[2], c23[1]),
+                            fmaf(c23[2], gy[3], c23[3])};
+              float du[4] = {o[0], o[1], o[2], o[3]};
+              act_grad_pre_n<4>(du, u, a.gn_act);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                ssum[q * 4 + j] += du[j];
+                ssq[q * 4 + j] = fmaf(du[j], gy[j], ssq[q * 4 + j]);
+              }
+            } else if (a.stats) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 ssum[q * 4 + j] += o[j];
@@ -307,23 +329,32 @@ bool conv_x3_supported(int cin, int cout, int ksize) { return ksize == 3 && cin 
 // the kernels address one sample through a buffer resource with 32-bit byte offsets
 bool conv_x3_fits(int d, int h, int w, int c) { return (double)d * h * w * c * 4.0 < 4294960000.0; }
 
-// GroupNorm partial rows per sample written by the forward kernel (0: no fused statistics for this shape).  Each wave keeps
-// {sum y, sum y^2} of everything it stores and writes ONE row at the end; that needs every workgroup to stay inside one sample
-// and one channel block and to have at least one brick: one channel block (Cout <= 32), the eight item ranges aligned with the
-// samples (n divides 8), at least one brick per workgroup.  Then rows = (ranges per sample) * (workgroups per range) * waves.
+// Partial rows per sample written by the forward-type kernel (0: not for this shape).  Each wave keeps per-channel sums of
+// everything it stores for one (sample, channel block) group and writes ONE row when the group changes / at the end: row =
+// (index of the workgroup among those that work on the group) * waves + wave, filled for the group's 32 channels.  Every cell
+// [n][row][channel] must be written exactly once, so every workgroup of a group's item range(s) needs at least one brick of the
+// group: with G = n * ncb groups over the 8 item ranges, either G divides 8 (a group spans 8 / G ranges, each workgroup one
+// group) or 8 divides G with >= grid / 8 bricks per group (a range holds G / 8 whole groups, each workgroup touches them all).
+static int x3_stats_xps(int n, int ncb, int tps, int grid) {  // ranges per group (>= 1), 0: not applicable
+  const int G = n * ncb, per_range = grid / 8;
+  if ((long long)G * tps % 8 != 0) return 0;
+  if (G <= 8 && 8 % G == 0) return (long long)G * tps / 8 >= per_range ? 8 / G : 0;
+  if (G % 8 == 0) return tps >= per_range ? 1 : 0;
+  return 0;
+}
 int conv_x3_stats_rows(int n, int d, int h, int w, int cout) {
   using G = X3Tile<1>;
   if (!tuning_option("x3_stats", 1)) return 0;
-  if (cout > 32 || n > 8 || 8 % n != 0) return 0;
   const int tps = ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
-  const int nitems = n * tps, grid = x3_grid();
-  if (nitems % 8 != 0 || nitems / 8 < grid / 8) return 0;
-  return (8 / n) * (grid / 8) * G::NWAVES;
+  const int grid = x3_grid();
+  const int xps = x3_stats_xps(n, (cout + 31) / 32, tps, grid);
+  return xps * (grid / 8) * G::NWAVES;
 }
 
 template <int STRIDE>
 static int launch_x3(const void* x, const void* sec_hi, size_t lo_delta, const float* bias, void* y, int n, int od, int oh, int ow,
-                     int id, int ih, int iw, int k, int m, float* stats, hipStream_t s) {
+                     int id, int ih, int iw, int k, int m, float* stats, hipStream_t s, const void* add = nullptr,
+                     const void* gn_y = nullptr, const float* gn_coef = nullptr, int gn_act = MEDNET_ACT_NONE) {
   using G = X3Tile<STRIDE>;
   constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
   constexpr size_t lds = ((size_t)4 * HZ * HY * HX + 2 * 27 * 2 * 32) * 16;
@@ -350,8 +381,13 @@ static int launch_x3(const void* x, const void* sec_hi, size_t lo_delta, const f
   a.nitems = n * a.tps * a.ncb;
   a.per_xcd = (a.nitems + 7) / 8;
   a.stats_rows = stats ? conv_x3_stats_rows(n, od, oh, ow, m) : 0;
-  a.xps = n <= 8 && 8 % n == 0 ? 8 / n : 1;
-  MEDNET_REQUIRE(!stats || (STRIDE == 1 && a.stats_rows > 0), MEDNET_E_UNSUPPORTED, "conv_x3: no fused statistics for this shape");
+  a.xps = stats ? x3_stats_xps(n, a.ncb, a.tps, x3_grid()) : 1;
+  MEDNET_REQUIRE(!stats || (STRIDE == 1 && a.stats_rows > 0), MEDNET_E_UNSUPPORTED, "conv_x3: no fused sums for this shape");
+  MEDNET_REQUIRE(!gn_y || (stats && gn_coef), MEDNET_E_SHAPE, "conv_x3: the GroupNorm-backward form needs gn_coef and the partial rows");
+  a.add = (const float*)add;
+  a.gn_y = (const float*)gn_y;
+  a.gn_coef = gn_coef;
+  a.gn_act = gn_act;
   a.bytes_in = (unsigned)((size_t)id * ih * iw * k * 4);
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[STRIDE]) {
@@ -366,6 +402,12 @@ static int launch_x3(const void* x, const void* sec_hi, size_t lo_delta, const f
 int launch_conv_x3(const void* x, const void* sec_hi, size_t lo_delta, const float* bias, void* y, int n, int d, int h, int w, int k,
                    int m, float* stats, hipStream_t s) {
   return launch_x3<1>(x, sec_hi, lo_delta, bias, y, n, d, h, w, d, h, w, k, m, stats, s);
+}
+// data gradient (x = dy with K = the layer's Cout channels, y = dx with M = its Cin) + a second gradient of dx's tensor summed in
+// (nullable) + the first pass of the backward of the GroupNorm in front of the layer (gn_y nullable; partial rows as above)
+int launch_conv_x3_dgrad(const void* dy, const void* sec_hi, size_t lo_delta, void* dx, int n, int d, int h, int w, int k, int m,
+                         const void* add, const void* gn_y, const float* gn_coef, int gn_act, float* gn_partial, hipStream_t s) {
+  return launch_x3<1>(dy, sec_hi, lo_delta, nullptr, dx, n, d, h, w, d, h, w, k, m, gn_partial, s, add, gn_y, gn_coef, gn_act);
 }
 int launch_convt_dgrad_x3(const void* dy, const void* sec_hi, size_t lo_delta, void* dx, int n, int d, int h, int w, int cin,
                           int cout, hipStream_t s) {
@@ -543,9 +585,10 @@ int launch_convt_fwd_x3(const void* x, const void* sec_hi, size_t lo_delta, cons
 //   R[tap][a][b] = sum_v A[v][a] * B[v + tap - 1][b]      A = dy (Cout), B = x (Cin);   dw[(a*KB + b)*27 + tap]
 // Brick 4x4x16 (halo 6x6x18); LDS rows [voxel][32 channels] bf16, a high and a low plane per operand; a k-step = 16
 // x-consecutive voxels, both MFMA operands through the transposing LDS read (lane mapping: conv_mfma.hip tr_operand,
-// tools/probes/tr_probe.hip).  A wave owns 7 of the 27 taps (7 x 16 accumulators; the wave with 6 recomputes tap 26, discarded),
-// one wave per SIMD: two operand sets, the reads of k-step s+1 in flight while the 21 MFMAs of k-step s run; the next brick's
-// 15 staging rounds are dealt out one per k-step.  Per-workgroup slabs, fixed-order reduce (no atomics).
+// tools/probes/tr_probe.hip).  Eight waves, two per SIMD (the partner covers a wave's LDS latency: with one wave per SIMD and two
+// operand sets the wait for the older set also waited for most of the younger one -- lgkmcnt counts to 15); a wave owns 3-4 of
+// the 27 taps (4 x 16 accumulators; waves 3..7 skip their 4th slot) and walks every k-step; the next
+// brick's 8 staging rounds are dealt out one per k-step.  Per-workgroup slabs, fixed-order reduce (no atomics).
 struct WgX3Args {
   const float* A;
   const float* B;
@@ -561,10 +604,11 @@ __device__ __forceinline__ bf16x8 x3_tr_operand(const char* base, int second) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256) void wgrad_x3_kernel(WgX3Args a) {
+__global__ __launch_bounds__(512) void wgrad_x3_kernel(WgX3Args a) {
   constexpr int TZ = 4, TY = 4, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
   constexpr int NA = TZ * TY * TX, NB = HZ * HY * HX;
-  constexpr int A_ROUNDS = NA * 4 / 256, B_ROUNDS = (NB * 4 + 255) / 256;
+  constexpr int NTHR = 512, TAPS = 4;  // 8 waves, two per SIMD; wave w owns taps w, w + 8, w + 16, w + 24
+  constexpr int A_ROUNDS = NA * 4 / NTHR, B_ROUNDS = (NB * 4 + NTHR - 1) / NTHR;
   constexpr int KSTEPS = NA / 16;
   static_assert(A_ROUNDS + B_ROUNDS <= KSTEPS, "one staging round per k-step");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -580,8 +624,7 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(WgX3Args a) {
 
   u32x4 regA[A_ROUNDS][2], regB[B_ROUNDS][2];
   struct Next {
-    int tz0, ty0, tx0;
-    bool valid;
+    int tz0, ty0, tx0, valid;
     __amdgpu_buffer_rsrc_t rA, rB;
   };
   auto plan = [&](int tile) {
@@ -601,20 +644,20 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(WgX3Args a) {
   };
   auto fetch_round = [&](int j, const Next& nx) {
     if (j < A_ROUNDS) {
-      const int c = j * 256 + tid;
+      const int c = j * NTHR + tid;
       const int v = c >> 2, part = c & 3;
       const int gz = nx.tz0 + v / (TX * TY), gy = nx.ty0 + (v / TX) % TY, gx = nx.tx0 + v % TX;
-      const bool ok = (gz < a.d) & (gy < a.h) & (gx < a.w) & (ab * 32 + part * 8 < a.ka) & nx.valid;
+      const bool ok = (gz < a.d) & (gy < a.h) & (gx < a.w) & (ab * 32 + part * 8 < a.ka) & (nx.valid != 0);
       const unsigned off = ok ? ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.ka + ab * 32 + part * 8) * 4u : X3_OOB;
       regA[j][0] = __builtin_amdgcn_raw_buffer_load_b128(nx.rA, off, 0, 0);
       regA[j][1] = __builtin_amdgcn_raw_buffer_load_b128(nx.rA, off + 16u, 0, 0);
     } else if (j < A_ROUNDS + B_ROUNDS) {
       const int it = j - A_ROUNDS;
-      const int c = it * 256 + tid;
+      const int c = it * NTHR + tid;
       const int v = c >> 2, part = c & 3;
       const int gz = nx.tz0 - 1 + v / (HX * HY), gy = nx.ty0 - 1 + (v / HX) % HY, gx = nx.tx0 - 1 + v % HX;
       const bool ok = (c < NB * 4) & ((unsigned)gz < (unsigned)a.d) & ((unsigned)gy < (unsigned)a.h) &
-                      ((unsigned)gx < (unsigned)a.w) & (bb * 32 + part * 8 < a.kb) & nx.valid;
+                      ((unsigned)gx < (unsigned)a.w) & (bb * 32 + part * 8 < a.kb) & (nx.valid != 0);
       const unsigned off = ok ? ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.kb + bb * 32 + part * 8) * 4u : X3_OOB;
       regB[it][0] = __builtin_amdgcn_raw_buffer_load_b128(nx.rB, off, 0, 0);
       regB[it][1] = __builtin_amdgcn_raw_buffer_load_b128(nx.rB, off + 16u, 0, 0);
@@ -623,14 +666,14 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(WgX3Args a) {
   auto commit = [&]() {
 #pragma unroll
     for (int it = 0; it < A_ROUNDS; ++it) {
-      const int c = it * 256 + tid;
+      const int c = it * NTHR + tid;
       const HiLo s = split8(regA[it][0], regA[it][1]);
       *reinterpret_cast<bf16x8*>(smem + c * 16) = s.hi;
       *reinterpret_cast<bf16x8*>(smem + A_LO + c * 16) = s.lo;
     }
 #pragma unroll
     for (int it = 0; it < B_ROUNDS; ++it) {
-      const int c = it * 256 + tid;
+      const int c = it * NTHR + tid;
       if (c < NB * 4) {
         const HiLo s = split8(regB[it][0], regB[it][1]);
         *reinterpret_cast<bf16x8*>(smem + B_HI + c * 16) = s.hi;
@@ -639,41 +682,20 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(WgX3Args a) {
     }
   };
 
-  f32x16 acc[7];
+  f32x16 acc[TAPS];
 #pragma unroll
-  for (int i = 0; i < 7; ++i)
+  for (int i = 0; i < TAPS; ++i)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-  int toff[7];
+  const bool has4 = tw < 3;  // waves 0..2 own four taps, waves 3..7 three (per SIMD pair w, w + 4: 7, 7, 7, 6)
+  int toff[TAPS];
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int tap = tw + 4 * i < 27 ? tw + 4 * i : 26;
+  for (int i = 0; i < TAPS; ++i) {
+    const int tap = tw + 8 * i < 27 ? tw + 8 * i : 26;
     toff[i] = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 64;
   }
   const char* Ab = smem + coloff;
   const char* Bb = smem + B_HI + coloff;
-  struct Set {
-    bf16x8 ah, al, bh[7], bl[7];
-  };
-  auto load_set = [&](int ks, Set& st) {
-    const char* arow = Ab + (ks * TX + 8 * hk + q) * 64;
-    st.ah = x3_tr_operand(arow, 4 * 64);
-    st.al = x3_tr_operand(arow + A_LO, 4 * 64);
-    const char* brow = Bb + (((ks / TY) * HY + ks % TY) * HX + 8 * hk + q) * 64;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      st.bh[i] = x3_tr_operand(brow + toff[i], 4 * 64);
-      st.bl[i] = x3_tr_operand(brow + (B_LO - B_HI) + toff[i], 4 * 64);
-    }
-  };
-  auto mfma_set = [&](const Set& st) {
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      acc[i] = X3_MFMA(st.al, st.bh[i], acc[i]);
-      acc[i] = X3_MFMA(st.ah, st.bl[i], acc[i]);
-      acc[i] = X3_MFMA(st.ah, st.bh[i], acc[i]);
-    }
-  };
 
   int tile = split;
   if (tile < a.ntiles) {
@@ -686,23 +708,36 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(WgX3Args a) {
     commit();
     __syncthreads();
     const Next nx = plan(tile + a.splits);
-    Set s0, s1;
-    load_set(0, s0);
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ks += 2) {
-      load_set(ks + 1, s1);
-      fetch_round(ks, nx);
-      mfma_set(s0);
-      if (ks + 2 < KSTEPS) load_set(ks + 2, s0);
-      fetch_round(ks + 1, nx);
-      mfma_set(s1);
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const char* arow = Ab + (ks * TX + 8 * hk + q) * 64;
+      const bf16x8 ah = x3_tr_operand(arow, 4 * 64);
+      const bf16x8 al = x3_tr_operand(arow + A_LO, 4 * 64);
+      const char* brow = Bb + (((ks / TY) * HY + ks % TY) * HX + 8 * hk + q) * 64;
+      bf16x8 bh[TAPS], bl[TAPS];
+#pragma unroll
+      for (int i = 0; i < TAPS; ++i) {
+        if (i < 3 || has4) {  // (wave-uniform: the 4th slot of waves 3..7 has no tap)
+          bh[i] = x3_tr_operand(brow + toff[i], 4 * 64);
+          bl[i] = x3_tr_operand(brow + (B_LO - B_HI) + toff[i], 4 * 64);
+        }
+      }
+      fetch_round(ks, nx);  // the next brick's staging rounds, one per k-step
+#pragma unroll
+      for (int i = 0; i < TAPS; ++i) {
+        if (i < 3 || has4) {
+          acc[i] = X3_MFMA(al, bh[i], acc[i]);
+          acc[i] = X3_MFMA(ah, bl[i], acc[i]);
+          acc[i] = X3_MFMA(ah, bh[i], acc[i]);
+        }
+      }
     }
   }
   float* out = a.part + (size_t)blockIdx.x * 27 * 1024;
   const int col = lane & 31;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int tap = tw + 4 * i;
+  for (int i = 0; i < TAPS; ++i) {
+    const int tap = tw + 8 * i;
     if (tap < 27) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) out[((size_t)tap * 32 + (j & 3) + 8 * (j >> 2) + 4 * hk) * 32 + col] = acc[i][j];
@@ -774,7 +809,7 @@ int launch_wgrad_x3(const void* x, const void* dy, float* dw, int n, int d, int 
       return fail(MEDNET_E_HIP, "wgrad_x3: cannot raise dynamic LDS to %zu", lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_x3_kernel, dim3(a.nab * a.nbb * a.splits), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(wgrad_x3_kernel, dim3(a.nab * a.nbb * a.splits), dim3(512), lds, s, a);
   int rc = check_launch("wgrad_x3");
   if (rc) return rc;
   const size_t total = (size_t)a.nab * a.nbb * 1024 * 27;

@@ -45,6 +45,8 @@ SIGNATURES = {
     "mednet_conv3d_act_fwd": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp, _i, _vp]),
     "mednet_conv3d_dgrad_add": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "mednet_conv3d_dgrad_gn_rows": (_i, [_i] * 7),
+    "mednet_conv3d_dgrad_gn_rows_dt": (_i, [_i] * 8),
+    "mednet_conv3d_dgrad_add_supported": (_i, [_i] * 8),
     "mednet_conv3d_dgrad_gn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 8 + [_vp]),
     "mednet_gn_act_bwd_fused": (_i, [_vp] * 6 + [_i, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mednet_gn_act_bwd_fused_res": (_i, [_vp] * 7 + [_i, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -113,9 +113,9 @@ def _conv_bwd(x, dy, packed, weight_p, need_dx, add=None, gnb=None):
         if need_dx:
             dx = ops.empty_cl(n, cin, d, h, w, x.dtype if x.dtype in (torch.float32, config.act_dtype()) else config.act_dtype(), dy.device)
             rows = 0
-            if gnb is not None and FUSE_GNB and dy.dtype in config.HALF_TYPES and dx.dtype == dy.dtype \
-                    and (add is None or add.dtype == dy.dtype):
-                rows = lib.mednet_conv3d_dgrad_gn_rows(n, d, h, w, cin, cout, config.conv_algo())
+            if gnb is not None and FUSE_GNB and dx.dtype == dy.dtype and (add is None or add.dtype == dy.dtype):
+                # (16-bit storage: the bf16 / fp16 matrix-core kernel; fp32 storage: the split-bf16 kernel)
+                rows = lib.mednet_conv3d_dgrad_gn_rows_dt(n, d, h, w, cin, cout, config.conv_algo(), L.dt(dy))
             if rows > 0:
                 y_prev, coef_prev, act_prev = gnb
                 partial = torch.empty((n, rows, cin, 2), dtype=torch.float32, device=dy.device)
@@ -181,8 +181,8 @@ class ResBlockFn(Function):
         # z1 feeds conv2 AND the residual add: the two gradients are summed in the epilogue of conv2's data gradient (bf16
         # matrix-core path), otherwise inside GroupNorm-1's backward (two more tensor reads)
         n_, c_, d_, h_, w_ = z1.shape
-        fuse = FUSE_DRES and dy2.dtype in config.HALF_TYPES and dres.dtype == dy2.dtype and bool(
-            L.lib().mednet_conv3d_act_supported(n_, d_, h_, w_, c_, c_, config.conv_algo()))
+        fuse = FUSE_DRES and dres.dtype == dy2.dtype and bool(
+            L.lib().mednet_conv3d_dgrad_add_supported(n_, d_, h_, w_, c_, c_, config.conv_algo(), L.dt(dy2)))
         dz1, dw2, part1 = _conv_bwd(z1, dy2, pk2, w2, True, add=dres if fuse else None, gnb=(y1, c1, act) if fuse else None)
         dy1, _, dg1, db1 = _gn_bwd(dz1, None if fuse else dres, y1, None, c1, s1, g1, b1, groups, act, False, partial=part1)
         dx, dw1, _ = _conv_bwd(xin, dy1, pk1, w1, ctx.needs_input_grad[0])
