@@ -274,17 +274,38 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) gs[k] = gq[k] = 0.f;
   };
-  // GNB: this lane's 8 channels (piece pj = lane & 3 of the channel block), {sum du, sum du * y}
-  float bs[GNB ? 8 : 1], bq[GNB ? 8 : 1];
+  // GNB: this lane's 8 channels (piece pj = lane & 3 of the channel block), {sum du, sum du * y}.  In the stride-1 form the 16
+  // running sums are PARKED in LDS between epilogues ([k][thread]: conflict-free 4-byte accesses of the owning thread, no
+  // barrier): held in registers across the tap loop they pushed the kernel over 256 registers (20 spilled).
+  constexpr bool PARK = GNB && STRIDE == 1;
+  auto park_of = [&]() {  // [16][256] floats behind the images (recomputed from an opaque thread id where it is used: as a
+    int t = tid;           // loop-invariant address it would be kept in a register across the tap loop)
+    asm volatile("" : "+v"(t));
+    return reinterpret_cast<float*>(smem + (size_t)(2 * NV + W_CHUNKS) * 16) + t;
+  };
+  float bs[GNB && !PARK ? 8 : 1], bq[GNB && !PARK ? 8 : 1];
 #pragma unroll
-  for (int k = 0; k < (GNB ? 8 : 1); ++k) bs[k] = bq[k] = 0.f;
+  for (int k = 0; k < (GNB && !PARK ? 8 : 1); ++k) bs[k] = bq[k] = 0.f;
+  if constexpr (PARK) {
+    float* park = park_of();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) park[k * 256] = 0.f;
+  }
   auto flush_bwd = [&](int nn, int row, int cbk) {  // sum over the 16 lanes that share a piece; lanes 0..3 write 64 bytes
     if constexpr (GNB) {
       float rs[8], rq[8];
+      float* park = park_of();
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        rs[k] = bs[k];
-        rq[k] = bq[k];
+        if constexpr (PARK) {
+          rs[k] = park[k * 256];
+          rq[k] = park[(8 + k) * 256];
+          park[k * 256] = 0.f;
+          park[(8 + k) * 256] = 0.f;
+        } else {
+          rs[k] = bs[k];
+          rq[k] = bq[k];
+        }
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -300,8 +321,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
           *reinterpret_cast<f32x4*>(dst + k * 2) = o;
         }
       }
+      if constexpr (!PARK) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) bs[k] = bq[k] = 0.f;
+        for (int k = 0; k < 8; ++k) bs[k] = bq[k] = 0.f;
+      }
     }
   };
   auto flush_any = [&](int nn, int row, int cbk) {
@@ -459,40 +482,64 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     const int swl = (et >> 1) & 7;  // (vl >> 1) & 7 does not depend on the round: 64 voxels per round
     const elt* rd = out_lds + et * 32 + (pj ^ (swl >> 1)) * 8;
     constexpr int ROUNDS = (TZ * TY * TX * 4) / 256;
-    eltx8 rows[ROUNDS];  // all LDS reads first (the accumulators' registers are free now), then the stores back to back:
-#pragma unroll            // read -> wait -> store per round exposed the LDS latency eight times
-    for (int it = 0; it < ROUNDS; ++it) rows[it] = *reinterpret_cast<const eltx8*>(rd + it * 64 * 32);
-    // GNB: the rows of y at the positions this lane stores, and the GroupNorm affine of its 8 channels (both through
-    // buffer resources: positions / channels outside the tensor read zeros), all in flight before the first use
-    eltx8 yrow[GNB ? ROUNDS : 1], zrow[GNB ? ROUNDS : 1];
+    // The GNB form walks the rounds in groups of at most 4: with all 8 rounds of the stride-1 brick in flight at once (8 output
+    // rows + 8 y rows + 8 z rows = 96 registers) on top of the next item's staged chunk, the kernel spilled 49 registers (200
+    // bytes of scratch per lane, in the epilogue AND around the tap loop).
+    constexpr int RG = (GNB && ROUNDS > 2) ? 2 : ROUNDS;
     float ca[GNB ? 8 : 1], cbf[GNB ? 8 : 1];
-    if constexpr (GNB) {
-      const auto rsrc_gy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_y + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
-      const auto rsrc_gz = __builtin_amdgcn_make_buffer_rsrc((void*)((a.gnb_z ? a.gnb_z : a.gnb_y) + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
+    const auto rsrc_gy = __builtin_amdgcn_make_buffer_rsrc((void*)((GNB ? a.gnb_y : a.y) + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
+    const auto rsrc_gz = __builtin_amdgcn_make_buffer_rsrc((void*)((GNB && a.gnb_z ? a.gnb_z : a.y) + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
+    auto load_coef = [&]() {  // the GroupNorm affine of this lane's 8 channels (64 bytes, cache resident)
+      if constexpr (GNB) {
+        if (!a.gnb_z) {
+          const auto rsrc_cf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_coef + (size_t)n * a.cout * 2), 0, (unsigned)a.cout * 8u, 0x00020000);
+          const unsigned coff = (unsigned)(cb * 32 + pj * 8) * 8u;
 #pragma unroll
-      for (int it = 0; it < ROUNDS; ++it) {
-        const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
-        const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
-        const unsigned soff = (unsigned)(((oz * a.oh + oyb) * a.ow + tx0) * a.cout + cb * 32) * 2u;
-        yrow[it] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_gy, ok ? vbase : OOB, soff, 0));
-        if (a.gnb_z) zrow[it] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_gz, ok ? vbase : OOB, soff, 0));
-      }
-      if (!a.gnb_z) {
-        const auto rsrc_cf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_coef + (size_t)n * a.cout * 2), 0, (unsigned)a.cout * 8u, 0x00020000);
-        const unsigned coff = (unsigned)(cb * 32 + pj * 8) * 8u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 c4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_cf, coff + q * 16, 0, 0));
-          ca[2 * q] = c4[0];
-          cbf[2 * q] = c4[1];
-          ca[2 * q + 1] = c4[2];
-          cbf[2 * q + 1] = c4[3];
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 c4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_cf, coff + q * 16, 0, 0));
+            ca[2 * q] = c4[0];
+            cbf[2 * q] = c4[1];
+            ca[2 * q + 1] = c4[2];
+            cbf[2 * q + 1] = c4[3];
+          }
         }
+      }
+    };
+    if constexpr (!PARK) load_coef();
+    float ebs[PARK ? 8 : 1], ebq[PARK ? 8 : 1];  // (the parked sums, in registers for the epilogue only)
+    float* park = park_of();
+    if constexpr (PARK) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        ebs[k] = park[k * 256];
+        ebq[k] = park[(8 + k) * 256];
       }
     }
 #pragma unroll
-    for (int it = 0; it < ROUNDS; ++it) {
-      eltx8 v = rows[it];
+    for (int it0 = 0; it0 < ROUNDS; it0 += RG) {
+    if (it0 > 0) __builtin_amdgcn_sched_barrier(0);  // (keeps the next group's loads behind this group's stores)
+    eltx8 rows[RG];  // all LDS reads of the group first (the accumulators' registers are free now), then the stores back to
+#pragma unroll        // back: read -> wait -> store per round exposed the LDS latency eight times
+    for (int it = 0; it < RG; ++it) rows[it] = *reinterpret_cast<const eltx8*>(rd + (it0 + it) * 64 * 32);
+    // GNB: the rows of y (and of the block output z) at the positions this lane stores, through buffer resources (positions /
+    // channels outside the tensor read zeros), all of the group in flight before the first use
+    eltx8 yrow[GNB ? RG : 1], zrow[GNB ? RG : 1];
+    if constexpr (PARK) load_coef();  // (per group: 16 registers that need not live through the whole epilogue)
+    if constexpr (GNB) {
+#pragma unroll
+      for (int itl = 0; itl < RG; ++itl) {
+        const int it = it0 + itl;
+        const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
+        const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
+        const unsigned soff = (unsigned)(((oz * a.oh + oyb) * a.ow + tx0) * a.cout + cb * 32) * 2u;
+        yrow[itl] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_gy, ok ? vbase : OOB, soff, 0));
+        if (a.gnb_z) zrow[itl] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_gz, ok ? vbase : OOB, soff, 0));
+      }
+    }
+#pragma unroll
+    for (int itl = 0; itl < RG; ++itl) {
+      const int it = it0 + itl;
+      eltx8 v = rows[itl];
       if (swl & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
       const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
       const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
@@ -509,15 +556,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
           if (a.gnb_z) {  // (wave-uniform) residual layer: act' from the block output
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              yy[k] = (float)yrow[it][k];
+              yy[k] = (float)yrow[itl][k];
               g[k] = (float)v[k];
-              u[k] = (float)zrow[it][k];
+              u[k] = (float)zrow[itl][k];
             }
             act_grad_n<8>(g, u, a.gnb_act);
           } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              yy[k] = (float)yrow[it][k];
+              yy[k] = (float)yrow[itl][k];
               g[k] = (float)v[k];
               u[k] = fmaf(ca[k], yy[k], cbf[k]);
             }
@@ -525,8 +572,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
           }
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            bs[k] += g[k];
-            bq[k] = fmaf(g[k], yy[k], bq[k]);
+            if constexpr (PARK) {
+              ebs[k] += g[k];
+              ebq[k] = fmaf(g[k], yy[k], ebq[k]);
+            } else {
+              bs[k] += g[k];
+              bq[k] = fmaf(g[k], yy[k], bq[k]);
+            }
           }
         }
       } else if (ok && a.gn_partial) {  // statistics of what is stored (the rounded values), exactly like the stand-alone pass
@@ -536,6 +588,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
           gs[k] = MEDNET_FDOT2(pr, ones, gs[k], false);
           gq[k] = MEDNET_FDOT2(pr, pr, gq[k], false);
         }
+      }
+    }
+    }
+    if constexpr (PARK) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        park[k * 256] = ebs[k];
+        park[(8 + k) * 256] = ebq[k];
       }
     }
     STAMP(13);
@@ -1598,13 +1658,15 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   }
   if constexpr (STRIDE == 1) {
     if (use_gnb) {
+      constexpr size_t lds_gnb = lds + 16 * 256 * sizeof(float);  // + the parked GroupNorm-backward sums (16 per thread)
+      static_assert(lds_gnb <= 80 * 1024, "two workgroups must fit one CU");
       static bool attr_gnb = false;
       if (!attr_gnb) {
-        if (hipFuncSetAttribute((const void*)conv_mfma_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-          return fail(MEDNET_E_HIP, "conv_mfma: cannot raise dynamic LDS to %zu", lds);
+        if (hipFuncSetAttribute((const void*)conv_mfma_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gnb) != hipSuccess)
+          return fail(MEDNET_E_HIP, "conv_mfma: cannot raise dynamic LDS to %zu", lds_gnb);
         attr_gnb = true;
       }
-      hipLaunchKernelGGL((conv_mfma_kernel<1, true>), dim3(grid), dim3(256), lds, s, a);
+      hipLaunchKernelGGL((conv_mfma_kernel<1, true>), dim3(grid), dim3(256), lds_gnb, s, a);
       return check_launch("conv_mfma(gnb)");
     }
   }
