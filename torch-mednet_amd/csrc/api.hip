@@ -338,7 +338,7 @@ extern "C" int mednet_head_dgrad_gn(const void* dy, const void* packed, void* dx
 
 extern "C" int mednet_conv3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int algo) {
   if (!tuning_option("conv_fuse_gnb", 1) || !mednet_conv3d_act_supported(n, d, h, w, cout, cin, algo)) return 0;
-  return conv_mfma_stats_chunks(n, d, h, w, cout, cin);  // (the kernel reads the layer's Cout channels, writes its Cin)
+  return conv_mfma_stats_chunks(n, d, h, w, cout, cin, true);  // (the kernel reads the layer's Cout channels, writes its Cin)
 }
 extern "C" int mednet_conv3d_dgrad_gn_rows_dt(int n, int d, int h, int w, int cin, int cout, int algo, int dtype) {
   if (dtype == MEDNET_F32)  // (the kernel writes the layer's Cin channels: they are its "output" channel blocks)

@@ -1539,11 +1539,16 @@ bool conv_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype,
 static bool conv32_applies(int ntiles, int cin, int cout) {
   return cin == 32 && cout == 32 && ntiles >= 512 && ::mednet_internal_cu_count() == 256 && tuning_option("conv32", 1);
 }
-static void conv_stats_plan(int n, int d, int h, int w, int cin, int cout, int& rows, int& accum) {
+// (A/B knob conv32_gnb=0: the data-gradient launches that also take a GroupNorm backward's first pass go to the general kernel,
+//  whose second workgroup per CU hides that epilogue; the specialisation's single wave per SIMD cannot)
+static bool conv32_takes(int ntiles, int cin, int cout, bool gnb) {
+  return conv32_applies(ntiles, cin, cout) && (!gnb || tuning_option("conv32_gnb", 1));
+}
+static void conv_stats_plan(int n, int d, int h, int w, int cin, int cout, int& rows, int& accum, bool gnb = false) {
   using G = FwdTile<1>;
   const int tps = ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
   const int ncb = (cout + 31) / 32, ntiles = n * tps;
-  if (conv32_applies(ntiles, cin, cout)) {  // always accumulating: one row per wave of the 256 workgroups
+  if (conv32_takes(ntiles, cin, cout, gnb)) {  // always accumulating: one row per wave of the 256 workgroups
     accum = 1;
     rows = 256 * 4;
     return;
@@ -1607,10 +1612,10 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   if (tuning_option("conv_persist", 1) && grid > 512u) grid = 512u;
   a.stats_accum = 0;
   a.stats_rows = 4 * a.tiles_z * a.tiles_y * a.tiles_x;
-  if (gn_partial && STRIDE == 1) conv_stats_plan(n, od, oh, ow, cin, cout, a.stats_rows, a.stats_accum);
+  if (gn_partial && STRIDE == 1) conv_stats_plan(n, od, oh, ow, cin, cout, a.stats_rows, a.stats_accum, use_gnb);
   a.xcd_chunk = 0;
   if constexpr (STRIDE == 1) {
-    if (conv32_applies(a.ntiles, cin, cout)) {
+    if (conv32_takes(a.ntiles, cin, cout, use_gnb)) {
       constexpr size_t lds32 = (size_t)2 * 4 * (HZ * HY * HX + 4) * 16 + 4 * 4096 + 256 * 16;
       static_assert(lds32 <= 160 * 1024, "two bricks of whole rows + the waves' epilogue areas + spare slots");
       a.xcd_chunk = a.ntiles % 8 == 0 ? a.ntiles / 8 : 0;
@@ -1701,9 +1706,9 @@ int launch_conv_mfma_gnb(const void* dy, const void* packed_section, void* dx, i
   g.act = gn_act;
   return launch_fwd<1>(dy, packed_section, dx, n, d, h, w, d, h, w, cin, cout, gn_partial, s, MEDNET_ACT_NONE, add, g);
 }
-int conv_mfma_stats_chunks(int n, int d, int h, int w, int cin, int cout) {
+int conv_mfma_stats_chunks(int n, int d, int h, int w, int cin, int cout, bool gnb) {
   int rows, accum;
-  conv_stats_plan(n, d, h, w, cin, cout, rows, accum);
+  conv_stats_plan(n, d, h, w, cin, cout, rows, accum, gnb);
   return rows;
 }
 
