@@ -154,10 +154,11 @@ static int conv_common_checks(const char* who, int n, int d, int h, int w, int c
 extern "C" int mednet_conv3d_fused_stats_chunks(int n, int d, int h, int w, int cin, int cout, int ksize, int x_dtype,
                                                 int y_dtype, int algo) {
   if (algo == MEDNET_ALGO_DIRECT || !tuning_option("conv_fuse_stats", 1)) return 0;
-  if (x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32)  // fp32 storage: the split-bf16 forward kernel keeps the sums per wave
-    return conv_f32_mfma_enabled() && (algo != MEDNET_ALGO_EXACT && conv_x3_enabled()) && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin)
-               ? conv_x3_stats_rows(n, d, h, w, cout)
-               : 0;
+  if (x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32) {  // fp32 storage: the split-bf16 forward kernels keep the sums per wave
+    if (!(conv_f32_mfma_enabled() && algo != MEDNET_ALGO_EXACT && conv_x3_enabled())) return 0;
+    if (conv_c1_x3_supported(cin, cout, ksize)) return tuning_option("x3_stats", 1) ? conv_c1_x3_stats_rows(d, h, w) : 0;
+    return conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin) ? conv_x3_stats_rows(n, d, h, w, cout) : 0;
+  }
   if (ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, false)) return conv_c1_stats_chunks(d, h, w);
   if (!ELT_CALL(y_dtype, conv_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, MEDNET_NDHWC, false)) return 0;
   return conv_mfma_stats_chunks(n, d, h, w, cin, cout);
@@ -190,9 +191,11 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
                         y_dtype == MEDNET_F32 && (x_layout == MEDNET_NDHWC || cin == 1) && y_layout == MEDNET_NDHWC;
   if (f32_mode && (algo != MEDNET_ALGO_EXACT && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin))
     return launch_conv_x3(x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), L.lo_delta, bias, y, n, d, h, w, cin, cout, gn_partial, s);
+  if (f32_mode && !dgrad && algo != MEDNET_ALGO_EXACT && conv_x3_enabled() && conv_c1_x3_supported(cin, cout, ksize))  // first layer
+    return launch_conv_c1_x3(x, (const float*)(base + L.f32_fwd), bias, y, n, d, h, w, cout, gn_partial, s);
   MEDNET_REQUIRE(gn_partial == nullptr, MEDNET_E_UNSUPPORTED,
                  "conv3d_fwd: fused GroupNorm partials are only produced by the MFMA paths (ask mednet_conv3d_fused_stats_chunks)");
-  // ... or, for the shapes that kernel does not take (first layer, odd channel counts), on the fp32 matrix-core instruction
+  // ... or, for the shapes those kernels do not take (odd channel counts; ALGO_EXACT), on the fp32 matrix-core instruction
   if (f32_mode)
     return launch_conv_f32_mfma(x, (const float*)(base + (dgrad ? L.f32_bwd : L.f32_fwd)), bias, y, n, d, h, w, cin, cout, s);
   // 1x1x1 head forward (channels-last features -> planar fp32 logits): the packed backward image Pb[t=0][co][ci] = W[m][k]

@@ -78,6 +78,10 @@ bool conv_x3_fits(int d, int h, int w, int c);
 int conv_x3_stats_rows(int n, int d, int h, int w, int cout);
 int launch_conv_x3(const void* x, const void* sec_hi, size_t lo_delta, const float* bias, void* y, int n, int d, int h, int w, int k,
                    int m, float* stats, hipStream_t s);
+bool conv_c1_x3_supported(int cin, int cout, int ksize);
+int conv_c1_x3_stats_rows(int d, int h, int w);
+int launch_conv_c1_x3(const void* x, const float* w_pf, const float* bias, void* y, int n, int d, int h, int w, int cout,
+                      float* stats, hipStream_t s);
 int launch_conv_x3_dgrad(const void* dy, const void* sec_hi, size_t lo_delta, void* dx, int n, int d, int h, int w, int k, int m,
                          const void* add, const void* gn_y, const float* gn_coef, int gn_act, float* gn_partial, hipStream_t s);
 int launch_convt_dgrad_x3(const void* dy, const void* sec_hi, size_t lo_delta, void* dx, int n, int d, int h, int w, int cin,

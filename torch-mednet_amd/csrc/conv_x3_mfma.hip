@@ -11,6 +11,7 @@
 //
 //   conv_x3_kernel<1>      nn.Conv3d 3^3 forward and data gradient (components.py:8-9,44), Cin and Cout multiples of 16
 //   conv_x3_kernel<2>      nn.ConvTranspose3d(k3,s2,p1,op1) data gradient (in = 2*out - 1 + tap)
+//   conv_c1_x3_kernel      the first layer (Cin = 1): contraction over the 27 taps
 //   convt_x3_kernel        nn.ConvTranspose3d forward + bias + skip (components.py:259-264,283-284), output-parity classes
 //   wgrad_x3_kernel        conv weight gradient (contraction over voxels, both operands through ds_read_b64_tr_b16)
 //
@@ -413,6 +414,137 @@ int launch_convt_dgrad_x3(const void* dy, const void* sec_hi, size_t lo_delta, v
                           int cout, hipStream_t s) {
   // dx (d,h,w; Cin) <- dy (2d,2h,2w; Cout): contraction over Cout
   return launch_x3<2>(dy, sec_hi, lo_delta, nullptr, dx, n, d, h, w, 2 * d, 2 * h, 2 * w, cout, cin, nullptr, s);
+}
+
+// ================================================================================================== first layer (Cin = 1)
+// model.py:171-174: the network input has ONE channel, so the contraction runs over the 27 taps (padded to 32 = two k-steps):
+//   D[co][voxel] = sum_tap W[tap][co] * x[voxel + tap - 1].   A = the weights (hi / lo fragments in registers for the whole
+// workgroup), B = each lane's own 16 input values gathered from the fp32 halo brick in LDS and split on the fly.  The kernel is
+// bound by writing y once (fp32); one statistics row per wave and brick when the GroupNorm partials are asked for.
+struct C1X3Args {
+  const float* x;  // N x (d,h,w), one channel
+  const float* wt;  // Pf[27][1][cout]
+  const float* bias;
+  float* y;        // N x (d,h,w) x cout
+  float* stats;    // nullable: [n][4 * bricks per sample][cout][2]
+  int n, d, h, w, cout, tiles_z, tiles_y, tiles_x, tps, ncb;
+};
+
+__global__ __launch_bounds__(256) void conv_c1_x3_kernel(C1X3Args a) {
+  constexpr int TZ = 4, TY = 8, TX = 16, HZ = 6, HY = 10, HX = 18, NV = HZ * HY * HX, NTW = 4;
+  __shared__ float in_lds[NV + 8];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x / a.ncb, cb = blockIdx.x % a.ncb;
+  const int n = tile / a.tps;
+  int tt = tile - n * a.tps;
+  const int tx0 = (tt % a.tiles_x) * TX;
+  tt /= a.tiles_x;
+  const int ty0 = (tt % a.tiles_y) * TY;
+  const int tz0 = (tt / a.tiles_y) * TZ;
+  const float* xs = a.x + (size_t)n * a.d * a.h * a.w;
+  for (int v = tid; v < NV; v += 256) {
+    const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
+    const int gz = tz0 - 1 + hz, gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+    const bool ok = ((unsigned)gz < (unsigned)a.d) & ((unsigned)gy < (unsigned)a.h) & ((unsigned)gx < (unsigned)a.w);
+    in_lds[v] = ok ? xs[((size_t)gz * a.h + gy) * a.w + gx] : 0.f;
+  }
+  // weights: k-step s, this lane's taps 16 s + 8 h + j of output channel cb * 32 + r
+  bf16x8 wa_hi[2], wa_lo[2];
+  int toff[2][8];  // LDS offsets of those taps (taps 27..31 do not exist: weight zero, offset 0)
+  const int co = cb * 32 + r;
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tap = 16 * s2 + 8 * h + j;
+      const float wv_f = (tap < 27 && co < a.cout) ? a.wt[(size_t)tap * a.cout + co] : 0.f;
+      const bf16 hi = (bf16)wv_f;
+      wa_hi[s2][j] = hi;
+      wa_lo[s2][j] = (bf16)(wv_f - (float)hi);
+      toff[s2][j] = tap < 27 ? ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3 : 0;
+    }
+  __syncthreads();
+  float ssum[16], ssq[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) ssum[i] = ssq[i] = 0.f;
+  const size_t ovol = (size_t)a.d * a.h * a.w;
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int g = wv * NTW + t;
+    const int lz = g / (TY / 2), ly = (g % (TY / 2)) * 2 + (r >> 4), lx = r & 15;
+    const int lvx = (lz * HY + ly) * HX + lx;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 xh, xl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = in_lds[lvx + toff[s2][j]];
+        const bf16 hi = (bf16)v;
+        xh[j] = hi;
+        xl[j] = (bf16)(v - (float)hi);
+      }
+      acc = X3_MFMA(wa_lo[s2], xh, acc);
+      acc = X3_MFMA(wa_hi[s2], xl, acc);
+      acc = X3_MFMA(wa_hi[s2], xh, acc);
+    }
+    const int oz = tz0 + lz, oy = ty0 + ly, ox = tx0 + lx;
+    if (oz < a.d && oy < a.h && ox < a.w) {
+      float* yp = a.y + ((size_t)n * ovol + ((size_t)oz * a.h + oy) * a.w + ox) * a.cout;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co0 = cb * 32 + 8 * q + 4 * h;
+        if (co0 < a.cout) {
+          f4 o = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
+          if (a.bias) o += *reinterpret_cast<const f4*>(a.bias + co0);
+          __builtin_nontemporal_store(o, reinterpret_cast<f4*>(yp + co0));
+          if (a.stats) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              ssum[q * 4 + j] += o[j];
+              ssq[q * 4 + j] = fmaf(o[j], o[j], ssq[q * 4 + j]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (a.stats) {  // one row per wave and brick: lanes with equal k-half hold the same 16 channels
+    const int row = (tile - n * a.tps) * 4 + wv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float s1 = ssum[i], s2 = ssq[i];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+      }
+      const int c = cb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+      if (r == 0 && c < a.cout) {
+        float* dst = a.stats + (((size_t)n * (4 * a.tps) + row) * a.cout + c) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+      }
+    }
+  }
+}
+
+bool conv_c1_x3_supported(int cin, int cout, int ksize) { return cin == 1 && ksize == 3 && cout % 4 == 0; }
+int conv_c1_x3_stats_rows(int d, int h, int w) { return 4 * ((d + 3) / 4) * ((h + 7) / 8) * ((w + 15) / 16); }
+int launch_conv_c1_x3(const void* x, const float* w_pf, const float* bias, void* y, int n, int d, int h, int w, int cout,
+                      float* stats, hipStream_t s) {
+  C1X3Args a;
+  a.x = (const float*)x; a.wt = w_pf; a.bias = bias; a.y = (float*)y; a.stats = stats;
+  a.n = n; a.d = d; a.h = h; a.w = w; a.cout = cout;
+  a.tiles_z = (d + 3) / 4; a.tiles_y = (h + 7) / 8; a.tiles_x = (w + 15) / 16;
+  a.tps = a.tiles_z * a.tiles_y * a.tiles_x;
+  a.ncb = (cout + 31) / 32;
+  MEDNET_REQUIRE((double)n * a.tps * a.ncb < 2147483647.0, MEDNET_E_UNSUPPORTED, "conv_c1_x3: grid too large");
+  hipLaunchKernelGGL(conv_c1_x3_kernel, dim3((unsigned)(n * a.tps * a.ncb)), dim3(256), 0, s, a);
+  return check_launch("conv_c1_x3");
 }
 
 // ================================================================================================== ConvTranspose3d forward
