@@ -151,6 +151,36 @@ def test_split_bf16_conv_family_in_the_fp32_mode(n, cin, cout, shape):
         assert not torch.equal(a, b), f"{name}: option x3 selected no other kernel"
 
 
+@pytest.mark.parametrize("n,cout,shape", [(2, 32, (9, 11, 21)), (1, 8, (5, 6, 7)), (3, 64, (4, 9, 17))])
+def test_split_bf16_first_layer_in_the_fp32_mode(n, cout, shape):
+    """The network's first convolution (one input channel, model.py:171-174) in the fp32 mode: contraction over the 27 taps as a
+    split-bf16 product (conv_c1_x3_kernel), with the GroupNorm partial sums of its output; against ATen in fp64."""
+    tag = f"x3c1{n}{cout}{shape}"
+    x, w = rnd(tag + "x", n, 1, *shape), rnd(tag + "w", cout, 1, 3, 3, 3, scale=0.3)
+    yr = F.conv3d(x.double(), w.double(), None, padding=1)
+    res = {}
+    try:
+        for x3 in (1, 0):
+            _set_option("x3", x3)
+            with mednet_hip.precision("fp32"):
+                conv = hnn.Conv3d(1, cout, 3, bias=False).to(DEV)
+                with torch.no_grad():
+                    conv.weight.copy_(w)
+                y, partial = conv.forward_with_stats(x.to(DEV))
+                res[x3] = (y.detach().cpu(), None if partial is None else partial.detach().cpu())
+    finally:
+        _set_option("x3", 1)
+    assert_close(res[1][0].double(), yr, 3e-5, "split-bf16 first layer")
+    assert_close(res[0][0].double(), yr, 3e-6, "fp32 mfma first layer")
+    assert not torch.equal(res[1][0], res[0][0])
+    part = res[1][1]
+    assert part is not None and part.shape[0] == n and part.shape[2] == cout
+    sums = part.double().sum(1)  # [n][cout][2]
+    ys = res[1][0].double()
+    assert_close(sums[..., 0], ys.sum((2, 3, 4)), 1e-5, "sum y from the kernel's partial rows")
+    assert_close(sums[..., 1], (ys * ys).sum((2, 3, 4)), 1e-5, "sum y^2 from the kernel's partial rows")
+
+
 @pytest.mark.parametrize("n,cin,cout,shape", [(2, 32, 16, (3, 5, 9)), (1, 64, 32, (4, 4, 8)), (1, 16, 48, (5, 3, 17))])
 def test_split_bf16_conv_transpose_in_the_fp32_mode(n, cin, cout, shape):
     """ConvTranspose3d + bias + skip (components.py:259-264,283-284) in the fp32 mode: forward and data gradient on the

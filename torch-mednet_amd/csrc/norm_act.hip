@@ -11,7 +11,9 @@
 #define GN_NT 1  // GroupNorm backward's apply pass reads dz and y for the last time: non-temporal loads
 #endif
 #ifndef GN_WAVES
-#define GN_WAVES 4  // waves per SIMD the streaming GroupNorm kernels are compiled for (register cap 512 / GN_WAVES)
+#define GN_WAVES 3  // waves per SIMD the streaming GroupNorm kernels are compiled for (register cap 512 / GN_WAVES).  At 4
+                    // the 8-wide backward kernels spilled 3-13 registers to scratch; A/B of the training step (same box, three
+                    // interleaved rounds, profiles/r03_ab.md): 4 / 3 / 2 waves all 21.5-21.6 ms -- so the setting without scratch
 #endif
 namespace mednet {
 
