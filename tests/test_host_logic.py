@@ -231,3 +231,36 @@ def test_predict_grid_and_crop_window_follow_the_reference():
     import pytest
     with pytest.raises(ValueError):
         HP.grid_positions([8, 8, 8], [4, 4, 4], [2, 2, 2])
+
+
+def test_exact_products_policy_follows_the_activation_kind():
+    """fp32 storage mode: networks with kinked activations (ReLU 'r', LeakyReLU 'l' -- piecewise linear, gradient discontinuous
+    in the pre-activations) ask for exact fp32 products (ALGO_EXACT), the smooth default order 'cge' takes the split-bf16
+    contraction (ALGO_AUTO); a scope only turns the request on, and backward replays the forward's choice."""
+    from mednet_hip import _lib as L, config
+    assert config.conv_algo() == L.ALGO_AUTO
+    assert not HC.SingleConv(8, 8, 3, "cge", 8)._kinked and not HC.SingleConv(8, 8, 3, "cg", 8)._kinked
+    assert HC.SingleConv(8, 8, 3, "gcr", 8)._kinked and HC.SingleConv(8, 8, 3, "cl", 8)._kinked
+    assert not HC.ExtResNetBlock(8, 8, order="cge")._kinked and HC.ExtResNetBlock(8, 8, order="cgr")._kinked
+    assert not any(getattr(m, "_kinked", False) for m in HM.ResidualUNet3D(1, 2, False, f_maps=[8, 16]).modules())
+    assert any(getattr(m, "_kinked", False) for m in HM.UNet3D(1, 2, False, f_maps=[8, 16]).modules())
+    with config.exact_products(False):
+        assert config.conv_algo() == L.ALGO_AUTO
+    with config.exact_products(True):
+        assert config.conv_algo() == L.ALGO_EXACT
+        with config.exact_products(False):  # an inner smooth layer inside a kinked network stays exact
+            assert config.conv_algo() == L.ALGO_EXACT
+        with config.algo_scope(L.ALGO_AUTO):  # a backward whose forward ran outside the scope
+            assert config.conv_algo() == L.ALGO_AUTO
+        assert config.conv_algo() == L.ALGO_EXACT
+    with config.algo_scope(L.ALGO_EXACT):
+        assert config.conv_algo() == L.ALGO_EXACT
+    with config.algo_scope(None):
+        assert config.conv_algo() == L.ALGO_AUTO
+    config.set_conv_algo("direct")
+    try:
+        with config.exact_products(True):  # an explicit algorithm choice is not overridden
+            assert config.conv_algo() == L.ALGO_DIRECT
+    finally:
+        config.set_conv_algo("auto")
+    assert config.conv_algo() == L.ALGO_AUTO
