@@ -153,18 +153,27 @@ def test_cfg2_128_against_reference_golden(golden_dir):
         loss = HL.DiceLoss(weight=torch.tensor([0.05, 1, 1, 1.0], device=DEV)).to(DEV)(lg, batch["label"][:, -1].long().to(DEV))
         loss.backward()
     s = int(rec["meta.stride"])
-    assert_close(lg[..., ::s, ::s, ::s], torch.from_numpy(rec["logits.strided"]), 1e-3, "strided logits")
+    rl = assert_close(lg[..., ::s, ::s, ::s], torch.from_numpy(rec["logits.strided"]), 1e-3, "strided logits")
     assert abs(float(loss) - float(rec["loss"])) <= 1e-4
     assert abs(float(lg.double().norm()) - float(rec["logits.norm"])) <= 1e-3 * float(rec["logits.norm"])
+    wn = wp = wh = 0.0
     for name, p in net.named_parameters():
         g = p.grad.detach().double().cpu().numpy().reshape(-1)
         norm = float(rec[f"grad.{name}.norm"])
-        assert abs(np.sqrt((g * g).sum()) - norm) <= 1e-3 * norm, name
+        dn = abs(np.sqrt((g * g).sum()) - norm) / norm
+        assert dn <= 1e-3, name
         pv = np.random.Generator(np.random.PCG64(zlib.crc32(("proj:" + name).encode()))).standard_normal(g.size)
         # |<g - g_ref, r>| <= ||g - g_ref|| * ||r||-ish: a 1e-3 relative error moves the projection by <= ~4e-3*norm
-        assert abs(g @ pv - float(rec[f"grad.{name}.proj"])) <= 4e-3 * norm, name
+        dp = abs(g @ pv - float(rec[f"grad.{name}.proj"])) / norm
+        assert dp <= 4e-3, name
         head = rec[f"grad.{name}.head"]
-        assert np.linalg.norm(g[: head.size] - head) <= 2e-3 * max(np.linalg.norm(head), 1e-3 * norm / np.sqrt(g.size) * 8), name
+        dh = np.linalg.norm(g[: head.size] - head) / max(np.linalg.norm(head), 1e-3 * norm / np.sqrt(g.size) * 8)
+        assert dh <= 2e-3, name
+        wn, wp, wh = max(wn, dn), max(wp, dp), max(wh, dh)
+    # (measured on an MI355X in the split-bf16 fp32 mode, round 3: strided logits 1.05e-5, loss diff 0, worst gradient-norm diff
+    #  2.6e-4, worst projection diff 2.9e-4, worst leading-elements rel-L2 3.1e-4; cfg4: 9.4e-6 / 2.5e-4 / 7.7e-5)
+    print(f"[cfg2 128^3 fp32 mode vs reference] strided logits {rl:.2e} (tol 1e-3)  loss diff {abs(float(loss) - float(rec['loss'])):.1e}"
+          f"  worst gradient-norm diff {wn:.2e} (tol 1e-3)  worst projection diff {wp:.2e} (tol 4e-3)  worst leading-elements rel-L2 {wh:.2e}")
 
 
 def test_cfg4_128_landmark_against_reference_golden(golden_dir):
@@ -181,17 +190,23 @@ def test_cfg4_128_landmark_against_reference_golden(golden_dir):
         tot, cl, rg = step._fwd_bwd({k: v.to(DEV) for k, v in batch.items()})
         torch.cuda.synchronize()
     s = int(rec["meta.stride"])
-    assert_close(lg[..., ::s, ::s, ::s], torch.from_numpy(rec["logits.strided"]), 1e-3, "strided logits")
+    rl = assert_close(lg[..., ::s, ::s, ::s], torch.from_numpy(rec["logits.strided"]), 1e-3, "strided logits")
     for got, key in ((tot, "loss"), (cl, "class_loss"), (rg, "regression_loss")):
         assert abs(float(got) - float(rec[key])) <= 1e-4 * max(1.0, abs(float(rec[key]))), key
     step.flat.grads_as_attr()
+    wn = wp = 0.0
     for name, p in net.named_parameters():
         g = p.grad.detach().double().cpu().numpy().reshape(-1)
         norm = float(rec[f"grad.{name}.norm"])
-        assert abs(np.sqrt((g * g).sum()) - norm) <= 1e-3 * norm, name
+        dn = abs(np.sqrt((g * g).sum()) - norm) / norm
+        assert dn <= 1e-3, name
         pv = np.random.Generator(np.random.PCG64(zlib.crc32(("proj:" + name).encode()))).standard_normal(g.size)
-        assert abs(g @ pv - float(rec[f"grad.{name}.proj"])) <= 4e-3 * norm, name
+        dp = abs(g @ pv - float(rec[f"grad.{name}.proj"])) / norm
+        assert dp <= 4e-3, name
+        wn, wp = max(wn, dn), max(wp, dp)
     step.flat.release()
+    print(f"[cfg4 128^3 fp32 mode vs reference] strided logits {rl:.2e} (tol 1e-3)  worst gradient-norm diff {wn:.2e} (tol 1e-3)"
+          f"  worst projection diff {wp:.2e} (tol 4e-3)")
 
 
 # ---- the BENCHMARKED path (bf16 storage: persistent matrix-core kernels with statistics accumulated over a workgroup's
