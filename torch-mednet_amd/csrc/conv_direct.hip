@@ -576,7 +576,9 @@ __global__ __launch_bounds__(256) void head_dgrad_vox_kernel(const float* __rest
 // a lane keeps 16 sums, lanes of one channel group are summed with DPP (LDS-free) and every wave writes one partial row.
 constexpr int HEAD_GN_VPT = 32;  // voxels per lane group
 constexpr int HEAD_GN_MAXM = 64;  // classes (LDS image of the weights)
-template <typename TO, int K>
+constexpr int HEAD_DPP_MAXM = 32;  // classes the lanes of a voxel split between them (registers: HEAD_DPP_MAXM / lanes per voxel)
+// MANY: the form for more than 8 classes, its own instantiation (the 4-class head of the segmentation nets keeps its registers)
+template <typename TO, int K, bool MANY>
 __global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restrict__ dy, const float* __restrict__ Pb /*[m][K]*/,
                                                             TO* __restrict__ dz, const TO* __restrict__ gy,
                                                             const TO* __restrict__ gz, float* __restrict__ partial,
@@ -587,9 +589,9 @@ __global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restr
   // the lane's slice of the weights (8 channels x m classes): in registers for up to 8 classes, else through LDS (per-lane
   // global loads inside the class loop made the 18-class landmark head compute-bound: 986 us)
   __shared__ float sPb[HEAD_GN_MAXM * K];
-  float wreg[8][8];
-  const bool in_regs = m <= 8;
-  if (in_regs) {
+  float wreg[MANY ? 1 : 8][8];
+  constexpr bool in_regs = !MANY;
+  if constexpr (in_regs) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -609,13 +611,48 @@ __global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restr
     F8 t;
 #pragma unroll
     for (int j = 0; j < 8; ++j) t.v[j] = 0.f;
-    if (in_regs) {
+    if constexpr (in_regs) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if (i < m) {
           const float d = dy[((size_t)n * m + i) * spatial + v];
 #pragma unroll
           for (int j = 0; j < 8; ++j) t.v[j] = fmaf(d, wreg[i][j], t.v[j]);
+        }
+      }
+    } else if (CG <= 4 && m <= HEAD_DPP_MAXM) {
+      // More than 8 classes (the landmark head: 16 heat maps + 2 classes, landmarks.py:71-75).  The CG lanes of a voxel split
+      // the classes between them -- lane c loads classes c, c + CG, ... -- and hand the values round with DPP quad
+      // permutes: ceil(m / CG) planar loads per lane, ALL in flight before the first use, instead of m loads of which two
+      // were in flight (18 classes: 986 us; the loop was latency-bound, not bandwidth-bound).
+      constexpr int MAXQ = HEAD_DPP_MAXM / CG;
+      float dreg[MAXQ];
+#pragma unroll
+      for (int q = 0; q < MAXQ; ++q) {
+        const int i = q * CG + cgi;
+        dreg[q] = (q * CG < m && i < m) ? dy[((size_t)n * m + i) * spatial + v] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < MAXQ; ++q) {
+        if (q * CG < m) {  // (wave-uniform)
+#pragma unroll
+          for (int c = 0; c < CG; ++c) {
+            const int i = q * CG + c;
+            if (i < m) {
+              // broadcast lane c of every CG-lane group: quad_perm [c,c,c,c] (CG = 4) or [c,c,2+c,2+c] (CG = 2)
+              constexpr int HI = CG == 4 ? 0 : 2;
+              const float d = c == 0 ? dpp_f32<(0) | (0 << 2) | ((HI + 0) << 4) | ((HI + 0) << 6)>(dreg[q])
+                            : c == 1 ? dpp_f32<(1) | (1 << 2) | ((HI + 1) << 4) | ((HI + 1) << 6)>(dreg[q])
+                            : c == 2 ? dpp_f32<(2) | (2 << 2) | (2 << 4) | (2 << 6)>(dreg[q])
+                                     : dpp_f32<(3) | (3 << 2) | (3 << 4) | (3 << 6)>(dreg[q]);
+              const f32x4 w0 = *reinterpret_cast<const f32x4*>(wsrc + i * K + cgi * 8), w1 = *reinterpret_cast<const f32x4*>(wsrc + i * K + cgi * 8 + 4);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                t.v[j] = fmaf(d, w0[j], t.v[j]);
+                t.v[4 + j] = fmaf(d, w1[j], t.v[4 + j]);
+              }
+            }
+          }
         }
       }
     } else {
@@ -661,7 +698,15 @@ int launch_head_dgrad_gn(const void* dy, const float* Pb, void* dz, const void* 
                          int n, size_t spatial, int m, int k, int dtype, hipStream_t s) {
   MEDNET_REQUIRE(head_dgrad_gn_rows(spatial, k, dtype) > 0, MEDNET_E_UNSUPPORTED, "head_dgrad_gn: K=%d dtype=%d", k, dtype);
   const dim3 grid((unsigned)(head_dgrad_gn_rows(spatial, k, dtype) / 4), n);
-#define HG_GO(TO_, K_) hipLaunchKernelGGL((head_dgrad_gn_kernel<TO_, K_>), grid, dim3(256), 0, s, (const float*)dy, Pb, (TO_*)dz, (const TO_*)gy, (const TO_*)gz, partial, spatial, m, act)
+#define HG_GO(TO_, K_)                                                                                                         \
+  do {                                                                                                                         \
+    if (m <= 8)                                                                                                                \
+      hipLaunchKernelGGL((head_dgrad_gn_kernel<TO_, K_, false>), grid, dim3(256), 0, s, (const float*)dy, Pb, (TO_*)dz,        \
+                         (const TO_*)gy, (const TO_*)gz, partial, spatial, m, act);                                            \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((head_dgrad_gn_kernel<TO_, K_, true>), grid, dim3(256), 0, s, (const float*)dy, Pb, (TO_*)dz,         \
+                         (const TO_*)gy, (const TO_*)gz, partial, spatial, m, act);                                            \
+  } while (0)
 #define HG_K(TO_) do { if (k == 16) HG_GO(TO_, 16); else if (k == 32) HG_GO(TO_, 32); else HG_GO(TO_, 64); } while (0)
   if (dtype == MEDNET_BF16) HG_K(bf16);
   else HG_K(f16);
@@ -733,8 +778,10 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
   const int cols = k / 8, rows = 256 / cols;
   const int col = threadIdx.x % cols, row = threadIdx.x / cols;
   const bool active = (int)threadIdx.x < rows * cols;
-  const int n = blockIdx.z, m0 = blockIdx.y * 8;
-  const size_t v0 = (size_t)blockIdx.x * chunk_vox;
+  // grid = (class blocks, chunks, n): the workgroups that read the SAME chunk of z for different class blocks (the landmark
+  // head has three) are dispatched next to each other, so z comes from HBM once and from the Infinity Cache after that
+  const int n = blockIdx.z, m0 = blockIdx.x * 8;
+  const size_t v0 = (size_t)blockIdx.y * chunk_vox;
   const size_t v1 = v0 + chunk_vox < spatial ? v0 + chunk_vox : spatial;
   float acc[8][8];
 #pragma unroll
@@ -772,7 +819,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
     }
   }
   // reduce the `rows` threads that share a column, one output row at a time
-  float* out = part + (((size_t)n * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * 8 * k;
+  float* out = part + (((size_t)n * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 * k;
   for (int i = 0; i < 8; ++i) {
     __syncthreads();
     if (active) {
@@ -826,7 +873,7 @@ int launch_wgrad_1x1(const void* z, const void* dy, float* dw, int n, size_t spa
   wgrad_1x1_plan(spatial, cin, cv, chunks);
   const int mblocks = (cout + 7) / 8;
   MEDNET_REQUIRE(ws_bytes >= wgrad_1x1_ws_bytes(n, spatial, cin, cout), MEDNET_E_WORKSPACE, "wgrad_1x1: workspace too small");
-  const dim3 grid(chunks, mblocks, n);
+  const dim3 grid(mblocks, chunks, n);
   float* part = (float*)ws;
   if (z_dtype == MEDNET_F32)
     hipLaunchKernelGGL(wgrad_1x1_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)z, part, spatial, cin, cout, cv);
