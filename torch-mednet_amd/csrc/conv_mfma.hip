@@ -747,7 +747,17 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
   //      BEFORE the tap loop ends -- their latency is otherwise exposed, 2 us per brick -- and have no registers for them:
   //      there the fragments of steps [TW0, TW1) are transient, fetched again (from L2) 30+ steps before their use in every
   //      tap loop, and the second operands take over their registers for the last 8 steps.
-  constexpr int NSEC = (ADD ? 8 : 0) + (GNB ? 8 : 0);  // second-operand rows (4 registers each, as a fragment)
+  //      Round 3: the GroupNorm input rows (GNB) do not go through registers at all any more.  The K-chunk-0 planes of the brick
+  //      being read are dead from step 27 on (steps 27..53 read the chunk-1 planes; B operands are read two steps ahead), and
+  //      the buffer is not written again before the next item's barrier: the wave's 8 rows (1 KB each, exactly in lane order)
+  //      are fetched by LDS-DMA (buffer_load ... lds) into that space at steps 27..34 -- 2 600 to 3 500 cycles before the
+  //      epilogue reads them back, instead of 128 to 1 024 -- and only the summed-gradient rows (ADD) still take over fragment
+  //      registers.  Option conv32_gnb_lds=0 (compile-time knob MEDNET_C32_GNB_LDS) restores the register form.
+#ifndef MEDNET_C32_GNB_LDS
+#define MEDNET_C32_GNB_LDS 1
+#endif
+  constexpr bool GNB_LDS = GNB && MEDNET_C32_GNB_LDS;
+  constexpr int NSEC = (ADD ? 8 : 0) + (GNB && !GNB_LDS ? 8 : 0);  // second-operand rows in registers (4 each, as a fragment)
   constexpr int SEC0 = 54 - 8, WT = NSEC, TW1 = SEC0, TW0 = TW1 - WT;
   eltx8 wreg[54];
   const u32x4* wp = reinterpret_cast<const u32x4*>(a.wpk) + h * 32 + r;
@@ -899,6 +909,9 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
     };
     auto row_soff = [&](int j) { return row_off[j]; };
     [[maybe_unused]] eltx8 adr[ADD ? 8 : 1], yrw[GNB ? 8 : 1];  // second operands: requested in the last 8 steps below
+    // (GNB_LDS: this wave's 8 KB inside the chunk-0 planes of the brick's own buffer, see above)
+    [[maybe_unused]] char* ydst = reinterpret_cast<char*>(in_lds + (size_t)buf * BUF_PIECES) + wv_s * 8192;
+    static_assert(!GNB_LDS || 4 * 8192 <= 2 * NVP * 16, "the four waves' rows fit the two dead planes");
 
     // ---- 54 steps (K chunk, tap) of 4 MFMAs; B operands are read TWO steps ahead (nobody else hides the LDS latency).
     //      Step 3k: round k of brick j + 1 goes from its registers to the other LDS buffer, then round k of brick j + 2 is
@@ -940,7 +953,16 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
         if (t == 2 && s54 >= SEC0) {  // second operands of row s54 - SEC0
           const int j = s54 - SEC0;
           if constexpr (ADD) adr[j] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(a.add, j), vb, row_soff(j), 0));
-          if constexpr (GNB) yrw[j] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(a.gnb_y, j), vb, row_soff(j), 0));
+          if constexpr (GNB && !GNB_LDS) yrw[j] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(a.gnb_y, j), vb, row_soff(j), 0));
+        }
+        if constexpr (GNB_LDS) {
+          if (t == 2 && s54 >= 27 && s54 < 35) {  // GroupNorm input row s54 - 27 -> LDS (row planned at step 24 + row)
+            const int j = s54 - 27;
+            // (the resource is built here, not by the row_rsrc lambda: handed a lambda's return value, hipcc 7.2 silently drops
+            //  the kernel's HOST stub -- the library then fails to load with an undefined kernel symbol)
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_y + (size_t)n * ovol * 32), 0, row_num[j], 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (__attribute__((address_space(3))) void*)(ydst + j * 1024), 16, vb, row_off[j], 0, 0);
+          }
         }
         if (staging) {
           if (t == 0) commit_one(buf ^ 1, round);
@@ -979,6 +1001,16 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
         const int vox = j * 16 + ev, swl = (vox >> 1) & 7;
         rows[4 * half + j] = *reinterpret_cast<const eltx8*>(wlds + vox * 32 + (pj ^ (swl >> 1)) * 8);
       }
+    }
+    if constexpr (GNB_LDS) {
+      // The rows' LDS-DMAs were this wave's vector-memory operations number 27..34 of the tap loop; younger than them are the
+      // staging loads of rounds 12..16 (steps 36..48) and, in the ADD variant, the 8 summed-gradient rows (steps 46..53), all
+      // issued unconditionally: waiting until at most that many are outstanding has the rows in LDS (nothing but the issuing
+      // wave's own vmcnt orders a ds_read behind an LDS-DMA).
+      if constexpr (ADD) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 8; ++j) yrw[j] = *reinterpret_cast<const eltx8*>(ydst + j * 1024 + lane * 16);
     }
     float ca[GNB ? 8 : 1], cbf[GNB ? 8 : 1];
     if constexpr (GNB) {  // (after the accumulators are gone: the register file is full until then)
