@@ -181,10 +181,12 @@ def test_split_bf16_first_layer_in_the_fp32_mode(n, cout, shape):
     assert_close(sums[..., 1], (ys * ys).sum((2, 3, 4)), 1e-5, "sum y^2 from the kernel's partial rows")
 
 
-@pytest.mark.parametrize("n,cin,cout,shape", [(2, 32, 16, (3, 5, 9)), (1, 64, 32, (4, 4, 8)), (1, 16, 48, (5, 3, 17))])
+@pytest.mark.parametrize("n,cin,cout,shape", [(2, 32, 16, (3, 5, 9)), (1, 64, 32, (4, 4, 8)), (1, 16, 48, (5, 3, 17)),
+                                              (2, 128, 64, (3, 6, 16))])
 def test_split_bf16_conv_transpose_in_the_fp32_mode(n, cin, cout, shape):
-    """ConvTranspose3d + bias + skip (components.py:259-264,283-284) in the fp32 mode: forward and data gradient on the
-    split-bf16 kernels (the weight gradient stays on the fp32 matrix-core kernel)."""
+    """ConvTranspose3d + bias + skip (components.py:259-264,283-284) in the fp32 mode: forward, data gradient and weight
+    gradient (output-parity planes of the gradient, one or two 32-channel blocks of x per workgroup) on the split-bf16
+    kernels."""
     tag = f"x3ct{n}{cin}{cout}{shape}"
     oshape = tuple(2 * s for s in shape)
     x, w = rnd(tag + "x", n, cin, *shape), rnd(tag + "w", cin, cout, 3, 3, 3, scale=0.1)
@@ -210,7 +212,7 @@ def test_split_bf16_conv_transpose_in_the_fp32_mode(n, cin, cout, shape):
     for name, a, b2, ref in zip(("y", "dx", "dw"), res[1], res[0], (yr, xr.grad, wr.grad)):
         assert_close(a.double(), ref, 3e-5, f"split-bf16 {name}")
         assert_close(b2.double(), ref, 3e-6, f"fp32 mfma {name}")
-    assert not torch.equal(res[1][0], res[0][0]) and not torch.equal(res[1][1], res[0][1])
+    assert not torch.equal(res[1][0], res[0][0]) and not torch.equal(res[1][1], res[0][1]) and not torch.equal(res[1][2], res[0][2])
 
 
 @pytest.mark.parametrize("n,c,shape", [(1, 32, (32, 64, 64)), (2, 64, (16, 32, 64)), (2, 256, (16, 32, 32))])

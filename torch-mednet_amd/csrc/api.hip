@@ -452,6 +452,8 @@ extern "C" size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int 
   size_t b = convt_wgrad_mfma_ws_bytes(n, d, h, w, cin, cout);
   const size_t f = wgrad_f32_mfma_ws_bytes(n, d, h, w, cin, cout, 1);
   if (f > b) b = f;
+  const size_t f3 = conv_x3_supported(cin, cout, 3) ? convt_wgrad_x3_ws_bytes(n, d, h, w, cin, cout) : 0;
+  if (f3 > b) b = f3;
   return align_up(a > b ? a : b, 256) + channel_sum_ws_bytes(n, (size_t)8 * d * h * w, cout) + 256;
 }
 
@@ -469,8 +471,12 @@ extern "C" int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, fl
     if (rc) return rc;
     ws_bytes = (ws_bytes - need) / 256 * 256;
   }
-  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32)
+  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32) {
+    if (algo != MEDNET_ALGO_EXACT && conv_x3_enabled() && tuning_option("x3_convt_wgrad", 1) && conv_x3_supported(cin, cout, 3) &&
+        conv_x3_fits(2 * d, 2 * h, 2 * w, cout) && conv_x3_fits(d, h, w, cin))
+      return launch_convt_wgrad_x3(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);  // split-bf16, output-parity planes
     return launch_convt_wgrad_f32_mfma(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
+  }
   const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0 && is16(x_dtype) && dy_dtype == x_dtype &&
                        wgrad_mfma_fits(n, d, h, w, cin > 8 * cout ? cin : 8 * cout, 1);
   if (algo == MEDNET_ALGO_MFMA && !mfma_ok)

@@ -92,4 +92,8 @@ size_t wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout);
 int launch_wgrad_x3(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, void* ws,
                     size_t ws_bytes, hipStream_t s);
 
+size_t convt_wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+int launch_convt_wgrad_x3(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, void* ws,
+                          size_t ws_bytes, hipStream_t s);
+
 }  // namespace mednet
