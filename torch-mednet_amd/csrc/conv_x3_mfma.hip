@@ -189,32 +189,76 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   };
-  // per-wave GroupNorm partials of the stored output: this lane's channels are 8q + 4h + j (16 of the block's 32)
-  float ssum[16], ssq[16];
+  // ---- epilogue.  The accumulator layout gives a lane four 16-byte pieces (channels 8q + 4h ..) of ITS voxel's row: stored as
+  // they stand, one instruction touches 64 rows with 16 bytes each (measured: the store-bound first-layer kernel wrote at
+  // 0.85 TB/s that way).  Stride 1: a tile goes through 4 KB of LDS private to the wave (behind the images; 16-byte pieces
+  // XOR-swizzled by voxel, so the writes and the reads are conflict-free and no barrier is needed: a wave's LDS operations
+  // execute in order) and leaves as whole rows -- 8 lanes per voxel, 8 voxels = 1 KB contiguous per instruction.  A lane then
+  // owns the SAME 4 channels (piece c = lane & 7) of every voxel it stores, which is also what the per-channel sums want:
+  // 8 registers instead of 32, reduced over the lanes of a class with DPP (lane_class_sum<8>), no LDS-queue shuffles.
+  constexpr bool EPI_LDS = STRIDE == 1;
+  [[maybe_unused]] f4* epi = reinterpret_cast<f4*>(smem + (size_t)(4 * NV + 2 * W_SLICE) * 16) + wv * 256;
+  constexpr int NS = EPI_LDS ? 4 : 16;  // channels a lane keeps sums of
+  float ssum[NS], ssq[NS];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) ssum[i] = ssq[i] = 0.f;
+  for (int i = 0; i < NS; ++i) ssum[i] = ssq[i] = 0.f;
   int stats_n = -1, stats_cb = 0;
   auto flush_stats = [&]() {
-    // sum over the wave's 32 voxel lanes of each k-half (lanes with equal h), then one row per wave of the workgroups that
-    // work on this sample (conv_x3_stats_rows: a workgroup stays inside one sample): entries [n][row][co][2]
+    // one row per wave of the workgroups that work on this (sample, channel block) group (conv_x3_stats_rows)
+    const int row = ((xcd % (a.xps > 0 ? a.xps : 1)) * slot_step + slot0) * NWAVES + wv;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float s = ssum[i], q2 = ssq[i];
+    for (int i = 0; i < NS; ++i) {
+      float s1, s2;
+      int co;
+      bool writer;
+      if constexpr (EPI_LDS) {
+        s1 = lane_class_sum<8>(ssum[i]);
+        s2 = lane_class_sum<8>(ssq[i]);
+        co = stats_cb * 32 + 4 * (lane & 7) + i;
+        writer = lane < 8;
+      } else {
+        s1 = ssum[i];
+        s2 = ssq[i];
 #pragma unroll
-      for (int o = 1; o < 32; o <<= 1) {
-        s += __shfl_xor(s, o);
-        q2 += __shfl_xor(q2, o);
-      }
-      if (r == 0 && stats_n >= 0) {
-        const int co = stats_cb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-        if (co < a.m) {
-          const int row = ((xcd % (a.xps > 0 ? a.xps : 1)) * slot_step + slot0) * NWAVES + wv;
-          float* dst = a.stats + (((size_t)stats_n * a.stats_rows + row) * a.m + co) * 2;
-          dst[0] = s;
-          dst[1] = q2;
+        for (int o = 1; o < 32; o <<= 1) {
+          s1 += __shfl_xor(s1, o);
+          s2 += __shfl_xor(s2, o);
         }
+        co = stats_cb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+        writer = r == 0;
+      }
+      if (writer && stats_n >= 0 && co < a.m) {
+        float* dst = a.stats + (((size_t)stats_n * a.stats_rows + row) * a.m + co) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
       }
       ssum[i] = ssq[i] = 0.f;
+    }
+  };
+  // what happens to a 16-byte piece `o` of the output row at element offset `eo` (channels co0 .. co0 + 3): bias, summed second
+  // gradient, store, and the sums (GroupNorm statistics, or the first pass of the previous GroupNorm's backward)
+  auto finish_piece = [&](f4 o, size_t eo, int co0, const Item& it, int si) {
+    if (a.bias) o += *reinterpret_cast<const f4*>(a.bias + co0);
+    if (a.add) o += __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.add + eo));
+    __builtin_nontemporal_store(o, reinterpret_cast<f4*>(a.y + eo));
+    if (a.gn_y) {
+      const f4 gy = *reinterpret_cast<const f4*>(a.gn_y + eo);
+      const float* cf = a.gn_coef + ((size_t)it.n * a.m + co0) * 2;
+      const f4 c01 = *reinterpret_cast<const f4*>(cf), c23 = *reinterpret_cast<const f4*>(cf + 4);
+      float u[4] = {fmaf(c01[0], gy[0], c01[1]), fmaf(c01[2], gy[1], c01[3]), fmaf(c23[0], gy[2], c23[1]), fmaf(c23[2], gy[3], c23[3])};
+      float du[4] = {o[0], o[1], o[2], o[3]};
+      act_grad_pre_n<4>(du, u, a.gn_act);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ssum[si + j] += du[j];
+        ssq[si + j] = fmaf(du[j], gy[j], ssq[si + j]);
+      }
+    } else if (a.stats) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ssum[si + j] += o[j];
+        ssq[si + j] = fmaf(o[j], o[j], ssq[si + j]);
+      }
     }
   };
   auto store = [&](const Item& it) {
@@ -227,36 +271,32 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int g = wv * NTW + t;
-      const int oz = it.tz0 + g / (TY / 2), oy = it.ty0 + (g % (TY / 2)) * 2 + (r >> 4), ox = it.tx0 + (r & 15);
-      if (oz < a.od && oy < a.oh && ox < a.ow) {
-        float* yp = a.y + ((size_t)it.n * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.m;
+      const int oz = it.tz0 + g / (TY / 2);
+      if constexpr (EPI_LDS) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int co0 = it.cb * 32 + 8 * q + 4 * h;
-          if (co0 < a.m) {
-            f4 o = {acc[t][q * 4], acc[t][q * 4 + 1], acc[t][q * 4 + 2], acc[t][q * 4 + 3]};
-            if (a.bias) o += *reinterpret_cast<const f4*>(a.bias + co0);
-            if (a.add) o += __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.add + (yp - a.y) + co0));
-            __builtin_nontemporal_store(o, reinterpret_cast<f4*>(yp + co0));
-            if (a.gn_y) {  // first pass of the backward of the GroupNorm (+ activation) that produced this layer's input
-              const f4 gy = *reinterpret_cast<const f4*>(a.gn_y + (yp - a.y) + co0);
-              const float* cf = a.gn_coef + ((size_t)it.n * a.m + co0) * 2;
-              const f4 c01 = *reinterpret_cast<const f4*>(cf), c23 = *reinterpret_cast<const f4*>(cf + 4);
-              float u[4] = {fmaf(c01[0], gy[0], c01[1]), fmaf(c01[2], gy[1], c01[3]), fmaf(c23[0], gy[2], c23[1]),
-                            fmaf(c23[2], gy[3], c23[3])};
-              float du[4] = {o[0], o[1], o[2], o[3]};
-              act_grad_pre_n<4>(du, u, a.gn_act);
+        for (int q = 0; q < 4; ++q) {  // lane (voxel r of the tile, k-half h) -> piece 2q + h of row r
+          const f4 o = {acc[t][q * 4], acc[t][q * 4 + 1], acc[t][q * 4 + 2], acc[t][q * 4 + 3]};
+          epi[r * 8 + ((2 * q + h) ^ (r & 7))] = o;
+        }
+        const int c = lane & 7, co0 = it.cb * 32 + 4 * c;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                ssum[q * 4 + j] += du[j];
-                ssq[q * 4 + j] = fmaf(du[j], gy[j], ssq[q * 4 + j]);
-              }
-            } else if (a.stats) {
+        for (int rd = 0; rd < 4; ++rd) {  // 8 voxels per instruction: voxel v of the tile = two x-rows of 16
+          const int v = rd * 8 + (lane >> 3);
+          const f4 o = epi[v * 8 + (c ^ (v & 7))];
+          const int oy = it.ty0 + (g % (TY / 2)) * 2 + (v >> 4), ox = it.tx0 + (v & 15);
+          if (oz < a.od && oy < a.oh && ox < a.ow && co0 < a.m)
+            finish_piece(o, ((size_t)it.n * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.m + co0, co0, it, 0);
+        }
+      } else {
+        const int oy = it.ty0 + (g % (TY / 2)) * 2 + (r >> 4), ox = it.tx0 + (r & 15);
+        if (oz < a.od && oy < a.oh && ox < a.ow) {
+          const size_t base = ((size_t)it.n * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.m;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                ssum[q * 4 + j] += o[j];
-                ssq[q * 4 + j] = fmaf(o[j], o[j], ssq[q * 4 + j]);
-              }
+          for (int q = 0; q < 4; ++q) {
+            const int co0 = it.cb * 32 + 8 * q + 4 * h;
+            if (co0 < a.m) {
+              const f4 o = {acc[t][q * 4], acc[t][q * 4 + 1], acc[t][q * 4 + 2], acc[t][q * 4 + 3]};
+              finish_piece(o, base + co0, co0, it, q * 4);
             }
           }
         }
@@ -359,7 +399,7 @@ static int launch_x3(const void* x, const void* sec_hi, size_t lo_delta, const f
                      const void* gn_y = nullptr, const float* gn_coef = nullptr, int gn_act = MEDNET_ACT_NONE) {
   using G = X3Tile<STRIDE>;
   constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
-  constexpr size_t lds = ((size_t)4 * HZ * HY * HX + 2 * 27 * 2 * 32) * 16;
+  constexpr size_t lds = ((size_t)4 * HZ * HY * HX + 2 * 27 * 2 * 32) * 16 + (STRIDE == 1 ? (size_t)G::NWAVES * 4096 : 0);  // + epilogue areas
   static_assert(lds <= 160 * 1024, "one workgroup per CU");
   MEDNET_REQUIRE(k % 16 == 0 && m % 16 == 0 && lo_delta != 0, MEDNET_E_UNSUPPORTED, "conv_x3: channels %d -> %d", k, m);
   X3Args a;
@@ -466,15 +506,19 @@ __global__ __launch_bounds__(256) void conv_c1_x3_kernel(C1X3Args a) {
       toff[s2][j] = tap < 27 ? ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3 : 0;
     }
   __syncthreads();
-  float ssum[16], ssq[16];
+  // epilogue through 4 KB of LDS private to the wave, as in conv_x3_kernel: whole rows leave, a lane owns 4 channels
+  __shared__ f4 epi_all[4 * 256];
+  f4* epi = epi_all + wv * 256;
+  float ssum[4], ssq[4];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) ssum[i] = ssq[i] = 0.f;
+  for (int i = 0; i < 4; ++i) ssum[i] = ssq[i] = 0.f;
   const size_t ovol = (size_t)a.d * a.h * a.w;
+  const int c = lane & 7, co0 = cb * 32 + 4 * c;
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const int g = wv * NTW + t;
-    const int lz = g / (TY / 2), ly = (g % (TY / 2)) * 2 + (r >> 4), lx = r & 15;
-    const int lvx = (lz * HY + ly) * HX + lx;
+    const int lz = g / (TY / 2), ly0 = (g % (TY / 2)) * 2;
+    const int lvx = (lz * HY + ly0 + (r >> 4)) * HX + (r & 15);
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -492,40 +536,37 @@ __global__ __launch_bounds__(256) void conv_c1_x3_kernel(C1X3Args a) {
       acc = X3_MFMA(wa_hi[s2], xl, acc);
       acc = X3_MFMA(wa_hi[s2], xh, acc);
     }
-    const int oz = tz0 + lz, oy = ty0 + ly, ox = tx0 + lx;
-    if (oz < a.d && oy < a.h && ox < a.w) {
-      float* yp = a.y + ((size_t)n * ovol + ((size_t)oz * a.h + oy) * a.w + ox) * a.cout;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co0 = cb * 32 + 8 * q + 4 * h;
-        if (co0 < a.cout) {
-          f4 o = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
-          if (a.bias) o += *reinterpret_cast<const f4*>(a.bias + co0);
-          __builtin_nontemporal_store(o, reinterpret_cast<f4*>(yp + co0));
-          if (a.stats) {
+    for (int q = 0; q < 4; ++q) {
+      const f4 o = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
+      epi[r * 8 + ((2 * q + h) ^ (r & 7))] = o;
+    }
+    const int oz = tz0 + lz;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              ssum[q * 4 + j] += o[j];
-              ssq[q * 4 + j] = fmaf(o[j], o[j], ssq[q * 4 + j]);
-            }
+    for (int rd = 0; rd < 4; ++rd) {
+      const int v = rd * 8 + (lane >> 3);
+      f4 o = epi[v * 8 + (c ^ (v & 7))];
+      const int oy = ty0 + ly0 + (v >> 4), ox = tx0 + (v & 15);
+      if (oz < a.d && oy < a.h && ox < a.w && co0 < a.cout) {
+        if (a.bias) o += *reinterpret_cast<const f4*>(a.bias + co0);
+        __builtin_nontemporal_store(o, reinterpret_cast<f4*>(a.y + ((size_t)n * ovol + ((size_t)oz * a.h + oy) * a.w + ox) * a.cout + co0));
+        if (a.stats) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            ssum[j] += o[j];
+            ssq[j] = fmaf(o[j], o[j], ssq[j]);
           }
         }
       }
     }
   }
-  if (a.stats) {  // one row per wave and brick: lanes with equal k-half hold the same 16 channels
+  if (a.stats) {  // one row per wave and brick: the lanes of a class (lane & 7) hold the same 4 channels
     const int row = (tile - n * a.tps) * 4 + wv;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float s1 = ssum[i], s2 = ssq[i];
-#pragma unroll
-      for (int o = 1; o < 32; o <<= 1) {
-        s1 += __shfl_xor(s1, o);
-        s2 += __shfl_xor(s2, o);
-      }
-      const int c = cb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-      if (r == 0 && c < a.cout) {
-        float* dst = a.stats + (((size_t)n * (4 * a.tps) + row) * a.cout + c) * 2;
+    for (int i = 0; i < 4; ++i) {
+      const float s1 = lane_class_sum<8>(ssum[i]), s2 = lane_class_sum<8>(ssq[i]);
+      if (lane < 8 && co0 + i < a.cout) {
+        float* dst = a.stats + (((size_t)n * (4 * a.tps) + row) * a.cout + co0 + i) * 2;
         dst[0] = s1;
         dst[1] = s2;
       }
