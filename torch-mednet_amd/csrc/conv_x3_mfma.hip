@@ -196,7 +196,10 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
   // execute in order) and leaves as whole rows -- 8 lanes per voxel, 8 voxels = 1 KB contiguous per instruction.  A lane then
   // owns the SAME 4 channels (piece c = lane & 7) of every voxel it stores, which is also what the per-channel sums want:
   // 8 registers instead of 32, reduced over the lanes of a class with DPP (lane_class_sum<8>), no LDS-queue shuffles.
-  constexpr bool EPI_LDS = STRIDE == 1;
+#ifndef MEDNET_X3_EPI_LDS
+#define MEDNET_X3_EPI_LDS 1
+#endif
+  constexpr bool EPI_LDS = STRIDE == 1 && MEDNET_X3_EPI_LDS;
   [[maybe_unused]] f4* epi = reinterpret_cast<f4*>(smem + (size_t)(4 * NV + 2 * W_SLICE) * 16) + wv * 256;
   constexpr int NS = EPI_LDS ? 4 : 16;  // channels a lane keeps sums of
   float ssum[NS], ssq[NS];
