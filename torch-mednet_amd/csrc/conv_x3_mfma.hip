@@ -196,11 +196,15 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
   // execute in order) and leaves as whole rows -- 8 lanes per voxel, 8 voxels = 1 KB contiguous per instruction.  A lane then
   // owns the SAME 4 channels (piece c = lane & 7) of every voxel it stores, which is also what the per-channel sums want:
   // 8 registers instead of 32, reduced over the lanes of a class with DPP (lane_class_sum<8>), no LDS-queue shuffles.
+  // (-DMEDNET_X3_EPI_LDS=0 restores the direct stores: profiles/r03_ab.md has the A/B, 3.4 ms per step.)
 #ifndef MEDNET_X3_EPI_LDS
 #define MEDNET_X3_EPI_LDS 1
 #endif
-  constexpr bool EPI_LDS = STRIDE == 1 && MEDNET_X3_EPI_LDS;
-  [[maybe_unused]] f4* epi = reinterpret_cast<f4*>(smem + (size_t)(4 * NV + 2 * W_SLICE) * 16) + wv * 256;
+  constexpr bool EPI_LDS = MEDNET_X3_EPI_LDS;
+  // stride 1: the areas sit behind the images; stride 2 (halo 5x9x33: 150 KB of images) has no room: there they alias the input
+  // planes, behind one more barrier per item (EPI_ALIAS)
+  constexpr bool EPI_ALIAS = EPI_LDS && STRIDE == 2;
+  [[maybe_unused]] f4* epi = reinterpret_cast<f4*>(smem + (EPI_ALIAS ? (size_t)0 : (size_t)(4 * NV + 2 * W_SLICE) * 16)) + wv * 256;
   constexpr int NS = EPI_LDS ? 4 : 16;  // channels a lane keeps sums of
   float ssum[NS], ssq[NS];
 #pragma unroll
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
       __builtin_amdgcn_sched_barrier(0);
     }
     if (last_chunk) {
+      if constexpr (EPI_ALIAS) __syncthreads();  // every wave is done with the images before the epilogue areas overwrite them
       store(cur);
       if (!nxt.valid) break;
       init_acc();
@@ -708,21 +713,40 @@ __global__ __launch_bounds__(256, 2) void convt_x3_kernel(CtX3Args a) {
       acc[pc] = X3_MFMA(wa_hi, xh[dl], acc[pc]);
     }
   }
+  // ---- epilogue: whole output rows through LDS (the images are dead: one barrier, then 4 KB per wave).  For an output parity
+  // (pz, py) and one of the tile's two low-resolution y-rows the classes px = 0, 1 of 16 lanes interleave to 32 consecutive
+  // output voxels of ONE output x-row: 4 KB contiguous per (pz, py, row) when Cout = 32, whole 128-byte segments otherwise.
   const int od = 2 * a.id, oh = 2 * a.ih, ow = 2 * a.iw;
-  const int jz = tz0 + lz, jy = ty0 + ly, jx = tx0 + lx;
-  if (jz < a.id && jy < a.ih && jx < a.iw) {
+  __syncthreads();
+  f4* epi = reinterpret_cast<f4*>(smem) + wv * 256;
+  const int c = lane & 7, co0 = cb * 32 + 4 * c;
+  const int jz = tz0 + lz;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int oz = 2 * jz + (p >> 2), oy = 2 * jy + ((p >> 1) & 1), ox = 2 * jx + (p & 1);
-      const size_t o = ((((size_t)n * od + oz) * oh + oy) * ow + ox) * a.m;
+  for (int pzy = 0; pzy < 4; ++pzy) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co0 = cb * 32 + 8 * q + 4 * h;
-        if (co0 < a.m) {
-          f4 v = {acc[p][q * 4], acc[p][q * 4 + 1], acc[p][q * 4 + 2], acc[p][q * 4 + 3]};
-          if (a.bias) v += *reinterpret_cast<const f4*>(a.bias + co0);
-          if (a.skip) v += *reinterpret_cast<const f4*>(a.skip + o + co0);
-          *reinterpret_cast<f4*>(a.y + o + co0) = v;
+    for (int yy = 0; yy < 2; ++yy) {
+      if ((r >> 4) == yy) {
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          const int ov = 2 * (r & 15) + px;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f4 o = {acc[pzy * 2 + px][q * 4], acc[pzy * 2 + px][q * 4 + 1], acc[pzy * 2 + px][q * 4 + 2], acc[pzy * 2 + px][q * 4 + 3]};
+            epi[ov * 8 + ((2 * q + h) ^ (ov & 7))] = o;
+          }
+        }
+      }
+      const int oz = 2 * jz + (pzy >> 1), oy = 2 * (ty0 + (wv % (TY / 2)) * 2 + yy) + (pzy & 1);
+#pragma unroll
+      for (int rd = 0; rd < 4; ++rd) {
+        const int v = rd * 8 + (lane >> 3);
+        f4 o = epi[v * 8 + (c ^ (v & 7))];
+        const int ox = 2 * tx0 + v;
+        if (oz < od && oy < oh && ox < ow && co0 < a.m) {
+          const size_t eo = ((((size_t)n * od + oz) * oh + oy) * ow + ox) * a.m + co0;
+          if (a.bias) o += *reinterpret_cast<const f4*>(a.bias + co0);
+          if (a.skip) o += *reinterpret_cast<const f4*>(a.skip + eo);
+          *reinterpret_cast<f4*>(a.y + eo) = o;
         }
       }
     }
