@@ -51,6 +51,15 @@ __device__ __forceinline__ HiLo split8(u32x4 ua, u32x4 ub) {
   return r;
 }
 
+// Lanes of ONE wave hand data to each other through LDS without a barrier (the hardware executes a wave's LDS operations in
+// order).  To the compiler that is a data race between threads: its alias analysis is per thread and it may move a lane's read
+// above the same lane's write when it can prove THOSE two addresses differ (it did, in the ConvTranspose epilogue: the first
+// read round came back stale).  This fence is no instruction; it pins the order of memory operations around it.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 constexpr unsigned X3_OOB = 0xFFFFFF00u;  // a buffer-load offset past every resource: the hardware returns zeros
 
 // ================================================================================================== forward / data gradient
@@ -285,11 +294,16 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
           const f4 o = {acc[t][q * 4], acc[t][q * 4 + 1], acc[t][q * 4 + 2], acc[t][q * 4 + 3]};
           epi[r * 8 + ((2 * q + h) ^ (r & 7))] = o;
         }
+        wave_lds_fence();
         const int c = lane & 7, co0 = it.cb * 32 + 4 * c;
+        f4 rows4[4];
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) rows4[rd] = epi[(rd * 8 + (lane >> 3)) * 8 + (c ^ ((rd * 8 + (lane >> 3)) & 7))];
+        wave_lds_fence();
 #pragma unroll
         for (int rd = 0; rd < 4; ++rd) {  // 8 voxels per instruction: voxel v of the tile = two x-rows of 16
           const int v = rd * 8 + (lane >> 3);
-          const f4 o = epi[v * 8 + (c ^ (v & 7))];
+          const f4 o = rows4[rd];
           const int oy = it.ty0 + (g % (TY / 2)) * 2 + (v >> 4), ox = it.tx0 + (v & 15);
           if (oz < a.od && oy < a.oh && ox < a.ow && co0 < a.m)
             finish_piece(o, ((size_t)it.n * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.m + co0, co0, it, 0);
@@ -549,11 +563,16 @@ __global__ __launch_bounds__(256) void conv_c1_x3_kernel(C1X3Args a) {
       const f4 o = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
       epi[r * 8 + ((2 * q + h) ^ (r & 7))] = o;
     }
+    wave_lds_fence();
     const int oz = tz0 + lz;
+    f4 rows4[4];
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) rows4[rd] = epi[(rd * 8 + (lane >> 3)) * 8 + (c ^ ((rd * 8 + (lane >> 3)) & 7))];
+    wave_lds_fence();
 #pragma unroll
     for (int rd = 0; rd < 4; ++rd) {
       const int v = rd * 8 + (lane >> 3);
-      f4 o = epi[v * 8 + (c ^ (v & 7))];
+      f4 o = rows4[rd];
       const int oy = ty0 + ly0 + (v >> 4), ox = tx0 + (v & 15);
       if (oz < a.d && oy < a.h && ox < a.w && co0 < a.cout) {
         if (a.bias) o += *reinterpret_cast<const f4*>(a.bias + co0);
@@ -736,11 +755,16 @@ __global__ __launch_bounds__(256, 2) void convt_x3_kernel(CtX3Args a) {
           }
         }
       }
+      wave_lds_fence();
       const int oz = 2 * jz + (pzy >> 1), oy = 2 * (ty0 + (wv % (TY / 2)) * 2 + yy) + (pzy & 1);
+      f4 rows4[4];
+#pragma unroll
+      for (int rd = 0; rd < 4; ++rd) rows4[rd] = epi[(rd * 8 + (lane >> 3)) * 8 + (c ^ ((rd * 8 + (lane >> 3)) & 7))];
+      wave_lds_fence();
 #pragma unroll
       for (int rd = 0; rd < 4; ++rd) {
         const int v = rd * 8 + (lane >> 3);
-        f4 o = epi[v * 8 + (c ^ (v & 7))];
+        f4 o = rows4[rd];
         const int ox = 2 * tx0 + v;
         if (oz < od && oy < oh && ox < ow && co0 < a.m) {
           const size_t eo = ((((size_t)n * od + oz) * oh + oy) * ow + ox) * a.m + co0;
