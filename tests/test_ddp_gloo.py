@@ -13,6 +13,14 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """A port nobody listens on right now (fixed ports collided with other runs on the same host)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, out):
     for p in (ROOT, os.path.join(ROOT, "torch-mednet_amd")):
         if p not in sys.path:
@@ -39,7 +47,7 @@ def _worker(rank, world, port, out):
 
 
 def test_flat_gradient_allreduce_world2(tmp_path):
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "r0.pt")
     r1 = torch.load(tmp_path / "r1.pt")
@@ -127,7 +135,7 @@ def _bucket_worker(rank, world, port, out):
 def test_bucketed_exchange_overlapped_with_backward_world2(tmp_path):
     """train.BucketedExchange: the early bucket (everything but the first two encoders) is all-reduced from a gradient
     hook INSIDE backward, the rest afterwards; the result is the mean of the per-rank gradients on every rank."""
-    port = 31500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_bucket_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "b0.pt")
     r1 = torch.load(tmp_path / "b1.pt")
@@ -196,7 +204,7 @@ def test_segmentation_step_call_world2(tmp_path, buckets):
     gradient exchange (single all-reduce, or the two-bucket overlapped form), 1/world folded into the Adam update, three
     steps.  Both ranks must hold identical parameters, equal to a one-process run that averages the two ranks' gradients
     (Dice over the LOCAL batch, then the mean of the gradients) and steps torch.optim.Adam."""
-    port = 33500 + (os.getpid() % 2000) + int(buckets)
+    port = _free_port()
     mp.spawn(_step_worker, args=(2, port, str(tmp_path), buckets), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "s0.pt")
     r1 = torch.load(tmp_path / "s1.pt")
