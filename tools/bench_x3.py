@@ -108,7 +108,32 @@ def gn_case(c, s):
           f"({5*nbytes/tb/1e9:5.2f} TB/s of 5 passes)", flush=True)
 
 
+def c1_case(cout, s):
+    """first layer (one input channel): forward only, with and without the fused GroupNorm sums"""
+    with mednet_hip.precision("fp32"):
+        x = torch.randn(N, 1, s, s, s, device=dev)
+        w = torch.randn(cout, 1, 3, 3, 3, device=dev) * 0.3
+        pk = ops.pack_conv_weight(w, 3, False)
+    y = torch.empty(N, cout, s, s, s, device=dev).contiguous(memory_format=CL)
+    st = torch.cuda.current_stream().cuda_stream
+    rows = lib.mednet_conv3d_fused_stats_chunks(N, s, s, s, 1, cout, 3, F32, F32, AUTO)
+    part = torch.empty(N, max(rows, 1), cout, 2, device=dev)
+    fwd = lambda p: L.check(lib.mednet_conv3d_fwd(x.data_ptr(), pk.data_ptr(), None, y.data_ptr(), N, s, s, s, 1, cout, 3, F32, NDHWC,
+                                                  F32, NDHWC, 0, AUTO, p, st), "fwd")
+    out = []
+    for x3 in (1, 0):
+        lib.mednet_set_option(b"x3", x3)
+        t0 = best(lambda: fwd(None))
+        t1 = best(lambda: fwd(part.data_ptr())) if (x3 and rows > 0) else None
+        out.append(f"{'split-bf16' if x3 else 'fp32 mfma '}: fwd {t0*1e3:7.1f} us ({y.numel()*4/t0/1e9:5.2f} TB/s written)"
+                   + (f" | with sums {t1*1e3:7.1f} us" if t1 else ""))
+    lib.mednet_set_option(b"x3", 1)
+    print(f"conv   1-> {cout} @{s}^3 N={N}\n   " + "\n   ".join(out), flush=True)
+
+
 which = os.environ.get("KB_WHICH", "conv,convt,gn")
+if "c1" in which.split(","):
+    c1_case(32, 128)
 if "conv" in which.split(","):
     for cin, cout, s in ((32, 32, 128), (64, 64, 64), (128, 128, 32), (256, 256, 16), (32, 64, 64)):
         conv_case(cin, cout, s)

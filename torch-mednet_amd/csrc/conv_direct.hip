@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restr
   }
 }
 int head_dgrad_gn_rows(size_t spatial, int k, int dtype) {
-  if (!(k == 16 || k == 32 || k == 64) || !(dtype == MEDNET_BF16 || dtype == MEDNET_F16)) return 0;
+  if (!(k == 16 || k == 32 || k == 64) || !dtype_ok(dtype)) return 0;  // (fp32 storage too, round 3)
   const size_t per_wg = (size_t)(256 / (k / 8)) * HEAD_GN_VPT;
   return 4 * (int)((spatial + per_wg - 1) / per_wg);
 }
@@ -708,7 +708,8 @@ int launch_head_dgrad_gn(const void* dy, const float* Pb, void* dz, const void* 
                          (const TO_*)gy, (const TO_*)gz, partial, spatial, m, act);                                            \
   } while (0)
 #define HG_K(TO_) do { if (k == 16) HG_GO(TO_, 16); else if (k == 32) HG_GO(TO_, 32); else HG_GO(TO_, 64); } while (0)
-  if (dtype == MEDNET_BF16) HG_K(bf16);
+  if (dtype == MEDNET_F32) HG_K(float);
+  else if (dtype == MEDNET_BF16) HG_K(bf16);
   else HG_K(f16);
 #undef HG_K
 #undef HG_GO

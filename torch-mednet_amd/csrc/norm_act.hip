@@ -1163,7 +1163,7 @@ extern "C" int mednet_pool2_bwd(const void* dy, const void* x, const void* add, 
 
 static bool pool2_gn_ok(int d, int h, int w, int c, int dtype) {
   const int cv = c / 8;
-  return c % 8 == 0 && cv <= 64 && (cv & (cv - 1)) == 0 && !((d | h | w) & 1) && (dtype == MEDNET_BF16 || dtype == MEDNET_F16);
+  return c % 8 == 0 && cv <= 64 && (cv & (cv - 1)) == 0 && !((d | h | w) & 1) && dtype_ok(dtype);  // (fp32 storage too, round 3)
 }
 extern "C" int mednet_pool2_bwd_gn_rows(int n, int d, int h, int w, int c, int dtype) {
   (void)n;
@@ -1179,7 +1179,10 @@ extern "C" int mednet_pool2_bwd_gn(const void* dy, const void* x, const void* ad
   MEDNET_REQUIRE(gn_y && gn_partial, MEDNET_E_SHAPE, "pool2_bwd_gn: gn_y and gn_partial are required");
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)(rows / 4), n);
-  if (dtype == MEDNET_BF16)
+  if (dtype == MEDNET_F32)
+    hipLaunchKernelGGL(pool2_bwd_gn_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)add,
+                       (float*)dx, (const float*)gn_y, gn_partial, d, h, w, c, mode, gn_act);
+  else if (dtype == MEDNET_BF16)
     hipLaunchKernelGGL(pool2_bwd_gn_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)add, (bf16*)dx,
                        (const bf16*)gn_y, gn_partial, d, h, w, c, mode, gn_act);
   else

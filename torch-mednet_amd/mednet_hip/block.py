@@ -192,7 +192,7 @@ class ResBlockFn(Function):
 def res_block(x, convs, norms, groups, eps, act):
     """convs / norms: the three mednet_hip.nn.Conv3d / GroupNorm modules of the block."""
     (k1, k2, k3), (n1, n2, n3) = convs, norms
-    hook = ops.GN3Hook() if (ops.FUSE_GN3 and config.is_half_mode() and torch.is_grad_enabled()) else None  # (training only)
+    hook = ops.GN3Hook() if (ops.FUSE_GN3 and torch.is_grad_enabled()) else None  # (training only)
     out = ResBlockFn.apply(x, k1.weight, n1.weight, n1.bias, k2.weight, n2.weight, n2.bias, k3.weight, n3.weight, n3.bias,
                            k1._packed(), k2._packed(), k3._packed(), groups, eps, act, hook)
     if hook is not None:

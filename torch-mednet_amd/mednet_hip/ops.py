@@ -217,8 +217,10 @@ GN3_COUNT = {"taken": 0, "declined": 0, "absent": 0, "masked": 0}  # (tests: how
 
 
 def _gn3_hook_of(x, dtype):
+    # (any storage type: the head's data gradient and the pooling backward take the sums in fp32 storage too; the
+    #  ConvTranspose data gradient answers rows = 0 there and the block runs its stand-alone pass)
     h = getattr(x, "_mednet_gn3", None) if FUSE_GN3 else None
-    if h is None or h.gn_in is None or h.gn_in.shape != x.shape or h.gn_in.dtype != dtype or dtype not in config.HALF_TYPES:
+    if h is None or h.gn_in is None or h.gn_in.shape != x.shape or h.gn_in.dtype != dtype:
         return None
     return h
 
