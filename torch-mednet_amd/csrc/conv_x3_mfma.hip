@@ -253,12 +253,14 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
   };
   // what happens to a 16-byte piece `o` of the output row at element offset `eo` (channels co0 .. co0 + 3): bias, summed second
   // gradient, store, and the sums (GroupNorm statistics, or the first pass of the previous GroupNorm's backward)
-  auto finish_piece = [&](f4 o, size_t eo, int co0, const Item& it, int si) {
+  // (`pre`: the piece's second operands are already in registers -- see store())
+  auto finish_piece = [&](f4 o, size_t eo, int co0, const Item& it, int si, bool pre = false, f4 pre_add = f4{0.f, 0.f, 0.f, 0.f},
+                          f4 pre_gy = f4{0.f, 0.f, 0.f, 0.f}) {
     if (a.bias) o += *reinterpret_cast<const f4*>(a.bias + co0);
-    if (a.add) o += __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.add + eo));
+    if (a.add) o += pre ? pre_add : __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.add + eo));
     __builtin_nontemporal_store(o, reinterpret_cast<f4*>(a.y + eo));
     if (a.gn_y) {
-      const f4 gy = *reinterpret_cast<const f4*>(a.gn_y + eo);
+      const f4 gy = pre ? pre_gy : *reinterpret_cast<const f4*>(a.gn_y + eo);
       const float* cf = a.gn_coef + ((size_t)it.n * a.m + co0) * 2;
       const f4 c01 = *reinterpret_cast<const f4*>(cf), c23 = *reinterpret_cast<const f4*>(cf + 4);
       float u[4] = {fmaf(c01[0], gy[0], c01[1]), fmaf(c01[2], gy[1], c01[3]), fmaf(c23[0], gy[2], c23[1]), fmaf(c23[2], gy[3], c23[3])};
@@ -284,6 +286,31 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
       stats_n = it.n;
       stats_cb = it.cb;
     }
+    // Data-gradient forms: the rows of the second operands (summed second gradient, the GroupNorm's input) that this wave's
+    // tiles need are requested HERE, before the first tile goes through LDS: the wave fences below pin every later load
+    // behind them, and a load issued where it is used costs a whole HBM latency per tile with all 8 waves of the workgroup in
+    // their epilogues at the same time (measured: 1.18 ms plain, 1.62 / 1.85 ms with one / both second operands at 32->32 @128^3).
+    [[maybe_unused]] f4 pre_add[NTW][4], pre_gy[NTW][4];
+    if constexpr (EPI_LDS) {
+      if (a.add || a.gn_y) {
+        const int c = lane & 7, co0 = it.cb * 32 + 4 * c;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          const int g = wv * NTW + t;
+          const int oz = it.tz0 + g / (TY / 2);
+#pragma unroll
+          for (int rd = 0; rd < 4; ++rd) {
+            const int v = rd * 8 + (lane >> 3);
+            const int oy = it.ty0 + (g % (TY / 2)) * 2 + (v >> 4), ox = it.tx0 + (v & 15);
+            const bool ok = oz < a.od && oy < a.oh && ox < a.ow && co0 < a.m;
+            const size_t eo = ((size_t)it.n * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.m + co0;
+            pre_add[t][rd] = pre_gy[t][rd] = f4{0.f, 0.f, 0.f, 0.f};
+            if (ok && a.add) pre_add[t][rd] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.add + eo));
+            if (ok && a.gn_y) pre_gy[t][rd] = *reinterpret_cast<const f4*>(a.gn_y + eo);
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int g = wv * NTW + t;
@@ -306,7 +333,8 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
           const f4 o = rows4[rd];
           const int oy = it.ty0 + (g % (TY / 2)) * 2 + (v >> 4), ox = it.tx0 + (v & 15);
           if (oz < a.od && oy < a.oh && ox < a.ow && co0 < a.m)
-            finish_piece(o, ((size_t)it.n * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.m + co0, co0, it, 0);
+            finish_piece(o, ((size_t)it.n * ovol + ((size_t)oz * a.oh + oy) * a.ow + ox) * a.m + co0, co0, it, 0, true, pre_add[t][rd],
+                         pre_gy[t][rd]);
         }
       } else {
         const int oy = it.ty0 + (g % (TY / 2)) * 2 + (r >> 4), ox = it.tx0 + (r & 15);
