@@ -62,15 +62,16 @@ int mednet_conv3d_pack(const float* w, void* packed, int cin, int cout, int ksiz
 /* Every 3x3x3 layer with matrix-core images in ONE launch (after an optimizer step all weights have moved; the reference
  * has no counterpart: torch.nn keeps no packed copies).  mednet_conv3d_pack_table turns the caller's job list into the
  * table the kernel reads (table_host: mednet_conv3d_pack_table_bytes(njobs) bytes of host memory, to be copied to the
- * device once); mednet_conv3d_pack_many repeats what mednet_conv3d_pack_elt does for each job. */
+ * device once; *blocks = the block count of the launch, to be handed back to mednet_conv3d_pack_many);
+ * mednet_conv3d_pack_many repeats what mednet_conv3d_pack_elt does for each job. */
 typedef struct mednet_pack_job {
   const float* w;      /* parameter, PyTorch layout, device */
   void* packed;        /* its pack buffer (mednet_conv3d_pack_bytes), device */
   int cin, cout, ksize, transposed_src;
 } mednet_pack_job;
 size_t mednet_conv3d_pack_table_bytes(int njobs);
-int mednet_conv3d_pack_table(const mednet_pack_job* jobs, int njobs, void* table_host, unsigned* max_blocks);
-int mednet_conv3d_pack_many(const void* table_device, int njobs, unsigned max_blocks, int elt_dtype, mednet_stream stream);
+int mednet_conv3d_pack_table(const mednet_pack_job* jobs, int njobs, void* table_host, unsigned* blocks);
+int mednet_conv3d_pack_many(const void* table_device, int njobs, unsigned blocks, int elt_dtype, mednet_stream stream);
 /* y[n,z,y,x,co] = bias[co] + sum_{tap,ci} x[n,z+dz-1,y+dy-1,x+dx-1,ci] * W[co,ci,tap].
  * dgrad=1 runs the data gradient with the same kernel: pass x := dy, cin := Cout, cout := Cin of the layer. */
 /* gn_partial (nullable): when the call takes the MFMA path the epilogue also writes the GroupNorm partial sums of the

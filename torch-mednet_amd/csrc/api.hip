@@ -128,10 +128,10 @@ extern "C" int mednet_conv3d_pack_table(const mednet_pack_job* jobs, int njobs, 
     t[i].nblocks = pack_mfma_blocks(j.cin, j.cout);
     MEDNET_REQUIRE(L.lo_delta < 0x7fffffffu, MEDNET_E_UNSUPPORTED, "conv3d_pack_table: layer %d too large", i);
     t[i].lo_delta = (int)L.lo_delta;
-    t[i].pad = 0;
-    if (t[i].nblocks > mb) mb = t[i].nblocks;
+    t[i].first_block = mb;
+    mb += t[i].nblocks;
   }
-  *max_blocks = mb;
+  *max_blocks = mb;  // (the launch's grid.x: every layer's blocks side by side, see pack_mfma_many_kernel)
   return MEDNET_OK;
 }
 extern "C" int mednet_conv3d_pack_many(const void* table_device, int njobs, unsigned max_blocks, int elt_dtype,

@@ -1445,8 +1445,8 @@ int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d,
 // mode 3: convT dgrad   Weff[m][k][t] = Wt[m][k][t]                             M=Cin  K=Cout
 __device__ __forceinline__ void pack_mfma_body(const float* __restrict__ w, elt* __restrict__ out0, elt* __restrict__ out1,
                                                int M0, int K0, int mode0, int mode1, float* __restrict__ Pf,
-                                               float* __restrict__ Pb, int transposed_src, size_t lo_delta) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+                                               float* __restrict__ Pb, int transposed_src, size_t lo_delta, unsigned blk) {
+  const size_t e = (size_t)blk * 256 + threadIdx.x;
   if (blockIdx.y == 2) {  // the fp32 tap-major images of the direct kernels ride along in the same launch
     const int cin = K0, cout = M0, T = 27;
     if (e >= (size_t)cin * cout * T) return;
@@ -1497,15 +1497,23 @@ __global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict_
                                                         elt* __restrict__ out1, int M0, int K0, int mode0, int mode1,
                                                         float* __restrict__ Pf, float* __restrict__ Pb, int transposed_src,
                                                         size_t lo_delta) {
-  pack_mfma_body(w, out0, out1, M0, K0, mode0, mode1, Pf, Pb, transposed_src, lo_delta);
+  pack_mfma_body(w, out0, out1, M0, K0, mode0, mode1, Pf, Pb, transposed_src, lo_delta, blockIdx.x);
 }
-// all 3x3x3 layers of a network in ONE launch (after the optimizer step every layer's weights have moved): blockIdx.z = layer,
+// all 3x3x3 layers of a network in ONE launch (after the optimizer step every layer's weights have moved): a block finds its layer in the table,
 // its descriptor comes from a device table built once (mednet_conv3d_pack_table); blocks beyond a layer's size exit
-__global__ __launch_bounds__(256) void pack_mfma_many_kernel(const PackJobDev* __restrict__ jobs) {
-  const PackJobDev j = jobs[blockIdx.z];
-  if (blockIdx.x >= j.nblocks) return;
+// (grid.x = the layers' block counts side by side: a (largest layer) x (layers) grid was 0.2 - 0.3 ms of blocks that exit at once)
+__global__ __launch_bounds__(256) void pack_mfma_many_kernel(const PackJobDev* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;  // the last layer whose first block is <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const PackJobDev j = jobs[lo];
+  const unsigned blk = blockIdx.x - j.first_block;
+  if (blk >= j.nblocks) return;
   pack_mfma_body(j.w, (elt*)j.sec_fwd, (elt*)j.sec_bwd, j.cout, j.cin, j.transposed ? 2 : 0, j.transposed ? 3 : 1, j.Pf, j.Pb,
-                 j.transposed, (size_t)j.lo_delta);
+                 j.transposed, (size_t)j.lo_delta, blk);
 }
 
 PackLayout pack_layout(int cin, int cout, int ksize) {
@@ -1546,8 +1554,7 @@ unsigned pack_mfma_blocks(int cin, int cout) {
   return (unsigned)((total + 255) / 256);
 }
 int launch_pack_mfma_many(const void* table_device, int njobs, unsigned max_blocks, hipStream_t s, int with_low) {
-  hipLaunchKernelGGL(pack_mfma_many_kernel, dim3(max_blocks, with_low ? 5 : 3, (unsigned)njobs), dim3(256), 0, s,
-                     (const PackJobDev*)table_device);
+  hipLaunchKernelGGL(pack_mfma_many_kernel, dim3(max_blocks, with_low ? 5 : 3), dim3(256), 0, s, (const PackJobDev*)table_device, njobs);
   return check_launch("pack_mfma_many");
 }
 

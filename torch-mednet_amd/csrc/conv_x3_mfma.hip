@@ -209,7 +209,10 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
 #ifndef MEDNET_X3_EPI_LDS
 #define MEDNET_X3_EPI_LDS 1
 #endif
-  constexpr bool EPI_LDS = MEDNET_X3_EPI_LDS;
+#ifndef MEDNET_X3_EPI_LDS_S2
+#define MEDNET_X3_EPI_LDS_S2 1
+#endif
+  constexpr bool EPI_LDS = MEDNET_X3_EPI_LDS && (STRIDE == 1 || MEDNET_X3_EPI_LDS_S2);
   // stride 1: the areas sit behind the images; stride 2 (halo 5x9x33: 150 KB of images) has no room: there they alias the input
   // planes, behind one more barrier per item (EPI_ALIAS)
   constexpr bool EPI_ALIAS = EPI_LDS && STRIDE == 2;
@@ -768,10 +771,26 @@ __global__ __launch_bounds__(256, 2) void convt_x3_kernel(CtX3Args a) {
   f4* epi = reinterpret_cast<f4*>(smem) + wv * 256;
   const int c = lane & 7, co0 = cb * 32 + 4 * c;
   const int jz = tz0 + lz;
+  // The encoder-feature rows of a (pzy, yy) group are requested ONE GROUP AHEAD, in front of the previous group's wave fences
+  // (which pin every later load behind them): requested where they are added, each of the 8 groups waited a whole HBM latency.
+  f4 sk_next[4];
+  auto request_skip = [&](int pzy, int yy) {
+    const int oz = 2 * jz + (pzy >> 1), oy = 2 * (ty0 + (wv % (TY / 2)) * 2 + yy) + (pzy & 1);
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+      const int ox = 2 * tx0 + rd * 8 + (lane >> 3);
+      sk_next[rd] = f4{0.f, 0.f, 0.f, 0.f};
+      if (a.skip && oz < od && oy < oh && ox < ow && co0 < a.m)
+        sk_next[rd] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.skip + ((((size_t)n * od + oz) * oh + oy) * ow + ox) * a.m + co0));
+    }
+  };
+  request_skip(0, 0);
 #pragma unroll
   for (int pzy = 0; pzy < 4; ++pzy) {
 #pragma unroll
     for (int yy = 0; yy < 2; ++yy) {
+      const f4 sk[4] = {sk_next[0], sk_next[1], sk_next[2], sk_next[3]};
+      if (pzy * 2 + yy + 1 < 8) request_skip((pzy * 2 + yy + 1) >> 1, (pzy * 2 + yy + 1) & 1);
       if ((r >> 4) == yy) {
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
@@ -797,7 +816,7 @@ __global__ __launch_bounds__(256, 2) void convt_x3_kernel(CtX3Args a) {
         if (oz < od && oy < oh && ox < ow && co0 < a.m) {
           const size_t eo = ((((size_t)n * od + oz) * oh + oy) * ow + ox) * a.m + co0;
           if (a.bias) o += *reinterpret_cast<const f4*>(a.bias + co0);
-          if (a.skip) o += *reinterpret_cast<const f4*>(a.skip + eo);
+          o += sk[rd];
           *reinterpret_cast<f4*>(a.y + eo) = o;
         }
       }
