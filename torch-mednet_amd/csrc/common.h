@@ -299,4 +299,13 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
   return t;
 }
 
+// Lanes of ONE wave hand data to each other through LDS without a barrier (the hardware executes a wave's LDS operations in
+// order).  To the compiler that is a data race between threads: its alias analysis is per thread and it may move a lane's read
+// above the same lane's write when it can prove THOSE two addresses differ (it did, in the ConvTranspose epilogue: the first
+// read round came back stale).  This fence is no instruction; it pins the order of memory operations around it.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace mednet

@@ -578,22 +578,23 @@ constexpr int HEAD_GN_VPT = 32;  // voxels per lane group
 constexpr int HEAD_GN_MAXM = 64;  // classes (LDS image of the weights)
 constexpr int HEAD_DPP_MAXM = 32;  // classes the lanes of a voxel split between them (registers: HEAD_DPP_MAXM / lanes per voxel)
 // MANY: the form for more than 8 classes, its own instantiation (the 4-class head of the segmentation nets keeps its registers)
-template <typename TO, int K, bool MANY>
+template <typename TO, int K, int MR>  // MR: classes whose weights a lane keeps in registers (4 or 8), 0 = the form for more
 __global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restrict__ dy, const float* __restrict__ Pb /*[m][K]*/,
                                                             TO* __restrict__ dz, const TO* __restrict__ gy,
                                                             const TO* __restrict__ gz, float* __restrict__ partial,
                                                             size_t spatial, int m, int act) {
+  constexpr bool MANY = MR == 0;
   constexpr int CG = K / 8, VPW = 256 / CG;  // lanes per voxel, voxels per workgroup pass
   const int n = blockIdx.y;
   const int cgi = threadIdx.x % CG, vi = threadIdx.x / CG;
   // the lane's slice of the weights (8 channels x m classes): in registers for up to 8 classes, else through LDS (per-lane
   // global loads inside the class loop made the 18-class landmark head compute-bound: 986 us)
   __shared__ float sPb[HEAD_GN_MAXM * K];
-  float wreg[MANY ? 1 : 8][8];
+  float wreg[MANY ? 1 : MR][8];
   constexpr bool in_regs = !MANY;
   if constexpr (in_regs) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MR; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) wreg[i][j] = i < m ? Pb[(size_t)i * K + cgi * 8 + j] : 0.f;
   } else if (m <= HEAD_GN_MAXM) {
@@ -612,14 +613,47 @@ __global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < 8; ++j) t.v[j] = 0.f;
     if constexpr (in_regs) {
+      // TWO voxels per trip, every load of both (logit gradients, block output, GroupNorm input) issued before the first use:
+      // one voxel per trip at 4 waves per SIMD kept too little in flight (581 us for 1.75 GB in the bf16 step: 3.0 TB/s)
+      const size_t vb = v + VPW;
+      const bool hb = (it + 1 < HEAD_GN_VPT) && vb < spatial;
+      float da[MANY ? 1 : MR], db[MANY ? 1 : MR];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < MR; ++i) {
+        da[i] = i < m ? dy[((size_t)n * m + i) * spatial + v] : 0.f;
+        db[i] = (i < m && hb) ? dy[((size_t)n * m + i) * spatial + vb] : 0.f;
+      }
+      const size_t rowa = ((size_t)n * spatial + v) * K + cgi * 8, rowb = ((size_t)n * spatial + (hb ? vb : v)) * K + cgi * 8;
+      const F8 zva = ld8(gz, rowa), yva = ld8(gy, rowa), zvb = ld8(gz, rowb), yvb = ld8(gy, rowb);
+      F8 u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u.v[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
         if (i < m) {
-          const float d = dy[((size_t)n * m + i) * spatial + v];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) t.v[j] = fmaf(d, wreg[i][j], t.v[j]);
+          for (int j = 0; j < 8; ++j) {
+            t.v[j] = fmaf(da[i], wreg[i][j], t.v[j]);
+            u.v[j] = fmaf(db[i], wreg[i][j], u.v[j]);
+          }
         }
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {  // the stored value is what GroupNorm-3's second pass reads
+        t.v[j] = (float)(TO)t.v[j];
+        u.v[j] = (float)(TO)u.v[j];
+      }
+      st8(dz, rowa, t);
+      if (hb) st8(dz, rowb, u);
+      act_grad_n<8>(t.v, zva.v, act);
+      act_grad_n<8>(u.v, zvb.v, act);  // (no second voxel: u = 0, and act' of every kind keeps a zero gradient zero)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ss[j] += t.v[j] + u.v[j];
+        sq[j] = fmaf(u.v[j], yvb.v[j], fmaf(t.v[j], yva.v[j], sq[j]));
+      }
+      ++it;  // (the trip took two voxels)
+      continue;
     } else if (CG <= 4 && m <= HEAD_DPP_MAXM) {
       // More than 8 classes (the landmark head: 16 heat maps + 2 classes, landmarks.py:71-75).  The CG lanes of a voxel split
       // the classes between them -- lane c loads classes c, c + CG, ... -- and hand the values round with DPP quad
@@ -700,11 +734,14 @@ int launch_head_dgrad_gn(const void* dy, const float* Pb, void* dz, const void* 
   const dim3 grid((unsigned)(head_dgrad_gn_rows(spatial, k, dtype) / 4), n);
 #define HG_GO(TO_, K_)                                                                                                         \
   do {                                                                                                                         \
-    if (m <= 8)                                                                                                                \
-      hipLaunchKernelGGL((head_dgrad_gn_kernel<TO_, K_, false>), grid, dim3(256), 0, s, (const float*)dy, Pb, (TO_*)dz,        \
+    if (m <= 4)                                                                                                                \
+      hipLaunchKernelGGL((head_dgrad_gn_kernel<TO_, K_, 4>), grid, dim3(256), 0, s, (const float*)dy, Pb, (TO_*)dz,            \
+                         (const TO_*)gy, (const TO_*)gz, partial, spatial, m, act);                                            \
+    else if (m <= 8)                                                                                                           \
+      hipLaunchKernelGGL((head_dgrad_gn_kernel<TO_, K_, 8>), grid, dim3(256), 0, s, (const float*)dy, Pb, (TO_*)dz,            \
                          (const TO_*)gy, (const TO_*)gz, partial, spatial, m, act);                                            \
     else                                                                                                                       \
-      hipLaunchKernelGGL((head_dgrad_gn_kernel<TO_, K_, true>), grid, dim3(256), 0, s, (const float*)dy, Pb, (TO_*)dz,         \
+      hipLaunchKernelGGL((head_dgrad_gn_kernel<TO_, K_, 0>), grid, dim3(256), 0, s, (const float*)dy, Pb, (TO_*)dz,            \
                          (const TO_*)gy, (const TO_*)gz, partial, spatial, m, act);                                            \
   } while (0)
 #define HG_K(TO_) do { if (k == 16) HG_GO(TO_, 16); else if (k == 32) HG_GO(TO_, 32); else HG_GO(TO_, 64); } while (0)

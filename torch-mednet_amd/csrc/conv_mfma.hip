@@ -1229,6 +1229,17 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
   typedef __attribute__((ext_vector_type(4))) float f4;
 #pragma unroll
   for (int pz = 0; pz < 2; ++pz) {
+    // the encoder-feature rows this thread adds in this half: requested before the two barriers and the LDS image (behind the
+    // barriers each of them waited its whole HBM latency where it was used)
+    eltx8 skr[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int vox = (it * 256 + tid) >> 2, piece = tid & 3;
+      const int oz = 2 * (tz0 + (vox >> 8)) + pz, oy = 2 * ty0 + ((vox >> 5) & 7), ox = 2 * tx0 + (vox & 31);
+      skr[it] = eltx8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (a.skip && oz < od && oy < oh && ox < ow)
+        skr[it] = *reinterpret_cast<const eltx8*>(a.skip + ((((size_t)n * od + oz) * oh + oy) * ow + ox) * a.cout + cb * 32 + piece * 8);
+    }
     __syncthreads();  // MFMA operand reads (first half) / the previous half's row reads are done
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
@@ -1254,8 +1265,7 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
       const int oz = 2 * (tz0 + lz2) + pz, oy = 2 * ty0 + oy_l, ox = 2 * tx0 + ox_l;
       if (oz < od && oy < oh && ox < ow) {
         const size_t o = ((((size_t)n * od + oz) * oh + oy) * ow + ox) * a.cout + cb * 32 + piece * 8;
-        eltx8 sk = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (a.skip) sk = *reinterpret_cast<const eltx8*>(a.skip + o);
+        const eltx8 sk = skr[it];
         eltx8 ov;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1315,6 +1325,7 @@ struct C1Args {
 __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
   constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, NV = HZ * HY * HX, NTW = 4;
   __shared__ float xs[NV];
+  __shared__ __attribute__((aligned(16))) elt epi[4 * 1024];  // per wave: one tile of 32 voxels x 32 channels on its way out
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
   const int tile = blockIdx.x / a.ncb, cb = blockIdx.x % a.ncb;
   int tt = tile;
@@ -1359,6 +1370,7 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
   for (int t = 0; t < NTW; ++t) {
     const int g = wv * NTW + t;
     const int lz = g / (TY / 2), ly = (g % (TY / 2)) * 2 + (r >> 4), lx = r & 15;
+    const int oz_t = tz0 + lz;
     const int base = (lz * HY + ly) * HX + lx;
     f32x16 acc;
 #pragma unroll
@@ -1375,21 +1387,42 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
       acc = MEDNET_MFMA_32x32x16(wa[ks], hi, acc, 0, 0, 0);
       acc = MEDNET_MFMA_32x32x16(wa[ks], lo, acc, 0, 0, 0);
     }
+    // The accumulator layout gives a lane four 8-byte pieces (channels 8q + 4h ..) of ITS voxel's 64-byte row: stored as they
+    // stand, one instruction touches 64 rows with 8 bytes each, and this kernel does little else than store (264 us for 537 MB).
+    // The tile goes through 2 KB of LDS private to the wave (8-byte pieces XOR-swizzled by voxel: conflict-free both ways, no
+    // barrier -- a wave's LDS operations execute in order, the fence keeps the compiler from reordering them) and leaves as whole
+    // rows: 4 lanes per voxel, 16 voxels = one x-row of the brick = 1 KB contiguous per instruction when Cout = 32.
     const int oz = tz0 + lz, oy = ty0 + ly, ox = tx0 + lx;
-    if (oz < a.d && oy < a.h && ox < a.w_) {
-      elt* yp = a.y + ((size_t)n * vol + ((size_t)oz * a.h + oy) * a.w_ + ox) * a.cout + cb * 32 + 4 * h;
+    const bool in_vol = oz < a.d && oy < a.h && ox < a.w_;
+    elt* tile_lds = epi + wv * 1024;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        eltx4 o;
+    for (int q = 0; q < 4; ++q) {
+      eltx4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          o[j] = (elt)acc[q * 4 + j];
-          const float f = (float)o[j];  // statistics of what is stored
-          ssum[q * 4 + j] += f;
-          ssq[q * 4 + j] = fmaf(f, f, ssq[q * 4 + j]);
-        }
-        *reinterpret_cast<eltx4*>(yp + 8 * q) = o;
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (elt)acc[q * 4 + j];
+        const float f = in_vol ? (float)o[j] : 0.f;  // statistics of what is stored
+        ssum[q * 4 + j] += f;
+        ssq[q * 4 + j] = fmaf(f, f, ssq[q * 4 + j]);
       }
+      *reinterpret_cast<eltx4*>(tile_lds + r * 32 + (((2 * q + h) ^ ((r >> 2) & 7)) * 4)) = o;
+    }
+    wave_lds_fence();
+    eltx8 rows2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = i * 16 + (lane >> 2), sw = (v >> 2) & 7;
+      eltx8 rv = *reinterpret_cast<const eltx8*>(tile_lds + v * 32 + (((lane & 3) ^ (sw >> 1)) * 8));
+      if (sw & 1) rv = __builtin_shufflevector(rv, rv, 4, 5, 6, 7, 0, 1, 2, 3);
+      rows2[i] = rv;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = i * 16 + (lane >> 2);
+      const int sy = ty0 + (g % (TY / 2)) * 2 + (v >> 4), sx = tx0 + (v & 15);
+      if (oz_t < a.d && sy < a.h && sx < a.w_)
+        __builtin_nontemporal_store(rows2[i], reinterpret_cast<eltx8*>(a.y + ((size_t)n * vol + ((size_t)oz_t * a.h + sy) * a.w_ + sx) * a.cout + cb * 32 + (lane & 3) * 8));
     }
   }
   if (a.gn_partial) {  // one row per wave: sum over the 32 voxel lanes of each k-half, lanes r == 0 write their 16 channels
