@@ -462,6 +462,79 @@ __global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(const float* __rest
     o[2] = k3;
   }
 }
+// passes 1b + 2a in ONE launch when a group's channel count divides 256 (every GroupNorm of the U-Nets here): a workgroup per
+// (n, g) sums the group's columns of the partial rows -- thread t always works on channel t % cg, rows t / cg, t / cg + 256 / cg,
+// ... four loads in flight, fp64, fixed order -- and goes on to S1, S2 and the coefficients.  As three launches (reduce, finalize,
+// parameter gradients: 18 us + three launch gaps per GroupNorm, 21 GroupNorms per step) this was 0.4 ms of the 22 ms step; the
+// parameter gradients ride in the apply kernel's first workgroup (GnParamGrad).
+// DUX: the rows hold {sum du, sum du * x} (conv epilogues) instead of {sum du, sum du * xhat} (gn_bwd_partial_kernel).
+template <bool DUX>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ stats,
+                                                                     const float* __restrict__ gamma, float* __restrict__ csum,
+                                                                     float* __restrict__ bcoef, int c, int groups, int rows,
+                                                                     double count) {
+  __shared__ double sha[256], shb[256];
+  const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cg = c / groups, t = threadIdx.x;
+  const int i = t % cg, r0 = t / cg, rstep = 256 / cg;
+  const float* base = partial + (size_t)n * rows * c * 2 + (size_t)(g * cg + i) * 2;
+  const size_t rs = (size_t)c * 2;
+  double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+  int r = r0;
+  for (; r + 3 * rstep < rows; r += 4 * rstep) {
+    const float2 p0 = *reinterpret_cast<const float2*>(base + r * rs), p1 = *reinterpret_cast<const float2*>(base + (r + rstep) * rs);
+    const float2 p2 = *reinterpret_cast<const float2*>(base + (r + 2 * rstep) * rs), p3 = *reinterpret_cast<const float2*>(base + (r + 3 * rstep) * rs);
+    a0 += (double)p0.x; b0 += (double)p0.y;
+    a1 += (double)p1.x; b1 += (double)p1.y;
+    a2 += (double)p2.x; b2 += (double)p2.y;
+    a3 += (double)p3.x; b3 += (double)p3.y;
+  }
+  for (; r < rows; r += rstep) {
+    const float2 p0 = *reinterpret_cast<const float2*>(base + r * rs);
+    a0 += (double)p0.x; b0 += (double)p0.y;
+  }
+  sha[t] = (a0 + a1) + (a2 + a3);
+  shb[t] = (b0 + b1) + (b2 + b3);
+  __syncthreads();
+  const double mean = stats[((size_t)n * groups + g) * 2], rstd = stats[((size_t)n * groups + g) * 2 + 1];
+  if (t < cg) {  // channel t of the group: its 256 / cg row classes, in order
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < rstep; ++k) {
+      a += sha[k * cg + t];
+      b += shb[k * cg + t];
+    }
+    if (DUX) b = rstd * (b - mean * a);
+    const float af = (float)a, bf = (float)b;  // (the finalize below reads what csum holds, as the three-launch form did)
+    csum[((size_t)n * c + g * cg + t) * 2] = af;
+    csum[((size_t)n * c + g * cg + t) * 2 + 1] = bf;
+    const double ga = gamma ? (double)gamma[g * cg + t] : 1.0;
+    sha[t] = ga * (double)af;
+    shb[t] = ga * (double)bf;
+  }
+  __syncthreads();
+  if (t < cg) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < cg; ++k) {
+      s1 += sha[k];
+      s2 += shb[k];
+    }
+    float* o = bcoef + ((size_t)n * c + g * cg + t) * 3;
+    o[0] = (float)rstd * (gamma ? gamma[g * cg + t] : 1.f);
+    o[1] = (float)(-rstd * rstd * s2 / count);
+    o[2] = (float)((rstd * rstd * s2 * mean - rstd * s1) / count);
+  }
+}
+static bool gn_bwd_one_launch(int c, int groups) {
+  const int cg = c / groups;
+  return cg >= 1 && cg <= 256 && 256 % cg == 0 && tuning_option("gn_bwd_one_launch", 1);
+}
+// the parameter gradients of pass 2b, computed by the first workgroup of the apply kernel when the one-launch form ran
+struct GnParamGrad {
+  const float* csum = nullptr;
+  float* dgamma = nullptr;
+  float* dbeta = nullptr;
+  int n = 0;
+};
 // pass 2b: dgamma_c = sum_n sum(du*xhat), dbeta_c = sum_n sum du
 __global__ __launch_bounds__(256) void gn_bwd_params_kernel(const float* __restrict__ csum, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int n, int c) {
@@ -482,7 +555,18 @@ __global__ __launch_bounds__(256, GN_WAVES) void gn_bwd_apply_kernel(const T* __
                                                            const float* __restrict__ coef,
                                                            const float* __restrict__ bcoef, T* __restrict__ dx,
                                                            T* __restrict__ dres, size_t spatial, int c, int act,
-                                                           size_t chunk_vox, int in_act) {
+                                                           size_t chunk_vox, int in_act, GnParamGrad pg) {
+  if (pg.csum && blockIdx.x == 0 && blockIdx.y == 0) {  // pass 2b (gn_bwd_params_kernel) without a launch of its own
+    for (int cc = threadIdx.x; cc < c; cc += 256) {
+      double a = 0.0, b = 0.0;
+      for (int i = 0; i < pg.n; ++i) {
+        a += (double)pg.csum[((size_t)i * c + cc) * 2];
+        b += (double)pg.csum[((size_t)i * c + cc) * 2 + 1];
+      }
+      if (pg.dbeta) pg.dbeta[cc] = (float)a;
+      if (pg.dgamma) pg.dgamma[cc] = (float)b;
+    }
+  }
   const Cols<VEC> L(c);
   if (!L.active) return;
   const int n = blockIdx.y;
@@ -1023,17 +1107,26 @@ extern "C" int mednet_gn_act_bwd(const void* dz, const void* dz2, const void* x,
 #undef GO
   int rc = check_launch("gn_bwd_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(n * c), dim3(64), 0, s, partial, csum, c, (int)chunks * (rpw > 0 ? rpw : 1));
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, stats, gamma, bcoef, c, groups,
-                     (double)spatial * (c / groups));
-  rc = check_launch("gn_bwd_finalize");
-  if (rc) return rc;
-  if (dgamma || dbeta) {
-    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((c + 255) / 256), dim3(256), 0, s, csum, dgamma, dbeta, n, c);
-    rc = check_launch("gn_bwd_params");
+  GnParamGrad pg;
+  if (gn_bwd_one_launch(c, groups)) {
+    hipLaunchKernelGGL(gn_bwd_reduce_finalize_kernel<false>, dim3(n * groups), dim3(256), 0, s, partial, stats, gamma, csum, bcoef, c,
+                       groups, (int)chunks * (rpw > 0 ? rpw : 1), (double)spatial * (c / groups));
+    rc = check_launch("gn_bwd_reduce_finalize");
     if (rc) return rc;
+    if (dgamma || dbeta) pg = GnParamGrad{csum, dgamma, dbeta, n};
+  } else {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n * c), dim3(64), 0, s, partial, csum, c, (int)chunks * (rpw > 0 ? rpw : 1));
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, stats, gamma, bcoef, c, groups,
+                       (double)spatial * (c / groups));
+    rc = check_launch("gn_bwd_finalize");
+    if (rc) return rc;
+    if (dgamma || dbeta) {
+      hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((c + 255) / 256), dim3(256), 0, s, csum, dgamma, dbeta, n, c);
+      rc = check_launch("gn_bwd_params");
+      if (rc) return rc;
+    }
   }
-#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv, in_act)
+#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)dz2, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv, in_act, pg)
   if (dtype == MEDNET_F32) { if (vec == 4) GO(float, 4); else if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
@@ -1057,21 +1150,31 @@ static int gn_act_bwd_fused_impl(const void* dz, const void* x, const void* z, c
   float* csum = bcoef + (size_t)n * c * 3;
   hipStream_t s = (hipStream_t)stream;
   const int skip = tuning_option("gn_bwd_skip", 0);  // timing probes only (tools/probes/stall_probe.py): bit k drops sub-kernel k
-  if (!(skip & 1))
-    hipLaunchKernelGGL(reduce_partials_dux_kernel, dim3(n * c), dim3(64), 0, s, fused_partial, stats, csum, c, groups, rows);
-  if (!(skip & 2))
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, stats, gamma, bcoef, c, groups,
-                       (double)spatial * (c / groups));
-  int rc = check_launch("gn_bwd_finalize");
-  if (rc) return rc;
-  if (skip & 8) return MEDNET_OK;
-  if ((dgamma || dbeta) && !(skip & 4)) {
-    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((c + 255) / 256), dim3(256), 0, s, csum, dgamma, dbeta, n, c);
-    rc = check_launch("gn_bwd_params");
+  GnParamGrad pg;
+  int rc;
+  if (gn_bwd_one_launch(c, groups) && !skip) {
+    hipLaunchKernelGGL(gn_bwd_reduce_finalize_kernel<true>, dim3(n * groups), dim3(256), 0, s, fused_partial, stats, gamma, csum, bcoef,
+                       c, groups, rows, (double)spatial * (c / groups));
+    rc = check_launch("gn_bwd_reduce_finalize");
     if (rc) return rc;
+    if (dgamma || dbeta) pg = GnParamGrad{csum, dgamma, dbeta, n};
+  } else {
+    if (!(skip & 1))
+      hipLaunchKernelGGL(reduce_partials_dux_kernel, dim3(n * c), dim3(64), 0, s, fused_partial, stats, csum, c, groups, rows);
+    if (!(skip & 2))
+      hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, stats, gamma, bcoef, c, groups,
+                         (double)spatial * (c / groups));
+    rc = check_launch("gn_bwd_finalize");
+    if (rc) return rc;
+    if (skip & 8) return MEDNET_OK;
+    if ((dgamma || dbeta) && !(skip & 4)) {
+      hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((c + 255) / 256), dim3(256), 0, s, csum, dgamma, dbeta, n, c);
+      rc = check_launch("gn_bwd_params");
+      if (rc) return rc;
+    }
   }
   const dim3 grid(chunks, n);
-#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)nullptr, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv, in_act)
+#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dz, (const T*)nullptr, (const T*)x, (const T*)z, coef, bcoef, (T*)dx, (T*)dres, spatial, c, act, cv, in_act, pg)
   if (dtype == MEDNET_F32) { if (vec == 4) GO(float, 4); else if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
