@@ -808,7 +808,9 @@ int launch_head_dgrad(const void* dy, const float* Pb, void* dz, int n, size_t s
 // ---- 1x1x1 head weight gradient: dw[m][k] = sum_v dy[m][v] (planar fp32 logits gradient) * z[v][k] (channels-last) ----
 // HBM-bound (one pass over z): a thread owns 8 input channels of a voxel column ("column persistent", like GroupNorm) and
 // an 8-row block of output channels; per-workgroup partials, fixed-order combine.
-template <typename TZ>
+// MB: classes of a block that are alive (4: the segmentation heads -- half the sums and four voxels per trip instead of two;
+// 8 otherwise).  The partial rows keep the 8-per-block layout either way.
+template <typename TZ, int MB>
 __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict__ dy, const TZ* __restrict__ z,
                                                         float* __restrict__ part, size_t spatial, int k, int m,
                                                         size_t chunk_vox) {
@@ -821,35 +823,38 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
   const int n = blockIdx.z, m0 = blockIdx.x * 8;
   const size_t v0 = (size_t)blockIdx.y * chunk_vox;
   const size_t v1 = v0 + chunk_vox < spatial ? v0 + chunk_vox : spatial;
-  float acc[8][8];
+  float acc[MB][8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MB; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
   if (active) {
     const TZ* zb = z + (size_t)n * spatial * k + (size_t)col * 8;
-    // two voxels per trip, all their loads issued before the first use (one voxel per trip left the pass latency-bound:
+    // VT voxels per trip, all their loads issued before the first use (one voxel per trip left the pass latency-bound:
     // 2.4 TB/s)
+    constexpr int VT = 16 / MB;
     const float* dyb = dy + ((size_t)n * m + m0) * spatial;
     size_t v = v0 + row;
-    for (; v + rows < v1; v += 2 * (size_t)rows) {
-      const F8 za = ld8(zb, v * k), zc = ld8(zb, (v + rows) * k);
-      float da[8], dc[8];
+    for (; v + (size_t)(VT - 1) * rows < v1; v += (size_t)VT * rows) {
+      F8 zv[VT];
+      float d[VT][MB];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        da[i] = (m0 + i < m) ? dyb[(size_t)i * spatial + v] : 0.f;
-        dc[i] = (m0 + i < m) ? dyb[(size_t)i * spatial + v + rows] : 0.f;
+      for (int t = 0; t < VT; ++t) {
+        zv[t] = ld8(zb, (v + (size_t)t * rows) * k);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) d[t][i] = (m0 + i < m) ? dyb[(size_t)i * spatial + v + (size_t)t * rows] : 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int t = 0; t < VT; ++t)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(dc[i], zc.v[j], fmaf(da[i], za.v[j], acc[i][j]));
-      }
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(d[t][i], zv[t].v[j], acc[i][j]);
     }
     for (; v < v1; v += rows) {
       const F8 zv = ld8(zb, v * k);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < MB; ++i) {
         const float d = (m0 + i < m) ? dyb[(size_t)i * spatial + v] : 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(d, zv.v[j], acc[i][j]);
@@ -858,7 +863,8 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
   }
   // reduce the `rows` threads that share a column, one output row at a time
   float* out = part + (((size_t)n * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 * k;
-  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
     __syncthreads();
     if (active) {
 #pragma unroll
@@ -913,12 +919,17 @@ int launch_wgrad_1x1(const void* z, const void* dy, float* dw, int n, size_t spa
   MEDNET_REQUIRE(ws_bytes >= wgrad_1x1_ws_bytes(n, spatial, cin, cout), MEDNET_E_WORKSPACE, "wgrad_1x1: workspace too small");
   const dim3 grid(mblocks, chunks, n);
   float* part = (float*)ws;
-  if (z_dtype == MEDNET_F32)
-    hipLaunchKernelGGL(wgrad_1x1_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)z, part, spatial, cin, cout, cv);
-  else if (z_dtype == MEDNET_BF16)
-    hipLaunchKernelGGL(wgrad_1x1_kernel<bf16>, grid, dim3(256), 0, s, (const float*)dy, (const bf16*)z, part, spatial, cin, cout, cv);
-  else
-    hipLaunchKernelGGL(wgrad_1x1_kernel<f16>, grid, dim3(256), 0, s, (const float*)dy, (const f16*)z, part, spatial, cin, cout, cv);
+#define W11_GO(TZ_)                                                                                                                   \
+  do {                                                                                                                                \
+    if (cout <= 4)                                                                                                                    \
+      hipLaunchKernelGGL((wgrad_1x1_kernel<TZ_, 4>), grid, dim3(256), 0, s, (const float*)dy, (const TZ_*)z, part, spatial, cin, cout, cv); \
+    else                                                                                                                              \
+      hipLaunchKernelGGL((wgrad_1x1_kernel<TZ_, 8>), grid, dim3(256), 0, s, (const float*)dy, (const TZ_*)z, part, spatial, cin, cout, cv); \
+  } while (0)
+  if (z_dtype == MEDNET_F32) W11_GO(float);
+  else if (z_dtype == MEDNET_BF16) W11_GO(bf16);
+  else W11_GO(f16);
+#undef W11_GO
   int rc = check_launch("wgrad_1x1");
   if (rc) return rc;
   hipLaunchKernelGGL(wgrad_1x1_final_kernel, dim3(cout * cin), dim3(64), 0, s, part, dw, (int)(n * chunks), mblocks, cin, cout);
