@@ -659,13 +659,25 @@ __global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restr
       // the classes between them -- lane c loads classes c, c + CG, ... -- and hand the values round with DPP quad
       // permutes: ceil(m / CG) planar loads per lane, ALL in flight before the first use, instead of m loads of which two
       // were in flight (18 classes: 986 us; the loop was latency-bound, not bandwidth-bound).
+      // TWO voxels per trip: each weight row comes out of LDS once for both (the 36 ds_read_b128 per voxel were a third of the
+      // kernel's time), and the rows of the block output / the GroupNorm input of both voxels are in flight with the logit
+      // gradients.
       constexpr int MAXQ = HEAD_DPP_MAXM / CG;
-      float dreg[MAXQ];
+      const size_t vb = v + VPW;
+      const bool hb = (it + 1 < HEAD_GN_VPT) && vb < spatial;
+      float dreg[MAXQ], dregb[MAXQ];
 #pragma unroll
       for (int q = 0; q < MAXQ; ++q) {
         const int i = q * CG + cgi;
-        dreg[q] = (q * CG < m && i < m) ? dy[((size_t)n * m + i) * spatial + v] : 0.f;
+        const bool live = q * CG < m && i < m;
+        dreg[q] = live ? dy[((size_t)n * m + i) * spatial + v] : 0.f;
+        dregb[q] = (live && hb) ? dy[((size_t)n * m + i) * spatial + vb] : 0.f;
       }
+      const size_t rowa = ((size_t)n * spatial + v) * K + cgi * 8, rowb = ((size_t)n * spatial + (hb ? vb : v)) * K + cgi * 8;
+      const F8 zva = ld8(gz, rowa), yva = ld8(gy, rowa), zvb = ld8(gz, rowb), yvb = ld8(gy, rowb);
+      F8 u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u.v[j] = 0.f;
 #pragma unroll
       for (int q = 0; q < MAXQ; ++q) {
         if (q * CG < m) {  // (wave-uniform)
@@ -675,20 +687,41 @@ __global__ __launch_bounds__(256) void head_dgrad_gn_kernel(const float* __restr
             if (i < m) {
               // broadcast lane c of every CG-lane group: quad_perm [c,c,c,c] (CG = 4) or [c,c,2+c,2+c] (CG = 2)
               constexpr int HI = CG == 4 ? 0 : 2;
-              const float d = c == 0 ? dpp_f32<(0) | (0 << 2) | ((HI + 0) << 4) | ((HI + 0) << 6)>(dreg[q])
-                            : c == 1 ? dpp_f32<(1) | (1 << 2) | ((HI + 1) << 4) | ((HI + 1) << 6)>(dreg[q])
-                            : c == 2 ? dpp_f32<(2) | (2 << 2) | (2 << 4) | (2 << 6)>(dreg[q])
-                                     : dpp_f32<(3) | (3 << 2) | (3 << 4) | (3 << 6)>(dreg[q]);
+              auto bc = [&](float x) {
+                return c == 0 ? dpp_f32<(0) | (0 << 2) | ((HI + 0) << 4) | ((HI + 0) << 6)>(x)
+                     : c == 1 ? dpp_f32<(1) | (1 << 2) | ((HI + 1) << 4) | ((HI + 1) << 6)>(x)
+                     : c == 2 ? dpp_f32<(2) | (2 << 2) | (2 << 4) | (2 << 6)>(x)
+                              : dpp_f32<(3) | (3 << 2) | (3 << 4) | (3 << 6)>(x);
+              };
+              const float d = bc(dreg[q]), db = bc(dregb[q]);
               const f32x4 w0 = *reinterpret_cast<const f32x4*>(wsrc + i * K + cgi * 8), w1 = *reinterpret_cast<const f32x4*>(wsrc + i * K + cgi * 8 + 4);
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 t.v[j] = fmaf(d, w0[j], t.v[j]);
                 t.v[4 + j] = fmaf(d, w1[j], t.v[4 + j]);
+                u.v[j] = fmaf(db, w0[j], u.v[j]);
+                u.v[4 + j] = fmaf(db, w1[j], u.v[4 + j]);
               }
             }
           }
         }
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {  // the stored value is what GroupNorm-3's second pass reads
+        t.v[j] = (float)(TO)t.v[j];
+        u.v[j] = (float)(TO)u.v[j];
+      }
+      st8(dz, rowa, t);
+      if (hb) st8(dz, rowb, u);
+      act_grad_n<8>(t.v, zva.v, act);
+      act_grad_n<8>(u.v, zvb.v, act);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ss[j] += t.v[j] + u.v[j];
+        sq[j] = fmaf(u.v[j], yvb.v[j], fmaf(t.v[j], yva.v[j], sq[j]));
+      }
+      ++it;  // (the trip took two voxels)
+      continue;
     } else {
 #pragma unroll 2
       for (int i = 0; i < m; ++i) {
@@ -839,10 +872,34 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
       F8 zv[VT];
       float d[VT][MB];
 #pragma unroll
-      for (int t = 0; t < VT; ++t) {
-        zv[t] = ld8(zb, (v + (size_t)t * rows) * k);
+      for (int t = 0; t < VT; ++t) zv[t] = ld8(zb, (v + (size_t)t * rows) * k);
+      if (cols == 4) {
+        // The four lanes of a voxel split the classes between them (lane c loads classes c, c + 4) and hand the values round
+        // with DPP quad permutes: MB / 4 planar 4-byte loads per lane and voxel instead of MB -- every one of those is a
+        // whole wave instruction for 64 useful bytes, and the 18-class landmark head (three class blocks: 740 us for 1.1 GB)
+        // was bound by issuing them.
+        float own[VT][MB / 4];
 #pragma unroll
-        for (int i = 0; i < MB; ++i) d[t][i] = (m0 + i < m) ? dyb[(size_t)i * spatial + v + (size_t)t * rows] : 0.f;
+        for (int t = 0; t < VT; ++t)
+#pragma unroll
+          for (int q = 0; q < MB / 4; ++q) {
+            const int i = q * 4 + col;
+            own[t][q] = (m0 + i < m) ? dyb[(size_t)i * spatial + v + (size_t)t * rows] : 0.f;
+          }
+#pragma unroll
+        for (int t = 0; t < VT; ++t)
+#pragma unroll
+          for (int q = 0; q < MB / 4; ++q) {
+            d[t][q * 4 + 0] = dpp_f32<(0) | (0 << 2) | (0 << 4) | (0 << 6)>(own[t][q]);
+            d[t][q * 4 + 1] = dpp_f32<(1) | (1 << 2) | (1 << 4) | (1 << 6)>(own[t][q]);
+            d[t][q * 4 + 2] = dpp_f32<(2) | (2 << 2) | (2 << 4) | (2 << 6)>(own[t][q]);
+            d[t][q * 4 + 3] = dpp_f32<(3) | (3 << 2) | (3 << 4) | (3 << 6)>(own[t][q]);
+          }
+      } else {
+#pragma unroll
+        for (int t = 0; t < VT; ++t)
+#pragma unroll
+          for (int i = 0; i < MB; ++i) d[t][i] = (m0 + i < m) ? dyb[(size_t)i * spatial + v + (size_t)t * rows] : 0.f;
       }
 #pragma unroll
       for (int t = 0; t < VT; ++t)
@@ -861,8 +918,34 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
       }
     }
   }
-  // reduce the `rows` threads that share a column, one output row at a time
   float* out = part + (((size_t)n * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 * k;
+  if (cols <= 8 && (cols & (cols - 1)) == 0) {
+    // The threads that share a column: first the 64 / cols of a wave with shuffles (fixed tree), then the four waves through LDS,
+    // every output summed by a thread of its own.  (One output row at a time with the column's `rows` values added up by ONE
+    // thread -- the form below -- was 512 dependent LDS reads per class: with 24 workgroups per CU it cost the 18-class head
+    // more than its pass over the data.)
+    for (int off = cols; off < 64; off <<= 1) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] += __shfl_xor(acc[i][j], off, 64);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane < cols) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds[((wv * cols + lane) * MB + i) * 8 + j] = acc[i][j];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < cols * MB * 8; o += 256) {  // o = (column, class, channel of the column)
+      const float sum = (lds[o] + lds[cols * MB * 8 + o]) + (lds[2 * cols * MB * 8 + o] + lds[3 * cols * MB * 8 + o]);
+      const int j = o % 8, i = (o / 8) % MB, cc = o / (8 * MB);
+      out[(size_t)i * k + cc * 8 + j] = sum;
+    }
+    return;
+  }
+  // (other column counts) reduce the `rows` threads that share a column, one output row at a time
 #pragma unroll
   for (int i = 0; i < MB; ++i) {
     __syncthreads();
