@@ -1476,66 +1476,88 @@ int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d,
 // mode 1: conv dgrad    Weff[m][k][t] = W[k][m][26-t]                           M=Cin  K=Cout
 // mode 2: convT fwd     Weff[m][k][t] = Wt[k][m][t]           (Wt: Cin,Cout,27) M=Cout K=Cin
 // mode 3: convT dgrad   Weff[m][k][t] = Wt[m][k][t]                             M=Cin  K=Cout
+// A launch's blocks per layer: one block per (channel block, K chunk) TILE of the forward image, then the tiles of the
+// data-gradient image.  A tile is 32 rows x 16 contraction channels x 27 taps = 13 824 elements that are CONTIGUOUS in the
+// fragment image; in the PyTorch tensor they are 32 (or 16) runs of 432 (864) consecutive floats.  The block reads the runs in
+// source order into LDS and writes the image in image order -- high and, in the fp32 storage mode, low elements from the same
+// LDS copy -- so both sides are coalesced.  The forward image's tile also holds what the two fp32 tap-major images of the
+// direct / exact-product kernels need of these 32 x 16 channels: they leave as 128-byte (Pf) and 64-byte (Pb) segments.
+// (The element-per-thread form gathered every image element with a stride of 27 floats and scattered the fp32 images four bytes
+// at a time: 0.21 / 0.30 ms per step for the 20 layers of config 2.)
+constexpr int PACK_TILE = 32 * 16 * 27;
+__host__ __device__ inline unsigned pack_img_tiles(int cin, int cout) {  // the larger of the two images' tile counts
+  const unsigned f = (unsigned)((cout + 31) / 32) * (unsigned)(cin / 16), b = (unsigned)((cin + 31) / 32) * (unsigned)(cout / 16);
+  return f > b ? f : b;
+}
 __device__ __forceinline__ void pack_mfma_body(const float* __restrict__ w, elt* __restrict__ out0, elt* __restrict__ out1,
                                                int M0, int K0, int mode0, int mode1, float* __restrict__ Pf,
-                                               float* __restrict__ Pb, int transposed_src, size_t lo_delta, unsigned blk) {
-  const size_t e = (size_t)blk * 256 + threadIdx.x;
-  if (blockIdx.y == 2) {  // the fp32 tap-major images of the direct kernels ride along in the same launch
-    const int cin = K0, cout = M0, T = 27;
-    if (e >= (size_t)cin * cout * T) return;
-    const int t = (int)(e % T);
-    if (!transposed_src) {  // w[co][ci][t]
-      const int ci = (int)((e / T) % cin), co = (int)(e / ((size_t)T * cin));
-      Pf[((size_t)t * cin + ci) * cout + co] = w[e];
-      Pb[((size_t)(T - 1 - t) * cout + co) * cin + ci] = w[e];
-    } else {  // w[ci][co][t]
-      const int co = (int)((e / T) % cout), ci = (int)(e / ((size_t)T * cout));
-      Pf[((size_t)t * cin + ci) * cout + co] = w[e];
-      Pb[((size_t)t * cout + co) * cin + ci] = w[e];
-    }
-    return;
-  }
-  // blockIdx.y = 0: forward image (M0 x K0), 1: data-gradient image (K0 x M0): one launch for both.
-  // blockIdx.y = 3 / 4 (fp32 storage mode only, bf16 build): the LOW images of the split-bf16 contraction (conv_x3_mfma.hip):
-  // element = bf16(w - float(bf16(w))), same order, `lo_delta` bytes behind the high image.
-  const bool low = blockIdx.y >= 3;
-  const int img = low ? blockIdx.y - 3 : blockIdx.y;
+                                               float* __restrict__ Pb, int transposed_src, size_t lo_delta, unsigned blk,
+                                               float* __restrict__ tile /* LDS, PACK_TILE floats */) {
+  const unsigned ntmax = pack_img_tiles(K0, M0);
+  const unsigned tq = blk;
+  const int img = (int)(tq / ntmax);  // 0: forward image (M0 x K0), 1: data-gradient image (K0 x M0)
+  if (img > 1) return;
   const int M = img ? K0 : M0, K = img ? M0 : K0, mode = img ? mode1 : mode0;
-  elt* out = img ? out1 : out0;
-  if (low) out = reinterpret_cast<elt*>(reinterpret_cast<char*>(out) + lo_delta);
-  const size_t total = (size_t)((M + 31) / 32 * 32) * K * 27;  // rows beyond M (a 16-channel side) are zero padding
-  if (e >= total) return;
-  size_t q = e;
-  const int j = (int)(q % 8);
-  q /= 8;
-  const int co = (int)(q % 32);
-  q /= 32;
-  const int h = (int)(q % 2);
-  q /= 2;
-  const int tap = (int)(q % 27);
-  q /= 27;
   const int nkc = K / 16;
-  const int kc = (int)(q % nkc);
-  const int cb = (int)(q / nkc);
-  const int m = cb * 32 + co, k = kc * 16 + h * 8 + j;
-  float v;
-  if (m >= M) v = 0.f;
-  else if (mode == 0) v = w[((size_t)m * K + k) * 27 + tap];
-  else if (mode == 1) v = w[((size_t)k * M + m) * 27 + (26 - tap)];
-  else if (mode == 2) v = w[((size_t)k * M + m) * 27 + tap];
-  else v = w[((size_t)m * K + k) * 27 + tap];
-  out[e] = low ? (elt)(v - (float)(elt)v) : (elt)v;
+  const unsigned tl = tq % ntmax;
+  if (tl >= (unsigned)((M + 31) / 32) * (unsigned)nkc) return;
+  const int kc = (int)(tl % nkc), cb = (int)(tl / nkc);
+  // source order -> LDS in image order: d = ((tap * 2 + h) * 32 + co) * 8 + j, k = 8 h + j
+  if (mode == 0 || mode == 3) {  // w[m][k][t]: per row m a run of 16 * 27 floats
+    for (int sidx = threadIdx.x; sidx < PACK_TILE; sidx += 256) {
+      const int ml = sidx / 432, rem = sidx % 432, kl = rem / 27, tap = rem % 27;
+      const int m = cb * 32 + ml;
+      const float v = m < M ? w[((size_t)m * K + kc * 16) * 27 + rem] : 0.f;
+      tile[((tap * 2 + (kl >> 3)) * 32 + ml) * 8 + (kl & 7)] = v;
+    }
+  } else {  // w[k][m][t] (mode 1: taps reversed): per k a run of 32 * 27 floats (rows past M: zeros)
+    for (int sidx = threadIdx.x; sidx < PACK_TILE; sidx += 256) {
+      const int kl = sidx / 864, rem = sidx % 864, ml = rem / 27, t = rem % 27;
+      const int m = cb * 32 + ml;
+      const float v = m < M ? w[((size_t)(kc * 16 + kl) * M + cb * 32) * 27 + rem] : 0.f;
+      const int tap = mode == 1 ? 26 - t : t;
+      tile[((tap * 2 + (kl >> 3)) * 32 + ml) * 8 + (kl & 7)] = v;
+    }
+  }
+  __syncthreads();
+  elt* out = (img ? out1 : out0) + (size_t)tl * PACK_TILE;  // (tl = cb * nkc + kc: the image's tile order)
+  elt* out_lo = lo_delta ? reinterpret_cast<elt*>(reinterpret_cast<char*>(out) + lo_delta) : nullptr;
+  for (int d = threadIdx.x * 8; d < PACK_TILE; d += 256 * 8) {
+    eltx8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = tile[d + j];
+      hi[j] = (elt)v;
+      lo[j] = (elt)(v - (float)hi[j]);
+    }
+    *reinterpret_cast<eltx8*>(out + d) = hi;
+    if (out_lo) *reinterpret_cast<eltx8*>(out_lo + d) = lo;  // the LOW image of the split-bf16 contraction (conv_x3_mfma.hip)
+  }
+  if (img == 0 && Pf) {  // Pf[t][ci][co] and Pb[t'][co][ci] (t' = 26 - t for a conv, t for a ConvTranspose) of this tile's channels
+    const int cin = K0, cout = M0;
+    for (int idx = threadIdx.x; idx < PACK_TILE; idx += 256) {
+      const int co = idx & 31, kl = (idx >> 5) & 15, t = idx >> 9;
+      if (cb * 32 + co < cout)
+        Pf[((size_t)t * cin + kc * 16 + kl) * cout + cb * 32 + co] = tile[((t * 2 + (kl >> 3)) * 32 + co) * 8 + (kl & 7)];
+    }
+    for (int idx = threadIdx.x; idx < PACK_TILE; idx += 256) {
+      const int kl = idx & 15, co = (idx >> 4) & 31, t = idx >> 9;
+      if (cb * 32 + co < cout)
+        Pb[((size_t)(transposed_src ? t : 26 - t) * cout + cb * 32 + co) * cin + kc * 16 + kl] = tile[((t * 2 + (kl >> 3)) * 32 + co) * 8 + (kl & 7)];
+    }
+  }
 }
 __global__ __launch_bounds__(256) void pack_mfma_kernel(const float* __restrict__ w, elt* __restrict__ out0,
                                                         elt* __restrict__ out1, int M0, int K0, int mode0, int mode1,
                                                         float* __restrict__ Pf, float* __restrict__ Pb, int transposed_src,
                                                         size_t lo_delta) {
-  pack_mfma_body(w, out0, out1, M0, K0, mode0, mode1, Pf, Pb, transposed_src, lo_delta, blockIdx.x);
+  __shared__ float tile[PACK_TILE];
+  pack_mfma_body(w, out0, out1, M0, K0, mode0, mode1, Pf, Pb, transposed_src, lo_delta, blockIdx.x, tile);
 }
-// all 3x3x3 layers of a network in ONE launch (after the optimizer step every layer's weights have moved): a block finds its layer in the table,
-// its descriptor comes from a device table built once (mednet_conv3d_pack_table); blocks beyond a layer's size exit
-// (grid.x = the layers' block counts side by side: a (largest layer) x (layers) grid was 0.2 - 0.3 ms of blocks that exit at once)
-__global__ __launch_bounds__(256) void pack_mfma_many_kernel(const PackJobDev* __restrict__ jobs, int njobs) {
+// all 3x3x3 layers of a network in ONE launch (after the optimizer step every layer's weights have moved): a block finds its
+// layer in the device table built once (mednet_conv3d_pack_table), whose entries carry the first block of every layer
+__global__ __launch_bounds__(256) void pack_mfma_many_kernel(const PackJobDev* __restrict__ jobs, int njobs, int with_low) {
+  __shared__ float tile[PACK_TILE];
   int lo = 0, hi = njobs - 1;  // the last layer whose first block is <= blockIdx.x
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -1546,7 +1568,7 @@ __global__ __launch_bounds__(256) void pack_mfma_many_kernel(const PackJobDev* _
   const unsigned blk = blockIdx.x - j.first_block;
   if (blk >= j.nblocks) return;
   pack_mfma_body(j.w, (elt*)j.sec_fwd, (elt*)j.sec_bwd, j.cout, j.cin, j.transposed ? 2 : 0, j.transposed ? 3 : 1, j.Pf, j.Pb,
-                 j.transposed, (size_t)j.lo_delta, blk);
+                 j.transposed, with_low ? (size_t)j.lo_delta : 0, blk, tile);
 }
 
 PackLayout pack_layout(int cin, int cout, int ksize) {
@@ -1568,26 +1590,17 @@ PackLayout pack_layout(int cin, int cout, int ksize) {
   return L;
 }
 
+unsigned pack_mfma_blocks(int cin, int cout) { return 2 * pack_img_tiles(cin, cout); }
 int launch_pack_mfma(const float* w, void* sec_fwd, void* sec_bwd, float* Pf, float* Pb, int cin, int cout, int T,
                      int transposed_src, hipStream_t s, size_t lo_delta) {
   if (T != 27) return MEDNET_OK;
-  const int cmax = cin > cout ? cin : cout, cmin = cin > cout ? cout : cin;
-  const size_t total = (size_t)((cmax + 31) / 32 * 32) * ((cmin + 31) / 32 * 32) * 27;  // covers both padded images
-  // y = 0/1: the two elt fragment images, 2: the fp32 images, 3/4: the low images (lo_delta != 0)
-  const dim3 grid((unsigned)((total + 255) / 256), lo_delta ? 5 : 3);
   // forward image: M = cout, K = cin; backward (data-gradient) image: M = cin, K = cout
-  hipLaunchKernelGGL(pack_mfma_kernel, grid, dim3(256), 0, s, w, (elt*)sec_fwd, (elt*)sec_bwd, cout, cin,
+  hipLaunchKernelGGL(pack_mfma_kernel, dim3(pack_mfma_blocks(cin, cout)), dim3(256), 0, s, w, (elt*)sec_fwd, (elt*)sec_bwd, cout, cin,
                      transposed_src ? 2 : 0, transposed_src ? 3 : 1, Pf, Pb, transposed_src, lo_delta);
   return check_launch("pack_mfma");
 }
-
-unsigned pack_mfma_blocks(int cin, int cout) {
-  const int cmax = cin > cout ? cin : cout, cmin = cin > cout ? cout : cin;
-  const size_t total = (size_t)((cmax + 31) / 32 * 32) * ((cmin + 31) / 32 * 32) * 27;
-  return (unsigned)((total + 255) / 256);
-}
 int launch_pack_mfma_many(const void* table_device, int njobs, unsigned max_blocks, hipStream_t s, int with_low) {
-  hipLaunchKernelGGL(pack_mfma_many_kernel, dim3(max_blocks, with_low ? 5 : 3), dim3(256), 0, s, (const PackJobDev*)table_device, njobs);
+  hipLaunchKernelGGL(pack_mfma_many_kernel, dim3(max_blocks), dim3(256), 0, s, (const PackJobDev*)table_device, njobs, with_low);
   return check_launch("pack_mfma_many");
 }
 
