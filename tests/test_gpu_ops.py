@@ -181,6 +181,32 @@ def test_split_bf16_first_layer_in_the_fp32_mode(n, cout, shape):
     assert_close(sums[..., 1], (ys * ys).sum((2, 3, 4)), 1e-5, "sum y^2 from the kernel's partial rows")
 
 
+@pytest.mark.parametrize("n,shape", [(2, (5, 9, 17)), (1, (8, 16, 32)), (3, (3, 7, 5))])
+def test_split_bf16_first_layer_weight_gradient_in_the_fp32_mode(n, shape):
+    """Weight gradient of the first convolution (one input channel, 32 outputs) in the fp32 mode: contraction over the voxels as
+    a split-bf16 product (wgrad_c1_x3_kernel: bricks of 4x8x16, several bricks per workgroup, ragged edges), against ATen in
+    fp64 and against the exact-product kernel (option x3=0), from which it must differ in the last bits."""
+    tag = f"x3c1w{n}{shape}"
+    x, w, cot = rnd(tag + "x", n, 1, *shape), rnd(tag + "w", 32, 1, 3, 3, 3, scale=0.3), rnd(tag + "g", n, 32, *shape)
+    wr = w.double().requires_grad_(True)
+    F.conv3d(x.double(), wr, None, padding=1).backward(cot.double())
+    res = {}
+    try:
+        for x3 in (1, 0):
+            _set_option("x3", x3)
+            with mednet_hip.precision("fp32"):
+                conv = hnn.Conv3d(1, 32, 3, bias=False).to(DEV)
+                with torch.no_grad():
+                    conv.weight.copy_(w)
+                conv(x.to(DEV)).backward(cot.to(DEV))
+                res[x3] = conv.weight.grad.detach().cpu()
+    finally:
+        _set_option("x3", 1)
+    assert_close(res[1].double(), wr.grad, 3e-5, "split-bf16 first-layer weight gradient")
+    assert_close(res[0].double(), wr.grad, 3e-6, "exact-product first-layer weight gradient")
+    assert not torch.equal(res[1], res[0])
+
+
 @pytest.mark.parametrize("n,cin,cout,shape", [(2, 32, 16, (3, 5, 9)), (1, 64, 32, (4, 4, 8)), (1, 16, 48, (5, 3, 17)),
                                               (2, 128, 64, (3, 6, 16))])
 def test_split_bf16_conv_transpose_in_the_fp32_mode(n, cin, cout, shape):

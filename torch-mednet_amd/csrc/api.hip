@@ -244,7 +244,7 @@ extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, flo
     ws_bytes = (ws_bytes - need) / 256 * 256;
   }
   if (algo != MEDNET_ALGO_DIRECT && wgrad_c1_supported(cin, cout, ksize, x_layout, dy_layout))
-    return launch_wgrad_c1(x, dy, dw, n, d, h, w, cout, x_dtype, dy_dtype, ws, ws_bytes, s);
+    return launch_wgrad_c1(x, dy, dw, n, d, h, w, cout, x_dtype, dy_dtype, ws, ws_bytes, s, algo != MEDNET_ALGO_EXACT && conv_x3_enabled());
   if (algo != MEDNET_ALGO_DIRECT && wgrad_1x1_supported(cin, cout, ksize, x_layout, dy_layout, dy_dtype))
     return launch_wgrad_1x1(x, dy, dw, n, (size_t)d * h * w, cin, cout, x_dtype, ws, ws_bytes, s);
   if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32 &&

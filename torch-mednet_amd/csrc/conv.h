@@ -48,7 +48,7 @@ int launch_wgrad_1x1(const void* z, const void* dy, float* dw, int n, size_t spa
 bool wgrad_c1_supported(int cin, int cout, int ksize, int x_layout, int dy_layout);
 size_t wgrad_c1_ws_bytes(int n, int d, int h, int w, int cout);
 int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cout, int x_dtype,
-                    int dy_dtype, void* ws, size_t ws_bytes, hipStream_t s);
+                    int dy_dtype, void* ws, size_t ws_bytes, hipStream_t s, bool split_bf16 = false);
 int launch_pack_f32(const float* w, float* Pf, float* Pb, int cin, int cout, int T, int transposed_src, hipStream_t s);
 
 // 16-bit matrix-core kernels, conv_mfma.hip (namespace mednet: bf16; api.hip declares the same set in namespace mednet_f16
@@ -89,6 +89,9 @@ int launch_convt_dgrad_x3(const void* dy, const void* sec_hi, size_t lo_delta, v
 int launch_convt_fwd_x3(const void* x, const void* sec_hi, size_t lo_delta, const float* bias, const void* skip, void* y, int n,
                         int d, int h, int w, int cin, int cout, hipStream_t s);
 size_t wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+bool wgrad_c1_x3_supported(int cout, int x_dtype, int dy_dtype);
+int wgrad_c1_x3_blocks(int n, int d, int h, int w);
+int launch_wgrad_c1_x3(const void* x, const void* dy, float* part, int n, int d, int h, int w, hipStream_t s);
 int launch_wgrad_x3(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, void* ws,
                     size_t ws_bytes, hipStream_t s);
 

@@ -1030,7 +1030,7 @@ size_t wgrad_c1_ws_bytes(int n, int d, int h, int w, int cout) {
   return (size_t)(b1 > b2 ? b1 : b2) * 27 * cout * sizeof(float);
 }
 int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cout, int x_dtype,
-                    int dy_dtype, void* ws, size_t ws_bytes, hipStream_t s) {
+                    int dy_dtype, void* ws, size_t ws_bytes, hipStream_t s, bool split_bf16) {
   const int tz = (d + W1_TZ - 1) / W1_TZ, ty = (h + W1_TY - 1) / W1_TY, tx = (w + W1_TX - 1) / W1_TX;
   const int nt = n * tz * ty * tx;
   int blocks = wgrad_c1_blocks(nt);
@@ -1038,6 +1038,15 @@ int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int 
   float* part = (float*)ws;
   const bool c1_mfma = dy_dtype == MEDNET_F16 ? mednet_f16::wgrad_c1_mfma_supported(cout, x_dtype, dy_dtype)
                                               : wgrad_c1_mfma_supported(cout, x_dtype, dy_dtype);
+  if (split_bf16 && tuning_option("wgrad_c1_x3", 1) && wgrad_c1_x3_supported(cout, x_dtype, dy_dtype)) {  // fp32 storage mode
+    blocks = wgrad_c1_x3_blocks(n, d, h, w);
+    MEDNET_REQUIRE(ws_bytes >= (size_t)blocks * 27 * cout * sizeof(float), MEDNET_E_WORKSPACE, "wgrad_c1: workspace too small");
+    const int rc = launch_wgrad_c1_x3(x, dy, part, n, d, h, w, s);
+    if (rc) return rc;
+    const size_t count = (size_t)27 * cout;
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, s, part, dw, count, blocks);
+    return check_launch("wgrad_c1_reduce");
+  }
   if (tuning_option("wgrad_c1_mfma", 1) && c1_mfma) {  // matrix-core form (16-bit modes)
     blocks = wgrad_c1_mfma_blocks(n, d, h, w);
     int rc = dy_dtype == MEDNET_F16 ? mednet_f16::launch_wgrad_c1_mfma(x, dy, part, n, d, h, w, cout, s, x_dtype)

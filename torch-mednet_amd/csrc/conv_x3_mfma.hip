@@ -1051,6 +1051,152 @@ size_t wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
   return (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
 }
 
+// ---- first-layer weight gradient (Cin = 1) of the fp32 storage mode ------------------------------------------------------
+//   dW[co][tap] = sum_v x[v + tap - 1] * dy[v][co]:  D[tap (27 of 32 rows)][co] += A[tap][k = voxel] * B[k = voxel][co],
+// as wgrad_c1_mfma_kernel (conv_mfma.hip) with both operands split: A gathered from the fp32 halo brick of x (lane = tap row: 8
+// x-consecutive values of its shifted row), B = the fp32 dy brick committed to a high and a low bf16 plane and read through the
+// transposing LDS read.  Bound by reading dy once (1.07 GB at config 2); the VALU kernel it replaces took 0.49 ms.
+struct Wc1X3Args {
+  const float* x;   // N x D x H x W
+  const float* dy;  // N x D x H x W x 32
+  float* part;      // [workgroup][32][27]
+  int n, d, h, w;
+  int tiles_z, tiles_y, tiles_x, ntiles;
+  unsigned bytes_x, bytes_dy;  // per sample
+};
+__global__ __launch_bounds__(256, 2) void wgrad_c1_x3_kernel(Wc1X3Args a) {
+  constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+  constexpr int NJ = TZ * TY * TX, NH = HZ * HY * HX;
+  constexpr int XH_BYTES = (NH * 4 + 255) / 256 * 256;  // fp32 halo brick of x
+  constexpr int DY_LO = NJ * 64;                        // bytes between the high and the low plane of dy
+  constexpr int DY_ROUNDS = NJ * 4 / 256, X_ROUNDS = (NH + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xh = reinterpret_cast<float*>(smem);
+  char* dyl = smem + XH_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hk = lane >> 5;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int coloff = (16 * (g & 1) + 4 * p) * 2;
+  const int tapc = r < 27 ? r : 26;  // rows 27..31 duplicate tap 26 and are dropped at write-out
+  const int abase = ((tapc / 9) * HY + (tapc / 3) % 3) * HX + tapc % 3 + 8 * hk;
+
+  u32x4 rdy[DY_ROUNDS][2];
+  float rx[X_ROUNDS];
+  auto fetch = [&](int tile) {
+    int tt = tile;
+    const int tx0 = (tt % a.tiles_x) * TX;
+    tt /= a.tiles_x;
+    const int ty0 = (tt % a.tiles_y) * TY;
+    tt /= a.tiles_y;
+    const int tz0 = (tt % a.tiles_z) * TZ;
+    const size_t svox = (size_t)(tt / a.tiles_z) * a.d * a.h * a.w;
+    const auto rD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + svox * 32), 0, a.bytes_dy, 0x00020000);
+    const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + svox), 0, a.bytes_x, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < DY_ROUNDS; ++it) {
+      const int c = it * 256 + tid;
+      const int part = c & 3, v = c >> 2;
+      const int gz = tz0 + v / (TX * TY), gy = ty0 + (v / TX) % TY, gx = tx0 + v % TX;
+      const bool in_vol = (gz < a.d) & (gy < a.h) & (gx < a.w);
+      const unsigned off = in_vol ? ((unsigned)((gz * a.h + gy) * a.w + gx) * 32u + part * 8) * 4u : X3_OOB;
+      rdy[it][0] = __builtin_amdgcn_raw_buffer_load_b128(rD, off, 0, 0);
+      rdy[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rD, off + 16u, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < X_ROUNDS; ++it) {
+      const int v = it * 256 + tid;
+      const int gz = tz0 - 1 + v / (HX * HY), gy = ty0 - 1 + (v / HX) % HY, gx = tx0 - 1 + v % HX;
+      const bool in_vol = (v < NH) & ((unsigned)gz < (unsigned)a.d) & ((unsigned)gy < (unsigned)a.h) & ((unsigned)gx < (unsigned)a.w);
+      rx[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, in_vol ? (unsigned)((gz * a.h + gy) * a.w + gx) * 4u : X3_OOB, 0, 0));
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < DY_ROUNDS; ++it) {
+      const int c = it * 256 + tid;
+      const HiLo sp = split8(rdy[it][0], rdy[it][1]);
+      *reinterpret_cast<bf16x8*>(dyl + c * 16) = sp.hi;
+      *reinterpret_cast<bf16x8*>(dyl + DY_LO + c * 16) = sp.lo;
+    }
+#pragma unroll
+    for (int it = 0; it < X_ROUNDS; ++it) {
+      const int v = it * 256 + tid;
+      if (v < NH) xh[v] = rx[it];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) fetch(tile);
+  for (; tile < a.ntiles; tile += gridDim.x) {
+    __syncthreads();  // previous brick fully consumed
+    commit();
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);  // flies while this brick is worked on
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const int row = wv * 8 + s8;  // (lz, ly) = (row / TY, row % TY): 16 x-consecutive voxels = one MFMA k-step
+      const float* px = xh + abase + ((row / TY) * HY + row % TY) * HX;
+      bf16x8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xv = px[j];
+        hi[j] = (__bf16)xv;
+        lo[j] = (__bf16)(xv - (float)hi[j]);
+      }
+      const char* brow = dyl + (row * TX + 8 * hk + q) * 64 + coloff;
+      const bf16x8 bh = x3_tr_operand(brow, 4 * 64), bl = x3_tr_operand(brow + DY_LO, 4 * 64);
+      acc = X3_MFMA(lo, bh, acc);
+      acc = X3_MFMA(hi, bl, acc);
+      acc = X3_MFMA(hi, bh, acc);
+    }
+  }
+  // ---- sum the 4 waves in LDS (fixed order), write the workgroup's partial in dW layout [co][27]
+  float* red = reinterpret_cast<float*>(smem);  // [4 waves][16][64 lanes]
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) red[(wv * 16 + j) * 64 + lane] = acc[j];
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float sum = (red[(0 * 16 + j) * 64 + lane] + red[(1 * 16 + j) * 64 + lane]) + (red[(2 * 16 + j) * 64 + lane] + red[(3 * 16 + j) * 64 + lane]);
+      const int tap = (j & 3) + 8 * (j >> 2) + 4 * hk, co = lane & 31;
+      if (tap < 27) a.part[((size_t)blockIdx.x * 32 + co) * 27 + tap] = sum;
+    }
+  }
+}
+bool wgrad_c1_x3_supported(int cout, int x_dtype, int dy_dtype) { return cout == 32 && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32; }
+int wgrad_c1_x3_blocks(int n, int d, int h, int w) {
+  const int nt = n * ((d + 3) / 4) * ((h + 7) / 8) * ((w + 15) / 16);
+  return nt < 1024 ? nt : 1024;
+}
+int launch_wgrad_c1_x3(const void* x, const void* dy, float* part, int n, int d, int h, int w, hipStream_t s) {
+  Wc1X3Args a;
+  a.x = (const float*)x;
+  a.dy = (const float*)dy;
+  a.part = part;
+  a.n = n; a.d = d; a.h = h; a.w = w;
+  a.tiles_z = (d + 3) / 4; a.tiles_y = (h + 7) / 8; a.tiles_x = (w + 15) / 16;
+  a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
+  MEDNET_REQUIRE((double)d * h * w * 32 * 4.0 < 4294960000.0, MEDNET_E_UNSUPPORTED, "wgrad_c1_x3: one sample must stay below 4 GB");
+  a.bytes_x = (unsigned)((size_t)d * h * w * 4);
+  a.bytes_dy = (unsigned)((size_t)d * h * w * 32 * 4);
+  constexpr size_t lds = 4352 + (size_t)2 * 512 * 64;  // halo of x + the two planes of dy (> the 16 KB of the final reduction)
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)wgrad_c1_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(MEDNET_E_HIP, "wgrad_c1_x3: cannot raise dynamic LDS to %zu", lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_c1_x3_kernel, dim3(wgrad_c1_x3_blocks(n, d, h, w)), dim3(256), lds, s, a);
+  return check_launch("wgrad_c1_x3");
+}
+
 int launch_wgrad_x3(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, void* ws,
                     size_t ws_bytes, hipStream_t s) {
   constexpr size_t lds = ((size_t)4 * 4 * 16 + 6 * 6 * 18) * 64 * 2;
