@@ -204,8 +204,8 @@ def fp32_parity_mode(dev, batch: int, patch: int, steps: int):
     rec = {"value": round(pps, 3), "unit": "patches/s", "ms_per_step": round(1e3 * dt / steps, 2), "steps": steps,
            "dtype": "fp32", "loss": round(float(loss), 6),
            "arithmetic": "fp32 storage of activations, gradients and parameters; 3x3x3 contractions as split-bf16 (hi*hi + "
-                         "hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation: ~2^-16 per product); first layer, "
-                         "ConvTranspose weight gradient on v_mfma_f32_32x32x2_f32; GroupNorm, head and losses fp32",
+                         "hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation: ~2^-16 per product) for every "
+                         "convolution, ConvTranspose and weight gradient incl. the first layer; GroupNorm, head and losses fp32",
            "tolerance_met": "1e-3 rel-L2 on logits and every gradient vs the reference "
                             "(tests: test_cfg2_128_against_reference_golden, test_cfg4_128_landmark_...)"}
     if patch == 128:  # three bf16 MFMAs per product
