@@ -677,6 +677,28 @@ def test_conv3d_mfma_fwd_dgrad_wgrad(n, cin, cout, shape):
     assert_close(dw, dwd, 2e-4, "dw vs direct kernel")
 
 
+@pytest.mark.parametrize("n,cin,cout,shape", [(2, 32, 32, (9, 11, 21)), (1, 64, 32, (8, 16, 16)), (1, 48, 80, (4, 8, 16)),
+                                              (3, 16, 32, (5, 6, 33))])
+def test_lean_weight_gradient_option(n, cin, cout, shape):
+    """Option wgrad_v3 (wgrad_mfma3_kernel: 120 registers, LDS-DMA staging into a double buffer, 4x4x16 bricks; an A/B knob, off
+    by default -- DESIGN.md section 9): the same weight gradient as the default kernel up to summation order."""
+    tag = f"wg3{n}{cin}{cout}{shape}"
+    x, w, cot = _conv_case(n, cin, cout, shape, tag)
+    res = {}
+    try:
+        for v3 in (0, 1):
+            _set_option("wgrad_v3", v3)
+            with mednet_hip.precision("bf16"):
+                conv = hnn.Conv3d(cin, cout, 3, bias=False).to(DEV)
+                with torch.no_grad():
+                    conv.weight.copy_(w)
+                conv(x.to(DEV).bfloat16()).backward(cot.to(DEV).bfloat16())
+                res[v3] = conv.weight.grad.cpu()
+    finally:
+        _set_option("wgrad_v3", 0)
+    assert_close(res[1], res[0], 1e-5, "lean weight gradient vs the default kernel")
+
+
 def _fuzz_cases_ct(k, seed):
     rng = np.random.default_rng(seed)
     return [(int(rng.integers(1, 3)), int(rng.choice([32, 64, 96])), int(rng.choice([32, 64])),
