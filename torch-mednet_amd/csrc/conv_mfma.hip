@@ -1503,20 +1503,43 @@ __device__ __forceinline__ void pack_mfma_body(const float* __restrict__ w, elt*
   if (tl >= (unsigned)((M + 31) / 32) * (unsigned)nkc) return;
   const int kc = (int)(tl % nkc), cb = (int)(tl / nkc);
   // source order -> LDS in image order: d = ((tap * 2 + h) * 32 + co) * 8 + j, k = 8 h + j
+  // (16-byte loads: a run starts at a multiple of 16 * 27 floats and is 432 or 864 floats long)
+  typedef __attribute__((ext_vector_type(4))) float pf4;
+  const bool al16 = (reinterpret_cast<size_t>(w) & 15) == 0;  // (a caller's parameter pointer may be only 4-byte aligned)
   if (mode == 0 || mode == 3) {  // w[m][k][t]: per row m a run of 16 * 27 floats
-    for (int sidx = threadIdx.x; sidx < PACK_TILE; sidx += 256) {
-      const int ml = sidx / 432, rem = sidx % 432, kl = rem / 27, tap = rem % 27;
+#pragma unroll 2
+    for (int s4 = threadIdx.x; s4 < PACK_TILE / 4; s4 += 256) {
+      const int ml = s4 / 108, rem0 = (s4 % 108) * 4;
       const int m = cb * 32 + ml;
-      const float v = m < M ? w[((size_t)m * K + kc * 16) * 27 + rem] : 0.f;
-      tile[((tap * 2 + (kl >> 3)) * 32 + ml) * 8 + (kl & 7)] = v;
+      pf4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < M) {
+        const float* src = w + ((size_t)m * K + kc * 16) * 27 + rem0;
+        if (al16) v = *reinterpret_cast<const pf4*>(src);
+        else v = pf4{src[0], src[1], src[2], src[3]};
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kl = (rem0 + e) / 27, tap = (rem0 + e) % 27;
+        tile[((tap * 2 + (kl >> 3)) * 32 + ml) * 8 + (kl & 7)] = v[e];
+      }
     }
   } else {  // w[k][m][t] (mode 1: taps reversed): per k a run of 32 * 27 floats (rows past M: zeros)
-    for (int sidx = threadIdx.x; sidx < PACK_TILE; sidx += 256) {
-      const int kl = sidx / 864, rem = sidx % 864, ml = rem / 27, t = rem % 27;
-      const int m = cb * 32 + ml;
-      const float v = m < M ? w[((size_t)(kc * 16 + kl) * M + cb * 32) * 27 + rem] : 0.f;
-      const int tap = mode == 1 ? 26 - t : t;
-      tile[((tap * 2 + (kl >> 3)) * 32 + ml) * 8 + (kl & 7)] = v;
+#pragma unroll 2
+    for (int s4 = threadIdx.x; s4 < PACK_TILE / 4; s4 += 256) {
+      const int kl = s4 / 216, rem0 = (s4 % 216) * 4;
+      pf4 v = {0.f, 0.f, 0.f, 0.f};
+      // (M is a multiple of 16: a run of valid rows ends on a 16-byte boundary)
+      if (cb * 32 + (rem0 + 3) / 27 < M) {
+        const float* src = w + ((size_t)(kc * 16 + kl) * M + cb * 32) * 27 + rem0;
+        if (al16) v = *reinterpret_cast<const pf4*>(src);
+        else v = pf4{src[0], src[1], src[2], src[3]};
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ml = (rem0 + e) / 27, t = (rem0 + e) % 27;
+        const int tap = mode == 1 ? 26 - t : t;
+        tile[((tap * 2 + (kl >> 3)) * 32 + ml) * 8 + (kl & 7)] = cb * 32 + ml < M ? v[e] : 0.f;
+      }
     }
   }
   __syncthreads();
@@ -1535,15 +1558,19 @@ __device__ __forceinline__ void pack_mfma_body(const float* __restrict__ w, elt*
   }
   if (img == 0 && Pf) {  // Pf[t][ci][co] and Pb[t'][co][ci] (t' = 26 - t for a conv, t for a ConvTranspose) of this tile's channels
     const int cin = K0, cout = M0;
-    for (int idx = threadIdx.x; idx < PACK_TILE; idx += 256) {
-      const int co = idx & 31, kl = (idx >> 5) & 15, t = idx >> 9;
-      if (cb * 32 + co < cout)
-        Pf[((size_t)t * cin + kc * 16 + kl) * cout + cb * 32 + co] = tile[((t * 2 + (kl >> 3)) * 32 + co) * 8 + (kl & 7)];
+    // 16-byte stores (cout and cin are multiples of 16, the images 256-byte aligned inside the pack buffer)
+    for (int i4 = threadIdx.x; i4 < PACK_TILE / 4; i4 += 256) {
+      const int co = (i4 & 7) * 4, kl = (i4 >> 3) & 15, t = i4 >> 7;
+      if (cb * 32 + co < cout) {
+        const float* src = tile + ((t * 2 + (kl >> 3)) * 32 + co) * 8 + (kl & 7);
+        *reinterpret_cast<pf4*>(Pf + ((size_t)t * cin + kc * 16 + kl) * cout + cb * 32 + co) = pf4{src[0], src[8], src[16], src[24]};
+      }
     }
-    for (int idx = threadIdx.x; idx < PACK_TILE; idx += 256) {
-      const int kl = idx & 15, co = (idx >> 4) & 31, t = idx >> 9;
+    for (int i4 = threadIdx.x; i4 < PACK_TILE / 4; i4 += 256) {
+      const int k4 = (i4 & 3) * 4, co = (i4 >> 2) & 31, t = i4 >> 7;
       if (cb * 32 + co < cout)
-        Pb[((size_t)(transposed_src ? t : 26 - t) * cout + cb * 32 + co) * cin + kc * 16 + kl] = tile[((t * 2 + (kl >> 3)) * 32 + co) * 8 + (kl & 7)];
+        *reinterpret_cast<pf4*>(Pb + ((size_t)(transposed_src ? t : 26 - t) * cout + cb * 32 + co) * cin + kc * 16 + k4) =
+            *reinterpret_cast<const pf4*>(tile + ((t * 2 + (k4 >> 3)) * 32 + co) * 8 + (k4 & 7));
     }
   }
 }
