@@ -50,7 +50,7 @@ int mednet_set_option(const char* name, int value);
 /* ---- nn.Conv3d(k=3,p=1 | k=1,p=0, stride 1)  components.py:8-9,44 ; model.py:77,179 ------------------------ */
 /* Weight packing: PyTorch (Cout,Cin,k,k,k) [or ConvTranspose3d's (Cin,Cout,k,k,k) when transposed_src=1] ->
  * opaque buffer holding the tap-major layouts the forward, data-gradient and MFMA kernels read. */
-size_t mednet_conv3d_pack_bytes(int cin, int cout, int ksize);
+size_t mednet_conv3d_pack_bytes(int cin, int cout, int ksize);  /* the buffer must be 16-byte aligned (hipMalloc / torch allocations are) */
 /* mednet_conv3d_pack writes the matrix-core fragment images in bf16; _elt takes the storage type of the activations the
  * layer will see (MEDNET_BF16 | MEDNET_F16: BASELINE config 5 stores fp16).  MEDNET_F32 (the fp32 storage mode, the one that
  * meets the reference within 1e-3): bf16 images of the HIGH halves bf16(w) plus images of the LOW halves

@@ -94,6 +94,7 @@ extern "C" int mednet_conv3d_pack_elt(const float* w, void* packed, int cin, int
   MEDNET_REQUIRE(is16(elt_dtype), MEDNET_E_DTYPE, "conv3d_pack: the matrix-core images are bf16 or fp16 (got dtype %d)", elt_dtype);
   MEDNET_REQUIRE(ksize == 3 || ksize == 1, MEDNET_E_UNSUPPORTED, "conv3d_pack: kernel size %d (supported: 1, 3)", ksize);
   MEDNET_REQUIRE(cin > 0 && cout > 0, MEDNET_E_SHAPE, "conv3d_pack: bad channels %d -> %d", cin, cout);
+  MEDNET_REQUIRE(((size_t)packed & 15) == 0, MEDNET_E_SHAPE, "conv3d_pack: the pack buffer must be 16-byte aligned (the images are written 16 bytes at a time)");
   const PackLayout L = pack_layout(cin, cout, ksize);
   char* base = (char*)packed;
   hipStream_t s = (hipStream_t)stream;
@@ -116,6 +117,7 @@ extern "C" int mednet_conv3d_pack_table(const mednet_pack_job* jobs, int njobs, 
     MEDNET_REQUIRE(j.ksize == 3 && L.mfma_bytes, MEDNET_E_UNSUPPORTED,
                    "conv3d_pack_table: layer %d (%d -> %d, k=%d) has no matrix-core images; pack it with mednet_conv3d_pack", i, j.cin,
                    j.cout, j.ksize);
+    MEDNET_REQUIRE(((size_t)j.packed & 15) == 0, MEDNET_E_SHAPE, "conv3d_pack_table: pack buffer of layer %d is not 16-byte aligned", i);
     char* base = (char*)j.packed;
     t[i].w = j.w;
     t[i].sec_fwd = base + L.mfma_fwd;
