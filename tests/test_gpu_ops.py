@@ -317,6 +317,31 @@ def test_group_norm_act(mode, c, groups, shape, act, res):
         assert_close(rg.grad, rr.grad, tol, "dres")
 
 
+@pytest.mark.parametrize("c,groups,shape", [(32, 8, (9, 10, 12)), (64, 8, (6, 7, 9)), (256, 8, (3, 4, 5)), (8, 1, (5, 6, 7))])
+def test_group_norm_backward_in_two_launches_equals_four(c, groups, shape):
+    """GroupNorm backward with the reduction of the partial rows, the per-group coefficients and the parameter gradients in two
+    launches (gn_bwd_reduce_finalize_kernel + the apply kernel's first workgroup; default) against the four-launch form
+    (option gn_bwd_one_launch=0): same gradients up to the summation order of the rows."""
+    tag = f"gn2l{c}{groups}"
+    x, cot = rnd(tag + "x", 2, c, *shape, scale=2.0) + 0.5, rnd(tag + "g", 2, c, *shape)
+    res = {}
+    try:
+        for one in (1, 0):
+            _set_option("gn_bwd_one_launch", one)
+            with mednet_hip.precision("fp32"):
+                gn = hnn.GroupNorm(groups, c).to(DEV)
+                with torch.no_grad():
+                    gn.weight.copy_(rnd(tag + "ga", c) * 0.3 + 1.0)
+                    gn.bias.copy_(rnd(tag + "be", c) * 0.3)
+                xg = x.to(DEV).requires_grad_(True)
+                (gn(xg, act=L.ACT_ELU) * cot.to(DEV)).sum().backward()
+                res[one] = (xg.grad.cpu(), gn.weight.grad.cpu(), gn.bias.grad.cpu())
+    finally:
+        _set_option("gn_bwd_one_launch", 1)
+    for a, b, name in zip(res[1], res[0], ("dx", "dgamma", "dbeta")):
+        assert_close(a, b, 2e-6, name)
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("act", ["relu", "leaky", "elu"])
 def test_standalone_activation(mode, act):
