@@ -2299,6 +2299,20 @@ static size_t wgrad2_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
 }
 
 // dw[(a*KB + b)*27 + tap] = sum_split part[(pair*splits + split)][tap][a%32][b%32]
+// (few slabs per output -- deep layers, where the channel-block pairs alone fill the chip: one thread per output)
+__global__ __launch_bounds__(256) void wgrad_mfma_reduce_kernel_few(const float* __restrict__ part, float* __restrict__ dw, int ka, int kb, int nbb,
+                                               int splits) {
+  const size_t total = (size_t)((ka + 31) / 32) * nbb * 1024 * 27;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int b32 = (int)(e % 32), a32 = (int)((e / 32) % 32), tap = (int)((e / 1024) % 27);
+  const int pair = (int)(e / (1024 * 27));
+  const int ab = pair / nbb, bb = pair % nbb;
+  const float* src = part + ((size_t)pair * splits) * 27 * 1024 + (size_t)tap * 1024 + a32 * 32 + b32;
+  float s0 = 0.f;
+  for (int k = 0; k < splits; ++k) s0 += src[(size_t)k * 27 * 1024];
+  if (ab * 32 + a32 < ka && bb * 32 + b32 < kb) dw[((size_t)(ab * 32 + a32) * kb + bb * 32 + b32) * 27 + tap] = s0;
+}
 __global__ __launch_bounds__(256) void wgrad_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int ka, int kb,
                                                               int nbb, int splits) {
   // 64 outputs per workgroup, the slabs dealt to its 4 waves (wave g: slabs g, g + 4, ..., four loads in flight), the four sums
@@ -2399,7 +2413,9 @@ static int launch_wg(const void* A, const void* B, float* dw, int n, int ad, int
   int rc = check_launch("wgrad_mfma");
   if (rc) return rc;
   const size_t total = (size_t)a.nab * a.nbb * 1024 * 27;
-  hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.part, dw, ka, kb,
+  if (a.splits < 4) hipLaunchKernelGGL(wgrad_mfma_reduce_kernel_few, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, ka, kb,
+                     a.nbb, a.splits);
+  else hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.part, dw, ka, kb,
                      a.nbb, a.splits);
   return check_launch("wgrad_mfma_reduce");
 }
@@ -2432,7 +2448,8 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
     int rc3 = check_launch("wgrad_mfma3");
     if (rc3) return rc3;
     const size_t total3 = (size_t)a.nab * a.nbb * 1024 * 27;
-    hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total3 + 63) / 64)), dim3(256), 0, s, a.part, dw, cout, cin, a.nbb, a.splits);
+    if (a.splits < 4) hipLaunchKernelGGL(wgrad_mfma_reduce_kernel_few, dim3((unsigned)((total3 + 255) / 256)), dim3(256), 0, s, a.part, dw, cout, cin, a.nbb, a.splits);
+  else hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total3 + 63) / 64)), dim3(256), 0, s, a.part, dw, cout, cin, a.nbb, a.splits);
     return check_launch("wgrad_mfma_reduce");
   }
   constexpr size_t lds = ((size_t)4 * 8 * 16 + 6 * 10 * 18) * 64;
@@ -2456,7 +2473,9 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
   int rc = check_launch("wgrad_mfma2");
   if (rc) return rc;
   const size_t total = (size_t)a.nab * a.nbb * 1024 * 27;
-  hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.part, dw, cout, cin,
+  if (a.splits < 4) hipLaunchKernelGGL(wgrad_mfma_reduce_kernel_few, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, cout, cin,
+                     a.nbb, a.splits);
+  else hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.part, dw, cout, cin,
                      a.nbb, a.splits);
   return check_launch("wgrad_mfma_reduce");
 }
@@ -2884,7 +2903,9 @@ int launch_convt_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int
   int rc = check_launch("convt_wgrad_mfma2");
   if (rc) return rc;
   const size_t total = (size_t)a.nab * a.nbb * 1024 * 27;
-  hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.part, dw, cin, cout,
+  if (a.splits < 4) hipLaunchKernelGGL(wgrad_mfma_reduce_kernel_few, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, cin, cout,
+                     a.nbb, a.splits);
+  else hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.part, dw, cin, cout,
                      a.nbb, a.splits);
   return check_launch("wgrad_mfma_reduce");
 }

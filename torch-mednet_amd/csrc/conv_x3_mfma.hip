@@ -1009,6 +1009,20 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(WgX3Args a) {
 }
 
 // dw[(a*KB + b)*27 + tap] = sum over the splits of part[(pair*splits + split)][tap][a%32][b%32], fixed order
+// (few slabs per output -- deep layers, where the channel-block pairs alone fill the chip: one thread per output)
+__global__ __launch_bounds__(256) void wgrad_x3_reduce_kernel_few(const float* __restrict__ part, float* __restrict__ dw, int ka, int kb, int nbb,
+                                               int splits) {
+  const size_t total = (size_t)((ka + 31) / 32) * nbb * 1024 * 27;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int b32 = (int)(e % 32), a32 = (int)((e / 32) % 32), tap = (int)((e / 1024) % 27);
+  const int pair = (int)(e / (1024 * 27));
+  const int ab = pair / nbb, bb = pair % nbb;
+  const float* src = part + ((size_t)pair * splits) * 27 * 1024 + (size_t)tap * 1024 + a32 * 32 + b32;
+  float s0 = 0.f;
+  for (int k = 0; k < splits; ++k) s0 += src[(size_t)k * 27 * 1024];
+  if (ab * 32 + a32 < ka && bb * 32 + b32 < kb) dw[((size_t)(ab * 32 + a32) * kb + bb * 32 + b32) * 27 + tap] = s0;
+}
 __global__ __launch_bounds__(256) void wgrad_x3_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int ka, int kb,
                                                               int nbb, int splits) {
   // 64 outputs per workgroup, the slabs dealt to its 4 waves (wave g: slabs g, g + 4, ..., four loads in flight), the four sums
@@ -1234,8 +1248,8 @@ int launch_wgrad_x3(const void* x, const void* dy, float* dw, int n, int d, int 
   int rc = check_launch("wgrad_x3");
   if (rc) return rc;
   const size_t total = (size_t)a.nab * a.nbb * 1024 * 27;
-  hipLaunchKernelGGL(wgrad_x3_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.part, dw, cout, cin, a.nbb,
-                     a.splits);
+  if (a.splits < 4) hipLaunchKernelGGL(wgrad_x3_reduce_kernel_few, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, cout, cin, a.nbb, a.splits);
+  else hipLaunchKernelGGL(wgrad_x3_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.part, dw, cout, cin, a.nbb, a.splits);
   return check_launch("wgrad_x3_reduce");
 }
 
