@@ -875,9 +875,9 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
       for (int t = 0; t < VT; ++t) zv[t] = ld8(zb, (v + (size_t)t * rows) * k);
       if (cols == 4) {
         // The four lanes of a voxel split the classes between them (lane c loads classes c, c + 4) and hand the values round
-        // with DPP quad permutes: MB / 4 planar 4-byte loads per lane and voxel instead of MB -- every one of those is a
-        // whole wave instruction for 64 useful bytes, and the 18-class landmark head (three class blocks: 740 us for 1.1 GB)
-        // was bound by issuing them.
+        // with DPP quad permutes: MB / 4 planar 4-byte loads per lane and voxel instead of MB (every one of those is a whole
+        // wave instruction for 64 useful bytes).  By itself this did not move the 18-class landmark head (758 us with three
+        // class blocks); the column sums at the end of the kernel did (492 us), see below.
         float own[VT][MB / 4];
 #pragma unroll
         for (int t = 0; t < VT; ++t)
