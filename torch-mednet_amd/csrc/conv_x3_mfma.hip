@@ -81,6 +81,7 @@ struct X3Args {
   int n, od, oh, ow, id, ih, iw, k, m;
   int tiles_z, tiles_y, tiles_x, tps, nkc, ncb, nitems, per_xcd, stats_rows, xps;  // xps: item ranges ("XCDs") per sample
   unsigned bytes_in;  // bytes of ONE sample of x (buffer resources are per sample: 32-bit offsets)
+  int yb;             // > 0: z-walk of the bricks in columns of yb x tiles_x (see decode); 0: x fastest, then y, then z
 };
 
 template <int STRIDE>
@@ -138,10 +139,22 @@ __global__ __launch_bounds__(X3Tile<STRIDE>::NWAVES * 64) void conv_x3_kernel(X3
     int tile = iv - grp * a.tps;
     it.n = grp / a.ncb;
     it.cb = grp - it.n * a.ncb;
-    it.tx0 = (tile % a.tiles_x) * TX;
-    tile /= a.tiles_x;
-    it.ty0 = (tile % a.tiles_y) * TY;
-    it.tz0 = (tile / a.tiles_y) * TZ;
+    if (a.yb > 0) {
+      // z-walk: the bricks an item range works on AT THE SAME TIME (its 32 workgroups take consecutive items) are one z-plane of a
+      // column of a.yb x tiles_x bricks, and the next round is the plane above it: the two z-planes of halo that neighbours in z
+      // share are then one round old (4 MB of input per round and XCD against 4 MB of L2) instead of tiles_y / yb rounds.  With
+      // x fastest, y, then z the 32 -> 32 @128^3 launches fetched 1.8 - 2.0 x their input (rocprofv3 FETCH_SIZE).
+      const int plane = a.yb * a.tiles_x, col = tile / (plane * a.tiles_z), rem = tile - col * plane * a.tiles_z;
+      const int tz = rem / plane, within = rem - tz * plane;
+      it.tx0 = (within % a.tiles_x) * TX;
+      it.ty0 = (col * a.yb + within / a.tiles_x) * TY;
+      it.tz0 = tz * TZ;
+    } else {
+      it.tx0 = (tile % a.tiles_x) * TX;
+      tile /= a.tiles_x;
+      it.ty0 = (tile % a.tiles_y) * TY;
+      it.tz0 = (tile / a.tiles_y) * TZ;
+    }
     it.base = (((STRIDE * it.tz0 - 1) * a.ih + (STRIDE * it.ty0 - 1)) * a.iw + (STRIDE * it.tx0 - 1)) * a.k * 4;
     it.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)it.n * a.id * a.ih * a.iw * a.k), 0, a.bytes_in, 0x00020000);
     return it;
@@ -475,6 +488,12 @@ static int launch_x3(const void* x, const void* sec_hi, size_t lo_delta, const f
   a.gn_coef = gn_coef;
   a.gn_act = gn_act;
   a.bytes_in = (unsigned)((size_t)id * ih * iw * k * 4);
+  // z-walk when a plane of (32 / tiles_x) x tiles_x bricks is what an item range's 32 workgroups hold at a time
+  a.yb = 0;
+  if (tuning_option("x3_zwalk", 1) && a.tiles_z > 1 && a.tiles_x <= 32 && 32 % a.tiles_x == 0) {
+    const int yb = 32 / a.tiles_x < a.tiles_y ? 32 / a.tiles_x : a.tiles_y;
+    if (a.tiles_y % yb == 0) a.yb = yb;
+  }
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[STRIDE]) {
     if (hipFuncSetAttribute((const void*)conv_x3_kernel<STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
