@@ -259,8 +259,10 @@ def test_bench_world_size_mismatch_is_an_error():
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the loud failure on a box WITHOUT GPUs")
-def test_bench_gpus2_without_gpus_fails_inside_both_ranks():
+def test_bench_gpus2_without_gpus_fails_inside_the_ranks():
     r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert r.returncode != 0
-    assert "rank 0/2 needs an MI355X" in r.stderr and "rank 1/2 needs an MI355X" in r.stderr
+    # (the launcher ends the other rank as soon as one has failed: usually both messages are there, at least one always is)
+    assert "rank 0/2 needs an MI355X" in r.stderr or "rank 1/2 needs an MI355X" in r.stderr
+    assert "launching 2 ranks" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]  # no 1-GPU number under an N-GPU label
