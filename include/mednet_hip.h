@@ -32,7 +32,10 @@ enum { MEDNET_POOL_MAX = 0, MEDNET_POOL_AVG = 1 };
 /* ALGO_EXACT = ALGO_AUTO, except that fp32-storage contractions use exact fp32 products (v_mfma_f32_32x32x2_f32) instead of
  * the split-bf16 contraction (three bf16 MFMAs per product, ~2^-16 relative): asked for by networks with ReLU / LeakyReLU,
  * whose gradients are discontinuous in the pre-activations (mednet_hip/config.py exact_products). */
-enum { MEDNET_ALGO_AUTO = 0, MEDNET_ALGO_DIRECT = 1, MEDNET_ALGO_MFMA = 2, MEDNET_ALGO_EXACT = 3 };
+enum { MEDNET_ALGO_AUTO = 0, MEDNET_ALGO_DIRECT = 1, MEDNET_ALGO_MFMA = 2, MEDNET_ALGO_EXACT = 3,
+       /* the same request OR-ed onto a base choice: MEDNET_ALGO_MFMA | MEDNET_ALGO_EXACT_BIT = matrix-core path required AND
+        * exact fp32 products (ALGO_MFMA alone takes the split-bf16 contraction in the fp32 storage mode) */
+       MEDNET_ALGO_EXACT_BIT = 4 };
 enum { MEDNET_REG_L2 = 0, MEDNET_REG_L1 = 1 };
 enum {
   MEDNET_OK = 0, MEDNET_E_SHAPE = -1, MEDNET_E_DTYPE = -2, MEDNET_E_WORKSPACE = -3, MEDNET_E_HIP = -4,
@@ -52,9 +55,12 @@ int mednet_set_option(const char* name, int value);
  * opaque buffer holding the tap-major layouts the forward, data-gradient and MFMA kernels read. */
 size_t mednet_conv3d_pack_bytes(int cin, int cout, int ksize);  /* the buffer must be 16-byte aligned (hipMalloc / torch allocations are) */
 /* mednet_conv3d_pack writes the matrix-core fragment images in bf16; _elt takes the storage type of the activations the
- * layer will see (MEDNET_BF16 | MEDNET_F16: BASELINE config 5 stores fp16).  MEDNET_F32 (the fp32 storage mode, the one that
- * meets the reference within 1e-3): bf16 images of the HIGH halves bf16(w) plus images of the LOW halves
- * bf16(w - bf16(w)) for the split-bf16 contraction (conv_x3_mfma.hip).  The buffer size is the same in every case. */
+ * layer will see.  MEDNET_BF16 and MEDNET_F32 write the same thing: bf16 images of the HIGH halves bf16(w) plus images of
+ * the LOW halves bf16(w - bf16(w)); 16-bit calls read the high images, fp32-storage calls (the mode that meets the reference
+ * within 1e-3) contract against both (split-bf16 product, conv_x3_mfma.hip) -- so a buffer packed either way serves both
+ * storage modes.  MEDNET_F16 (BASELINE config 5 stores fp16) writes fp16 high images and serves fp16-storage calls ONLY: the
+ * exact-product fp32 kernels (MEDNET_ALGO_EXACT) still work on it, they read the fp32 tap-major images every pack holds, but
+ * an automatic-algorithm fp32-storage call on an fp16 pack is a caller error.  The buffer size is the same in every case. */
 int mednet_conv3d_pack_elt(const float* w, void* packed, int cin, int cout, int ksize, int transposed_src, int elt_dtype,
                            mednet_stream stream);
 int mednet_conv3d_pack(const float* w, void* packed, int cin, int cout, int ksize, int transposed_src,
@@ -79,6 +85,16 @@ int mednet_conv3d_pack_many(const void* table_device, int njobs, unsigned blocks
  * call cannot fuse them); mednet_gn_finalize turns them into statistics without another pass over y.  The sums are
  * kept per channel PAIR (entry 2j = channels 2j and 2j+1 together, entry 2j+1 = 0): exact for GroupNorm whenever the
  * channels per group are even -- ask for them only then. */
+/* Audit aid (no device needed): the launch plan of the 16-bit matrix-core kernel that produces a 3x3x3 layer's partial rows,
+ * from the launcher's own planning code.  gnb: the data-gradient form with GroupNorm-backward sums (pass the kernel's Cin /
+ * Cout, i.e. the layer's Cout / Cin); stride 2: the ConvTranspose3d data gradient with GroupNorm-3 sums (d, h, w = the
+ * low-resolution grid).  out13 = {kind (2: one row per wave and brick, row = 4 * brick-in-sample + wave; 3: accumulate mode,
+ * a wave keeps its sums over its workgroup's items and writes row ((wg >> 3) / ncb * 8 + (wg & 7)) * 4 + wave for EVERY
+ * sample; 4: the 32 -> 32 specialisation, row = 4 * wg + wave for every sample), grid, work items, channel blocks, bricks,
+ * bricks per sample, accumulate flag, rows per sample, and for kind 4 bricks per XCD, z-slab height, brick counts in x, y, z}.
+ * Work item i of the general kernel = (brick (i >> 3) / ncb * 8 + (i & 7), channel block (i >> 3) % ncb); workgroup b takes
+ * items b, b + grid, ... and stops at the first brick >= bricks (padding items). */
+int mednet_conv3d_stats_plan(int n, int d, int h, int w, int cin, int cout, int dtype, int gnb, int stride, int* out13);
 int mednet_conv3d_fused_stats_chunks(int n, int d, int h, int w, int cin, int cout, int ksize, int x_dtype,
                                      int y_dtype, int algo);
 int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void* y, int n, int d, int h, int w,

@@ -1,0 +1,167 @@
+"""Host-side audit of the fused partial-row plans -- runs WITHOUT a GPU, through the C ABI.
+
+For every 3x3x3 layer of BASELINE config 5 (160x160x96, N=2) and config 2 / 4 (128^3, N=4), in the forward form, the
+data-gradient form with GroupNorm-backward sums and the ConvTranspose data-gradient form, `mednet_conv3d_stats_plan` returns the
+launch plan made by the launcher's own planning code (kernel, grid, work items, rows per sample).  The test walks that plan
+with the row rule the header documents for each kernel and asserts that
+
+  * the set of (sample, row, channel block) slots the kernel WRITES equals the set the reducers READ -- all `rows` rows of
+    all channel blocks of all samples (mednet_gn_finalize / mednet_gn_act_bwd_fused read partial[n][0..rows)[0..C)) -- each
+    written exactly once;
+  * every (brick, channel block) of the output is computed exactly once;
+  * a workgroup that accumulates over its items sees non-decreasing sample indices and a constant channel block (its
+    running sums are flushed when the sample changes, never re-opened).
+The rows the producers of `mednet_head_dgrad_gn` / `mednet_pool2_bwd_gn` / the first-layer kernel write are one per wave of a
+grid that is derived from the row count itself; they are covered by the GPU poison test (tests/test_gpu_ops.py).
+"""
+import ctypes as C
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "torch-mednet_amd"))
+from mednet_hip import _lib as L  # noqa: E402
+
+BF16, F16 = L.BF16, L.F16
+
+
+def plan(n, d, h, w, cin, cout, dtype, gnb, stride):
+    lib = L.lib()
+    lib.mednet_set_option(b"assume_cus", 256)  # the MI355X's CU count (the 32 -> 32 specialisation is laid out for it)
+    out = (C.c_int * 13)()
+    rc = lib.mednet_conv3d_stats_plan(n, d, h, w, cin, cout, dtype, int(gnb), stride, C.addressof(out))
+    lib.mednet_set_option(b"assume_cus", 0)
+    assert rc == 0, lib.mednet_last_error().decode()
+    keys = ("kind", "grid", "nitems", "ncb", "ntiles", "tps", "accum", "rows", "xcd_chunk", "zslab", "tiles_x", "tiles_y", "tiles_z")
+    return dict(zip(keys, out))
+
+
+def audit(n, p):
+    """Walk the plan; returns (written slots as a dict (sample, row, cb) -> count, computed (brick, cb) -> count)."""
+    written, computed = {}, {}
+
+    def put(table, key):
+        table[key] = table.get(key, 0) + 1
+
+    if p["kind"] in (2, 3):
+        grid, ncb = p["grid"], p["ncb"]
+        for b in range(grid):
+            items = []
+            i = b
+            while i < p["nitems"]:
+                tile, cb = (i >> 3) // ncb * 8 + (i & 7), (i >> 3) % ncb
+                if tile >= p["ntiles"]:
+                    break  # padding item: the kernel returns (first item) or stops (later ones)
+                items.append((tile, cb))
+                i += grid
+            for tile, cb in items:
+                put(computed, (tile, cb))
+            if p["kind"] == 2:
+                for tile, cb in items:
+                    for wv in range(4):
+                        put(written, (tile // p["tps"], (tile % p["tps"]) * 4 + wv, cb))
+            elif items:  # accumulate mode: one row per wave for EVERY sample, in the workgroup's (constant) channel block
+                assert len({cb for _, cb in items}) == 1, f"workgroup {b} changes its channel block"
+                samples = [t // p["tps"] for t, _ in items]
+                assert samples == sorted(samples), f"workgroup {b} re-opens a sample: {samples}"
+                row0 = ((b >> 3) // ncb * 8 + (b & 7)) * 4
+                for nn in range(n):
+                    for wv in range(4):
+                        put(written, (nn, row0 + wv, items[0][1]))
+    elif p["kind"] == 4:
+        grid = p["grid"]
+        assert grid == 256 and p["ncb"] == 1
+        for b in range(grid):
+            xcd = b & 7
+            seq, step, end = (b >> 3, grid >> 3, p["xcd_chunk"]) if p["xcd_chunk"] else (b, grid, p["ntiles"])
+            samples = []
+            q = seq
+            while q < end:
+                if p["zslab"]:
+                    tx, qd = q % p["tiles_x"], q // p["tiles_x"]
+                    ty, zz = qd // p["zslab"], xcd * p["zslab"] + qd % p["zslab"]
+                    nn, tz = zz // p["tiles_z"], zz % p["tiles_z"]
+                else:
+                    tt = xcd * p["xcd_chunk"] + q if p["xcd_chunk"] else q
+                    tx, tt = tt % p["tiles_x"], tt // p["tiles_x"]
+                    ty, tt = tt % p["tiles_y"], tt // p["tiles_y"]
+                    tz, nn = tt % p["tiles_z"], tt // p["tiles_z"]
+                assert 0 <= tx < p["tiles_x"] and 0 <= ty < p["tiles_y"] and 0 <= tz < p["tiles_z"] and 0 <= nn < n, (b, q)
+                put(computed, (((nn * p["tiles_z"] + tz) * p["tiles_y"] + ty) * p["tiles_x"] + tx, 0))
+                samples.append(nn)
+                q += step
+            assert samples == sorted(samples), f"workgroup {b} re-opens a sample"
+            for nn in range(n):  # (workgroups without bricks still owe their zero rows)
+                for wv in range(4):
+                    put(written, (nn, b * 4 + wv, 0))
+    else:
+        raise AssertionError(f"unknown plan kind {p['kind']}")
+    return written, computed
+
+
+def check(n, d, h, w, cin, cout, dtype, gnb, stride):
+    p = plan(n, d, h, w, cin, cout, dtype, gnb, stride)
+    written, computed = audit(n, p)
+    what = f"n={n} {d}x{h}x{w} {cin}->{cout} gnb={gnb} stride={stride} plan={p}"
+    want_rows = {(nn, r, cb) for nn in range(n) for r in range(p["rows"]) for cb in range(p["ncb"])}
+    missing = want_rows - set(written)
+    extra = set(written) - want_rows
+    assert not missing, f"{what}: {len(missing)} partial rows are read by the reducer but never written, e.g. {sorted(missing)[:4]}"
+    assert not extra, f"{what}: rows written outside the buffer the reducer reads, e.g. {sorted(extra)[:4]}"
+    assert all(c == 1 for c in written.values()), f"{what}: rows written more than once"
+    want_out = {(t, cb) for t in range(p["ntiles"]) for cb in range(p["ncb"])}
+    assert set(computed) == want_out and all(c == 1 for c in computed.values()), f"{what}: output bricks not covered exactly once"
+    return p
+
+
+def unet_layers(f_maps, size, n):
+    """(n, d, h, w, cin, cout) of every 3x3x3 Conv3d of ResidualUNet3D(f_maps) except the 1-channel first layer, and (n, d, h, w,
+    cin, cout) of every ConvTranspose3d at its LOW-resolution grid (model.py:140-214, components.py:136-180,259-264)."""
+    convs, convts = [], []
+    d, h, w = size
+    for lvl, f in enumerate(f_maps):
+        if lvl:
+            d, h, w = d // 2, h // 2, w // 2
+            convs.append((n, d, h, w, f_maps[lvl - 1], f))  # conv1 of the encoder's ExtResNetBlock
+        convs.append((n, d, h, w, f, f))  # conv2 / conv3 (and the decoder block's three convs at this level)
+    d, h, w = size
+    dims = [(d >> k, h >> k, w >> k) for k in range(len(f_maps))]
+    for lvl in range(len(f_maps) - 1, 0, -1):
+        convts.append((n,) + dims[lvl] + (f_maps[lvl], f_maps[lvl - 1]))
+    return convs, convts
+
+
+CFG = {"cfg5": ([64, 128, 256, 512, 1024], (160, 160, 96), 2), "cfg2": ([32, 64, 128, 256], (128, 128, 128), 4),
+       "cfg2_n1": ([32, 64, 128, 256], (128, 128, 128), 1), "odd": ([32, 64, 96], (36, 44, 20), 3)}
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("cfg", sorted(CFG))
+def test_every_partial_row_is_written_exactly_once(cfg, dtype):
+    f_maps, size, n = CFG[cfg]
+    convs, convts = unet_layers(f_maps, size, n)
+    kinds = set()
+    for (nn, d, h, w, cin, cout) in convs:
+        kinds.add(check(nn, d, h, w, cin, cout, dtype, False, 1)["kind"])  # forward + GroupNorm statistics
+        kinds.add(check(nn, d, h, w, cout, cin, dtype, True, 1)["kind"])  # data gradient + GroupNorm-backward sums
+    for (nn, d, h, w, cin, cout) in convts:
+        kinds.add(check(nn, d, h, w, cin, cout, dtype, True, 2)["kind"])  # ConvTranspose data gradient + GroupNorm-3 sums
+    if cfg == "cfg5":
+        assert kinds == {2, 3}, kinds  # per-brick rows (levels 3, 4) and accumulate mode (levels 0 - 2)
+    if cfg == "cfg2":
+        assert kinds == {2, 3, 4}, kinds  # + the 32 -> 32 specialisation
+
+
+@pytest.mark.parametrize("shape", [(9, 11, 21), (4, 8, 16), (130, 70, 34), (64, 64, 64), (5, 300, 17)])
+@pytest.mark.parametrize("n", [1, 2, 5])
+@pytest.mark.parametrize("chan", [(16, 16), (32, 32), (32, 64), (96, 32), (48, 80)])
+def test_ragged_shapes(shape, n, chan):
+    """Brick counts that are not multiples of 8 (padding items), 16-channel half blocks, channel block counts that do not
+    divide 64 (no accumulate mode), the 32 -> 32 specialisation with and without the z-slab walk."""
+    d, h, w = shape
+    for gnb in (False, True):
+        check(n, d, h, w, chan[0], chan[1], BF16, gnb, 1)
+    if chan[0] % 32 == 0 and chan[1] % 32 == 0:
+        check(n, d, h, w, chan[0], chan[1], BF16, True, 2)

@@ -592,6 +592,10 @@ def main():
         ("res_cfg5_small", R, dict(in_channels=1, out_channels=4, final_sigmoid=False,
                                    f_maps=[64, 128, 256, 512, 1024]), (32, 32, 16), 1, 4, 0, "dice", seg_w4, 0, 8,
          False, True),
+        # BASELINE config 5 at its real size (one sample: the CPU run peaks at ~30 GB and takes minutes)
+        ("res_cfg5_full", R, dict(in_channels=1, out_channels=4, final_sigmoid=False,
+                                  f_maps=[64, 128, 256, 512, 1024]), (160, 160, 96), 1, 4, 0, "dice", seg_w4, 0, 16,
+         False, True),
     ]
     for (tag, (rc, oc), ctor, shape, n, ncls, nh, lk, w, fl, stride, adam, large) in nets:
         if not want(tag) or (large and a.skip_large):

@@ -33,6 +33,8 @@ int mednet_internal_tuning_option(const char* name, int default_value) {
 
 // CUs of the current device, asked once (the one-workgroup-per-CU kernels are laid out for the MI355X's 256)
 int mednet_internal_cu_count(void) {
+  const int assumed = mednet_internal_tuning_option("assume_cus", 0);  // plan audits without a device (tests/test_plan_audit.py)
+  if (assumed > 0) return assumed;
   static int cus = -1;
   if (cus < 0) {
     int dev = 0, n = 0;
@@ -51,6 +53,11 @@ using namespace mednet;
 // the 16-bit matrix-core family by element type: `dt` is the dtype of the 16-bit operand(s) of the call
 #define ELT_CALL(dt, fn, ...) ((dt) == MEDNET_F16 ? mednet_f16::fn(__VA_ARGS__) : mednet::fn(__VA_ARGS__))
 static inline bool is16(int dt) { return dt == MEDNET_BF16 || dt == MEDNET_F16; }
+// `algo` arguments: a base choice (AUTO / DIRECT / MFMA) and, separately, the request for exact fp32 products in the fp32
+// storage mode (MEDNET_ALGO_EXACT_BIT; MEDNET_ALGO_EXACT = AUTO with that request).  MFMA + exact = "the matrix-core path
+// is required AND its products must be exact": the fp32 matrix instruction, never the split-bf16 contraction.
+static inline bool algo_exact(int a) { return a == MEDNET_ALGO_EXACT || (a > MEDNET_ALGO_EXACT && (a & MEDNET_ALGO_EXACT_BIT)); }
+static inline int algo_base(int a) { return (a & 3) == MEDNET_ALGO_EXACT ? MEDNET_ALGO_AUTO : (a & 3); }
 
 extern "C" int mednet_set_option(const char* name, int value) {
   for (int i = 0; i < g_noptions; ++i)
@@ -88,9 +95,13 @@ extern "C" int mednet_conv3d_pack(const float* w, void* packed, int cin, int cou
 }
 extern "C" int mednet_conv3d_pack_elt(const float* w, void* packed, int cin, int cout, int ksize, int transposed_src,
                                       int elt_dtype, mednet_stream stream) {
-  // MEDNET_F32 = the fp32 storage mode: bf16 high images + the low images of the split-bf16 contraction (conv_x3_mfma.hip)
-  const bool with_low = elt_dtype == MEDNET_F32;
-  if (with_low) elt_dtype = MEDNET_BF16;
+  // Every bf16 pack also holds the LOW images of the split-bf16 contraction (conv_x3_mfma.hip), so a buffer packed for
+  // bf16 storage serves fp32-storage calls too: they contract against bf16(w) + bf16(w - bf16(w)) and must never find that
+  // region unwritten (round 3 wrote it for MEDNET_F32 only; a caller who packed with mednet_conv3d_pack, as the header of
+  // round 2 said, then ran an fp32 conv got uninitialised memory).  MEDNET_F32 = MEDNET_BF16 here.  An fp16 pack has fp16
+  // images in the high slots and no room for bf16 ones: it serves fp16-storage calls only (include/mednet_hip.h).
+  if (elt_dtype == MEDNET_F32) elt_dtype = MEDNET_BF16;
+  const bool with_low = elt_dtype == MEDNET_BF16;
   MEDNET_REQUIRE(is16(elt_dtype), MEDNET_E_DTYPE, "conv3d_pack: the matrix-core images are bf16 or fp16 (got dtype %d)", elt_dtype);
   MEDNET_REQUIRE(ksize == 3 || ksize == 1, MEDNET_E_UNSUPPORTED, "conv3d_pack: kernel size %d (supported: 1, 3)", ksize);
   MEDNET_REQUIRE(cin > 0 && cout > 0, MEDNET_E_SHAPE, "conv3d_pack: bad channels %d -> %d", cin, cout);
@@ -138,8 +149,8 @@ extern "C" int mednet_conv3d_pack_table(const mednet_pack_job* jobs, int njobs, 
 }
 extern "C" int mednet_conv3d_pack_many(const void* table_device, int njobs, unsigned max_blocks, int elt_dtype,
                                        mednet_stream stream) {
-  const bool with_low = elt_dtype == MEDNET_F32;  // fp32 storage mode: bf16 high + low images (see mednet_conv3d_pack_elt)
-  if (with_low) elt_dtype = MEDNET_BF16;
+  if (elt_dtype == MEDNET_F32) elt_dtype = MEDNET_BF16;
+  const bool with_low = elt_dtype == MEDNET_BF16;  // bf16 high + low images always (see mednet_conv3d_pack_elt)
   MEDNET_REQUIRE(is16(elt_dtype), MEDNET_E_DTYPE, "conv3d_pack_many: the matrix-core images are bf16 or fp16 (got dtype %d)", elt_dtype);
   MEDNET_REQUIRE(table_device && njobs > 0 && njobs <= 65535 && max_blocks > 0, MEDNET_E_SHAPE, "conv3d_pack_many: bad arguments");
   return ELT_CALL(elt_dtype, launch_pack_mfma_many, table_device, njobs, max_blocks, (hipStream_t)stream, with_low ? 1 : 0);
@@ -155,15 +166,26 @@ static int conv_common_checks(const char* who, int n, int d, int h, int w, int c
 
 extern "C" int mednet_conv3d_fused_stats_chunks(int n, int d, int h, int w, int cin, int cout, int ksize, int x_dtype,
                                                 int y_dtype, int algo) {
-  if (algo == MEDNET_ALGO_DIRECT || !tuning_option("conv_fuse_stats", 1)) return 0;
+  if (algo_base(algo) == MEDNET_ALGO_DIRECT || !tuning_option("conv_fuse_stats", 1)) return 0;
   if (x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32) {  // fp32 storage: the split-bf16 forward kernels keep the sums per wave
-    if (!(conv_f32_mfma_enabled() && algo != MEDNET_ALGO_EXACT && conv_x3_enabled())) return 0;
+    if (!(conv_f32_mfma_enabled() && !algo_exact(algo) && conv_x3_enabled())) return 0;
     if (conv_c1_x3_supported(cin, cout, ksize)) return tuning_option("x3_stats", 1) ? conv_c1_x3_stats_rows(d, h, w) : 0;
     return conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin) ? conv_x3_stats_rows(n, d, h, w, cout) : 0;
   }
   if (ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, false)) return conv_c1_stats_chunks(d, h, w);
   if (!ELT_CALL(y_dtype, conv_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, MEDNET_NDHWC, false)) return 0;
   return conv_mfma_stats_chunks(n, d, h, w, cin, cout);
+}
+
+// Launch plan of the producer of a 3x3x3 layer's fused partial rows, computed by the launcher's own planning code (no device
+// needed): which kernel, its grid, its work items and how rows are assigned.  tests/test_plan_audit.py derives from it the set
+// of (sample, row, channel block) slots the kernel writes and asserts it equals the set mednet_gn_finalize /
+// mednet_gn_act_bwd_fused read.
+extern "C" int mednet_conv3d_stats_plan(int n, int d, int h, int w, int cin, int cout, int dtype, int gnb, int stride, int* out13) {
+  MEDNET_REQUIRE(out13 && n > 0 && d > 0 && h > 0 && w > 0 && (stride == 1 || stride == 2), MEDNET_E_SHAPE, "conv3d_stats_plan: bad arguments");
+  MEDNET_REQUIRE(is16(dtype) && cin % 16 == 0 && cout % 16 == 0, MEDNET_E_UNSUPPORTED,
+                 "conv3d_stats_plan: the 16-bit matrix-core kernels only (dtype %d, %d -> %d)", dtype, cin, cout);
+  return ELT_CALL(dtype, conv_mfma_plan, n, d, h, w, cin, cout, gnb != 0, stride, out13);
 }
 
 extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void* y, int n, int d, int h,
@@ -177,23 +199,23 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = ELT_CALL(y_dtype, conv_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, x_layout, y_layout, bias != nullptr) &&
                        conv_mfma_fits(n, d, h, w, cin);
-  if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
+  if (algo_base(algo) == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_fwd: MFMA path does not take cin=%d cout=%d k=%d dtypes %d->%d", cin, cout,
                 ksize, x_dtype, y_dtype);
-  if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
+  if (mfma_ok && algo_base(algo) != MEDNET_ALGO_DIRECT)
     return ELT_CALL(y_dtype, launch_conv_mfma, x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), y, n, d, h, w, cin, cout, x_dtype,
                     y_dtype, gn_partial, s, MEDNET_ACT_NONE, nullptr);
   // first layer (one input channel): contraction over the 27 taps on the matrix cores
-  if (!dgrad && algo != MEDNET_ALGO_DIRECT && x_layout == MEDNET_NDHWC &&
+  if (!dgrad && algo_base(algo) != MEDNET_ALGO_DIRECT && x_layout == MEDNET_NDHWC &&
       ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, y_layout, bias != nullptr))
     return ELT_CALL(y_dtype, launch_conv_c1_mfma, x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, gn_partial, s, x_dtype);
   // fp32 storage (the 1e-3 parity mode): 3x3x3 forward / data gradient as a split-bf16 contraction on the bf16 matrix cores
   // (three MFMAs per product; the pack must hold the low images: mednet_conv3d_pack_elt(MEDNET_F32)) ...
-  const bool f32_mode = algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 &&
+  const bool f32_mode = algo_base(algo) != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 &&
                         y_dtype == MEDNET_F32 && (x_layout == MEDNET_NDHWC || cin == 1) && y_layout == MEDNET_NDHWC;
-  if (f32_mode && (algo != MEDNET_ALGO_EXACT && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin))
+  if (f32_mode && (!algo_exact(algo) && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin))
     return launch_conv_x3(x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), L.lo_delta, bias, y, n, d, h, w, cin, cout, gn_partial, s);
-  if (f32_mode && !dgrad && algo != MEDNET_ALGO_EXACT && conv_x3_enabled() && conv_c1_x3_supported(cin, cout, ksize))  // first layer
+  if (f32_mode && !dgrad && !algo_exact(algo) && conv_x3_enabled() && conv_c1_x3_supported(cin, cout, ksize))  // first layer
     return launch_conv_c1_x3(x, (const float*)(base + L.f32_fwd), bias, y, n, d, h, w, cout, gn_partial, s);
   MEDNET_REQUIRE(gn_partial == nullptr, MEDNET_E_UNSUPPORTED,
                  "conv3d_fwd: fused GroupNorm partials are only produced by the MFMA paths (ask mednet_conv3d_fused_stats_chunks)");
@@ -201,11 +223,11 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
   if (f32_mode)
     return launch_conv_f32_mfma(x, (const float*)(base + (dgrad ? L.f32_bwd : L.f32_fwd)), bias, y, n, d, h, w, cin, cout, s);
   // 1x1x1 head forward (channels-last features -> planar fp32 logits): the packed backward image Pb[t=0][co][ci] = W[m][k]
-  if (!dgrad && algo != MEDNET_ALGO_DIRECT && ksize == 1 && x_layout == MEDNET_NDHWC && y_layout == MEDNET_NCDHW &&
+  if (!dgrad && algo_base(algo) != MEDNET_ALGO_DIRECT && ksize == 1 && x_layout == MEDNET_NDHWC && y_layout == MEDNET_NCDHW &&
       y_dtype == MEDNET_F32 && head_vox_supported(cin))
     return launch_head_fwd_vox(x, (const float*)(base + L.f32_bwd), bias, (float*)y, n, (size_t)d * h * w, cin, cout, x_dtype, s);
   // data gradient of the 1x1x1 head: the packed backward image Pb[t=0][co][ci] is exactly W[m][k]
-  if (dgrad && !bias && algo != MEDNET_ALGO_DIRECT && head_dgrad_supported(cin, cout, ksize, x_dtype, x_layout, y_layout))
+  if (dgrad && !bias && algo_base(algo) != MEDNET_ALGO_DIRECT && head_dgrad_supported(cin, cout, ksize, x_dtype, x_layout, y_layout))
     return launch_head_dgrad(x, (const float*)(base + L.f32_bwd), y, n, (size_t)d * h * w, cin, cout, y_dtype, s);
   ConvGeom g;
   g.n = n; g.od = d; g.oh = h; g.ow = w; g.id = d; g.ih = h; g.iw = w;
@@ -245,22 +267,22 @@ extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, flo
     if (rc) return rc;
     ws_bytes = (ws_bytes - need) / 256 * 256;
   }
-  if (algo != MEDNET_ALGO_DIRECT && wgrad_c1_supported(cin, cout, ksize, x_layout, dy_layout))
-    return launch_wgrad_c1(x, dy, dw, n, d, h, w, cout, x_dtype, dy_dtype, ws, ws_bytes, s, algo != MEDNET_ALGO_EXACT && conv_x3_enabled());
-  if (algo != MEDNET_ALGO_DIRECT && wgrad_1x1_supported(cin, cout, ksize, x_layout, dy_layout, dy_dtype))
+  if (algo_base(algo) != MEDNET_ALGO_DIRECT && wgrad_c1_supported(cin, cout, ksize, x_layout, dy_layout))
+    return launch_wgrad_c1(x, dy, dw, n, d, h, w, cout, x_dtype, dy_dtype, ws, ws_bytes, s, !algo_exact(algo) && conv_x3_enabled());
+  if (algo_base(algo) != MEDNET_ALGO_DIRECT && wgrad_1x1_supported(cin, cout, ksize, x_layout, dy_layout, dy_dtype))
     return launch_wgrad_1x1(x, dy, dw, n, (size_t)d * h * w, cin, cout, x_dtype, ws, ws_bytes, s);
-  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32 &&
+  if (algo_base(algo) != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32 &&
       (x_layout == MEDNET_NDHWC || cin == 1) && dy_layout == MEDNET_NDHWC) {
     const int cmax = cin > cout ? cin : cout;
-    if ((algo != MEDNET_ALGO_EXACT && conv_x3_enabled()) && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cmax))
+    if ((!algo_exact(algo) && conv_x3_enabled()) && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cmax))
       return launch_wgrad_x3(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);  // split-bf16 contraction over the voxels
     return launch_wgrad_f32_mfma(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
   }
   const bool mfma_ok = ELT_CALL(dy_dtype, wgrad_mfma_supported, cin, cout, ksize, x_dtype, dy_dtype, x_layout, dy_layout) &&
                        wgrad_mfma_fits(n, d, h, w, cin > cout ? cin : cout, 1);
-  if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
+  if (algo_base(algo) == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_wgrad: MFMA path does not take cin=%d cout=%d k=%d", cin, cout, ksize);
-  if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
+  if (mfma_ok && algo_base(algo) != MEDNET_ALGO_DIRECT)
     return ELT_CALL(dy_dtype, launch_wgrad_mfma, x, dy, dw, n, d, h, w, cin, cout, x_dtype, ws, ws_bytes, s);
   WgradGeom g;
   g.n = n; g.ad = d; g.ah = h; g.aw = w; g.bd = d; g.bh = h; g.bw = w;
@@ -272,7 +294,7 @@ extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, flo
 
 // conv 3x3x3 (no bias) + activation in the epilogue: the 'gcr' / 'gcl' / 'gce' orders of components.py:12-67 (UNet3D)
 extern "C" int mednet_conv3d_act_supported(int n, int d, int h, int w, int cin, int cout, int algo) {
-  return algo != MEDNET_ALGO_DIRECT &&
+  return algo_base(algo) != MEDNET_ALGO_DIRECT &&
          conv_mfma_supported(cin, cout, 3, MEDNET_BF16, MEDNET_BF16, MEDNET_NDHWC, MEDNET_NDHWC, false) &&
          conv_mfma_fits(n, d, h, w, cin) && conv_mfma_fits(n, d, h, w, cout);
 }
@@ -294,7 +316,7 @@ extern "C" int mednet_conv3d_act_fwd(const void* x, const void* packed, void* y,
 // the layer Cin -> Cout?
 static bool x3_dgrad_ok(int n, int d, int h, int w, int cin, int cout, int algo) {
   (void)n;
-  return algo != MEDNET_ALGO_DIRECT && algo != MEDNET_ALGO_EXACT && conv_f32_mfma_enabled() && conv_x3_enabled() &&
+  return algo_base(algo) != MEDNET_ALGO_DIRECT && !algo_exact(algo) && conv_f32_mfma_enabled() && conv_x3_enabled() &&
          conv_x3_supported(cin, cout, 3) && conv_x3_fits(d, h, w, cout);
 }
 extern "C" int mednet_conv3d_dgrad_add_supported(int n, int d, int h, int w, int cin, int cout, int algo, int dtype) {
@@ -384,13 +406,13 @@ extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float
   if (rc) return rc;
   const PackLayout L = pack_layout(cin, cout, 3);
   const bool mfma_ok = L.mfma_bytes && cin % 32 == 0 && cout % 32 == 0 && is16(x_dtype) && y_dtype == x_dtype;
-  if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
+  if (algo_base(algo) == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_fwd: MFMA path does not take cin=%d cout=%d", cin, cout);
-  if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
+  if (mfma_ok && algo_base(algo) != MEDNET_ALGO_DIRECT)
     return ELT_CALL(x_dtype, launch_convt_fwd_mfma, x, (const char*)packed + L.mfma_fwd, bias, skip, y, n, d, h, w, cin, cout,
                     (hipStream_t)stream);
-  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32) {
-    if ((algo != MEDNET_ALGO_EXACT && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, 3))
+  if (algo_base(algo) != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32) {
+    if ((!algo_exact(algo) && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, 3))
       return launch_convt_fwd_x3(x, (const char*)packed + L.mfma_fwd, L.lo_delta, bias, skip, y, n, d, h, w, cin, cout,
                                  (hipStream_t)stream);
     return launch_convt_fwd_f32_mfma(x, (const float*)((const char*)packed + L.f32_fwd), bias, skip, y, n, d, h, w, cin, cout,
@@ -410,13 +432,13 @@ extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx
   const PackLayout L = pack_layout(cin, cout, 3);
   const bool mfma_ok = L.mfma_bytes && cin % 32 == 0 && cout % 32 == 0 && is16(dy_dtype) && dx_dtype == dy_dtype &&
                        conv_mfma_fits(n, 2 * d, 2 * h, 2 * w, cout);
-  if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
+  if (algo_base(algo) == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_dgrad: MFMA path does not take cin=%d cout=%d", cin, cout);
-  if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
+  if (mfma_ok && algo_base(algo) != MEDNET_ALGO_DIRECT)
     return ELT_CALL(dy_dtype, launch_convt_dgrad_mfma, dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cin, cout,
                     (hipStream_t)stream);
-  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && dy_dtype == MEDNET_F32 && dx_dtype == MEDNET_F32) {
-    if ((algo != MEDNET_ALGO_EXACT && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, 3) && conv_x3_fits(2 * d, 2 * h, 2 * w, cout))
+  if (algo_base(algo) != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && dy_dtype == MEDNET_F32 && dx_dtype == MEDNET_F32) {
+    if ((!algo_exact(algo) && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, 3) && conv_x3_fits(2 * d, 2 * h, 2 * w, cout))
       return launch_convt_dgrad_x3(dy, (const char*)packed + L.mfma_bwd, L.lo_delta, dx, n, d, h, w, cin, cout, (hipStream_t)stream);
     return launch_convt_dgrad_f32_mfma(dy, (const float*)((const char*)packed + L.f32_bwd), dx, n, d, h, w, cin, cout,
                                        (hipStream_t)stream);
@@ -433,7 +455,7 @@ static bool convt_dgrad_mfma_ok(int n, int d, int h, int w, int cin, int cout, i
   return L.mfma_bytes && cin % 32 == 0 && cout % 32 == 0 && is16(dtype) && conv_mfma_fits(n, 2 * d, 2 * h, 2 * w, cout);
 }
 extern "C" int mednet_convt3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int dtype, int algo) {
-  if (algo == MEDNET_ALGO_DIRECT || !tuning_option("gn3_fuse", 1) || !convt_dgrad_mfma_ok(n, d, h, w, cin, cout, dtype)) return 0;
+  if (algo_base(algo) == MEDNET_ALGO_DIRECT || !tuning_option("gn3_fuse", 1) || !convt_dgrad_mfma_ok(n, d, h, w, cin, cout, dtype)) return 0;
   return ELT_CALL(dtype, convt_dgrad_gn_rows, d, h, w);
 }
 extern "C" int mednet_convt3d_dgrad_gn(const void* dy, const void* packed, void* dx, const void* gn_y, const void* gn_z, int gn_act,
@@ -473,17 +495,17 @@ extern "C" int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, fl
     if (rc) return rc;
     ws_bytes = (ws_bytes - need) / 256 * 256;
   }
-  if (algo != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32) {
-    if (algo != MEDNET_ALGO_EXACT && conv_x3_enabled() && tuning_option("x3_convt_wgrad", 1) && conv_x3_supported(cin, cout, 3) &&
+  if (algo_base(algo) != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32) {
+    if (!algo_exact(algo) && conv_x3_enabled() && tuning_option("x3_convt_wgrad", 1) && conv_x3_supported(cin, cout, 3) &&
         conv_x3_fits(2 * d, 2 * h, 2 * w, cout) && conv_x3_fits(d, h, w, cin))
       return launch_convt_wgrad_x3(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);  // split-bf16, output-parity planes
     return launch_convt_wgrad_f32_mfma(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
   }
   const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0 && is16(x_dtype) && dy_dtype == x_dtype &&
                        wgrad_mfma_fits(n, d, h, w, cin > 8 * cout ? cin : 8 * cout, 1);
-  if (algo == MEDNET_ALGO_MFMA && !mfma_ok)
+  if (algo_base(algo) == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_wgrad: MFMA path does not take cin=%d cout=%d", cin, cout);
-  if (mfma_ok && algo != MEDNET_ALGO_DIRECT)
+  if (mfma_ok && algo_base(algo) != MEDNET_ALGO_DIRECT)
     return ELT_CALL(x_dtype, launch_convt_wgrad_mfma, x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
   WgradGeom g;
   g.n = n; g.ad = d; g.ah = h; g.aw = w; g.bd = 2 * d; g.bh = 2 * h; g.bw = 2 * w;

@@ -956,6 +956,11 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
           if constexpr (GNB && !GNB_LDS) yrw[j] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(a.gnb_y, j), vb, row_soff(j), 0));
         }
         if constexpr (GNB_LDS) {
+          // The DMAs below overwrite chunk-0 planes that OTHER waves read as B operands (a wave's z-plane needs the halo planes
+          // of its neighbours) until THEIR step 26.  This wave is past its own (the MFMAs of step 26 have consumed them), but
+          // waves of a workgroup are not in lockstep: one barrier here -- every wave arrives within a few hundred cycles of
+          // the others, one wave per SIMD -- makes "dead from step 27 on" true for the workgroup, not only for this wave.
+          if (t == 2 && s54 == 27) __builtin_amdgcn_s_barrier();
           if (t == 2 && s54 >= 27 && s54 < 35) {  // GroupNorm input row s54 - 27 -> LDS (row planned at step 24 + row)
             const int j = s54 - 27;
             // (the resource is built here, not by the row_rsrc lambda: handed a lambda's return value, hipcc 7.2 silently drops
@@ -981,9 +986,13 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
     const int e_lx = ((r & 15) - (r >> 4) * HX) & 15;
     const int e_sw = (e_lx >> 1) & 7;
     eltx8 rows[8];
-    // LDS operations of a wave execute in order: half 1's writes may follow half 0's reads directly
+    // LDS operations of a wave execute in order, so the hardware needs no barrier between a half's writes, the other lanes'
+    // reads of them and the next half's writes.  The COMPILER does: to it the lanes are threads, its alias analysis is per
+    // thread, and it may move a lane's read above that lane's own write (it did, in the ConvTranspose epilogue of the split-bf16
+    // kernels, commit 29d6f66).  wave_lds_fence() emits no instruction; it pins the order of the memory operations.
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+      wave_lds_fence();  // (half 1: the reads of half 0 stay above these writes)
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int t = 2 * half + tt;
@@ -996,6 +1005,7 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
           *reinterpret_cast<eltx4*>(wlds + vl * 32 + ((2 * q + h) ^ e_sw) * 4) = o;
         }
       }
+      wave_lds_fence();  // the rows below were written by OTHER lanes of this wave
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int vox = j * 16 + ev, swl = (vox >> 1) & 7;
@@ -1671,6 +1681,13 @@ static void conv_stats_plan(int n, int d, int h, int w, int cin, int cout, int& 
   rows = accum ? (512 / ncb) * 4 : 4 * tps;
 }
 
+// What a launch of the forward / data-gradient family is made of, for audits without a device (mednet_conv3d_stats_plan,
+// tests/test_plan_audit.py): the launcher fills it from the SAME code path that launches and returns before the launch.
+struct FwdPlanProbe {
+  int kind;  // 2: general kernel, one statistics row per wave and brick; 3: general kernel, accumulate mode; 4: conv32_mfma_kernel
+  int grid, nitems, ncb, ntiles, tiles_per_sample, accum, rows, xcd_chunk, zslab, tiles_x, tiles_y, tiles_z;
+};
+
 struct GnbSpec {  // fused first pass of a GroupNorm backward (see FwdArgs::gnb_y); partial goes through gn_partial
   const void* y = nullptr;
   const float* coef = nullptr;
@@ -1681,7 +1698,7 @@ struct GnbSpec {  // fused first pass of a GroupNorm backward (see FwdArgs::gnb_
 template <int STRIDE>
 static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, int oh, int ow, int id, int ih, int iw,
                       int cin, int cout, float* gn_partial, hipStream_t s, int act = MEDNET_ACT_NONE,
-                      const void* add = nullptr, GnbSpec gnb = GnbSpec()) {
+                      const void* add = nullptr, GnbSpec gnb = GnbSpec(), FwdPlanProbe* probe = nullptr) {
   using G = FwdTile<STRIDE>;
   constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
   constexpr size_t lds = ((size_t)2 * HZ * HY * HX + 27 * 2 * 32) * 16;
@@ -1740,6 +1757,11 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
       const int variant = use_gnb ? (C32_GNB | (add ? C32_ADD : 0))
                                   : ((add ? C32_ADD : 0) | (gn_partial ? C32_STATS : 0) | (act != MEDNET_ACT_NONE ? C32_ACT : 0));
       MEDNET_REQUIRE(!use_gnb || act == MEDNET_ACT_NONE, MEDNET_E_UNSUPPORTED, "conv32_mfma: no activation in the data-gradient form");
+      if (probe) {
+        *probe = FwdPlanProbe{4, 256, a.ntiles, a.ncb, a.ntiles, a.tiles_z * a.tiles_y * a.tiles_x, a.stats_accum, a.stats_rows,
+                              a.xcd_chunk, a.zslab, a.tiles_x, a.tiles_y, a.tiles_z};
+        return MEDNET_OK;
+      }
       static bool attr32[16] = {};
       auto go = [&](auto kernel) -> int {
         if (!attr32[variant]) {
@@ -1766,6 +1788,11 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
       if (rc32) return rc32;
       return check_launch("conv32_mfma");
     }
+  }
+  if (probe) {
+    *probe = FwdPlanProbe{a.stats_accum ? 3 : 2, (int)grid, a.nitems, a.ncb, a.ntiles, a.tiles_z * a.tiles_y * a.tiles_x,
+                          a.stats_accum, a.stats_rows, 0, 0, a.tiles_x, a.tiles_y, a.tiles_z};
+    return MEDNET_OK;
   }
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[STRIDE]) {
@@ -1817,6 +1844,30 @@ int launch_conv_mfma_gnb(const void* dy, const void* packed_section, void* dx, i
   g.coef = gn_coef;
   g.act = gn_act;
   return launch_fwd<1>(dy, packed_section, dx, n, d, h, w, d, h, w, cin, cout, gn_partial, s, MEDNET_ACT_NONE, add, g);
+}
+// plan of launch_conv_mfma / launch_conv_mfma_gnb (stride 1) or launch_convt_dgrad_gn_mfma (stride 2; d, h, w = the LOW-resolution
+// grid the data gradient writes), with fused sums: out[13] = the fields of FwdPlanProbe in order
+int conv_mfma_plan(int n, int d, int h, int w, int cin, int cout, bool gnb, int stride, int* out) {
+  FwdPlanProbe p{};
+  float dummy_partial;  // (never dereferenced: the probe returns before the launch)
+  GnbSpec g;
+  int rc;
+  if (stride == 2) {
+    g.y = g.z = &dummy_partial;
+    rc = launch_fwd<2>(nullptr, nullptr, nullptr, n, d, h, w, 2 * d, 2 * h, 2 * w, cout, cin, &dummy_partial, nullptr, MEDNET_ACT_NONE,
+                       nullptr, g, &p);
+  } else {
+    if (gnb) {
+      g.y = &dummy_partial;
+      g.coef = &dummy_partial;
+    }
+    rc = launch_fwd<1>(nullptr, nullptr, nullptr, n, d, h, w, d, h, w, cin, cout, &dummy_partial, nullptr, MEDNET_ACT_NONE, nullptr, g, &p);
+  }
+  if (rc) return rc;
+  const int v[13] = {p.kind, p.grid, p.nitems, p.ncb, p.ntiles, p.tiles_per_sample, p.accum, p.rows, p.xcd_chunk, p.zslab,
+                     p.tiles_x, p.tiles_y, p.tiles_z};
+  for (int i = 0; i < 13; ++i) out[i] = v[i];
+  return MEDNET_OK;
 }
 int conv_mfma_stats_chunks(int n, int d, int h, int w, int cin, int cout, bool gnb) {
   int rows, accum;

@@ -19,6 +19,7 @@ NDHWC, NCDHW = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3
 POOL_MAX, POOL_AVG = 0, 1
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_EXACT = 0, 1, 2, 3
+ALGO_EXACT_BIT = 4  # OR-ed onto ALGO_MFMA: matrix-core path required AND exact fp32 products
 REG_L2, REG_L1 = 0, 1
 PAD_CONSTANT, PAD_SYMMETRIC = 0, 1
 F16, U8 = 2, 3  # storage types of resident volumes (mednet_crop_patches only)
@@ -38,6 +39,7 @@ SIGNATURES = {
     "mednet_conv3d_pack_table_bytes": (_sz, [_i]),
     "mednet_conv3d_pack_table": (_i, [_vp, _i, _vp, _vp]),
     "mednet_conv3d_pack_many": (_i, [_vp, _i, C.c_uint, _i, _vp]),
+    "mednet_conv3d_stats_plan": (_i, [_i] * 9 + [_vp]),
     "mednet_conv3d_fused_stats_chunks": (_i, [_i] * 10),
     "mednet_conv3d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _vp]),
     "mednet_gn_finalize": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _f, _vp, _sz, _vp]),

@@ -16,7 +16,7 @@ from torch.autograd import Function
 import os
 
 from . import _lib as L
-from . import config, ops
+from . import config, debug, ops
 
 ENABLED = os.environ.get("MEDNET_BLOCK_NODE", "1") == "1"
 WGRAD_FIRST = os.environ.get("MEDNET_WGRAD_FIRST", "1") == "1"  # A/B knob: launch order of the two gradients
@@ -158,6 +158,8 @@ class ResBlockFn(Function):
         z2, s2, c2 = _gn_fwd(y2, p2, g2, b2, groups, eps, act, None)
         y3, p3 = _conv_fwd(z2, pk3, cout, fuse)
         out, s3, c3 = _gn_fwd(y3, p3, g3, b3, groups, eps, act, z1)
+        if debug.TRACE is not None:
+            debug.trace("resblock.fwd", y1, p1, s1, c1, z1, y2, p2, s2, c2, z2, y3, p3, s3, c3, out)
         ctx.save_for_backward(xin, y1, z1, y2, z2, y3, out, s1, c1, s2, c2, s3, c3, pk1, pk2, pk3)
         ctx.params = (w1, g1, b1, w2, g2, b2, w3, g3, b3)
         ctx.meta = (groups, act)
@@ -186,6 +188,8 @@ class ResBlockFn(Function):
         dz1, dw2, part1 = _conv_bwd(z1, dy2, pk2, w2, True, add=dres if fuse else None, gnb=(y1, c1, act) if fuse else None)
         dy1, _, dg1, db1 = _gn_bwd(dz1, None if fuse else dres, y1, None, c1, s1, g1, b1, groups, act, False, partial=part1)
         dx, dw1, _ = _conv_bwd(xin, dy1, pk1, w1, ctx.needs_input_grad[0])
+        if debug.TRACE is not None:
+            debug.trace("resblock.bwd", dout, part3, dy3, dres, dz2, part2, dy2, dz1, part1, dy1, dx)
         return (dx, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + (None,) * 7
 
 

@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import threading
 
 import torch
 
@@ -46,12 +47,40 @@ def set_conv_algo(name: str):
     _state["algo"] = {"auto": _lib.ALGO_AUTO, "direct": _lib.ALGO_DIRECT, "mfma": _lib.ALGO_MFMA}[name]
 
 
+# Scopes (exact_products, algo_scope) are per THREAD: backward runs on autograd's worker thread while another model may
+# be in its forward on the main thread, and two threads driving two models must not see each other's request.
+_tls = threading.local()
+
+
+def _scope():
+    if not hasattr(_tls, "exact"):
+        _tls.exact, _tls.algo = False, None  # algo: the base choice replayed by a backward (None: the process setting)
+    return _tls
+
+
+def _compose(base: int, exact: bool) -> int:
+    """The C-ABI `algo` argument of a base choice plus the exact-products request (include/mednet_hip.h)."""
+    if not exact or base == _lib.ALGO_DIRECT:  # (the direct kernels' fp32 products are exact anyway)
+        return base
+    return _lib.ALGO_EXACT if base == _lib.ALGO_AUTO else (base | _lib.ALGO_EXACT_BIT)
+
+
+def _decompose(algo: int):
+    if algo == _lib.ALGO_EXACT:
+        return _lib.ALGO_AUTO, True
+    if algo > _lib.ALGO_EXACT and algo & _lib.ALGO_EXACT_BIT:
+        return algo & 3, True
+    return algo, False
+
+
 def conv_algo() -> int:
-    """Algorithm argument of the conv-family C-ABI calls.  Inside an `exact_products` scope the automatic choice becomes
-    ALGO_EXACT: in the fp32 storage mode the contraction then runs on exact fp32 products (v_mfma_f32_32x32x2_f32) instead of
-    the split-bf16 contraction (~2^-16 per product); nothing changes for the 16-bit modes."""
-    a = _state["algo"]
-    return _lib.ALGO_EXACT if (a == _lib.ALGO_AUTO and _state.get("exact")) else a
+    """Algorithm argument of the conv-family C-ABI calls: the base choice (set_conv_algo / MEDNET_CONV_ALGO, or the one a
+    backward replays) and -- kept SEPARATE from it -- the exact-products request of the enclosing scopes.  With the request on,
+    fp32-storage contractions run on exact fp32 products (v_mfma_f32_32x32x2_f32) instead of the split-bf16 contraction
+    (~2^-16 per product), whether the base choice is 'auto' (ALGO_EXACT) or 'mfma' (ALGO_MFMA | ALGO_EXACT_BIT); nothing
+    changes for the 16-bit modes."""
+    sc = _scope()
+    return _compose(_state["algo"] if sc.algo is None else sc.algo, sc.exact)
 
 
 @contextlib.contextmanager
@@ -61,27 +90,30 @@ def exact_products(on: bool = True):
     output flips a few activation masks and moves first-layer gradients by more than the 1e-3 budget (measured: UNet3D 'gcr'
     at 32^3, 1.4e-3).  Such layers therefore ask for exact fp32 products; the smooth default order 'cge' (ELU) does not.
     A scope only turns the request ON (an inner smooth layer inside a kinked network stays exact)."""
-    old = _state.get("exact", False)
+    sc = _scope()
+    old = sc.exact
     if on:
-        _state["exact"] = True
+        sc.exact = True
     try:
         yield
     finally:
-        _state["exact"] = old
+        sc.exact = old
 
 
 @contextlib.contextmanager
 def algo_scope(algo):
-    """Backward passes run outside the forward's scopes: replay the algorithm choice an op captured at forward."""
+    """Backward passes run outside the forward's scopes (and on another thread): replay the choice an op captured at
+    forward -- its base algorithm and its exact-products request, whatever scope the caller of backward() is in."""
     if algo is None:
         yield
         return
-    old = (_state["algo"], _state.get("exact", False))
-    _state["algo"], _state["exact"] = (_lib.ALGO_AUTO, True) if algo == _lib.ALGO_EXACT else (algo, False)
+    sc = _scope()
+    old = (sc.algo, sc.exact)
+    sc.algo, sc.exact = _decompose(algo)
     try:
         yield
     finally:
-        _state["algo"], _state["exact"] = old
+        sc.algo, sc.exact = old
 
 
 @contextlib.contextmanager

@@ -13,7 +13,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
-from . import config
+from . import config, debug
 
 CL = torch.channels_last_3d
 
@@ -255,6 +255,8 @@ class Conv3dFn(Function):
         ctx.meta = (ksize, out_planar, cin, cout, bias is not None, x.dtype)
         ctx.params = (weight, bias)
         ctx.gn3 = _gn3_hook_of(x, xin.dtype) if (ksize == 1 and out_planar and xin is x) else None
+        if debug.TRACE is not None:
+            debug.trace(f"conv3d.fwd k{ksize} {cin}->{cout}", y, partial)
         if not want_stats:
             return y
         if partial is None:
@@ -410,6 +412,8 @@ class ConvT3dFn(Function):
         ctx.save_for_backward(x, packed)
         ctx.meta = (cin, cout, bias is not None, skip is not None, None if skip is None else skip.dtype)
         ctx.params = (weight, bias)
+        if debug.TRACE is not None:
+            debug.trace(f"convt3d.fwd {cin}->{cout}", y)
         return y
 
     @staticmethod
@@ -450,6 +454,8 @@ class ConvT3dFn(Function):
                         "convt3d_wgrad")
         if has_skip and ctx.needs_input_grad[3]:
             dskip = dy if dy.dtype == skip_dtype else dy.to(skip_dtype)
+        if debug.TRACE is not None:
+            debug.trace(f"convt3d.bwd {cin}->{cout}", dx, ctx.gn3.partial if ctx.gn3 is not None else None)
         return dx, (None if direct_w else dw), (None if direct_b else db), dskip, None
 
 
@@ -710,6 +716,8 @@ class SkipPool2Fn(Function):
         ctx.save_for_backward(x)
         ctx.mode = mode
         ctx.gn3 = _gn3_hook_of(x0, x.dtype) if x is x0 else None
+        if debug.TRACE is not None:
+            debug.trace(f"skip_pool2.fwd c{c}", y)
         return x.view_as(x), y
 
     @staticmethod
@@ -730,9 +738,13 @@ class SkipPool2Fn(Function):
                                                 hook.act, partial.data_ptr(), n, d, h, w, c, ctx.mode, L.dt(x), L.stream()),
                     "pool2_bwd_gn")
             hook.offer(dx, partial)
+            if debug.TRACE is not None:
+                debug.trace(f"skip_pool2.bwd c{c}", dx, partial)
             return dx, None
         L.check(L.lib().mednet_pool2_bwd(dy.data_ptr(), x.data_ptr(), L.ptr(dskip), dx.data_ptr(), n, d, h, w, c, ctx.mode,
                                          L.dt(x), L.stream()), "pool2_bwd")
+        if debug.TRACE is not None:
+            debug.trace(f"skip_pool2.bwd c{c}", dx)
         return dx, None
 
 
@@ -817,6 +829,8 @@ class DiceLossFn(Function):
         ctx.save_for_backward(lg, lab, wt, saved)
         ctx.meta = (eps, int(sigmoid), ii, sn, sc, logits.dtype)
         ctx.split = getattr(logits, "_mednet_split", None) if lg is logits else None
+        if debug.TRACE is not None:
+            debug.trace("dice.fwd", lg, loss, saved)
         return loss
 
     @staticmethod
@@ -830,6 +844,8 @@ class DiceLossFn(Function):
         L.check(L.lib().mednet_dice_bwd(lg.data_ptr(), lab.data_ptr(), L.ptr(wt), saved.data_ptr(), dl.data_ptr(),
                                         dlogits.data_ptr(), n, c, spatial, sn, sc, eps, sigmoid, ii, L.stream()),
                 "dice_bwd")
+        if debug.TRACE is not None:
+            debug.trace("dice.bwd", dlogits)
         return dlogits.to(in_dtype), None, None, None, None, None
 
 

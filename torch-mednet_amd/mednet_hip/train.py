@@ -73,10 +73,21 @@ class FlatAdam:
         return sd
 
     def load_state_dict(self, sd, scaler: "LossScaler | None" = None):
+        """Restores the moments, the step count and the hyper-parameters the state was saved with (torch.optim.Adam's
+        load_state_dict restores its param_groups too).  A run that trains behind a loss scaler must find the scaler's state
+        in `sd`: resuming fp16 training with a fresh scale of 65536 and a device step count of 0 would silently restart the
+        bias correction."""
         self.m.copy_(sd["m"].to(self.m.device))
         self.v.copy_(sd["v"].to(self.v.device))
         self.t = int(sd["t"])
-        if scaler is not None and "scaler" in sd:
+        self.lr = sd.get("lr", self.lr)
+        self.betas = tuple(sd.get("betas", self.betas))
+        self.eps = sd.get("eps", self.eps)
+        self.wd = sd.get("weight_decay", self.wd)
+        if scaler is not None:
+            if "scaler" not in sd:
+                raise KeyError("FlatAdam.load_state_dict: a LossScaler was passed but the saved state has no 'scaler' entry "
+                               "(it was saved by a run without loss scaling)")
             scaler.load_state_dict(sd["scaler"])
 
     def _form(self, scaled: bool):
@@ -178,7 +189,12 @@ class LossScaler:
                 "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval}
 
     def load_state_dict(self, sd):
-        self.state.copy_(sd["state"].to(self.state.device))
+        st = sd["state"].to(self.state.device).reshape(-1)
+        if st.numel() > self.state.numel():
+            raise ValueError(f"LossScaler.load_state_dict: saved state has {st.numel()} entries, this build keeps {self.state.numel()}")
+        # (earlier builds kept 4 entries {scale, good steps, steps taken, found_inf}; the counters added since start at 0)
+        self.state.zero_()
+        self.state[:st.numel()].copy_(st)
         self.growth_factor, self.backoff_factor = sd["growth_factor"], sd["backoff_factor"]
         self.growth_interval = sd["growth_interval"]
 
@@ -242,29 +258,26 @@ class BucketedExchange:
     compute stream wait for both.  Sums are identical to the single exchange (disjoint slices)."""
 
     def __init__(self, model, flat: FlatParams, world_size: int, force: bool = False, levels: int = 2):
-        self.flat, self.world, self.work = flat, world_size, None
+        self.flat, self.world, self.work, self.force = flat, world_size, None, bool(force)
         self.split = late_bucket_split(model, flat, levels) if (world_size > 1 or force) else None
-        # MEDNET_BUCKETS=1/0 forces the choice; unset it follows the size of the exchange: in the one-rank RCCL rehearsal on
-        # an MI355X the collective launched inside backward cost the compute stream 0.6 ms, four times what the single
-        # 35 MB all-reduce of cfg3 costs after backward (0.14 ms; its ring time over xGMI is ~0.4 ms of a 22 ms step), so
-        # small models keep ONE exchange; cfg5's 565 MB is ~6.5 ms single-ring against a 52 ms step (SURVEY section 5) and
-        # goes under the backward of the full-resolution encoders.
+        # The overlapped form is OPT-IN (MEDNET_BUCKETS=1) until a multi-GPU measurement exists: the only measurement taken,
+        # the one-rank RCCL rehearsal on an MI355X, had the collective launched inside backward cost the compute stream
+        # 0.6 ms -- four times the single 35 MB all-reduce of cfg3 after backward (0.14 ms; its ring time over xGMI is ~0.4 ms
+        # of a 22 ms step).  For cfg5 (565 MB, ~6.5 ms single-ring against a 49 ms step, SURVEY section 5) hiding the
+        # exchange under the backward of the full-resolution encoders is the obvious candidate, to be switched on by a
+        # scaling run, not by a guess (ADVICE r3).
         self.enabled = self.split is not None and self.overlap_selected(flat.total * 4)
         if self.enabled:
             list(model.encoders)[levels - 1].register_forward_hook(self._on_forward)
 
-    AUTO_OVERLAP_BYTES = 128 << 20
-
     @classmethod
     def overlap_selected(cls, grad_bytes: int) -> bool:
-        forced = os.environ.get("MEDNET_BUCKETS")
-        if forced in ("0", "1"):
-            return forced == "1"
-        return grad_bytes > cls.AUTO_OVERLAP_BYTES
+        """MEDNET_BUCKETS=1 selects the two-bucket overlapped exchange (any size); default: one all-reduce after backward."""
+        return os.environ.get("MEDNET_BUCKETS") == "1"
 
     def describe(self) -> str:
         """For bench records: which exchange this step runs."""
-        if not (self.world > 1 or getattr(self, "force", False)):
+        if not (self.world > 1 or self.force):
             return "none (1 rank)"
         mb = self.flat.total * 4 / 1e6
         if self.enabled:
@@ -298,7 +311,7 @@ class BucketedExchange:
             dist.all_reduce(self.flat.grad[:self.split], op=dist.ReduceOp.SUM)
             self.work.wait()
             self.work = None
-        elif self.world > 1 or getattr(self, "force", False):
+        elif self.world > 1 or self.force:
             dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
         return 1.0 / self.world
 
@@ -369,7 +382,6 @@ class SegmentationStep(_GraphedStep):
         force = getattr(self, "force_allreduce", False)
         if self._exchange is None:  # (built lazily: bench.py sets force_allreduce after construction)
             self._exchange = BucketedExchange(self.model, self.flat, self.world, force)
-            self._exchange.force = force
         (loss,) = self._run(batch)
         scale = self._exchange.finish()  # 1/world is folded into Adam
         if self.scaler is None:
