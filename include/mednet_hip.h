@@ -25,7 +25,10 @@ extern "C" {
 
 typedef void* mednet_stream; /* hipStream_t */
 
-enum { MEDNET_F32 = 0, MEDNET_BF16 = 1 };
+enum { MEDNET_F32 = 0, MEDNET_BF16 = 1,
+       MEDNET_F16 = 2, /* third activation storage type (fp16, with loss scaling: train.LossScaler); resident image volumes */
+       MEDNET_U8 = 3,  /* label / heat-map volumes (mednet_crop_patches), labels of the fused head + Dice kernels */
+       MEDNET_I64 = 4  /* labels as the reference's callers pass them (`.long()`, segmentation.py:60) */ };
 enum { MEDNET_NDHWC = 0, MEDNET_NCDHW = 1 };
 enum { MEDNET_ACT_NONE = 0, MEDNET_ACT_RELU = 1, MEDNET_ACT_LEAKY = 2, MEDNET_ACT_ELU = 3 };
 enum { MEDNET_POOL_MAX = 0, MEDNET_POOL_AVG = 1 };
@@ -235,6 +238,27 @@ int mednet_dice_fwd(const float* logits, const int64_t* labels, const float* wei
 int mednet_dice_bwd(const float* logits, const int64_t* labels, const float* weight, const float* saved,
                     const float* dloss, float* dlogits, int n, int c, size_t spatial, int64_t stride_n,
                     int64_t stride_c, float eps, int sigmoid, int ignore_index, mednet_stream stream);
+/* The 1x1x1 head (model.py:207 final_conv: nn.Conv3d(f_maps[0], out_channels, 1)) fused with DiceLoss (loss.py:114-130) --
+ * what `outputs = self(inputs); loss = self.loss(outputs, labels)` (segmentation.py:61-62) runs between the last decoder block and
+ * the scalar loss.  Forward: logits (N x C x spatial fp32, written once, for the caller) + loss + saved[c] = {I_c, D_c} in one pass
+ * over the channels-last features z (N x spatial x Cin; f32 / bf16 / f16).  Backward: dz = W^T dlogits (Cin in {16, 32, 64},
+ * C <= 4 classes), dW, dbias and -- when gn_y is given -- the first pass of the producing ExtResNetBlock's GroupNorm-3 backward
+ * (gn_partial[n][mednet_head_dice_gn_rows][Cin][2], as mednet_head_dgrad_gn) in ONE pass; the logit gradient is never stored.
+ * labels: MEDNET_I64 or MEDNET_U8, N x spatial with element stride label_stride_n between samples (the last channel of a
+ * uint8 label volume is consumed where it lies).  packed: the head's pack buffer (mednet_conv3d_pack, ksize 1).
+ * Logits, loss, dz and the GroupNorm sums are bit-identical to mednet_conv3d_fwd + mednet_dice_fwd / mednet_dice_bwd +
+ * mednet_head_dgrad_gn; dW / dbias are summed in another fixed order than mednet_conv3d_wgrad's. */
+int mednet_head_dice_supported(int cin, int cout, int dtype, int label_dtype);
+size_t mednet_head_dice_ws_bytes(int n, size_t spatial, int cin, int cout);
+int mednet_head_dice_gn_rows(int n, size_t spatial, int cin);
+int mednet_head_dice_fwd(const void* z, const void* packed, const float* bias, const void* labels, int label_dtype,
+                         int64_t label_stride_n, const float* weight, float* logits, float* loss, float* saved, int n,
+                         size_t spatial, int cin, int cout, float eps, int sigmoid, int ignore_index, int z_dtype, void* ws,
+                         size_t ws_bytes, mednet_stream stream);
+int mednet_head_dice_bwd(const float* logits, const void* labels, int label_dtype, int64_t label_stride_n, const void* packed,
+                         const float* weight, const float* saved, const float* dloss, void* dz, const void* gn_y, const void* z,
+                         int gn_act, float* gn_partial, float* dw, float* dbias, int n, size_t spatial, int cin, int cout,
+                         float eps, int sigmoid, int ignore_index, int z_dtype, void* ws, size_t ws_bytes, mednet_stream stream);
 /* nn.CrossEntropyLoss(weight)  segmentation.py:49: sum w_y * -log softmax_y / sum w_y.  saved[0] = sum w_y. */
 int mednet_ce_fwd(const float* logits, const int64_t* labels, const float* weight, float* loss, float* saved,
                   int n, int c, size_t spatial, int64_t stride_n, int64_t stride_c, int ignore_index, void* ws,
@@ -283,8 +307,6 @@ int mednet_predict_assemble(const float* logits, const int* pos, uint8_t* result
                             int crop_start2, int crop_d, int crop_h, int crop_w, mednet_stream stream);
 
 /* ---- training-patch sampler ------------------------------------------------------------------ */
-enum { MEDNET_F16 = 2, MEDNET_U8 = 3 }; /* F16: third activation storage type (fp16, with loss scaling: train.LossScaler) and
-                                          * the type of resident image volumes; U8: label / heat-map volumes (mednet_crop_patches) */
 /* MedDataset.__getitem__'s crop + cast (dataset.py:313-331) from a device-resident volume src (C x D x H x W; f16 / f32
  * images, u8 labels or heat maps): for i < count,
  *   out[slot[i]][c_off + c][z][y][x] = cast(src[c][pos[i][0] + z][pos[i][1] + y][pos[i][2] + x])

@@ -373,64 +373,6 @@ def test_loss_scaler_skips_overflowing_steps_and_recovers():
     flat.release()
 
 
-def _fresh_step_run(ctor, mode, batch, traced=False):
-    """One forward + loss + backward of a FRESH network and trainer (both streams) -> (loss, flat gradient buffer, trace)."""
-    from mednet_hip import debug
-    from mednet_hip.train import SegmentationStep
-    with mednet_hip.precision(mode):
-        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
-        step = SegmentationStep(net, loss_weight=[0.05, 1.0, 1.0, 1.0], lr=1e-3)
-        if traced:
-            debug.open_trace()
-        (loss,) = step._fwd_bwd(batch)
-        torch.cuda.synchronize()
-        trace = debug.close_trace() if traced else None
-        out = (float(loss), step.flat.grad.clone(), trace)
-        step.flat.release()
-        del net, step
-    return out
-
-
-def _assert_step_is_bitwise_repeatable(ctor, mode, batch, what):
-    """Two fresh runs of the same step must agree bit for bit (no atomics, fixed-order reductions, two streams).  If they do
-    not, the step is run twice more with mednet_hip.debug's trace open -- a checksum of every tensor the ops produce -- so
-    that the failure names the first kernel output that differs, not only the loss."""
-    from mednet_hip import debug
-    a = _fresh_step_run(ctor, mode, batch)
-    b = _fresh_step_run(ctor, mode, batch)
-    assert np.isfinite(a[0]) and bool(torch.isfinite(a[1]).all()), what
-    assert float(a[1].abs().max()) > 0
-    if a[0] == b[0] and torch.equal(a[1], b[1]):
-        return a
-    t0 = _fresh_step_run(ctor, mode, batch, traced=True)
-    t1 = _fresh_step_run(ctor, mode, batch, traced=True)
-    where = debug.first_difference(t0[2], t1[2])
-    raise AssertionError(f"{what}: two runs differ -- loss {a[0]!r} vs {b[0]!r}, {int((a[1] != b[1]).sum())} of {a[1].numel()} "
-                         f"gradient values; traced re-runs: losses {t0[0]!r} / {t1[0]!r}, first differing trace point: {where}")
-
-
-@pytest.mark.parametrize("MODE16", ["fp16", "bf16"])
-def test_cfg5_full_size_properties(MODE16):
-    """BASELINE config 5 at its full size and batch (5 levels, 64 base channels, 160x160x96, N = 2) in fp16 storage with loss
-    scaling (the mode BASELINE names) and in bf16: every loss and gradient finite, two runs bitwise identical.  (Parity at this
-    size is test_cfg5_full_size_against_reference_golden.)"""
-    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[64, 128, 256, 512, 1024])
-    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(2, 1, (160, 160, 96), 4, 0, seed=1234).items()}
-    loss, _, _ = _assert_step_is_bitwise_repeatable(ctor, MODE16, batch, f"cfg5 full size {MODE16}")
-    print(f"[cfg5 full size] {MODE16} loss {loss:.6f}, two runs bit-identical")
-
-
-@pytest.mark.parametrize("mode", ["bf16", "fp32"])
-def test_cfg2_benchmarked_shape_is_bitwise_repeatable(mode):
-    """The shape bench.py times (BASELINE config 2: [32, 64, 128, 256], 128^3, N = 4, SegmentationStep._fwd_bwd, weight
-    gradients on the side stream): the 32 -> 32 specialisation with its register-resident weights, LDS-DMA rows and
-    accumulate-mode statistics, the persistent general kernel, the split-bf16 kernels in the fp32 mode."""
-    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64, 128, 256])
-    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(4, 1, (128, 128, 128), 4, 0, seed=99).items()}
-    loss, _, _ = _assert_step_is_bitwise_repeatable(ctor, mode, batch, f"cfg2 128^3 N=4 {mode}")
-    print(f"[cfg2 benchmarked shape] {mode} loss {loss:.6f}, two runs bit-identical")
-
-
 # cfg5 at full size against the reference (tests/golden/res_cfg5_full.npz: the reference's ResidualUNet3D
 # [64 .. 1024] on one 160 x 160 x 96 patch, fp32 on the CPU, bit-equal to the oracle; tools/make_golden.py).
 # fp32 storage: the north-star 1e-3.  16-bit storage: the bounds of the 128^3 tests of the same modes.
@@ -933,22 +875,6 @@ def test_batched_repack_after_the_optimizer_step_equals_per_layer_packing(mode):
         step.flat.release()
 
 
-def test_bitwise_reproducible_step():
-    """No float atomics anywhere: two runs of the same step give identical bits (race screen)."""
-    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64])
-    batch = O.synthetic_batch(2, 1, (16, 16, 16), 4, 0, seed=7)
-    outs = []
-    for mode in ("bf16", "bf16", "fp32", "fp32"):
-        with mednet_hip.precision(mode):
-            net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
-            lg = net(batch["data"].to(DEV))
-            HL.DiceLoss().to(DEV)(lg, batch["label"][:, -1].long().to(DEV)).backward()
-            outs.append([lg.detach().clone()] + [p.grad.clone() for p in net.parameters()])
-    for a, b in ((outs[0], outs[1]), (outs[2], outs[3])):
-        for u, v in zip(a, b):
-            assert torch.equal(u, v)
-
-
 def test_trainer_direct_gradients_and_fused_adam(golden_dir):
     """train.SegmentationStep (flat buffers, kernels writing gradients in place, fused Adam) follows the same
     trajectory as the oracle + torch.optim.Adam for three steps (segmentation.py:58-65,119-120)."""
@@ -1086,3 +1012,40 @@ def test_bf16_training_mode_tracks_fp32_mode_loss_curve():
     a, b = np.array(curves["fp32"]), np.array(curves["bf16"])
     assert a[-1] < a[0] - 0.02 and b[-1] < b[0] - 0.02, (a, b)
     assert np.all(np.abs(a - b) <= 0.02 * np.abs(a)), (a, b)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32", "fp16"])
+def test_fused_head_and_loss_step_equals_the_two_node_step(mode):
+    """train.SegmentationStep with the 1x1x1 head and DiceLoss as one node (ops.head_dice; model.py:207 + loss.py:114-130,
+    segmentation.py:61-62) against the same step with the two calls as they stand: loss and every gradient in front of the
+    head BIT-identical (the feature gradient and the GroupNorm-3 sums the fused kernel hands to the last decoder block are
+    the unfused kernels' values), the head's own weight / bias gradient to 1e-5."""
+    from mednet_hip import ops
+    from mednet_hip.train import SegmentationStep
+    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64])
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(2, 1, (24, 40, 32), 4, 0, seed=31).items()}
+    res = {}
+    old = ops.FUSE_HEAD_LOSS
+    try:
+        for fused in (False, True):
+            ops.FUSE_HEAD_LOSS = fused
+            with mednet_hip.precision(mode):
+                net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+                step = SegmentationStep(net, loss_weight=[0.05, 1.0, 1.0, 1.0], lr=1e-3)
+                before = dict(ops.GN3_COUNT)
+                (loss,) = step._fwd_bwd(batch)
+                torch.cuda.synchronize()
+                taken = ops.GN3_COUNT["taken"] - before["taken"]
+                names = [(n, off, p.numel()) for (n, p), off in zip(net.named_parameters(), step.flat.offsets)]
+                res[fused] = (float(loss), step.flat.grad.clone(), taken)
+                step.flat.release()
+    finally:
+        ops.FUSE_HEAD_LOSS = old
+    assert res[True][0] == res[False][0]
+    assert res[True][2] == res[False][2] and res[True][2] > 0  # the last decoder block took its GroupNorm-3 sums both ways
+    for name, off, cnt in names:
+        a, b = res[True][1][off:off + cnt], res[False][1][off:off + cnt]
+        if name.startswith("final_conv."):
+            assert_close(a, b, 1e-5, name)
+        else:
+            assert torch.equal(a, b), f"{name}: gradient differs between the fused and the two-node step"

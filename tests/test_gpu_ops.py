@@ -702,28 +702,6 @@ def test_conv3d_mfma_fwd_dgrad_wgrad(n, cin, cout, shape):
     assert_close(dw, dwd, 2e-4, "dw vs direct kernel")
 
 
-@pytest.mark.parametrize("n,cin,cout,shape", [(2, 32, 32, (9, 11, 21)), (1, 64, 32, (8, 16, 16)), (1, 48, 80, (4, 8, 16)),
-                                              (3, 16, 32, (5, 6, 33))])
-def test_lean_weight_gradient_option(n, cin, cout, shape):
-    """Option wgrad_v3 (wgrad_mfma3_kernel: 120 registers, LDS-DMA staging into a double buffer, 4x4x16 bricks; an A/B knob, off
-    by default -- DESIGN.md section 9): the same weight gradient as the default kernel up to summation order."""
-    tag = f"wg3{n}{cin}{cout}{shape}"
-    x, w, cot = _conv_case(n, cin, cout, shape, tag)
-    res = {}
-    try:
-        for v3 in (0, 1):
-            _set_option("wgrad_v3", v3)
-            with mednet_hip.precision("bf16"):
-                conv = hnn.Conv3d(cin, cout, 3, bias=False).to(DEV)
-                with torch.no_grad():
-                    conv.weight.copy_(w)
-                conv(x.to(DEV).bfloat16()).backward(cot.to(DEV).bfloat16())
-                res[v3] = conv.weight.grad.cpu()
-    finally:
-        _set_option("wgrad_v3", 0)
-    assert_close(res[1], res[0], 1e-5, "lean weight gradient vs the default kernel")
-
-
 def _fuzz_cases_ct(k, seed):
     rng = np.random.default_rng(seed)
     return [(int(rng.integers(1, 3)), int(rng.choice([32, 64, 96])), int(rng.choice([32, 64])),
@@ -1033,3 +1011,85 @@ def test_head_dgrad_kernel(cin, cout):
         xg = x.to(DEV).bfloat16().requires_grad_(True)
         (conv(xg) * cot.to(DEV)).sum().backward()
     assert_close(xg.grad, xr.grad, 4e-3, "dz of the 1x1x1 head")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("cin,cout,shape,labels_u8,sigmoid,ignore", [
+    (32, 4, (9, 11, 21), True, False, None), (32, 4, (16, 16, 32), False, False, None), (64, 4, (8, 12, 10), True, False, None),
+    (16, 2, (5, 7, 33), True, False, None), (32, 3, (12, 8, 8), False, True, None), (32, 4, (6, 10, 12), True, False, 0),
+    (64, 1, (4, 6, 7), False, True, None)])
+def test_fused_head_dice_against_the_unfused_launches(mode, cin, cout, shape, labels_u8, sigmoid, ignore):
+    """ops.head_dice (mednet_head_dice_fwd / _bwd: model.py:207 + loss.py:114-130 in one node) against final_conv + DiceLoss as
+    two nodes: logits, loss and the feature gradient BIT-identical (every per-voxel expression is the unfused kernels', in
+    their order), the head's weight / bias gradients to 1e-5 (they are summed in another fixed order), and all of it within
+    the mode's tolerance of ATen on the CPU.  Label forms: int64 N x D x H x W, and the last channel of a uint8 N x C x D x H
+    x W volume consumed where it lies (segmentation.py:60)."""
+    n = 2
+    tag = f"hd{cin}{cout}{shape}"
+    x, w, b = _prep(mode, rnd(tag + "x", n, cin, *shape))[0], rnd(tag + "w", cout, cin, 1, 1, 1, scale=0.3), rnd(tag + "b", cout)
+    g = np.random.Generator(np.random.PCG64(77))
+    lab_vol = torch.from_numpy(g.integers(0, max(cout, 2) if cout > 1 else 2, size=(n, 3) + shape).astype(np.uint8))
+    if cout == 1:
+        lab_vol.zero_()  # (one sigmoid channel: every voxel's label is class 0)
+    wt = torch.tensor([0.05, 1.0, 1.0, 1.0][:cout]) if cout > 1 else None
+    # ATen on the CPU (fp32) from the same rounded features
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    lr = F.conv3d(xr, wr, br)
+    loss_r = O.DiceLoss(weight=wt, sigmoid_normalization=sigmoid, ignore_index=ignore)(lr, lab_vol[:, -1].long())
+    loss_r.backward()
+    res = {}
+    # (the feature gradient is STORED in the mode's 16-bit type: a Dice gradient of ~1e-7 per voxel sits in fp16's subnormals, which
+    #  is what train.LossScaler is for -- the test scales the loss like it does)
+    gscale = 3.0 * 16384.0 if mode == "fp16" else 3.0
+    with mednet_hip.precision(mode):
+        for fused in (False, True):
+            conv = hnn.Conv3d(cin, cout, 1, planar_output=True).to(DEV)
+            with torch.no_grad():
+                conv.weight.copy_(w)
+                conv.bias.copy_(b)
+            xg = ops.to_cl(x.to(DEV).to(mednet_hip.config.act_dtype())).requires_grad_(True)
+            lab_dev = lab_vol.to(DEV)
+            lab = lab_dev[:, -1] if labels_u8 else lab_dev[:, -1].long()
+            wd = None if wt is None else wt.to(DEV)
+            if fused:
+                assert ops.head_dice_supported(xg, cin, cout, lab)
+                lg, loss = ops.head_dice(xg, conv.weight, conv.bias, conv._packed(), lab, wd, 1e-5, sigmoid, ignore)
+            else:
+                lg = conv(xg)
+                loss = ops.dice_loss(lg, lab.long(), wd, 1e-5, sigmoid, ignore)
+            (loss * gscale).backward()
+            res[fused] = (lg.detach(), loss.detach(), xg.grad, conv.weight.grad, conv.bias.grad)
+    (l0, s0, dx0, dw0, db0), (l1, s1, dx1, dw1, db1) = res[False], res[True]
+    assert torch.equal(l0, l1), "logits differ between the fused and the unfused head"
+    assert torch.equal(s0, s1), (float(s0), float(s1))
+    assert torch.equal(dx0, dx1), "feature gradient differs between the fused and the unfused path"
+    assert_close(dw1, dw0, 1e-5, "dW fused vs unfused")
+    assert_close(db1, db0, 1e-5, "db fused vs unfused")
+    tol = TOL[mode]
+    assert_close(l1, lr, tol, "logits vs ATen")
+    assert abs(float(s1) - float(loss_r)) <= tol
+    assert_close(dx1.float() / gscale, xr.grad, max(tol, 1e-4), "dx vs ATen")
+    assert_close(dw1 / gscale, wr.grad, max(tol, 1e-4), "dW vs ATen")
+    assert_close(db1 / gscale, br.grad, max(tol, 1e-4), "db vs ATen")
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(32, 32, (9, 11, 21)), (16, 48, (8, 8, 16)), (64, 32, (4, 8, 16))])
+def test_plain_bf16_pack_serves_an_fp32_storage_call(cin, cout, shape):
+    """mednet_conv3d_pack (the round-2 entry point, bf16 images) followed by an fp32-storage convolution.  The
+    split-bf16 kernels contract against the high AND the low weight images; every bf16 pack now writes both, so the call is the
+    1e-3 product, not a contraction against whatever the buffer held before."""
+    n = 1
+    tag = f"pk{cin}{cout}"
+    x, w = rnd(tag + "x", n, cin, *shape), rnd(tag + "w", cout, cin, 3, 3, 3, scale=0.2)
+    yr = F.conv3d(x.double(), w.double(), padding=1)
+    lib = L.lib()
+    wd = w.to(DEV).contiguous()
+    buf = torch.empty(lib.mednet_conv3d_pack_bytes(cin, cout, 3), dtype=torch.uint8, device=DEV)
+    buf.view(torch.int32)[: buf.numel() // 4].fill_(0x7FC07FC0)  # what an unwritten low image would look like: NaNs
+    L.check(lib.mednet_conv3d_pack(wd.data_ptr(), buf.data_ptr(), cin, cout, 3, 0, L.stream()), "conv3d_pack")
+    xd = ops.to_cl(x.to(DEV))
+    y = ops.empty_cl(n, cout, *shape, torch.float32, DEV)
+    L.check(lib.mednet_conv3d_fwd(xd.data_ptr(), buf.data_ptr(), None, y.data_ptr(), n, *shape, cin, cout, 3, L.F32, L.NDHWC, L.F32,
+                                  L.NDHWC, 0, L.ALGO_AUTO, None, L.stream()), "conv3d_fwd")
+    assert bool(torch.isfinite(y).all())
+    assert_close(y, yr.float(), 3e-5, "fp32-storage conv on a plain bf16 pack")

@@ -1,0 +1,117 @@
+"""Race screens -- run LAST (the file name sorts behind every other -m gpu file): bitwise run-to-run identity of whole training
+steps at the sizes that are benchmarked, and insensitivity of the step to what free memory holds.
+
+Round 3's GPU run went red on one of these (two bf16 steps of config 5 three fp32 ulp apart in the loss) 30 tests into an
+`-x` run, which left 287 parity tests unreached.  The deviation has not been seen again in ~2 700 forward passes and ~600 full
+steps on four other MI355X, so these tests now (a) sit behind the parity tests and (b) localise a
+failure themselves: on a mismatch the step is re-run with mednet_hip.debug's trace open and the assertion names the first
+tensor that differs."""
+import numpy as np
+import pytest
+import torch
+
+import mednet_hip
+from mednet_hip.unet import loss as HL
+from mednet_hip.unet import model as HM
+from oracle import ref_cpu as O
+
+from gpu_util import DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh_step_run(ctor, mode, batch, traced=False):
+    """One forward + loss + backward of a FRESH network and trainer (both streams) -> (loss, flat gradient buffer, trace)."""
+    from mednet_hip import debug
+    from mednet_hip.train import SegmentationStep
+    with mednet_hip.precision(mode):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+        step = SegmentationStep(net, loss_weight=[0.05, 1.0, 1.0, 1.0], lr=1e-3)
+        if traced:
+            debug.open_trace()
+        (loss,) = step._fwd_bwd(batch)
+        torch.cuda.synchronize()
+        trace = debug.close_trace() if traced else None
+        out = (float(loss), step.flat.grad.clone(), trace)
+        step.flat.release()
+        del net, step
+    return out
+
+
+def _assert_step_is_bitwise_repeatable(ctor, mode, batch, what):
+    """Two fresh runs of the same step must agree bit for bit (no atomics, fixed-order reductions, two streams).  If they do
+    not, the step is run twice more with mednet_hip.debug's trace open -- a checksum of every tensor the ops produce -- so
+    that the failure names the first kernel output that differs, not only the loss."""
+    from mednet_hip import debug
+    a = _fresh_step_run(ctor, mode, batch)
+    b = _fresh_step_run(ctor, mode, batch)
+    assert np.isfinite(a[0]) and bool(torch.isfinite(a[1]).all()), what
+    assert float(a[1].abs().max()) > 0
+    if a[0] == b[0] and torch.equal(a[1], b[1]):
+        return a
+    t0 = _fresh_step_run(ctor, mode, batch, traced=True)
+    t1 = _fresh_step_run(ctor, mode, batch, traced=True)
+    where = debug.first_difference(t0[2], t1[2])
+    raise AssertionError(f"{what}: two runs differ -- loss {a[0]!r} vs {b[0]!r}, {int((a[1] != b[1]).sum())} of {a[1].numel()} "
+                         f"gradient values; traced re-runs: losses {t0[0]!r} / {t1[0]!r}, first differing trace point: {where}")
+
+
+@pytest.mark.parametrize("MODE16", ["fp16", "bf16"])
+def test_cfg5_full_size_properties(MODE16):
+    """BASELINE config 5 at its full size and batch (5 levels, 64 base channels, 160x160x96, N = 2) in fp16 storage with loss
+    scaling (the mode BASELINE names) and in bf16: every loss and gradient finite, two runs bitwise identical.  (Parity at this
+    size is test_cfg5_full_size_against_reference_golden.)"""
+    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[64, 128, 256, 512, 1024])
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(2, 1, (160, 160, 96), 4, 0, seed=1234).items()}
+    loss, _, _ = _assert_step_is_bitwise_repeatable(ctor, MODE16, batch, f"cfg5 full size {MODE16}")
+    print(f"[cfg5 full size] {MODE16} loss {loss:.6f}, two runs bit-identical")
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_cfg2_benchmarked_shape_is_bitwise_repeatable(mode):
+    """The shape bench.py times (BASELINE config 2: [32, 64, 128, 256], 128^3, N = 4, SegmentationStep._fwd_bwd, weight
+    gradients on the side stream): the 32 -> 32 specialisation with its register-resident weights, LDS-DMA rows and
+    accumulate-mode statistics, the persistent general kernel, the split-bf16 kernels in the fp32 mode."""
+    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64, 128, 256])
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(4, 1, (128, 128, 128), 4, 0, seed=99).items()}
+    loss, _, _ = _assert_step_is_bitwise_repeatable(ctor, mode, batch, f"cfg2 128^3 N=4 {mode}")
+    print(f"[cfg2 benchmarked shape] {mode} loss {loss:.6f}, two runs bit-identical")
+
+
+def test_bitwise_reproducible_step():
+    """No float atomics anywhere: two runs of the same step give identical bits (race screen)."""
+    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64])
+    batch = O.synthetic_batch(2, 1, (16, 16, 16), 4, 0, seed=7)
+    outs = []
+    for mode in ("bf16", "bf16", "fp32", "fp32"):
+        with mednet_hip.precision(mode):
+            net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+            lg = net(batch["data"].to(DEV))
+            HL.DiceLoss().to(DEV)(lg, batch["label"][:, -1].long().to(DEV)).backward()
+            outs.append([lg.detach().clone()] + [p.grad.clone() for p in net.parameters()])
+    for a, b in ((outs[0], outs[1]), (outs[2], outs[3])):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("cfg", ["cfg5_n2_bf16", "cfg2_n4_bf16", "cfg2_n1_fp32"])
+def test_the_step_does_not_read_memory_nobody_wrote(cfg):
+    """Every byte the caching allocator can hand out, and the library's workspaces, are filled with NaN patterns (then with
+    huge finite values) before the step runs (mednet_hip.debug.poison): a GroupNorm partial row, a weight-gradient slab, a
+    loss partial or a pack image that a reducer reads but no producer wrote would turn the loss or a gradient into NaN -- or
+    simply change it.  Loss and every gradient must equal the unpoisoned run bit for bit."""
+    from mednet_hip import debug
+    ctor, shape, n, mode = {
+        "cfg5_n2_bf16": (dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[64, 128, 256, 512, 1024]), (160, 160, 96), 2, "bf16"),
+        "cfg2_n4_bf16": (dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64, 128, 256]), (128, 128, 128), 4, "bf16"),
+        "cfg2_n1_fp32": (dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64, 128, 256]), (128, 128, 128), 1, "fp32"),
+    }[cfg]
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(n, 1, shape, 4, 0, seed=5).items()}
+    ref = _fresh_step_run(ctor, mode, batch)
+    assert np.isfinite(ref[0])
+    for pattern in (0x7FC07FC0, 0x7F7F7F7F):
+        debug.poison(pattern=pattern, big_gb=40.0, small_mb=768)
+        got = _fresh_step_run(ctor, mode, batch)
+        assert got[0] == ref[0], f"{cfg}: loss {got[0]!r} with poisoned memory (pattern {pattern:#x}), {ref[0]!r} without"
+        assert torch.equal(got[1], ref[1]), f"{cfg}: gradients change with what free memory holds (pattern {pattern:#x})"
+    torch.cuda.empty_cache()

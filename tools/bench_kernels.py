@@ -63,10 +63,7 @@ def conv_case(cin, cout, s):
             lib.mednet_set_option(b"wgrad_v2", av)
             wres[av] = min(wres.get(av, 1e9), timeit(wg))
     lib.mednet_set_option(b"wgrad_v2", 1)
-    lib.mednet_set_option(b"wgrad_v3", 1)  # the lean form (120 registers, LDS-DMA staging)
-    wres[2] = min(timeit(wg) for _ in range(3))
-    lib.mednet_set_option(b"wgrad_v3", 0)
-    print("   wgrad v1/v2/v3: " + " | ".join(f"v{k+1}: {v*1e3:6.1f} us {flop/v/1e9:6.1f} TF/s" for k, v in wres.items()))
+    print("   wgrad v1/v2: " + " | ".join(f"v{k+1}: {v*1e3:6.1f} us {flop/v/1e9:6.1f} TF/s" for k, v in wres.items()))
     txt = " | ".join(f" {min(t for p, t in res if p == pv)*1e3:6.1f} us {flop/min(t for p, t in res if p == pv)/1e9:6.1f} TF/s" for pv in variants)
     print(f"conv {cin:3d}->{cout:3d} @{s:3d}^3 N={N}: fwd {txt} | wgrad {tw*1e3:7.1f} us {flop/tw/1e9:7.1f} TF/s", flush=True)
 

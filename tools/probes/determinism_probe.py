@@ -36,10 +36,22 @@ CONFIGS = {
 }
 
 
-def one_run(cfg, mode, batch, traced=False):
+_WEIGHTS = {}  # keyed initialisation of a config's network, made once on the CPU (141 M parameters take seconds per run)
+
+
+def fresh_net(cfg):
     ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=cfg["f_maps"])
+    key = tuple(cfg["f_maps"])
+    if key not in _WEIGHTS:
+        _WEIGHTS[key] = {k: v.clone() for k, v in O.keyed_init_(HM.ResidualUNet3D(**ctor)).state_dict().items()}
+    net = HM.ResidualUNet3D(**ctor)
+    net.load_state_dict(_WEIGHTS[key])
+    return net.to("cuda")
+
+
+def one_run(cfg, mode, batch, traced=False):
     with mednet_hip.precision(mode):
-        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to("cuda")
+        net = fresh_net(cfg)
         step = SegmentationStep(net, loss_weight=[0.05, 1.0, 1.0, 1.0], lr=1e-3)
         if traced:
             debug.open_trace()
@@ -114,6 +126,7 @@ def main():
     ap.add_argument("--traced", type=int, default=6)
     ap.add_argument("--poisoned", type=int, default=4)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--churn", type=int, default=0, help="full steps cycling through the storage modes (allocator churn)")
     ap.add_argument("--soak", type=int, default=0, help="forward-only passes with per-module checksums")
     ap.add_argument("--exit-zero", action="store_true", help="report only (a chain of probes in one GPU call)")
     a = ap.parse_args()
@@ -126,6 +139,23 @@ def main():
         rec.update(config=a.config, mode=a.mode)
         failed |= rec["n_deviations"] > 0
         print(json.dumps(rec), flush=True)
+
+    if a.churn:
+        # the driver's failing sequence, many times: runs of the 16-bit mode interleaved with runs in the other storage modes
+        # (different tensor sizes: the caching allocator hands every run another layout of recycled blocks)
+        refs, bad = {}, []
+        order = [a.mode, a.mode, "fp32", "fp16" if a.mode == "bf16" else "bf16", a.mode]
+        for i in range(a.churn):
+            md = order[i % len(order)]
+            l1, g1, nm, _ = one_run(cfg, md, batch)
+            if md not in refs:
+                refs[md] = (l1, g1)
+            elif l1 != refs[md][0] or not torch.equal(g1, refs[md][1]):
+                bad.append({"run": i, "mode": md, "loss": l1, "loss_ref": refs[md][0], "grad_tensors_differing": len(grad_diffs(refs[md][1], g1, nm))})
+        rec = {"phase": "churn", "config": a.config, "runs": a.churn, "order": order, "mismatches": bad[:20], "n_mismatches": len(bad)}
+        failed |= bool(bad)
+        print(json.dumps(rec), flush=True)
+        del refs
 
     l0, g0, names, _ = one_run(cfg, a.mode, batch)
     rec = {"phase": "plain", "config": a.config, "mode": a.mode, "runs": a.plain, "loss0": l0, "mismatches": []}

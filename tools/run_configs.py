@@ -78,6 +78,15 @@ if "unet3d" in which:
     run("cfg2 with UNet3D [32,64,128,256] 4-class, 128^3, batch 4, bf16",
         lambda: SegmentationStep(keyed_init_(UNet3D(1, 4, False, f_maps=[32, 64, 128, 256])).to(dev), [0.05, 1, 1, 1.0]), b,
         dominant=(32, 32, 128))
+    if "fp32" in precs:
+        # the slow corner of the 1e-3 mode: UNet3D's default order 'gcr' has ReLU, so every contraction asks for EXACT fp32
+        # products (config.exact_products -> MEDNET_ALGO_EXACT: v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) instead of the
+        # split-bf16 contraction the smooth 'cge' networks take
+        PEAK["fp32"] = 157.3
+        run("cfg2 with UNet3D [32,64,128,256] 'gcr' 4-class, 128^3, batch 4, fp32 storage, exact fp32 products (ALGO_EXACT)",
+            lambda: SegmentationStep(keyed_init_(UNet3D(1, 4, False, f_maps=[32, 64, 128, 256])).to(dev), [0.05, 1, 1, 1.0]), b,
+            steps=3, warmup=1, precision="fp32", dominant=(32, 32, 128))
+        PEAK["fp32"] = 2500.0 / 3
 if "cfg5" in which:
     b = {k: v.to(dev) for k, v in synthetic_batch(2, 1, (160, 160, 96), 4, 0, seed=1234).items()}
     for prec in ["fp16"] + precs:

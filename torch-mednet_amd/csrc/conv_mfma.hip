@@ -107,6 +107,9 @@ struct FwdArgs {
   const elt* gnb_z;       // nullable: the layer in front is the RESIDUAL layer of an ExtResNetBlock (GroupNorm-3, components.py:
                           // 170-178): this kernel's output is the block's output gradient, the activation derivative comes from
                           // the block OUTPUT z (shape of this kernel's output) and gnb_coef is not used
+  const float* xf_coef;   // conv_mfma_kernel<1, false, 1> (measurement probe, option conv_xform_probe): [n][cin][2] = {ca, cb} of the
+                          // GroupNorm in front; the kernel reads the conv OUTPUT y of the previous layer and applies
+                          // z = ELU(ca * y + cb) while it commits the staged pieces to LDS (profiles/r04_ab.md)
   int xcd_chunk;          // conv32_mfma_kernel: bricks per XCD when the brick count divides by 8 (each XCD then works through a
                           // CONTIGUOUS part of the volume, so neighbouring bricks' halos meet in its L2), else 0
   int zslab;              // conv32_mfma_kernel: z-layers of bricks per XCD (> 0: the x-z-y walk of origin(); implies xcd_chunk)
@@ -126,7 +129,7 @@ struct FwdArgs {
 #define STAMP(i) do { } while (0)
 #endif
 
-template <int STRIDE, bool GNB = false>
+template <int STRIDE, bool GNB = false, int XF = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   using G = FwdTile<STRIDE>;
   constexpr int TZ = G::TZ, TY = G::TY, TX = G::TX;
@@ -209,6 +212,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   };
 
   u32x4 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
+  [[maybe_unused]] u32x4 cf_reg[XF ? 4 : 1];  // XF: {ca, cb} of this thread's 8 channels (k-half tid & 1) of the chunk in flight
+  auto cf_rsrc = [&]() {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(a.xf_coef + (size_t)pn * a.cin * 2), 0, (unsigned)a.cin * 8u, 0x00020000);
+  };
   auto prefetch = [&](int cb, int kc) {  // 15 loads issued back to back, nothing waits on them until commit()
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)pn * a.id * a.ih * a.iw * a.cin), 0, a.bytes_x, 0x00020000);
 #pragma unroll
@@ -218,11 +225,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + ((size_t)cb * a.nkc + kc) * (W_CHUNKS * 8)), 0, W_CHUNKS * 16, 0x00020000);
 #pragma unroll
     for (int it = 0; it < W_ROUNDS; ++it) w_reg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16 + it * 4096, 0, 0);
+    if constexpr (XF != 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cf_reg[q] = __builtin_amdgcn_raw_buffer_load_b128(cf_rsrc(), (unsigned)((kc * 16 + hh * 8) * 8 + q * 16), 0, 0);
+    }
   };
   auto commit = [&]() {
 #pragma unroll
     for (int it = 0; it < IN_ROUNDS; ++it) {
       const int p = it * 256 + tid;
+      if constexpr (XF != 0) {  // z = ELU(ca * y + cb) per channel, zero outside the volume (the padding is of z, not of y)
+        const eltx8 yv = __builtin_bit_cast(eltx8, in_reg[it]);
+        eltx8 zv;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const f32x4 c4 = __builtin_bit_cast(f32x4, cf_reg[k >> 1]);
+          const float u = fmaf(c4[(k & 1) * 2], (float)yv[k], c4[(k & 1) * 2 + 1]);
+          const float e = __builtin_amdgcn_exp2f(u * 1.44269504088896340736f) - 1.f;
+          zv[k] = (elt)(u > 0.f ? u : e);
+        }
+        in_reg[it] = goff[it] != OOB ? __builtin_bit_cast(u32x4, zv) : u32x4{0u, 0u, 0u, 0u};
+      }
       if (p < 2 * NV) in_lds[(p & 1) * NV + (p >> 1)] = in_reg[it];
     }
 #pragma unroll
@@ -416,10 +439,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
           in_reg[tap] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, goff[tap] | kill, pf_kc * 32, 0);
         else if (tap < IN_ROUNDS + W_ROUNDS)
           w_reg[tap - IN_ROUNDS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(tid * 16 + (tap - IN_ROUNDS) * 4096) | kill, 0, 0);
+        else if (XF != 0 && tap < IN_ROUNDS + W_ROUNDS + 4)
+          cf_reg[XF ? tap - IN_ROUNDS - W_ROUNDS : 0] = __builtin_amdgcn_raw_buffer_load_b128(cf_rsrc(), (unsigned)((pf_kc * 16 + hh * 8) * 8 + (tap - IN_ROUNDS - W_ROUNDS) * 16) | kill, 0, 0);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[t] = MEDNET_MFMA_32x32x16(wa[cur], xb[cur][t], acc[t], 0, 0, 0);
         if (tap + PD < 27) __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);  // DS reads of tap+PD first ...
-        if (tap < IN_ROUNDS + W_ROUNDS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // ... one staging load ...
+        if (tap < IN_ROUNDS + W_ROUNDS + (XF ? 4 : 0)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // ... one staging load ...
         __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                          // ... then the MFMAs of tap
       }
       __builtin_amdgcn_s_setprio(0);
@@ -1743,6 +1768,7 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   a.stats_rows = 4 * a.tiles_z * a.tiles_y * a.tiles_x;
   if (gn_partial && STRIDE == 1) conv_stats_plan(n, od, oh, ow, cin, cout, a.stats_rows, a.stats_accum, use_gnb);
   a.xcd_chunk = 0;
+  a.xf_coef = nullptr;
   if constexpr (STRIDE == 1) {
     if (conv32_takes(a.ntiles, cin, cout, use_gnb)) {
       constexpr size_t lds32 = (size_t)2 * 4 * (HZ * HY * HX + 4) * 16 + 4 * 4096 + 256 * 16;
@@ -1824,6 +1850,21 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
       }
       hipLaunchKernelGGL((conv_mfma_kernel<2, true>), dim3(grid), dim3(256), lds, s, a);
       return check_launch("conv_mfma(gnb, stride 2)");
+    }
+  }
+  if constexpr (STRIDE == 1) {
+    if (tuning_option("conv_xform_probe", 0) && !use_gnb && !add && act == MEDNET_ACT_NONE) {
+      // measurement probe (tools/probes/xform_probe.py): the GroupNorm apply + ELU of the layer in front inside commit()
+      a.xf_coef = (const float*)(((unsigned long long)(unsigned)tuning_option("conv_xf_hi", 0) << 32) | (unsigned)tuning_option("conv_xf_lo", 0));
+      MEDNET_REQUIRE(a.xf_coef != nullptr, MEDNET_E_SHAPE, "conv_xform_probe: set conv_xf_hi / conv_xf_lo to the coefficient tensor");
+      static bool attr_xf = false;
+      if (!attr_xf) {
+        if (hipFuncSetAttribute((const void*)conv_mfma_kernel<1, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+          return fail(MEDNET_E_HIP, "conv_mfma: cannot raise dynamic LDS to %zu", lds);
+        attr_xf = true;
+      }
+      hipLaunchKernelGGL((conv_mfma_kernel<1, false, 1>), dim3(grid), dim3(256), lds, s, a);
+      return check_launch("conv_mfma(xform probe)");
     }
   }
   hipLaunchKernelGGL((conv_mfma_kernel<STRIDE>), dim3(grid), dim3(256), lds, s, a);
@@ -2197,134 +2238,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
   }
 }
 
-// ---- weight gradient, third generation ("lean"): at most 128 registers per lane and 57 KB of LDS per workgroup -----------
-// wgrad_mfma2_kernel fills a CU (8 waves x 244 registers, 100 KB): while it runs nothing else does, and nothing of it runs beside
-// a data-gradient kernel, so the HBM-bound GroupNorm passes of the main stream never overlap the matrix work of the side stream
-// (DESIGN.md section 9).  This form is the split-bf16 weight gradient's layout with one MFMA per product: 8 waves, wave w owns
-// taps w, w + 8, w + 16 (, w + 24) = 64 accumulator registers, every wave walks all 16 k-steps of a 4x4x16 brick, the next
-// brick's 8 staging rounds are dealt out one per k-step, straight into LDS (no staging registers).  One workgroup per CU leaves
-// more than half of the register file and 32 KB of LDS to other kernels.
-__global__ __launch_bounds__(512, 2) void wgrad_mfma3_kernel(Wg2Args a) {
-  constexpr int TZ = 4, TY = 4, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
-  constexpr int NA = TZ * TY * TX, NB = HZ * HY * HX;
-  constexpr int NTHR = 512, TAPS = 4;
-  constexpr int A_ROUNDS = NA * 4 / NTHR, B_ROUNDS = (NB * 4 + NTHR - 1) / NTHR;
-  constexpr int KSTEPS = NA / 16;
-  static_assert(A_ROUNDS + B_ROUNDS <= KSTEPS, "one staging round per k-step");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // Staging by LDS-DMA (buffer_load ... lds: no staging registers, no commit phase), double buffered: the next brick lands in the
-  // other buffer while this one is on the matrix cores, one barrier per brick.  A round = 512 pieces of 16 bytes = 8 KB, a wave's
-  // 64 pieces are 1 KB contiguous (what the DMA writes); the last B round is padded (pieces past the halo read zeros).
-  constexpr int B_OFF = NA * 64, BUF = (A_ROUNDS + B_ROUNDS) * NTHR * 16;
-  constexpr unsigned OOB = 0xFFFFFF00u;
-
-  const int pair = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
-  const int ab = pair / a.nbb, bb = pair % a.nbb;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int tw = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, hk = lane >> 5;
-  const int coloff = (16 * (g & 1) + 4 * p) * 2;
-
-  // one staging round of brick `tile` into buffer `buf` (the resources are built here, not handed over from a lambda: see conv32)
-  auto fetch_round = [&](int j, int tile, int buf) {
-    if (j >= A_ROUNDS + B_ROUNDS) return;
-    const bool valid = tile < a.ntiles;
-    int tt = valid ? tile : 0;
-    int qd = fastdiv(tt, a.tiles_x, a.rcp_tiles_x);
-    const int tx0 = (tt - qd * a.tiles_x) * TX;
-    tt = qd;
-    qd = fastdiv(tt, a.tiles_y, a.rcp_tiles_y);
-    const int ty0 = (tt - qd * a.tiles_y) * TY;
-    tt = qd;
-    qd = fastdiv(tt, a.tiles_z, a.rcp_tiles_z);
-    const int tz0 = (tt - qd * a.tiles_z) * TZ;
-    const size_t svox = (size_t)qd * a.d * a.h * a.w;
-    char* dst = smem + buf * BUF + (j * NTHR + tw * 64) * 16;  // (wave-uniform; lane L's 16 bytes land at dst + 16 L)
-    if (j < A_ROUNDS) {
-      const int c = j * NTHR + tid;
-      const int v = c >> 2, part = c & 3;
-      const int gz = tz0 + v / (TX * TY), gy = ty0 + (v / TX) % TY, gx = tx0 + v % TX;
-      const bool ok = (gz < a.d) & (gy < a.h) & (gx < a.w) & (ab * 32 + part * 8 < a.ka) & valid;
-      const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + svox * a.ka), 0, a.bytesA, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)dst, 16,
-                                               ok ? ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.ka + ab * 32 + part * 8) * 2u : OOB, 0, 0, 0);
-    } else {
-      const int c = (j - A_ROUNDS) * NTHR + tid;
-      const int v = c >> 2, part = c & 3;
-      const int gz = tz0 - 1 + v / (HX * HY), gy = ty0 - 1 + (v / HX) % HY, gx = tx0 - 1 + v % HX;
-      const bool ok = (c < NB * 4) & ((unsigned)gz < (unsigned)a.d) & ((unsigned)gy < (unsigned)a.h) &
-                      ((unsigned)gx < (unsigned)a.w) & (bb * 32 + part * 8 < a.kb) & valid;
-      const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + svox * a.kb), 0, a.bytesB, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)dst, 16,
-                                               ok ? ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.kb + bb * 32 + part * 8) * 2u : OOB, 0, 0, 0);
-    }
-  };
-
-  f32x16 acc[TAPS];
-#pragma unroll
-  for (int i = 0; i < TAPS; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-  const bool has4 = tw < 3;  // waves 0..2 own four taps, waves 3..7 three
-  int toff[TAPS];
-#pragma unroll
-  for (int i = 0; i < TAPS; ++i) {
-    const int tap = tw + 8 * i < 27 ? tw + 8 * i : 26;
-    toff[i] = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 64;
-  }
-
-  int tile = split, buf = 0;
-  if (tile < a.ntiles) {
-#pragma unroll
-    for (int j = 0; j < A_ROUNDS + B_ROUNDS; ++j) fetch_round(j, tile, 0);
-  }
-  for (; tile < a.ntiles; tile += a.splits, buf ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the brick have landed ...
-    __syncthreads();                                   // ... and everybody's; the other buffer's readers are done
-    const char* Ab = smem + buf * BUF + coloff;
-    const char* Bb = Ab + B_OFF;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      const eltx8 fa = tr_operand(Ab + (ks * TX + 8 * hk + q) * 64, 4 * 64);
-      const char* brow = Bb + (((ks / TY) * HY + ks % TY) * HX + 8 * hk + q) * 64;
-      eltx8 fb[TAPS];
-#pragma unroll
-      for (int i = 0; i < TAPS; ++i)
-        if (i < 3 || has4) fb[i] = tr_operand(brow + toff[i], 4 * 64);  // (wave-uniform: the 4th slot of waves 3..7 has no tap)
-      fetch_round(ks, tile + a.splits, buf ^ 1);  // the next brick's staging rounds, one per k-step
-#pragma unroll
-      for (int i = 0; i < TAPS; ++i)
-        if (i < 3 || has4) acc[i] = MEDNET_MFMA_32x32x16(fa, fb[i], acc[i], 0, 0, 0);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (rounds requested for a brick past the end: nothing may be in flight at exit)
-  float* out = a.part + (size_t)blockIdx.x * 27 * 1024;
-  const int col = lane & 31;
-#pragma unroll
-  for (int i = 0; i < TAPS; ++i) {
-    const int tap = tw + 8 * i;
-    if (tap < 27) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) out[((size_t)tap * 32 + (j & 3) + 8 * (j >> 2) + 4 * hk) * 32 + col] = acc[i][j];
-    }
-  }
-}
-static void wgrad3_plan(int n, int d, int h, int w, int ka, int kb, Wg2Args& a) {
-  a.tiles_z = (d + 3) / 4;
-  a.tiles_y = (h + 3) / 4;
-  a.tiles_x = (w + 15) / 16;
-  a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
-  auto rcp = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
-  a.rcp_tiles_x = rcp(a.tiles_x); a.rcp_tiles_y = rcp(a.tiles_y); a.rcp_tiles_z = rcp(a.tiles_z);
-  a.nab = (ka + 31) / 32;
-  a.nbb = (kb + 31) / 32;
-  const int pairs = a.nab * a.nbb;
-  const int target = tuning_option("wgrad3_wgs", 512);  // workgroups per launch (512 = two per CU)
-  int splits = (target + pairs - 1) / pairs;
-  if (splits > a.ntiles) splits = a.ntiles;
-  if (splits < 1) splits = 1;
-  a.splits = splits;
-}
 static void wgrad2_plan(int n, int d, int h, int w, int ka, int kb, Wg2Args& a) {
   a.tiles_z = (d + 3) / 4;
   a.tiles_y = (h + 7) / 8;
@@ -2342,11 +2255,9 @@ static void wgrad2_plan(int n, int d, int h, int w, int ka, int kb, Wg2Args& a) 
   a.splits = splits;
 }
 static size_t wgrad2_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
-  Wg2Args a, b;
+  Wg2Args a;
   wgrad2_plan(n, d, h, w, cout, cin, a);
-  wgrad3_plan(n, d, h, w, cout, cin, b);  // (either generation may take the call: the larger of the two)
-  const int sp = a.splits > b.splits ? a.splits : b.splits;
-  return (size_t)a.nab * a.nbb * sp * 27 * 1024 * sizeof(float);
+  return (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
 }
 
 // dw[(a*KB + b)*27 + tap] = sum_split part[(pair*splits + split)][tap][a%32][b%32]
@@ -2477,32 +2388,6 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
   // conv: A = dy (Cout rows), B = x (Cin cols) shifted by tap - 1
   if (!tuning_option("wgrad_v2", 1) && cin % 32 == 0 && cout % 32 == 0)
     return launch_wg<1>(dy, x, dw, n, d, h, w, d, h, w, cout, cin, ws, ws_bytes, s);
-  if (tuning_option("wgrad_v3", 0)) {  // the lean form (A/B knob; see wgrad_mfma3_kernel)
-    constexpr size_t lds3 = (size_t)2 * (2 + 6) * 512 * 16;  // two buffers of 8 staging rounds
-    Wg2Args a;
-    a.A = (const elt*)dy;
-    a.B = (const elt*)x;
-    a.part = (float*)ws;
-    a.n = n; a.d = d; a.h = h; a.w = w; a.ka = cout; a.kb = cin;
-    wgrad3_plan(n, d, h, w, cout, cin, a);
-    a.bytesA = (unsigned)((size_t)d * h * w * cout * 2);
-    a.bytesB = (unsigned)((size_t)d * h * w * cin * 2);
-    const size_t need = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
-    MEDNET_REQUIRE(ws_bytes >= need, MEDNET_E_WORKSPACE, "wgrad_mfma3: workspace %zu < %zu", ws_bytes, need);
-    static bool attr3 = false;
-    if (!attr3) {
-      if (hipFuncSetAttribute((const void*)wgrad_mfma3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)
-        return fail(MEDNET_E_HIP, "wgrad_mfma3: cannot raise dynamic LDS to %zu", lds3);
-      attr3 = true;
-    }
-    hipLaunchKernelGGL(wgrad_mfma3_kernel, dim3(a.nab * a.nbb * a.splits), dim3(512), lds3, s, a);
-    int rc3 = check_launch("wgrad_mfma3");
-    if (rc3) return rc3;
-    const size_t total3 = (size_t)a.nab * a.nbb * 1024 * 27;
-    if (a.splits < 4) hipLaunchKernelGGL(wgrad_mfma_reduce_kernel_few, dim3((unsigned)((total3 + 255) / 256)), dim3(256), 0, s, a.part, dw, cout, cin, a.nbb, a.splits);
-  else hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total3 + 63) / 64)), dim3(256), 0, s, a.part, dw, cout, cin, a.nbb, a.splits);
-    return check_launch("wgrad_mfma_reduce");
-  }
   constexpr size_t lds = ((size_t)4 * 8 * 16 + 6 * 10 * 18) * 64;
   Wg2Args a;
   a.A = (const elt*)dy;

@@ -22,7 +22,7 @@ ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_EXACT = 0, 1, 2, 3
 ALGO_EXACT_BIT = 4  # OR-ed onto ALGO_MFMA: matrix-core path required AND exact fp32 products
 REG_L2, REG_L1 = 0, 1
 PAD_CONSTANT, PAD_SYMMETRIC = 0, 1
-F16, U8 = 2, 3  # storage types of resident volumes (mednet_crop_patches only)
+F16, U8, I64 = 2, 3, 4  # F16: fp16 storage / resident volumes; U8, I64: label types
 NO_IGNORE = -(2 ** 31)
 
 _vp, _i, _sz, _f, _i64 = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_int64
@@ -78,6 +78,11 @@ SIGNATURES = {
     "mednet_loss_ws_bytes": (_sz, [_i, _i, _sz]),
     "mednet_dice_fwd": (_i, [_vp] * 6 + [_i, _i, _sz, _i64, _i64, _f, _i, _i, _vp, _sz, _vp]),
     "mednet_dice_bwd": (_i, [_vp] * 6 + [_i, _i, _sz, _i64, _i64, _f, _i, _i, _vp]),
+    "mednet_head_dice_supported": (_i, [_i] * 4),
+    "mednet_head_dice_ws_bytes": (_sz, [_i, _sz, _i, _i]),
+    "mednet_head_dice_gn_rows": (_i, [_i, _sz, _i]),
+    "mednet_head_dice_fwd": (_i, [_vp] * 4 + [_i, _i64, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp]),
+    "mednet_head_dice_bwd": (_i, [_vp, _vp, _i, _i64] + [_vp] * 7 + [_i, _vp, _vp, _vp, _i, _sz, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp]),
     "mednet_ce_fwd": (_i, [_vp] * 5 + [_i, _i, _sz, _i64, _i64, _i, _vp, _sz, _vp]),
     "mednet_ce_bwd": (_i, [_vp] * 6 + [_i, _i, _sz, _i64, _i64, _i, _vp]),
     "mednet_heatmap_loss_fwd": (_i, [_vp] * 4 + [_i, _i, _sz, _i64, _i64, _i, _i, _vp, _sz, _vp]),

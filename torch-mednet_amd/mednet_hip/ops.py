@@ -853,6 +853,102 @@ def dice_loss(logits, labels, weight=None, eps=1e-5, sigmoid=False, ignore_index
     return DiceLossFn.apply(logits, labels, weight, eps, sigmoid, ignore_index)
 
 
+# ------------------------------------------------------------------------------------------------- 1x1x1 head + Dice, one node
+FUSE_HEAD_LOSS = os.environ.get("MEDNET_FUSE_HEAD_LOSS", "1") == "1"  # A/B knob
+
+
+def _label_view(labels: torch.Tensor, n: int, spatial_shape):
+    """Labels as the fused kernels take them: uint8 or int64, N x spatial, each sample's block dense; the stride between samples
+    is free (the last channel of a uint8 N x C x D x H x W label volume is consumed where it lies, segmentation.py:60)."""
+    if labels.dtype not in (torch.uint8, torch.int64):
+        labels = labels.long()
+    if tuple(labels.shape) != (n,) + tuple(spatial_shape):
+        raise AssertionError("'input' and 'target' must have the same shape")
+    dense, acc = [], 1
+    for sdim in reversed(spatial_shape):
+        dense.insert(0, acc)
+        acc *= sdim
+    if tuple(labels.stride()[1:]) != tuple(dense) or (n > 1 and labels.stride(0) < acc):
+        labels = labels.contiguous()
+    return labels, (labels.stride(0) if n > 1 else acc), (L.U8 if labels.dtype == torch.uint8 else L.I64)
+
+
+def head_dice_supported(x: torch.Tensor, cin: int, cout: int, labels: torch.Tensor) -> bool:
+    if not (FUSE_HEAD_LOSS and x.is_cuda and x.dim() == 5 and labels.is_cuda):
+        return False
+    if x.dtype != config.act_dtype() or not x.is_contiguous(memory_format=CL):
+        return False
+    ld = L.U8 if labels.dtype == torch.uint8 else L.I64
+    return bool(L.lib().mednet_head_dice_supported(cin, cout, L.dt(x), ld))
+
+
+class HeadDiceFn(Function):
+    """logits = final_conv(x) (model.py:207, 1x1x1 with bias, planar fp32) and loss = DiceLoss(logits, labels) (loss.py:114-130)
+    as ONE autograd node: forward is one pass over the features (mednet_head_dice_fwd), backward one pass that produces the
+    feature gradient, the head's weight and bias gradients and the first pass of the producing block's GroupNorm-3 backward
+    without ever storing the logit gradient (mednet_head_dice_bwd).  Returns (logits, loss); the logits are a result for the
+    caller (metrics, `outputs`), not a differentiable output of this node."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, packed, labels, loss_weight, eps, sigmoid, ignore_index):
+        L.require_gpu(x, "head_dice")
+        n, cin, d, h, w = x.shape
+        cout = weight.shape[0]
+        spatial = d * h * w
+        lab, lab_sn, lab_dt = _label_view(labels, n, (d, h, w))
+        wt = None if loss_weight is None else loss_weight.to(device=x.device, dtype=torch.float32).contiguous()
+        logits = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        saved = torch.empty((cout, 2), dtype=torch.float32, device=x.device)
+        lib = L.lib()
+        ws = L.workspace(lib.mednet_head_dice_ws_bytes(n, spatial, cin, cout), x.device)
+        ii = L.NO_IGNORE if ignore_index is None else int(ignore_index)
+        L.check(lib.mednet_head_dice_fwd(x.data_ptr(), packed.data_ptr(), L.ptr(bias), lab.data_ptr(), lab_dt, lab_sn, L.ptr(wt),
+                                         logits.data_ptr(), loss.data_ptr(), saved.data_ptr(), n, spatial, cin, cout, eps,
+                                         int(sigmoid), ii, L.dt(x), ws.data_ptr(), ws.numel(), L.stream()), "head_dice_fwd")
+        ctx.save_for_backward(x, packed, logits, lab, wt, saved)
+        ctx.meta = (eps, int(sigmoid), ii, lab_sn, lab_dt, cin, cout)
+        ctx.params = (weight, bias)
+        ctx.gn3 = _gn3_hook_of(x, x.dtype)
+        ctx.mark_non_differentiable(logits)
+        if debug.TRACE is not None:
+            debug.trace("head_dice.fwd", logits, loss, saved)
+        return logits, loss
+
+    @staticmethod
+    def backward(ctx, _dlogits, dloss):
+        x, packed, logits, lab, wt, saved = ctx.saved_tensors
+        eps, sigmoid, ii, lab_sn, lab_dt, cin, cout = ctx.meta
+        weight, bias = ctx.params
+        n, _, d, h, w = x.shape
+        spatial = d * h * w
+        lib = L.lib()
+        dl = dloss.to(torch.float32).contiguous()
+        dx = torch.empty_like(x, memory_format=CL)
+        dw, direct_w = _grad_target(weight, (cout, cin, 1, 1, 1))
+        db, direct_b = (None, True) if bias is None else _grad_target(bias, (cout,))
+        hook = ctx.gn3
+        partial = None
+        if hook is not None:
+            partial = torch.empty((n, lib.mednet_head_dice_gn_rows(n, spatial, cin), cin, 2), dtype=torch.float32, device=x.device)
+        ws = L.workspace(lib.mednet_head_dice_ws_bytes(n, spatial, cin, cout), x.device)
+        L.check(lib.mednet_head_dice_bwd(logits.data_ptr(), lab.data_ptr(), lab_dt, lab_sn, packed.data_ptr(), L.ptr(wt),
+                                         saved.data_ptr(), dl.data_ptr(), dx.data_ptr(),
+                                         None if hook is None else hook.gn_in.data_ptr(), x.data_ptr(),
+                                         0 if hook is None else hook.act, L.ptr(partial), dw.data_ptr(), L.ptr(db), n, spatial, cin,
+                                         cout, eps, sigmoid, ii, L.dt(x), ws.data_ptr(), ws.numel(), L.stream()), "head_dice_bwd")
+        if hook is not None:
+            hook.offer(dx, partial)
+        if debug.TRACE is not None:
+            debug.trace("head_dice.bwd", dx, partial, dw, db)
+        return dx, (None if direct_w else dw), (None if (bias is None or direct_b) else db), None, None, None, None, None, None
+
+
+def head_dice(x, weight, bias, packed, labels, loss_weight=None, eps=1e-5, sigmoid=False, ignore_index=None):
+    """-> (logits N x C x D x H x W fp32, Dice loss)."""
+    return HeadDiceFn.apply(x, weight, bias, packed, labels, loss_weight, eps, sigmoid, ignore_index)
+
+
 def per_channel_dice(logits, labels, weight=None, eps=1e-5, sigmoid=False, ignore_index=None):
     """dice_metric  -- loss.py:51-55 (no gradient)."""
     L.require_gpu(logits, "dice_metric")

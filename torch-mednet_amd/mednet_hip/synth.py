@@ -1,5 +1,5 @@
 """Deterministic synthetic inputs and name-keyed weights for benchmarks and demos.  Same streams as the
-test oracle's generators (tests/test_synth_matches_oracle.py pins that), but owned by the product so bench.py's GPU
+test oracle's generators (tests/test_ddp_gloo.py::test_synth_generators_match_oracle pins that), but owned by the product so bench.py's GPU
 leg never touches oracle/."""
 from __future__ import annotations
 

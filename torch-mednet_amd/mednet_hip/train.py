@@ -369,11 +369,27 @@ class SegmentationStep(_GraphedStep):
         self._init_graph(graph)
         self._exchange = None
 
+    def _head_loss(self, inputs, label_u8):
+        """`outputs = self(inputs); loss = self.loss(outputs, labels)` (segmentation.py:61-62).  When the model is this package's
+        U-Net with a 1x1x1 head of at most 4 classes and the loss is DiceLoss, the head and the loss run as one fused node
+        (ops.head_dice: logits written once, no logit-gradient tensor, the label volume's uint8 channel consumed where it
+        lies); anything else takes the two calls as they stand."""
+        from .unet.model import _UNetCore
+        m, fc = self.model, getattr(self.model, "final_conv", None)
+        if (isinstance(m, _UNetCore) and not m.testing and isinstance(self.loss, HL.DiceLoss) and not self.loss.skip_last_target
+                and fc is not None and getattr(fc, "planar_output", False) and fc.kernel_size[0] == 1 and inputs.is_cuda):
+            feats = m.forward_features(inputs)
+            if ops.head_dice_supported(feats, fc.in_channels, fc.out_channels, label_u8):
+                return ops.head_dice(feats, fc.weight, fc.bias, fc._packed(), label_u8, self.loss.weight, self.loss.epsilon,
+                                     self.loss.sigmoid_normalization, self.loss.ignore_index)
+            outputs = fc(feats)
+        else:
+            outputs = m(inputs)
+        return outputs, self.loss(outputs, label_u8.long())
+
     def _fwd_bwd(self, batch):
         inputs = batch["data"].float()
-        labels = batch["label"][:, -1, ...].long()
-        outputs = self.model(inputs)
-        loss = self.loss(outputs, labels)
+        _, loss = self._head_loss(inputs, batch["label"][:, -1, ...])
         (loss if self.scaler is None else self.scaler.scale_loss(loss)).backward()
         finish_backward()
         return (loss.detach(),)

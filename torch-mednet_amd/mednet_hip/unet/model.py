@@ -100,7 +100,20 @@ class _UNetCore(*((_Base,) if _Base is not nn.Module else (_CheckpointCompat, nn
         with config.exact_products(kinked):
             return self._forward(x)
 
+    def forward_features(self, x):
+        """Everything in front of `final_conv` (model.py:189-206): the last decoder block's output, channels-last.  The fused
+        head + Dice step (train.SegmentationStep, ops.head_dice) continues from here."""
+        kinked = any(getattr(m, "_kinked", False) for m in self.modules())
+        with config.exact_products(kinked):
+            return self._features(x)
+
     def _forward(self, x):
+        x = self.final_conv(self._features(x))
+        if self.testing and self.final_activation is not None:
+            x = self.final_activation(x)
+        return x
+
+    def _features(self, x):
         skips = []
         for i, enc in enumerate(self.encoders):
             if i == 0:
@@ -110,9 +123,6 @@ class _UNetCore(*((_Base,) if _Base is not nn.Module else (_CheckpointCompat, nn
             skips.insert(0, x)
         for dec, skip in zip(self.decoders, skips[1:]):
             x = dec(skip, x)
-        x = self.final_conv(x)
-        if self.testing and self.final_activation is not None:
-            x = self.final_activation(x)
         return x
 
 
