@@ -22,6 +22,32 @@ constexpr int HL_BLOCK_VOX = 256 * 8;  // = LOSS_BLOCK_VOX of loss.hip: the part
 constexpr int HL_MAXC = 4;              // classes kept in registers (the segmentation heads of the callers: 2 and 4)
 constexpr int HL_VPT = 32;              // = HEAD_GN_VPT of conv_direct.hip: the GroupNorm rows are head_dgrad_gn_kernel's
 
+// a voxel's 8-channel piece as it lies in memory (4 registers for the 16-bit types): converted where it is used, so rows in
+// flight do not hold 8 registers each
+template <typename T>
+struct Raw8;
+template <>
+struct Raw8<bf16> {
+  bf16x8 r;
+  __device__ __forceinline__ void load(const bf16* p, size_t i) { r = *reinterpret_cast<const bf16x8*>(p + i); }
+  __device__ __forceinline__ float at(int j) const { return (float)r[j]; }
+};
+template <>
+struct Raw8<f16> {
+  f16x8 r;
+  __device__ __forceinline__ void load(const f16* p, size_t i) { r = *reinterpret_cast<const f16x8*>(p + i); }
+  __device__ __forceinline__ float at(int j) const { return (float)r[j]; }
+};
+template <>
+struct Raw8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p, size_t i) {
+    a = *reinterpret_cast<const f32x4*>(p + i);
+    b = *reinterpret_cast<const f32x4*>(p + i + 4);
+  }
+  __device__ __forceinline__ float at(int j) const { return j < 4 ? a[j] : b[j - 4]; }
+};
+
 template <typename TL>
 __device__ __forceinline__ int label_at(const TL* __restrict__ lab, size_t i) { return (int)lab[i]; }
 
@@ -122,7 +148,7 @@ __global__ __launch_bounds__(256) void head_dice_fwd_kernel(const TI* __restrict
 // ---- backward: K/8 lanes per voxel, each owns 8 channels of the voxel's row; two voxels per trip --------------------------
 // wpart[n][block][wave][m * K + m]: this wave's partial of dW (row-major [class][channel]) and, behind it, of db
 template <typename TO, int K, typename TL>
-__global__ __launch_bounds__(256) void head_dice_bwd_kernel(const float* __restrict__ lgs, const TL* __restrict__ lab, int64_t lab_sn,
+__global__ __launch_bounds__(256, sizeof(TO) == 2 ? 3 : 2) void head_dice_bwd_kernel(const float* __restrict__ lgs, const TL* __restrict__ lab, int64_t lab_sn,
                                                             const float* __restrict__ Pb /*[m][K]*/, const float* __restrict__ weight,
                                                             const float* __restrict__ saved, const float* __restrict__ dloss,
                                                             float eps, int sigmoid, int ignore, TO* __restrict__ dz,
@@ -191,11 +217,15 @@ __global__ __launch_bounds__(256) void head_dice_bwd_kernel(const float* __restr
     }
     const int ya = label_at(lab, (size_t)n * lab_sn + v), yb = label_at(lab, (size_t)n * lab_sn + vbs);
     const size_t rowa = ((size_t)n * spatial + v) * K + cgi * 8, rowb = ((size_t)n * spatial + vbs) * K + cgi * 8;
-    const F8 zva = ld8(gz, rowa), zvb = ld8(gz, rowb);
-    F8 yva, yvb;
+    Raw8<TO> zva, zvb, yva, yvb;
+    zva.load(gz, rowa);
+    zvb.load(gz, rowb);
     if (gy) {
-      yva = ld8(gy, rowa);
-      yvb = ld8(gy, rowb);
+      yva.load(gy, rowa);
+      yvb.load(gy, rowb);
+    } else {
+      yva = zva;
+      yvb = zvb;
     }
     float da[HL_MAXC], db[HL_MAXC];
     dlogits_of(la, ya, da);
@@ -214,7 +244,7 @@ __global__ __launch_bounds__(256) void head_dice_bwd_kernel(const float* __restr
         for (int j = 0; j < 8; ++j) {
           t.v[j] = fmaf(da[i], wreg[i][j], t.v[j]);
           u.v[j] = fmaf(db[i], wreg[i][j], u.v[j]);
-          wacc[i][j] = fmaf(db[i], zvb.v[j], fmaf(da[i], zva.v[j], wacc[i][j]));  // dW[i][k] += dl_i * z_k
+          wacc[i][j] = fmaf(db[i], zvb.at(j), fmaf(da[i], zva.at(j), wacc[i][j]));  // dW[i][k] += dl_i * z_k
         }
         bacc[i] += da[i] + db[i];
       }
@@ -227,12 +257,18 @@ __global__ __launch_bounds__(256) void head_dice_bwd_kernel(const float* __restr
     st8(dz, rowa, t);
     if (hb) st8(dz, rowb, u);
     if (gy) {
-      act_grad_n<8>(t.v, zva.v, act);
-      act_grad_n<8>(u.v, zvb.v, act);
+      float za[8], zb[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        za[j] = zva.at(j);
+        zb[j] = zvb.at(j);
+      }
+      act_grad_n<8>(t.v, za, act);
+      act_grad_n<8>(u.v, zb, act);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         ss[j] += t.v[j] + u.v[j];
-        sq[j] = fmaf(u.v[j], yvb.v[j], fmaf(t.v[j], yva.v[j], sq[j]));
+        sq[j] = fmaf(u.v[j], yvb.at(j), fmaf(t.v[j], yva.at(j), sq[j]));
       }
     }
   }
@@ -264,22 +300,32 @@ __global__ __launch_bounds__(256) void head_dice_bwd_kernel(const float* __restr
   }
 }
 
-// dW[e] (e < m * K) and db[e - m * K]: one wave per output, lanes stride the partial rows, fp64, fixed order
-__global__ __launch_bounds__(64) void head_dice_wfinal_kernel(const float* __restrict__ wpart, float* __restrict__ dw,
-                                                              float* __restrict__ dbias, int rows, int mk, int m) {
-  const int e = blockIdx.x;
-  const size_t stride = (size_t)mk + m;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int r = threadIdx.x;
-  for (; r + 192 < rows; r += 256) {
-    s0 += (double)wpart[(size_t)r * stride + e];
-    s1 += (double)wpart[(size_t)(r + 64) * stride + e];
-    s2 += (double)wpart[(size_t)(r + 128) * stride + e];
-    s3 += (double)wpart[(size_t)(r + 192) * stride + e];
+// dW[e] (e < m * K) and db[e - m * K] from the waves' partial rows, in two coalesced stages (one wave per output walking 16 384
+// rows with a 528-byte stride took 60 us): stage 1, workgroup g sums its slice of the rows, thread e one output (consecutive
+// threads read consecutive floats of a row), fp64, into part2[g][e]; stage 2 sums the HL_WF_GROUPS partials in order.
+constexpr int HL_WF_GROUPS = 128;
+__global__ __launch_bounds__(192) void head_dice_wfinal1_kernel(const float* __restrict__ wpart, double* __restrict__ part2, int rows,
+                                                                int width) {
+  const int per = (rows + HL_WF_GROUPS - 1) / HL_WF_GROUPS;
+  const int r0 = blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+  for (int e = threadIdx.x; e < width; e += 192) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+      s0 += (double)wpart[(size_t)r * width + e];
+      s1 += (double)wpart[(size_t)(r + 1) * width + e];
+      s2 += (double)wpart[(size_t)(r + 2) * width + e];
+      s3 += (double)wpart[(size_t)(r + 3) * width + e];
+    }
+    for (; r < r1; ++r) s0 += (double)wpart[(size_t)r * width + e];
+    part2[(size_t)blockIdx.x * width + e] = (s0 + s1) + (s2 + s3);
   }
-  for (; r < rows; r += 64) s0 += (double)wpart[(size_t)r * stride + e];
-  const double s = wave_sum((s0 + s1) + (s2 + s3));
-  if (threadIdx.x == 0) {
+}
+__global__ __launch_bounds__(192) void head_dice_wfinal2_kernel(const double* __restrict__ part2, float* __restrict__ dw,
+                                                                float* __restrict__ dbias, int width, int mk) {
+  for (int e = threadIdx.x; e < width; e += 192) {
+    double s = 0.0;
+    for (int g = 0; g < HL_WF_GROUPS; ++g) s += part2[(size_t)g * width + e];
     if (e < mk) dw[e] = (float)s;
     else if (dbias) dbias[e - mk] = (float)s;
   }
@@ -305,7 +351,8 @@ extern "C" int mednet_head_dice_supported(int cin, int cout, int dtype, int labe
 }
 extern "C" size_t mednet_head_dice_ws_bytes(int n, size_t spatial, int cin, int cout) {
   const size_t fwd = ((size_t)n * hl_fwd_blocks(spatial) * cout * 2 + 64) * sizeof(float);
-  const size_t bwd = ((size_t)n * hl_bwd_blocks(spatial, cin) * 4 * ((size_t)cout * cin + cout) + 64) * sizeof(float);
+  const size_t width = (size_t)cout * cin + cout;
+  const size_t bwd = ((size_t)n * hl_bwd_blocks(spatial, cin) * 4 * width + 64) * sizeof(float) + (size_t)HL_WF_GROUPS * width * sizeof(double) + 16;
   return fwd > bwd ? fwd : bwd;
 }
 extern "C" int mednet_head_dice_gn_rows(int n, size_t spatial, int cin) {
@@ -369,6 +416,9 @@ extern "C" int mednet_head_dice_bwd(const float* logits, const void* labels, int
 #undef HB
   int rc = check_launch("head_dice_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(head_dice_wfinal_kernel, dim3(cout * cin + cout), dim3(64), 0, s, wpart, dw, dbias, (int)(n * nb * 4), cout * cin, cout);
+  const int width = cout * cin + cout, rows = (int)(n * nb * 4);
+  double* part2 = (double*)((char*)ws + (((size_t)rows * width + 64) * sizeof(float) + 7) / 8 * 8);
+  hipLaunchKernelGGL(head_dice_wfinal1_kernel, dim3(HL_WF_GROUPS), dim3(192), 0, s, wpart, part2, rows, width);
+  hipLaunchKernelGGL(head_dice_wfinal2_kernel, dim3(1), dim3(192), 0, s, part2, dw, dbias, width, cout * cin);
   return check_launch("head_dice_wfinal");
 }
