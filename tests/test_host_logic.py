@@ -264,3 +264,53 @@ def test_exact_products_policy_follows_the_activation_kind():
     finally:
         config.set_conv_algo("auto")
     assert config.conv_algo() == L.ALGO_AUTO
+
+
+def test_exact_request_is_separate_from_the_algorithm_and_per_thread():
+    """with set_conv_algo('mfma') a ReLU network in fp32 storage must still get exact products (the request rides on
+    the base choice as MEDNET_ALGO_EXACT_BIT instead of being dropped), a backward replays base + request, and a scope opened in
+    one thread is invisible to another (autograd's worker thread, or a second model driven from a second thread)."""
+    import threading
+    from mednet_hip import _lib as L, config
+    config.set_conv_algo("mfma")
+    try:
+        assert config.conv_algo() == L.ALGO_MFMA
+        with config.exact_products(True):
+            assert config.conv_algo() == (L.ALGO_MFMA | L.ALGO_EXACT_BIT)
+            captured = config.conv_algo()
+            with config.algo_scope(L.ALGO_MFMA):  # replaying a forward that ran WITHOUT the request
+                assert config.conv_algo() == L.ALGO_MFMA
+        with config.algo_scope(captured):  # ... and one that ran with it, from outside the scope
+            assert config.conv_algo() == (L.ALGO_MFMA | L.ALGO_EXACT_BIT)
+        assert config.conv_algo() == L.ALGO_MFMA
+    finally:
+        config.set_conv_algo("auto")
+    seen = []
+    with config.exact_products(True):
+        t = threading.Thread(target=lambda: seen.append(config.conv_algo()))
+        t.start()
+        t.join()
+        assert config.conv_algo() == L.ALGO_EXACT
+    assert seen == [L.ALGO_AUTO]
+
+
+def test_optimizer_and_scaler_state_round_trip():
+    """FlatAdam.load_state_dict restores the hyper-parameters it saved and refuses to resume a scaled run without the
+    scaler's state; LossScaler.load_state_dict accepts the 4-entry state of earlier builds (new counters start at 0)."""
+    from mednet_hip.train import FlatAdam, FlatParams, LossScaler
+    lin = torch.nn.Linear(8, 8)
+    flat = FlatParams(lin)
+    opt = FlatAdam(flat, lr=3e-4, betas=(0.8, 0.95), eps=1e-6, weight_decay=0.01)
+    opt.t = 7
+    sd = opt.state_dict()
+    opt2 = FlatAdam(FlatParams(torch.nn.Linear(8, 8)), lr=1e-3)
+    opt2.load_state_dict(sd)
+    assert (opt2.lr, opt2.betas, opt2.eps, opt2.wd, opt2.t) == (3e-4, (0.8, 0.95), 1e-6, 0.01, 7)
+    sc = LossScaler("cpu")
+    with pytest.raises(KeyError):
+        opt2.load_state_dict(sd, scaler=sc)  # saved without a scaler: resuming WITH one must not silently restart at 65536
+    sc.load_state_dict({"state": torch.tensor([1024.0, 5.0, 40.0, 0.0]), "growth_factor": 2.0, "backoff_factor": 0.5,
+                        "growth_interval": 100})
+    assert sc.state.tolist() == [1024.0, 5.0, 40.0, 0.0, 0.0, 0.0, 0.0, 0.0] and sc.growth_interval == 100
+    with pytest.raises(ValueError):
+        sc.load_state_dict({"state": torch.zeros(9), "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 100})

@@ -14,6 +14,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the probe instantiation lives in its own build: make -C torch-mednet_amd/csrc probe
+os.environ.setdefault("MEDNET_LIB_PATH", os.path.join(ROOT, "torch-mednet_amd", "mednet_hip", "libmednet_hip_probe.so"))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "torch-mednet_amd")]
 import torch  # noqa: E402
 

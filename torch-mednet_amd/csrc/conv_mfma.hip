@@ -985,7 +985,9 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
           // of its neighbours) until THEIR step 26.  This wave is past its own (the MFMAs of step 26 have consumed them), but
           // waves of a workgroup are not in lockstep: one barrier here -- every wave arrives within a few hundred cycles of
           // the others, one wave per SIMD -- makes "dead from step 27 on" true for the workgroup, not only for this wave.
+#ifndef MEDNET_C32_NO_MIDBARRIER  // (A/B builds only: profiles/r04_ab.md)
           if (t == 2 && s54 == 27) __builtin_amdgcn_s_barrier();
+#endif
           if (t == 2 && s54 >= 27 && s54 < 35) {  // GroupNorm input row s54 - 27 -> LDS (row planned at step 24 + row)
             const int j = s54 - 27;
             // (the resource is built here, not by the row_rsrc lambda: handed a lambda's return value, hipcc 7.2 silently drops
@@ -1852,6 +1854,7 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
       return check_launch("conv_mfma(gnb, stride 2)");
     }
   }
+#ifdef MEDNET_XFORM_PROBE  // (`make probe`: libmednet_hip_probe.so; the shipped library does not carry this instantiation)
   if constexpr (STRIDE == 1) {
     if (tuning_option("conv_xform_probe", 0) && !use_gnb && !add && act == MEDNET_ACT_NONE) {
       // measurement probe (tools/probes/xform_probe.py): the GroupNorm apply + ELU of the layer in front inside commit()
@@ -1867,6 +1870,7 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
       return check_launch("conv_mfma(xform probe)");
     }
   }
+#endif
   hipLaunchKernelGGL((conv_mfma_kernel<STRIDE>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_mfma");
 }
