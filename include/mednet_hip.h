@@ -238,6 +238,14 @@ int mednet_dice_fwd(const float* logits, const int64_t* labels, const float* wei
 int mednet_dice_bwd(const float* logits, const int64_t* labels, const float* weight, const float* saved,
                     const float* dloss, float* dlogits, int n, int c, size_t spatial, int64_t stride_n,
                     int64_t stride_c, float eps, int sigmoid, int ignore_index, mednet_stream stream);
+/* The same with the labels as they lie: MEDNET_I64 or MEDNET_U8, element stride label_stride_n between samples (the last channel
+ * of a uint8 N x C x D x H x W label volume: `batch['label'][:, -1]`, segmentation.py:60 / landmarks.py:70, without the cast). */
+int mednet_dice_fwd_lt(const float* logits, const void* labels, int label_dtype, int64_t label_stride_n, const float* weight,
+                       float* loss, float* saved, float* dice_out, int n, int c, size_t spatial, int64_t stride_n,
+                       int64_t stride_c, float eps, int sigmoid, int ignore_index, void* ws, size_t ws_bytes, mednet_stream stream);
+int mednet_dice_bwd_lt(const float* logits, const void* labels, int label_dtype, int64_t label_stride_n, const float* weight,
+                       const float* saved, const float* dloss, float* dlogits, int n, int c, size_t spatial, int64_t stride_n,
+                       int64_t stride_c, float eps, int sigmoid, int ignore_index, mednet_stream stream);
 /* The 1x1x1 head (model.py:207 final_conv: nn.Conv3d(f_maps[0], out_channels, 1)) fused with DiceLoss (loss.py:114-130) --
  * what `outputs = self(inputs); loss = self.loss(outputs, labels)` (segmentation.py:61-62) runs between the last decoder block and
  * the scalar loss.  Forward: logits (N x C x spatial fp32, written once, for the caller) + loss + saved[c] = {I_c, D_c} in one pass
@@ -275,6 +283,14 @@ int mednet_heatmap_loss_fwd(const float* out, const void* target, const float* c
 int mednet_heatmap_loss_bwd(const float* out, const void* target, const float* cweight, const float* dloss,
                             float* dout, int n, int c, size_t spatial, int64_t stride_n, int64_t stride_c, int kind,
                             int tgt_u8, mednet_stream stream);
+/* ... with an element stride between the samples of `target` (channel ch of sample n at + n * target_stride_n + ch * spatial): the
+ * heat-map channels of a label volume (`batch['label'][:, :-1]`, landmarks.py:68) are consumed where they lie, no copy. */
+int mednet_heatmap_loss_fwd_strided(const float* out, const void* target, int64_t target_stride_n, const float* cweight, float* loss,
+                                    int n, int c, size_t spatial, int64_t stride_n, int64_t stride_c, int kind, int tgt_u8, void* ws,
+                                    size_t ws_bytes, mednet_stream stream);
+int mednet_heatmap_loss_bwd_strided(const float* out, const void* target, int64_t target_stride_n, const float* cweight,
+                                    const float* dloss, float* dout, int n, int c, size_t spatial, int64_t stride_n,
+                                    int64_t stride_c, int kind, int tgt_u8, mednet_stream stream);
 
 /* ---- torch.optim.Adam(lr) step  segmentation.py:119-120 (betas .9/.999, eps 1e-8, wd 0), flat fp32 buffers --- */
 int mednet_adam_step(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,

@@ -1093,3 +1093,29 @@ def test_plain_bf16_pack_serves_an_fp32_storage_call(cin, cout, shape):
                                   L.NDHWC, 0, L.ALGO_AUTO, None, L.stream()), "conv3d_fwd")
     assert bool(torch.isfinite(y).all())
     assert_close(y, yr.float(), 3e-5, "fp32-storage conv on a plain bf16 pack")
+
+
+def test_losses_take_the_label_volume_where_it_lies():
+    """landmarks.py:68-70 / segmentation.py:60 slice a uint8 N x (H + 1) x D x H x W label volume into heat maps [:, :-1] and class
+    labels [:, -1].  ops.dice_loss takes the uint8 label view as it is (no `.long()` cast kernel), ops.heatmap_loss the strided
+    heat-map view (no `.contiguous()` copy); both must equal the int64 / contiguous forms bit for bit, forward and backward."""
+    n, nh, nc, shape = 2, 3, 2, (9, 10, 21)
+    g = np.random.Generator(np.random.PCG64(5))
+    vol = torch.from_numpy(g.integers(0, 256, size=(n, nh + 1) + shape).astype(np.uint8))
+    vol[:, -1] = torch.from_numpy(g.integers(0, nc, size=(n,) + shape).astype(np.uint8))
+    vol = vol.to(DEV)
+    lg = rnd("lvl", n, nh + nc, *shape).to(DEV)
+    w = torch.tensor([0.05, 1.0], device=DEV)
+    res = []
+    for direct in (False, True):
+        x = lg.clone().requires_grad_(True)
+        out_hm, out_cls = x[:, :nh], x[:, nh:]
+        labels = vol[:, -1] if direct else vol[:, -1].long()
+        heat = vol[:, :-1] if direct else vol[:, :-1].contiguous()
+        if direct:
+            assert labels.dtype == torch.uint8 and not heat.is_contiguous()
+        loss = ops.dice_loss(out_cls, labels, w) + ops.heatmap_loss(out_hm, heat, [0.015, 0.02, 0.03], "L2")
+        loss.backward()
+        res.append((loss.detach().clone(), x.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float(res[0][1].abs().max()) > 0

@@ -46,8 +46,8 @@ __device__ __forceinline__ void probs_of(const float* __restrict__ lg, size_t ba
 }
 
 // partial[n][block][c][2] = {sum p*t*mask, sum (p+t)*mask}
-template <int MAXC>
-__global__ __launch_bounds__(256) void dice_fwd_kernel(const float* __restrict__ lg, const int64_t* __restrict__ lab,
+template <int MAXC, typename TL>
+__global__ __launch_bounds__(256) void dice_fwd_kernel(const float* __restrict__ lg, const TL* __restrict__ lab, int64_t lab_sn,
                                                        float* __restrict__ partial, int c, size_t spatial, int64_t sn,
                                                        int64_t sc, int sigmoid, int ignore) {
   __shared__ float scratch[4];
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const float* __restrict__
     if (v < spatial) {
       float p[MAXC];
       probs_of<MAXC>(lg, (size_t)n * sn + v, sc, c, sigmoid, p);
-      const int y = (int)lab[(size_t)n * spatial + v];
+      const int y = (int)lab[(size_t)n * lab_sn + v];
       // A label outside [0, C) makes the reference raise (scatter_ index error, loss.py:81-86).  Raising from a kernel
       // would cost a host sync per step; instead the loss (and with it every gradient) becomes NaN: loud, not silent.
       bad |= (unsigned)y >= (unsigned)c;
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void dice_finalize_kernel(const float* __restr
   }
 }
 
-template <int MAXC>
-__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ lg, const int64_t* __restrict__ lab,
+template <int MAXC, typename TL>
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ lg, const TL* __restrict__ lab, int64_t lab_sn,
                                                        const float* __restrict__ weight,
                                                        const float* __restrict__ saved, const float* __restrict__ dloss,
                                                        float* __restrict__ dlg, int c, size_t spatial, int64_t sn,
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__
     if (v < spatial) {
       float p[MAXC], g[MAXC];
       probs_of<MAXC>(lg, (size_t)n * sn + v, sc, c, sigmoid, p);
-      const int y = (int)lab[(size_t)n * spatial + v];
+      const int y = (int)lab[(size_t)n * lab_sn + v];
       float dot = 0.f;
 #pragma unroll
       for (int k = 0; k < MAXC; ++k)
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 
 // ---- heat-map regression: partial[(n*c + ch)][block] = sum f(out - tgt) -----------------------------------------
 template <typename TT>
-__global__ __launch_bounds__(256) void hm_fwd_kernel(const float* __restrict__ out, const TT* __restrict__ tgt,
+__global__ __launch_bounds__(256) void hm_fwd_kernel(const float* __restrict__ out, const TT* __restrict__ tgt, int64_t tgt_sn,
                                                      float* __restrict__ partial, int c, size_t spatial, int64_t sn,
                                                      int64_t sc, int kind) {
   __shared__ float scratch[4];
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void hm_fwd_kernel(const float* __restrict__ o
   for (int it = 0; it < 8; ++it) {
     const size_t v = v0 + (size_t)it * 256 + threadIdx.x;
     if (v < spatial) {
-      const float d = out[(size_t)n * sn + (size_t)ch * sc + v] - ld(tgt, ((size_t)n * c + ch) * spatial + v);
+      const float d = out[(size_t)n * sn + (size_t)ch * sc + v] - ld(tgt, (size_t)n * tgt_sn + (size_t)ch * spatial + v);
       s += kind == MEDNET_REG_L2 ? d * d : fabsf(d);
     }
   }
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(1024) void hm_finalize_kernel(const float* __restri
   }
 }
 template <typename TT>
-__global__ __launch_bounds__(256) void hm_bwd_kernel(const float* __restrict__ out, const TT* __restrict__ tgt,
+__global__ __launch_bounds__(256) void hm_bwd_kernel(const float* __restrict__ out, const TT* __restrict__ tgt, int64_t tgt_sn,
                                                      const float* __restrict__ cweight, const float* __restrict__ dloss,
                                                      float* __restrict__ dout, int c, size_t spatial, int64_t sn,
                                                      int64_t sc, int kind, float inv_count) {
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void hm_bwd_kernel(const float* __restrict__ o
   for (int it = 0; it < 8; ++it) {
     const size_t v = v0 + (size_t)it * 256 + threadIdx.x;
     if (v < spatial) {
-      const size_t o = ((size_t)n * c + ch) * spatial + v, os = (size_t)n * sn + (size_t)ch * sc + v;
+      const size_t o = (size_t)n * tgt_sn + (size_t)ch * spatial + v, os = (size_t)n * sn + (size_t)ch * sc + v;
       const float d = out[os] - ld(tgt, o);
       dout[os] = kind == MEDNET_REG_L2 ? 2.f * d * scale : (d > 0.f ? scale : (d < 0.f ? -scale : 0.f));
     }
@@ -353,17 +353,28 @@ extern "C" size_t mednet_loss_ws_bytes(int n, int c, size_t spatial) {
     else { CALL(32); }                 \
   } while (0)
 
-extern "C" int mednet_dice_fwd(const float* logits, const int64_t* labels, const float* weight, float* loss,
-                               float* saved, float* dice_out, int n, int c, size_t spatial, int64_t stride_n,
-                               int64_t stride_c, float eps, int sigmoid, int ignore_index, void* ws, size_t ws_bytes,
-                               mednet_stream stream) {
+// labels: MEDNET_I64 (N x spatial, the reference's `.long()`) or MEDNET_U8, element stride label_stride_n between samples (the last
+// channel of a uint8 label volume is consumed where it lies: no cast kernel, landmarks.py:70 / segmentation.py:60)
+extern "C" int mednet_dice_fwd_lt(const float* logits, const void* labels, int label_dtype, int64_t label_stride_n, const float* weight,
+                                  float* loss, float* saved, float* dice_out, int n, int c, size_t spatial, int64_t stride_n,
+                                  int64_t stride_c, float eps, int sigmoid, int ignore_index, void* ws, size_t ws_bytes,
+                                  mednet_stream stream) {
   MEDNET_REQUIRE(c >= 1 && c <= 32, MEDNET_E_UNSUPPORTED, "dice_fwd: C=%d (supported: 1..32)", c);
   MEDNET_REQUIRE(n > 0 && spatial > 0, MEDNET_E_SHAPE, "dice_fwd: empty input");
+  MEDNET_REQUIRE(label_dtype == MEDNET_I64 || label_dtype == MEDNET_U8, MEDNET_E_DTYPE, "dice_fwd: labels are int64 or uint8 (got %d)", label_dtype);
   MEDNET_REQUIRE(ws_bytes >= mednet_loss_ws_bytes(n, c, spatial), MEDNET_E_WORKSPACE, "dice_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const unsigned nb = loss_blocks(spatial);
   float* partial = (float*)ws;
-#define CALL(M) hipLaunchKernelGGL(dice_fwd_kernel<M>, dim3(nb, n), dim3(256), 0, s, logits, labels, partial, c, spatial, stride_n, stride_c, sigmoid, ignore_index)
+#define CALL(M)                                                                                                                        \
+  do {                                                                                                                                 \
+    if (label_dtype == MEDNET_U8)                                                                                                      \
+      hipLaunchKernelGGL((dice_fwd_kernel<M, uint8_t>), dim3(nb, n), dim3(256), 0, s, logits, (const uint8_t*)labels, label_stride_n, \
+                         partial, c, spatial, stride_n, stride_c, sigmoid, ignore_index);                                             \
+    else                                                                                                                               \
+      hipLaunchKernelGGL((dice_fwd_kernel<M, int64_t>), dim3(nb, n), dim3(256), 0, s, logits, (const int64_t*)labels, label_stride_n, \
+                         partial, c, spatial, stride_n, stride_c, sigmoid, ignore_index);                                             \
+  } while (0)
   LOSS_DISPATCH_C(c, CALL);
 #undef CALL
   int rc = check_launch("dice_fwd");
@@ -371,17 +382,39 @@ extern "C" int mednet_dice_fwd(const float* logits, const int64_t* labels, const
   hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, s, partial, weight, loss, saved, dice_out, c, (int)(nb * n), eps);
   return check_launch("dice_finalize");
 }
+extern "C" int mednet_dice_fwd(const float* logits, const int64_t* labels, const float* weight, float* loss,
+                               float* saved, float* dice_out, int n, int c, size_t spatial, int64_t stride_n,
+                               int64_t stride_c, float eps, int sigmoid, int ignore_index, void* ws, size_t ws_bytes,
+                               mednet_stream stream) {
+  return mednet_dice_fwd_lt(logits, labels, MEDNET_I64, (int64_t)spatial, weight, loss, saved, dice_out, n, c, spatial, stride_n, stride_c,
+                            eps, sigmoid, ignore_index, ws, ws_bytes, stream);
+}
 
-extern "C" int mednet_dice_bwd(const float* logits, const int64_t* labels, const float* weight, const float* saved,
-                               const float* dloss, float* dlogits, int n, int c, size_t spatial, int64_t stride_n,
-                               int64_t stride_c, float eps, int sigmoid, int ignore_index, mednet_stream stream) {
+extern "C" int mednet_dice_bwd_lt(const float* logits, const void* labels, int label_dtype, int64_t label_stride_n, const float* weight,
+                                  const float* saved, const float* dloss, float* dlogits, int n, int c, size_t spatial,
+                                  int64_t stride_n, int64_t stride_c, float eps, int sigmoid, int ignore_index, mednet_stream stream) {
   MEDNET_REQUIRE(c >= 1 && c <= 32, MEDNET_E_UNSUPPORTED, "dice_bwd: C=%d (supported: 1..32)", c);
+  MEDNET_REQUIRE(label_dtype == MEDNET_I64 || label_dtype == MEDNET_U8, MEDNET_E_DTYPE, "dice_bwd: labels are int64 or uint8 (got %d)", label_dtype);
   hipStream_t s = (hipStream_t)stream;
   const unsigned nb = loss_blocks(spatial);
-#define CALL(M) hipLaunchKernelGGL(dice_bwd_kernel<M>, dim3(nb, n), dim3(256), 0, s, logits, labels, weight, saved, dloss, dlogits, c, spatial, stride_n, stride_c, eps, sigmoid, ignore_index)
+#define CALL(M)                                                                                                                        \
+  do {                                                                                                                                 \
+    if (label_dtype == MEDNET_U8)                                                                                                      \
+      hipLaunchKernelGGL((dice_bwd_kernel<M, uint8_t>), dim3(nb, n), dim3(256), 0, s, logits, (const uint8_t*)labels, label_stride_n, \
+                         weight, saved, dloss, dlogits, c, spatial, stride_n, stride_c, eps, sigmoid, ignore_index);                  \
+    else                                                                                                                               \
+      hipLaunchKernelGGL((dice_bwd_kernel<M, int64_t>), dim3(nb, n), dim3(256), 0, s, logits, (const int64_t*)labels, label_stride_n, \
+                         weight, saved, dloss, dlogits, c, spatial, stride_n, stride_c, eps, sigmoid, ignore_index);                  \
+  } while (0)
   LOSS_DISPATCH_C(c, CALL);
 #undef CALL
   return check_launch("dice_bwd");
+}
+extern "C" int mednet_dice_bwd(const float* logits, const int64_t* labels, const float* weight, const float* saved,
+                               const float* dloss, float* dlogits, int n, int c, size_t spatial, int64_t stride_n,
+                               int64_t stride_c, float eps, int sigmoid, int ignore_index, mednet_stream stream) {
+  return mednet_dice_bwd_lt(logits, labels, MEDNET_I64, (int64_t)spatial, weight, saved, dloss, dlogits, n, c, spatial, stride_n, stride_c,
+                            eps, sigmoid, ignore_index, stream);
 }
 
 extern "C" int mednet_ce_fwd(const float* logits, const int64_t* labels, const float* weight, float* loss, float* saved,
@@ -413,29 +446,43 @@ extern "C" int mednet_ce_bwd(const float* logits, const int64_t* labels, const f
   return check_launch("ce_bwd");
 }
 
-extern "C" int mednet_heatmap_loss_fwd(const float* out, const void* target, const float* cweight, float* loss, int n,
-                                       int c, size_t spatial, int64_t stride_n, int64_t stride_c, int kind, int tgt_u8,
-                                       void* ws, size_t ws_bytes, mednet_stream stream) {
+// target_stride_n: element stride between the samples of `target` (channel ch of sample n at + n * target_stride_n + ch * spatial):
+// the heat-map channels of a label volume are consumed where they lie, no .contiguous() copy (landmarks.py:68)
+extern "C" int mednet_heatmap_loss_fwd_strided(const float* out, const void* target, int64_t target_stride_n, const float* cweight,
+                                               float* loss, int n, int c, size_t spatial, int64_t stride_n, int64_t stride_c, int kind,
+                                               int tgt_u8, void* ws, size_t ws_bytes, mednet_stream stream) {
   MEDNET_REQUIRE(n > 0 && c > 0 && spatial > 0 && c <= 65535 && n <= 65535, MEDNET_E_SHAPE, "heatmap_loss_fwd: bad shape");
   MEDNET_REQUIRE(ws_bytes >= mednet_loss_ws_bytes(n, c, spatial), MEDNET_E_WORKSPACE, "heatmap_loss_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const unsigned nb = loss_blocks(spatial);
   float* partial = (float*)ws;
-  if (tgt_u8) hipLaunchKernelGGL(hm_fwd_kernel<uint8_t>, dim3(nb, c, n), dim3(256), 0, s, out, (const uint8_t*)target, partial, c, spatial, stride_n, stride_c, kind);
-  else hipLaunchKernelGGL(hm_fwd_kernel<float>, dim3(nb, c, n), dim3(256), 0, s, out, (const float*)target, partial, c, spatial, stride_n, stride_c, kind);
+  if (tgt_u8) hipLaunchKernelGGL(hm_fwd_kernel<uint8_t>, dim3(nb, c, n), dim3(256), 0, s, out, (const uint8_t*)target, target_stride_n, partial, c, spatial, stride_n, stride_c, kind);
+  else hipLaunchKernelGGL(hm_fwd_kernel<float>, dim3(nb, c, n), dim3(256), 0, s, out, (const float*)target, target_stride_n, partial, c, spatial, stride_n, stride_c, kind);
   int rc = check_launch("heatmap_loss_fwd");
   if (rc) return rc;
   hipLaunchKernelGGL(hm_finalize_kernel, dim3(1), dim3(1024), 0, s, partial, cweight, loss, n, c, (int)nb, (double)n * (double)spatial);
   return check_launch("heatmap_loss_finalize");
 }
+extern "C" int mednet_heatmap_loss_fwd(const float* out, const void* target, const float* cweight, float* loss, int n,
+                                       int c, size_t spatial, int64_t stride_n, int64_t stride_c, int kind, int tgt_u8,
+                                       void* ws, size_t ws_bytes, mednet_stream stream) {
+  return mednet_heatmap_loss_fwd_strided(out, target, (int64_t)c * (int64_t)spatial, cweight, loss, n, c, spatial, stride_n, stride_c, kind,
+                                         tgt_u8, ws, ws_bytes, stream);
+}
 
-extern "C" int mednet_heatmap_loss_bwd(const float* out, const void* target, const float* cweight, const float* dloss,
-                                       float* dout, int n, int c, size_t spatial, int64_t stride_n, int64_t stride_c,
-                                       int kind, int tgt_u8, mednet_stream stream) {
+extern "C" int mednet_heatmap_loss_bwd_strided(const float* out, const void* target, int64_t target_stride_n, const float* cweight,
+                                               const float* dloss, float* dout, int n, int c, size_t spatial, int64_t stride_n,
+                                               int64_t stride_c, int kind, int tgt_u8, mednet_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   const unsigned nb = loss_blocks(spatial);
   const float inv = (float)(1.0 / ((double)n * (double)spatial));
-  if (tgt_u8) hipLaunchKernelGGL(hm_bwd_kernel<uint8_t>, dim3(nb, c, n), dim3(256), 0, s, out, (const uint8_t*)target, cweight, dloss, dout, c, spatial, stride_n, stride_c, kind, inv);
-  else hipLaunchKernelGGL(hm_bwd_kernel<float>, dim3(nb, c, n), dim3(256), 0, s, out, (const float*)target, cweight, dloss, dout, c, spatial, stride_n, stride_c, kind, inv);
+  if (tgt_u8) hipLaunchKernelGGL(hm_bwd_kernel<uint8_t>, dim3(nb, c, n), dim3(256), 0, s, out, (const uint8_t*)target, target_stride_n, cweight, dloss, dout, c, spatial, stride_n, stride_c, kind, inv);
+  else hipLaunchKernelGGL(hm_bwd_kernel<float>, dim3(nb, c, n), dim3(256), 0, s, out, (const float*)target, target_stride_n, cweight, dloss, dout, c, spatial, stride_n, stride_c, kind, inv);
   return check_launch("heatmap_loss_bwd");
+}
+extern "C" int mednet_heatmap_loss_bwd(const float* out, const void* target, const float* cweight, const float* dloss,
+                                       float* dout, int n, int c, size_t spatial, int64_t stride_n, int64_t stride_c,
+                                       int kind, int tgt_u8, mednet_stream stream) {
+  return mednet_heatmap_loss_bwd_strided(out, target, (int64_t)c * (int64_t)spatial, cweight, dloss, dout, n, c, spatial, stride_n, stride_c,
+                                         kind, tgt_u8, stream);
 }

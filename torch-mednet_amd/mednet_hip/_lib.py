@@ -83,6 +83,10 @@ SIGNATURES = {
     "mednet_head_dice_gn_rows": (_i, [_i, _sz, _i]),
     "mednet_head_dice_fwd": (_i, [_vp] * 4 + [_i, _i64, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp]),
     "mednet_head_dice_bwd": (_i, [_vp, _vp, _i, _i64] + [_vp] * 7 + [_i, _vp, _vp, _vp, _i, _sz, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp]),
+    "mednet_dice_fwd_lt": (_i, [_vp, _vp, _i, _i64] + [_vp] * 4 + [_i, _i, _sz, _i64, _i64, _f, _i, _i, _vp, _sz, _vp]),
+    "mednet_dice_bwd_lt": (_i, [_vp, _vp, _i, _i64] + [_vp] * 4 + [_i, _i, _sz, _i64, _i64, _f, _i, _i, _vp]),
+    "mednet_heatmap_loss_fwd_strided": (_i, [_vp, _vp, _i64, _vp, _vp] + [_i, _i, _sz, _i64, _i64, _i, _i, _vp, _sz, _vp]),
+    "mednet_heatmap_loss_bwd_strided": (_i, [_vp, _vp, _i64, _vp, _vp, _vp] + [_i, _i, _sz, _i64, _i64, _i, _i, _vp]),
     "mednet_ce_fwd": (_i, [_vp] * 5 + [_i, _i, _sz, _i64, _i64, _i, _vp, _sz, _vp]),
     "mednet_ce_bwd": (_i, [_vp] * 6 + [_i, _i, _sz, _i64, _i64, _i, _vp]),
     "mednet_heatmap_loss_fwd": (_i, [_vp] * 4 + [_i, _i, _sz, _i64, _i64, _i, _i, _vp, _sz, _vp]),

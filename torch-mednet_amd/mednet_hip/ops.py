@@ -816,18 +816,18 @@ class DiceLossFn(Function):
         lg, sn, sc = _planar_logits(logits)
         n, c = lg.shape[:2]
         spatial = lg[0, 0].numel()
-        lab = _labels_i64(labels, (n,) + tuple(lg.shape[2:]))
+        lab, lab_sn, lab_dt = _label_view(labels, n, tuple(lg.shape[2:]))  # uint8 / int64 as they lie (no cast kernel)
         wt = None if weight is None else weight.to(device=lg.device, dtype=torch.float32).contiguous()
         loss = torch.empty((), dtype=torch.float32, device=lg.device)
         saved = torch.empty((c, 2), dtype=torch.float32, device=lg.device)
         lib = L.lib()
         ws = L.workspace(lib.mednet_loss_ws_bytes(n, c, spatial), lg.device)
         ii = L.NO_IGNORE if ignore_index is None else int(ignore_index)
-        L.check(lib.mednet_dice_fwd(lg.data_ptr(), lab.data_ptr(), L.ptr(wt), loss.data_ptr(), saved.data_ptr(), None, n,
-                                    c, spatial, sn, sc, eps, int(sigmoid), ii, ws.data_ptr(), ws.numel(), L.stream()),
+        L.check(lib.mednet_dice_fwd_lt(lg.data_ptr(), lab.data_ptr(), lab_dt, lab_sn, L.ptr(wt), loss.data_ptr(), saved.data_ptr(),
+                                       None, n, c, spatial, sn, sc, eps, int(sigmoid), ii, ws.data_ptr(), ws.numel(), L.stream()),
                 "dice_fwd")
         ctx.save_for_backward(lg, lab, wt, saved)
-        ctx.meta = (eps, int(sigmoid), ii, sn, sc, logits.dtype)
+        ctx.meta = (eps, int(sigmoid), ii, sn, sc, logits.dtype, lab_sn, lab_dt)
         ctx.split = getattr(logits, "_mednet_split", None) if lg is logits else None
         if debug.TRACE is not None:
             debug.trace("dice.fwd", lg, loss, saved)
@@ -836,13 +836,13 @@ class DiceLossFn(Function):
     @staticmethod
     def backward(ctx, dloss):
         lg, lab, wt, saved = ctx.saved_tensors
-        eps, sigmoid, ii, sn, sc, in_dtype = ctx.meta
+        eps, sigmoid, ii, sn, sc, in_dtype, lab_sn, lab_dt = ctx.meta
         n, c = lg.shape[:2]
         spatial = lg[0, 0].numel()
         dl = dloss.to(torch.float32).contiguous()
         dlogits = _loss_grad_like(lg, ctx.split)
-        L.check(L.lib().mednet_dice_bwd(lg.data_ptr(), lab.data_ptr(), L.ptr(wt), saved.data_ptr(), dl.data_ptr(),
-                                        dlogits.data_ptr(), n, c, spatial, sn, sc, eps, sigmoid, ii, L.stream()),
+        L.check(L.lib().mednet_dice_bwd_lt(lg.data_ptr(), lab.data_ptr(), lab_dt, lab_sn, L.ptr(wt), saved.data_ptr(), dl.data_ptr(),
+                                           dlogits.data_ptr(), n, c, spatial, sn, sc, eps, sigmoid, ii, L.stream()),
                 "dice_bwd")
         if debug.TRACE is not None:
             debug.trace("dice.bwd", dlogits)
@@ -955,15 +955,15 @@ def per_channel_dice(logits, labels, weight=None, eps=1e-5, sigmoid=False, ignor
     lg, sn, sc = _planar_logits(logits.detach())
     n, c = lg.shape[:2]
     spatial = lg[0, 0].numel()
-    lab = _labels_i64(labels, (n,) + tuple(lg.shape[2:]))
+    lab, lab_sn, lab_dt = _label_view(labels, n, tuple(lg.shape[2:]))
     wt = None if weight is None else weight.to(device=lg.device, dtype=torch.float32).contiguous()
     saved = torch.empty((c, 2), dtype=torch.float32, device=lg.device)
     dice = torch.empty((c,), dtype=torch.float32, device=lg.device)
     lib = L.lib()
     ws = L.workspace(lib.mednet_loss_ws_bytes(n, c, spatial), lg.device)
     ii = L.NO_IGNORE if ignore_index is None else int(ignore_index)
-    L.check(lib.mednet_dice_fwd(lg.data_ptr(), lab.data_ptr(), L.ptr(wt), None, saved.data_ptr(), dice.data_ptr(), n, c,
-                                spatial, sn, sc, eps, int(sigmoid), ii, ws.data_ptr(), ws.numel(), L.stream()), "dice_fwd")
+    L.check(lib.mednet_dice_fwd_lt(lg.data_ptr(), lab.data_ptr(), lab_dt, lab_sn, L.ptr(wt), None, saved.data_ptr(), dice.data_ptr(),
+                                   n, c, spatial, sn, sc, eps, int(sigmoid), ii, ws.data_ptr(), ws.numel(), L.stream()), "dice_fwd")
     return dice
 
 
@@ -1018,29 +1018,36 @@ class HeatmapLossFn(Function):
         if tuple(target.shape) != tuple(lg.shape):
             raise RuntimeError(f"heatmap_loss: target shape {tuple(target.shape)} != output {tuple(lg.shape)}")
         tgt = target if target.dtype in (torch.uint8, torch.float32) else target.float()
-        tgt = tgt.contiguous()
+        # channels dense, any stride between samples: the heat-map channels of a label volume are read where they lie
+        dense, acc = [], 1
+        for sdim in reversed(tuple(tgt.shape[1:])):
+            dense.insert(0, acc)
+            acc *= sdim
+        if tuple(tgt.stride()[1:]) != tuple(dense) or (n > 1 and tgt.stride(0) < c * spatial):
+            tgt = tgt.contiguous()
+        tgt_sn = tgt.stride(0) if n > 1 else c * spatial
         wt = None if cweight is None else torch.as_tensor(cweight, dtype=torch.float32, device=lg.device).contiguous()
         loss = torch.empty((), dtype=torch.float32, device=lg.device)
         lib = L.lib()
         ws = L.workspace(lib.mednet_loss_ws_bytes(n, c, spatial), lg.device)
         u8 = int(tgt.dtype == torch.uint8)
-        L.check(lib.mednet_heatmap_loss_fwd(lg.data_ptr(), tgt.data_ptr(), L.ptr(wt), loss.data_ptr(), n, c, spatial, sn,
-                                            sc, kind, u8, ws.data_ptr(), ws.numel(), L.stream()), "heatmap_loss_fwd")
+        L.check(lib.mednet_heatmap_loss_fwd_strided(lg.data_ptr(), tgt.data_ptr(), tgt_sn, L.ptr(wt), loss.data_ptr(), n, c, spatial,
+                                                    sn, sc, kind, u8, ws.data_ptr(), ws.numel(), L.stream()), "heatmap_loss_fwd")
         ctx.save_for_backward(lg, tgt, wt)
-        ctx.meta = (kind, u8, sn, sc, out.dtype)
+        ctx.meta = (kind, u8, sn, sc, out.dtype, tgt_sn)
         ctx.split = getattr(out, "_mednet_split", None) if lg is out else None
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
         lg, tgt, wt = ctx.saved_tensors
-        kind, u8, sn, sc, in_dtype = ctx.meta
+        kind, u8, sn, sc, in_dtype, tgt_sn = ctx.meta
         n, c = lg.shape[:2]
         spatial = lg[0, 0].numel()
         dl = dloss.to(torch.float32).contiguous()
         dout = _loss_grad_like(lg, ctx.split)
-        L.check(L.lib().mednet_heatmap_loss_bwd(lg.data_ptr(), tgt.data_ptr(), L.ptr(wt), dl.data_ptr(), dout.data_ptr(),
-                                                n, c, spatial, sn, sc, kind, u8, L.stream()), "heatmap_loss_bwd")
+        L.check(L.lib().mednet_heatmap_loss_bwd_strided(lg.data_ptr(), tgt.data_ptr(), tgt_sn, L.ptr(wt), dl.data_ptr(), dout.data_ptr(),
+                                                        n, c, spatial, sn, sc, kind, u8, L.stream()), "heatmap_loss_bwd")
         return dout.to(in_dtype), None, None, None
 
 

@@ -461,7 +461,9 @@ class LandmarkStep(_GraphedStep):
         inputs = batch["data"].float()
         heatmaps = batch["label"][:, :-1, ...]  # uint8 is consumed directly by the fused regression kernel
         nh = heatmaps.shape[1]
-        labels = batch["label"][:, -1, ...].long()
+        labels = batch["label"][:, -1, ...]  # uint8, consumed where it lies (ops.dice_loss takes uint8 or int64 labels)
+        if not labels.is_cuda:
+            labels = labels.long()
         outputs = self.model(inputs)
         out_hm, out_cls = ops.split_channels(outputs, nh)  # (= outputs[:, :nh], outputs[:, nh:]; one gradient join)
         class_loss = self.loss_class(out_cls, labels)
