@@ -1,11 +1,11 @@
 #!/bin/bash
 # Register / scratch / LDS usage of every kernel as hipcc reports it (-Rpass-analysis=kernel-resource-usage), one line per
 # kernel -> profiles/${ROUND}_kernel_resource_usage.txt.  Runs on the build container (cross-compiles, no GPU).
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 cd "$(dirname "$0")/../torch-mednet_amd/csrc" || exit 1
 OUT=../../profiles/${ROUND}_kernel_resource_usage.txt
 echo "# hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage, $(git rev-parse --short HEAD 2>/dev/null)" > $OUT
-for f in conv_mfma.hip conv_x3_mfma.hip conv_f32_mfma.hip conv_direct.hip norm_act.hip loss.hip predict.hip augment.hip; do
+for f in conv_mfma.hip conv_x3_mfma.hip conv_f32_mfma.hip conv_direct.hip norm_act.hip loss.hip head_loss.hip predict.hip augment.hip; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -Rpass-analysis=kernel-resource-usage -c $f -o /tmp/ru.o 2>&1 |
   python3 -c "
 import re,sys,subprocess
