@@ -215,6 +215,12 @@ int mednet_pool2_fwd(const void* x, void* y, int n, int d, int h, int w, int c, 
                      mednet_stream stream);
 /* dx has the INPUT shape; ties route to the first maximum in (z,y,x) scan order like ATen.  `add` (nullable, input
  * shape): a second gradient of the same tensor -- the decoder's skip join of model.py:199-205 -- summed in the same pass. */
+/* GroupNorm apply (+ residual + activation, as mednet_gn_act_fwd) fused with the 2x2x2 pooling that consumes its output (an
+ * encoder block's last layer followed by the next level's pooling, components.py:177-178 -> :222-224): writes z AND the pooled
+ * tensor in one pass; both bit-identical to mednet_gn_act_fwd + mednet_pool2_fwd.  Even d, h, w; C a multiple of 8; bf16 / fp16. */
+int mednet_gn_act_pool_supported(int d, int h, int w, int c, int dtype);
+int mednet_gn_act_pool_fwd(const void* x, const float* coef, const void* residual, void* z, void* pooled, int n, int d, int h,
+                           int w, int c, int act, int mode, int dtype, mednet_stream stream);
 int mednet_pool2_bwd(const void* dy, const void* x, const void* add, void* dx, int n, int d, int h, int w, int c,
                      int mode, int dtype, mednet_stream stream);
 

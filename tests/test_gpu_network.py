@@ -1049,3 +1049,29 @@ def test_fused_head_and_loss_step_equals_the_two_node_step(mode):
             assert_close(a, b, 1e-5, name)
         else:
             assert torch.equal(a, b), f"{name}: gradient differs between the fused and the two-node step"
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_pooling_inside_the_block_output_pass_changes_nothing(mode):
+    """Encoder blocks write the next level's pooled input in the pass that writes their output (block.PoolStash, model.py:194-199):
+    loss and every gradient of a three-level network bit-identical to the step with a stand-alone pooling launch."""
+    from mednet_hip import block
+    from mednet_hip.train import SegmentationStep
+    ctor = dict(in_channels=1, out_channels=3, final_sigmoid=False, f_maps=[32, 64, 96])
+    res = {}
+    for shape in ((16, 24, 32), (8, 12, 20)):
+        batch = {k: v.to(DEV) for k, v in O.synthetic_batch(2, 1, shape, 3, 0, seed=3).items()}
+        old = block.FUSE_POOL
+        try:
+            for fused in (False, True):
+                block.FUSE_POOL = fused
+                with mednet_hip.precision(mode):
+                    net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+                    step = SegmentationStep(net, loss_weight=None, lr=1e-3)
+                    (loss,) = step._fwd_bwd(batch)
+                    torch.cuda.synchronize()
+                    res[fused] = (float(loss), step.flat.grad.clone())
+                    step.flat.release()
+        finally:
+            block.FUSE_POOL = old
+        assert res[True][0] == res[False][0] and torch.equal(res[True][1], res[False][1]), shape

@@ -1119,3 +1119,29 @@ def test_losses_take_the_label_volume_where_it_lies():
         res.append((loss.detach().clone(), x.grad.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert float(res[0][1].abs().max()) > 0
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("n,c,shape,pool,residual", [(2, 32, (8, 12, 16), "max", True), (1, 64, (6, 4, 10), "avg", True),
+                                                     (2, 16, (4, 8, 6), "max", False), (1, 128, (2, 2, 2), "max", True)])
+def test_groupnorm_apply_fused_with_the_pooling_that_follows(mode, n, c, shape, pool, residual):
+    """mednet_gn_act_pool_fwd (an encoder block's last GroupNorm apply + residual + ELU and the next level's 2x2x2 pooling in one
+    pass, components.py:177-178 -> :222-224) against mednet_gn_act_fwd followed by mednet_pool2_fwd: block output and pooled tensor
+    bit-identical (max with ties and avg)."""
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[mode]
+    d, h, w = shape
+    y = ops.to_cl((rnd("gp_y", n, c, *shape) * 2).round().div(2).to(dt).to(DEV))  # (coarse values: ties inside pooling windows)
+    r = ops.to_cl(rnd("gp_r", n, c, *shape).to(dt).to(DEV)) if residual else None
+    coef = torch.stack((torch.ones(n, c), torch.zeros(n, c)), dim=-1).to(DEV).contiguous()  # identity affine keeps the ties
+    lib = L.lib()
+    pm = L.POOL_MAX if pool == "max" else L.POOL_AVG
+    assert lib.mednet_gn_act_pool_supported(d, h, w, c, L.dt_of(dt))
+    z0, z1 = torch.empty_like(y, memory_format=ops.CL), torch.empty_like(y, memory_format=ops.CL)
+    p0, p1 = (ops.empty_cl(n, c, d // 2, h // 2, w // 2, dt, DEV) for _ in range(2))
+    L.check(lib.mednet_gn_act_fwd(y.data_ptr(), coef.data_ptr(), L.ptr(r), z0.data_ptr(), n, d * h * w, c, L.ACT_ELU, L.dt_of(dt),
+                                  L.dt_of(dt), L.stream()), "gn_act_fwd")
+    L.check(lib.mednet_pool2_fwd(z0.data_ptr(), p0.data_ptr(), n, d, h, w, c, pm, L.dt_of(dt), L.stream()), "pool2_fwd")
+    L.check(lib.mednet_gn_act_pool_fwd(y.data_ptr(), coef.data_ptr(), L.ptr(r), z1.data_ptr(), p1.data_ptr(), n, d, h, w, c, L.ACT_ELU,
+                                       pm, L.dt_of(dt), L.stream()), "gn_act_pool_fwd")
+    assert torch.equal(z0, z1) and torch.equal(p0, p1)
+    assert not lib.mednet_gn_act_pool_supported(5, h, w, c, L.dt_of(dt))  # odd extents keep the two launches

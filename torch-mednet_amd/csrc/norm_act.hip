@@ -702,6 +702,75 @@ __global__ __launch_bounds__(256) void pool2_fwd_kernel(const T* __restrict__ x,
   VecIO<T, VEC>::store(y, i * VEC, best);
 }
 
+// GroupNorm apply (+ residual, + activation) of an encoder block's last layer AND the 2x2x2 pooling that consumes the block's
+// output (components.py:177-178 -> :222-224), in one pass: a thread owns one POOLED voxel and 8 channels, normalises the 8 voxels of
+// its window (reads y and the residual, writes the block output z) and writes their maximum / mean to the pooled tensor -- the
+// stand-alone pooling pass and its re-read of z are gone.  z is computed and rounded exactly as gn_act_fwd_kernel
+// does, the pooling runs on the ROUNDED values in pool2_fwd_kernel's scan order: both outputs are bit-identical to the two
+// launches.  Even d, h, w.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_act_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ coef,
+                                                              const T* __restrict__ res, T* __restrict__ z, T* __restrict__ pooled,
+                                                              int n, int d, int h, int w, int c, int act, int mode) {
+  constexpr int VEC = 8;
+  const int od = d / 2, oh = h / 2, ow = w / 2, cv = c / VEC;
+  const size_t total = (size_t)n * od * oh * ow * cv;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cc = (int)(i % cv);
+  size_t v = i / cv;
+  const int ox = (int)(v % ow);
+  v /= ow;
+  const int oy = (int)(v % oh);
+  v /= oh;
+  const int oz = (int)(v % od);
+  const int nn = (int)(v / od);
+  float a[VEC], b[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    a[k] = coef[((size_t)nn * c + cc * VEC + k) * 2];
+    b[k] = coef[((size_t)nn * c + cc * VEC + k) * 2 + 1];
+  }
+  size_t src[8];
+  F8 xv[8], rv[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int iz = 2 * oz + (t >> 2), iy = 2 * oy + ((t >> 1) & 1), ix = 2 * ox + (t & 1);
+    src[t] = ((((size_t)nn * d + iz) * h + iy) * w + ix) * c + (size_t)cc * VEC;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) xv[t] = VecIO<T, VEC>::load(x, src[t]);
+  if (res) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) rv[t] = VecIO<T, VEC>::load(res, src[t]);
+  }
+  F8 best;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) best.v[k] = mode == MEDNET_POOL_MAX ? -INFINITY : 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    F8 o;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      o.v[k] = fmaf(a[k], xv[t].v[k], b[k]);
+      if (res) o.v[k] += rv[t].v[k];
+    }
+    act_apply_n<VEC>(o.v, act);
+    VecIO<T, VEC>::store(z, src[t], o);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float s = (float)(T)o.v[k];  // what the pooling pass would read back
+      if (mode == MEDNET_POOL_MAX) best.v[k] = (s > best.v[k] || s != s) ? s : best.v[k];
+      else best.v[k] += s;
+    }
+  }
+  if (mode == MEDNET_POOL_AVG) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) best.v[k] *= 0.125f;
+  }
+  VecIO<T, VEC>::store(pooled, i * VEC, best);
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void pool2_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                         const T* __restrict__ add, T* __restrict__ dx, int n, int d,
@@ -1244,6 +1313,25 @@ extern "C" int mednet_pool2_fwd(const void* x, void* y, int n, int d, int h, int
 #undef GO
   return check_launch("pool2_fwd");
 }
+extern "C" int mednet_gn_act_pool_supported(int d, int h, int w, int c, int dtype) {
+  return d >= 2 && h >= 2 && w >= 2 && d % 2 == 0 && h % 2 == 0 && w % 2 == 0 && c % 8 == 0 && (dtype == MEDNET_BF16 || dtype == MEDNET_F16) &&
+         tuning_option("gn_pool_fuse", 1);
+}
+extern "C" int mednet_gn_act_pool_fwd(const void* x, const float* coef, const void* residual, void* z, void* pooled, int n, int d,
+                                      int h, int w, int c, int act, int mode, int dtype, mednet_stream stream) {
+  MEDNET_REQUIRE(mednet_gn_act_pool_supported(d, h, w, c, dtype), MEDNET_E_UNSUPPORTED,
+                 "gn_act_pool_fwd: even dims, C %% 8 == 0 and 16-bit storage only (%dx%dx%d, C=%d, dtype %d)", d, h, w, c, dtype);
+  MEDNET_REQUIRE(n > 0 && x && coef && z && pooled, MEDNET_E_SHAPE, "gn_act_pool_fwd: bad arguments");
+  const size_t total = (size_t)n * (d / 2) * (h / 2) * (w / 2) * (c / 8);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == MEDNET_BF16)
+    hipLaunchKernelGGL((gn_act_pool_fwd_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x, coef, (const bf16*)residual, (bf16*)z, (bf16*)pooled, n, d, h, w, c, act, mode);
+  else
+    hipLaunchKernelGGL((gn_act_pool_fwd_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x, coef, (const f16*)residual, (f16*)z, (f16*)pooled, n, d, h, w, c, act, mode);
+  return check_launch("gn_act_pool_fwd");
+}
+
 extern "C" int mednet_pool2_bwd(const void* dy, const void* x, const void* add, void* dx, int n, int d, int h, int w,
                                 int c, int mode, int dtype, mednet_stream stream) {
   MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "pool2_bwd: bad dtype");

@@ -72,6 +72,8 @@ SIGNATURES = {
     "mednet_act_bwd": (_i, [_vp, _vp, _vp, _sz, _i, _i, _vp]),
     "mednet_add": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "mednet_pool2_fwd": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
+    "mednet_gn_act_pool_supported": (_i, [_i] * 5),
+    "mednet_gn_act_pool_fwd": (_i, [_vp] * 5 + [_i] * 8 + [_vp]),
     "mednet_pool2_bwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
     "mednet_upcat_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "mednet_upcat_bwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),

@@ -37,7 +37,12 @@ def _conv_fwd(x, packed, cout, want_stats):
     return y, partial
 
 
-def _gn_fwd(y, partial, gamma, beta, groups, eps, act, residual):
+FUSE_POOL = os.environ.get("MEDNET_FUSE_POOL", "1") == "1"  # A/B knob: the next level's pooling inside the block's last apply pass
+
+
+def _gn_fwd(y, partial, gamma, beta, groups, eps, act, residual, pool_mode=None):
+    """-> (z, stats, coef[, pooled]).  `pool_mode`: also write the 2x2x2-pooled z in the same pass (mednet_gn_act_pool_fwd) when the
+    shape allows; the fourth result is then the pooled tensor, else None."""
     n, c, d, h, w = y.shape
     spatial = d * h * w
     lib = L.lib()
@@ -52,9 +57,14 @@ def _gn_fwd(y, partial, gamma, beta, groups, eps, act, residual):
         L.check(lib.mednet_gn_stats(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), coef.data_ptr(), n,
                                     spatial, c, groups, eps, L.dt(y), ws.data_ptr(), ws.numel(), L.stream()), "gn_stats")
     z = torch.empty_like(y, memory_format=ops.CL)
+    if pool_mode is not None and FUSE_POOL and lib.mednet_gn_act_pool_supported(d, h, w, c, L.dt(y)):
+        pooled = ops.empty_cl(n, c, d // 2, h // 2, w // 2, y.dtype, y.device)
+        L.check(lib.mednet_gn_act_pool_fwd(y.data_ptr(), coef.data_ptr(), L.ptr(residual), z.data_ptr(), pooled.data_ptr(), n, d, h, w,
+                                           c, act, pool_mode, L.dt(y), L.stream()), "gn_act_pool_fwd")
+        return z, stats, coef, pooled
     L.check(lib.mednet_gn_act_fwd(y.data_ptr(), coef.data_ptr(), L.ptr(residual), z.data_ptr(), n, spatial, c, act, L.dt(y),
                                   L.dt(z), L.stream()), "gn_act_fwd")
-    return z, stats, coef
+    return (z, stats, coef, None) if pool_mode is not None else (z, stats, coef)
 
 
 def _gn_bwd(dz, dz2, y, z, coef, stats, gamma_p, beta_p, groups, act, want_dres, partial=None):
@@ -145,7 +155,7 @@ def _conv_bwd(x, dy, packed, weight_p, need_dx, add=None, gnb=None):
 
 class ResBlockFn(Function):
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, pk1, pk2, pk3, groups, eps, act, hook=None):
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, pk1, pk2, pk3, groups, eps, act, hook=None, pool=None):
         L.require_gpu(x, "ExtResNetBlock")
         ctx.algo = config.conv_algo()
         x = ops._as_act(x)
@@ -157,7 +167,13 @@ class ResBlockFn(Function):
         y2, p2 = _conv_fwd(z1, pk2, cout, fuse)
         z2, s2, c2 = _gn_fwd(y2, p2, g2, b2, groups, eps, act, None)
         y3, p3 = _conv_fwd(z2, pk3, cout, fuse)
-        out, s3, c3 = _gn_fwd(y3, p3, g3, b3, groups, eps, act, z1)
+        # `pool`: a holder the caller reads the pooled output from (the next encoder level pools this block's output: one pass
+        # writes both; ops.SkipPool2Fn uses the stash instead of launching the pooling kernel)
+        if pool is not None:
+            out, s3, c3, pooled = _gn_fwd(y3, p3, g3, b3, groups, eps, act, z1, pool_mode=pool.mode)
+            pool.pooled = pooled
+        else:
+            out, s3, c3 = _gn_fwd(y3, p3, g3, b3, groups, eps, act, z1)
         if debug.TRACE is not None:
             debug.trace("resblock.fwd", y1, p1, s1, c1, z1, y2, p2, s2, c2, z2, y3, p3, s3, c3, out)
         ctx.save_for_backward(xin, y1, z1, y2, z2, y3, out, s1, c1, s2, c2, s3, c3, pk1, pk2, pk3)
@@ -190,15 +206,29 @@ class ResBlockFn(Function):
         dx, dw1, _ = _conv_bwd(xin, dy1, pk1, w1, ctx.needs_input_grad[0])
         if debug.TRACE is not None:
             debug.trace("resblock.bwd", dout, part3, dy3, dres, dz2, part2, dy2, dz1, part1, dy1, dx)
-        return (dx, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + (None,) * 7
+        return (dx, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + (None,) * 8
 
 
-def res_block(x, convs, norms, groups, eps, act):
-    """convs / norms: the three mednet_hip.nn.Conv3d / GroupNorm modules of the block."""
+class PoolStash:
+    """Carried by a block output whose consumer is a 2x2x2 pooling of `mode`: the pooled tensor the block's last apply pass wrote
+    beside the output (or None when the shape did not allow it).  ops.SkipPool2Fn / Pool2Fn take it instead of launching."""
+    __slots__ = ("mode", "pooled")
+
+    def __init__(self, mode):
+        self.mode, self.pooled = mode, None
+
+
+def res_block(x, convs, norms, groups, eps, act, pool_mode=None):
+    """convs / norms: the three mednet_hip.nn.Conv3d / GroupNorm modules of the block.  `pool_mode`: the block's output goes into a
+    2x2x2 pooling of that mode next (the next encoder level): the pooled tensor is produced in the same pass and stashed on the
+    output (`_mednet_pooled`)."""
     (k1, k2, k3), (n1, n2, n3) = convs, norms
     hook = ops.GN3Hook() if (ops.FUSE_GN3 and torch.is_grad_enabled()) else None  # (training only)
+    stash = PoolStash(pool_mode) if (pool_mode is not None and FUSE_POOL and config.is_half_mode()) else None
     out = ResBlockFn.apply(x, k1.weight, n1.weight, n1.bias, k2.weight, n2.weight, n2.bias, k3.weight, n3.weight, n3.bias,
-                           k1._packed(), k2._packed(), k3._packed(), groups, eps, act, hook)
+                           k1._packed(), k2._packed(), k3._packed(), groups, eps, act, hook, stash)
     if hook is not None:
         out._mednet_gn3 = hook  # see ops.GN3Hook: the consumer of `out` may take GroupNorm-3's first backward pass
+    if stash is not None and stash.pooled is not None:
+        out._mednet_pooled = stash
     return out

@@ -677,10 +677,15 @@ class Pool2Fn(Function):
     @staticmethod
     def forward(ctx, x, mode):
         L.require_gpu(x, "pool3d")
+        x0 = x
         x = to_cl(_as_act(x))
         n, c, d, h, w = x.shape
-        y = empty_cl(n, c, d // 2, h // 2, w // 2, x.dtype, x.device)
-        L.check(L.lib().mednet_pool2_fwd(x.data_ptr(), y.data_ptr(), n, d, h, w, c, mode, L.dt(x), L.stream()), "pool2_fwd")
+        stash = getattr(x0, "_mednet_pooled", None) if x is x0 else None
+        if stash is not None and stash.mode == mode and stash.pooled is not None and stash.pooled.dtype == x.dtype:
+            y, stash.pooled = stash.pooled, None  # written by the producing block's last apply pass (block.PoolStash)
+        else:
+            y = empty_cl(n, c, d // 2, h // 2, w // 2, x.dtype, x.device)
+            L.check(L.lib().mednet_pool2_fwd(x.data_ptr(), y.data_ptr(), n, d, h, w, c, mode, L.dt(x), L.stream()), "pool2_fwd")
         ctx.save_for_backward(x)
         ctx.mode = mode
         return y
@@ -711,8 +716,12 @@ class SkipPool2Fn(Function):
         x0 = x
         x = to_cl(_as_act(x))
         n, c, d, h, w = x.shape
-        y = empty_cl(n, c, d // 2, h // 2, w // 2, x.dtype, x.device)
-        L.check(L.lib().mednet_pool2_fwd(x.data_ptr(), y.data_ptr(), n, d, h, w, c, mode, L.dt(x), L.stream()), "pool2_fwd")
+        stash = getattr(x0, "_mednet_pooled", None) if x is x0 else None
+        if stash is not None and stash.mode == mode and stash.pooled is not None and stash.pooled.dtype == x.dtype:
+            y, stash.pooled = stash.pooled, None  # written by the producing block's last apply pass (block.PoolStash)
+        else:
+            y = empty_cl(n, c, d // 2, h // 2, w // 2, x.dtype, x.device)
+            L.check(L.lib().mednet_pool2_fwd(x.data_ptr(), y.data_ptr(), n, d, h, w, c, mode, L.dt(x), L.stream()), "pool2_fwd")
         ctx.save_for_backward(x)
         ctx.mode = mode
         ctx.gn3 = _gn3_hook_of(x0, x.dtype) if x is x0 else None

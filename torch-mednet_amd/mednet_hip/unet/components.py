@@ -178,15 +178,18 @@ class ExtResNetBlock(nn.Module):
             return None
         return convs, norms
 
-    def forward(self, x):
+    def forward(self, x, pool_mode=None):
+        """`pool_mode` (not part of the reference's signature; components.py:167-180 takes x only): the caller will pool this
+        block's output with a 2x2x2 pooling of that mode next -- the single-node path then writes the pooled tensor in the pass
+        that writes the output.  Purely an optimisation hint: the result is the same tensor either way."""
         with config.exact_products(self._kinked):
-            return self._forward(x)
+            return self._forward(x, pool_mode)
 
-    def _forward(self, x):
+    def _forward(self, x, pool_mode=None):
         plain = self._plain() if (x.is_cuda and block.ENABLED) else None
         if plain is not None:
             convs, norms = plain
-            return block.res_block(x, convs, norms, norms[0].num_groups, norms[0].eps, self.non_linearity.code)
+            return block.res_block(x, convs, norms, norms[0].num_groups, norms[0].eps, self.non_linearity.code, pool_mode=pool_mode)
         residual = self.conv1(x)
         out = self.conv2(residual)
         return self.conv3(out, residual=residual, final_act=self.non_linearity.code)
@@ -211,19 +214,26 @@ class Encoder(nn.Module):
         self.basic_module = basic_module(in_channels, out_channels, encoder=True, kernel_size=conv_kernel_size,
                                          order=conv_layer_order, num_groups=num_groups)
 
-    def forward(self, x, with_skip=False):
+    def forward(self, x, with_skip=False, pool_next=None):
         """forward(x) is the reference's Encoder.forward (components.py:222-226).  `with_skip=True` -> (skip, out): `skip` is
         x as the decoder will use it, `out` = forward(x).  With the 2x2x2 pooling of this package the split is one autograd
         node (ops.SkipPool2Fn), so the two gradients of x meet inside the pooling backward kernel; any other pooling module
         takes the plain path (autograd adds them).  Both forms go through `__call__`, so module hooks see every level."""
+        # `pool_next`: the mode of the NEXT level's 2x2x2 pooling, when the caller knows this level's output goes there (the U-Net's
+        # own forward does): an ExtResNetBlock then writes the pooled tensor beside its output (block.PoolStash)
+        def body(t):
+            if pool_next is not None and isinstance(self.basic_module, ExtResNetBlock):
+                return self.basic_module(t, pool_mode=pool_next)
+            return self.basic_module(t)
+
         if not with_skip:
             if self.pooling is not None:
                 x = self.pooling(x)
-            return self.basic_module(x)
+            return body(x)
         if _FUSE_SKIP_POOL and isinstance(self.pooling, hnn._Pool2) and torch.is_tensor(x) and x.is_cuda and x.requires_grad:
             skip, pooled = ops.skip_pool2(x, self.pooling.mode)
-            return skip, self.basic_module(pooled)
-        return x, self.forward(x)
+            return skip, body(pooled)
+        return x, self.forward(x, pool_next=pool_next)
 
     def forward_with_skip(self, x):
         return self(x, with_skip=True)

@@ -116,10 +116,13 @@ class _UNetCore(*((_Base,) if _Base is not nn.Module else (_CheckpointCompat, nn
     def _features(self, x):
         skips = []
         for i, enc in enumerate(self.encoders):
+            # the next level pools this level's output (model.py:194-199): tell the block, it writes the pooled tensor as well
+            nxt = self.encoders[i + 1] if i + 1 < len(self.encoders) else None
+            pool_next = nxt.pooling.mode if (nxt is not None and isinstance(nxt.pooling, hnn._Pool2)) else None
             if i == 0:
-                x = enc(x)
+                x = enc(x, pool_next=pool_next)
             else:  # x is both the previous level's skip tensor and this level's pooling input (model.py:194-199)
-                skips[0], x = enc(x, with_skip=True)
+                skips[0], x = enc(x, with_skip=True, pool_next=pool_next)
             skips.insert(0, x)
         for dec, skip in zip(self.decoders, skips[1:]):
             x = dec(skip, x)
