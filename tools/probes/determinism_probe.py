@@ -27,7 +27,7 @@ import mednet_hip  # noqa: E402
 from mednet_hip import debug  # noqa: E402
 from mednet_hip.train import SegmentationStep  # noqa: E402
 from mednet_hip.unet import model as HM  # noqa: E402
-from oracle import ref_cpu as O  # noqa: E402  (synthetic batch + keyed initialisation only)
+from mednet_hip import synth as O  # noqa: E402  (the product's own synthetic batch + keyed initialisation: nothing from oracle/)
 
 CONFIGS = {
     "cfg5": dict(f_maps=[64, 128, 256, 512, 1024], size=(160, 160, 96), n=2),

@@ -210,10 +210,27 @@ __global__ __launch_bounds__(256, sizeof(TO) == 2 ? 3 : 2) void head_dice_bwd_ke
     const size_t vbs = hb ? vb : v;
     // every load of both voxels before the first use
     float la[HL_MAXC], lb[HL_MAXC];
+    if constexpr (CG == 4) {
+      // the lanes of a voxel are one DPP quad (32 features; with 64 the extra registers spilled): lane q of the quad loads class q for both voxels and the quad hands the
+      // values round -- 2 planar loads per lane and trip instead of 8 (each a whole wave instruction for 64 useful bytes)
+      const int cq = threadIdx.x & 3;
+      const float oa = cq < m ? lgs[((size_t)n * m + cq) * spatial + v] : 0.f;
+      const float ob = cq < m ? lgs[((size_t)n * m + cq) * spatial + vbs] : 0.f;
+      la[0] = dpp_f32<(0) | (0 << 2) | (0 << 4) | (0 << 6)>(oa);
+      la[1] = dpp_f32<(1) | (1 << 2) | (1 << 4) | (1 << 6)>(oa);
+      la[2] = dpp_f32<(2) | (2 << 2) | (2 << 4) | (2 << 6)>(oa);
+      la[3] = dpp_f32<(3) | (3 << 2) | (3 << 4) | (3 << 6)>(oa);
+      lb[0] = dpp_f32<(0) | (0 << 2) | (0 << 4) | (0 << 6)>(ob);
+      lb[1] = dpp_f32<(1) | (1 << 2) | (1 << 4) | (1 << 6)>(ob);
+      lb[2] = dpp_f32<(2) | (2 << 2) | (2 << 4) | (2 << 6)>(ob);
+      lb[3] = dpp_f32<(3) | (3 << 2) | (3 << 4) | (3 << 6)>(ob);
+      static_assert(HL_MAXC == 4, "one class per lane of a quad");
+    } else {
 #pragma unroll
-    for (int i = 0; i < HL_MAXC; ++i) {
-      la[i] = i < m ? lgs[((size_t)n * m + i) * spatial + v] : 0.f;
-      lb[i] = i < m ? lgs[((size_t)n * m + i) * spatial + vbs] : 0.f;
+      for (int i = 0; i < HL_MAXC; ++i) {
+        la[i] = i < m ? lgs[((size_t)n * m + i) * spatial + v] : 0.f;
+        lb[i] = i < m ? lgs[((size_t)n * m + i) * spatial + vbs] : 0.f;
+      }
     }
     const int ya = label_at(lab, (size_t)n * lab_sn + v), yb = label_at(lab, (size_t)n * lab_sn + vbs);
     const size_t rowa = ((size_t)n * spatial + v) * K + cgi * 8, rowb = ((size_t)n * spatial + vbs) * K + cgi * 8;
