@@ -217,7 +217,7 @@ int mednet_pool2_fwd(const void* x, void* y, int n, int d, int h, int w, int c, 
  * shape): a second gradient of the same tensor -- the decoder's skip join of model.py:199-205 -- summed in the same pass. */
 /* GroupNorm apply (+ residual + activation, as mednet_gn_act_fwd) fused with the 2x2x2 pooling that consumes its output (an
  * encoder block's last layer followed by the next level's pooling, components.py:177-178 -> :222-224): writes z AND the pooled
- * tensor in one pass; both bit-identical to mednet_gn_act_fwd + mednet_pool2_fwd.  Even d, h, w; C a multiple of 8; bf16 / fp16. */
+ * tensor in one pass; both bit-identical to mednet_gn_act_fwd + mednet_pool2_fwd.  Even d, h, w; C a multiple of 8. */
 int mednet_gn_act_pool_supported(int d, int h, int w, int c, int dtype);
 int mednet_gn_act_pool_fwd(const void* x, const float* coef, const void* residual, void* z, void* pooled, int n, int d, int h,
                            int w, int c, int act, int mode, int dtype, mednet_stream stream);

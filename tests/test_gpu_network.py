@@ -1051,7 +1051,7 @@ def test_fused_head_and_loss_step_equals_the_two_node_step(mode):
             assert torch.equal(a, b), f"{name}: gradient differs between the fused and the two-node step"
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "fp32"])
 def test_pooling_inside_the_block_output_pass_changes_nothing(mode):
     """Encoder blocks write the next level's pooled input in the pass that writes their output (block.PoolStash, model.py:194-199):
     loss and every gradient of a three-level network bit-identical to the step with a stand-alone pooling launch."""

@@ -1121,14 +1121,14 @@ def test_losses_take_the_label_volume_where_it_lies():
     assert float(res[0][1].abs().max()) > 0
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "fp32"])
 @pytest.mark.parametrize("n,c,shape,pool,residual", [(2, 32, (8, 12, 16), "max", True), (1, 64, (6, 4, 10), "avg", True),
                                                      (2, 16, (4, 8, 6), "max", False), (1, 128, (2, 2, 2), "max", True)])
 def test_groupnorm_apply_fused_with_the_pooling_that_follows(mode, n, c, shape, pool, residual):
     """mednet_gn_act_pool_fwd (an encoder block's last GroupNorm apply + residual + ELU and the next level's 2x2x2 pooling in one
     pass, components.py:177-178 -> :222-224) against mednet_gn_act_fwd followed by mednet_pool2_fwd: block output and pooled tensor
     bit-identical (max with ties and avg)."""
-    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[mode]
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[mode]
     d, h, w = shape
     y = ops.to_cl((rnd("gp_y", n, c, *shape) * 2).round().div(2).to(dt).to(DEV))  # (coarse values: ties inside pooling windows)
     r = ops.to_cl(rnd("gp_r", n, c, *shape).to(dt).to(DEV)) if residual else None

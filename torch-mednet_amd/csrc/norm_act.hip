@@ -708,11 +708,10 @@ __global__ __launch_bounds__(256) void pool2_fwd_kernel(const T* __restrict__ x,
 // stand-alone pooling pass and its re-read of z are gone.  z is computed and rounded exactly as gn_act_fwd_kernel
 // does, the pooling runs on the ROUNDED values in pool2_fwd_kernel's scan order: both outputs are bit-identical to the two
 // launches.  Even d, h, w.
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void gn_act_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ coef,
                                                               const T* __restrict__ res, T* __restrict__ z, T* __restrict__ pooled,
                                                               int n, int d, int h, int w, int c, int act, int mode) {
-  constexpr int VEC = 8;
   const int od = d / 2, oh = h / 2, ow = w / 2, cv = c / VEC;
   const size_t total = (size_t)n * od * oh * ow * cv;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1314,21 +1313,23 @@ extern "C" int mednet_pool2_fwd(const void* x, void* y, int n, int d, int h, int
   return check_launch("pool2_fwd");
 }
 extern "C" int mednet_gn_act_pool_supported(int d, int h, int w, int c, int dtype) {
-  return d >= 2 && h >= 2 && w >= 2 && d % 2 == 0 && h % 2 == 0 && w % 2 == 0 && c % 8 == 0 && (dtype == MEDNET_BF16 || dtype == MEDNET_F16) &&
-         tuning_option("gn_pool_fuse", 1);
+  return d >= 2 && h >= 2 && w >= 2 && d % 2 == 0 && h % 2 == 0 && w % 2 == 0 && c % 8 == 0 && dtype_ok(dtype) && tuning_option("gn_pool_fuse", 1);
 }
 extern "C" int mednet_gn_act_pool_fwd(const void* x, const float* coef, const void* residual, void* z, void* pooled, int n, int d,
                                       int h, int w, int c, int act, int mode, int dtype, mednet_stream stream) {
   MEDNET_REQUIRE(mednet_gn_act_pool_supported(d, h, w, c, dtype), MEDNET_E_UNSUPPORTED,
-                 "gn_act_pool_fwd: even dims, C %% 8 == 0 and 16-bit storage only (%dx%dx%d, C=%d, dtype %d)", d, h, w, c, dtype);
+                 "gn_act_pool_fwd: even dims and C %% 8 == 0 only (%dx%dx%d, C=%d, dtype %d)", d, h, w, c, dtype);
   MEDNET_REQUIRE(n > 0 && x && coef && z && pooled, MEDNET_E_SHAPE, "gn_act_pool_fwd: bad arguments");
-  const size_t total = (size_t)n * (d / 2) * (h / 2) * (w / 2) * (c / 8);
+  const int vec = dtype == MEDNET_F32 ? 4 : 8;  // (fp32: one 16-byte access per lane and tensor, as the other fp32 GroupNorm kernels)
+  const size_t total = (size_t)n * (d / 2) * (h / 2) * (w / 2) * (c / vec);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)((total + 255) / 256));
   if (dtype == MEDNET_BF16)
-    hipLaunchKernelGGL((gn_act_pool_fwd_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x, coef, (const bf16*)residual, (bf16*)z, (bf16*)pooled, n, d, h, w, c, act, mode);
+    hipLaunchKernelGGL((gn_act_pool_fwd_kernel<bf16, 8>), grid, dim3(256), 0, s, (const bf16*)x, coef, (const bf16*)residual, (bf16*)z, (bf16*)pooled, n, d, h, w, c, act, mode);
+  else if (dtype == MEDNET_F16)
+    hipLaunchKernelGGL((gn_act_pool_fwd_kernel<f16, 8>), grid, dim3(256), 0, s, (const f16*)x, coef, (const f16*)residual, (f16*)z, (f16*)pooled, n, d, h, w, c, act, mode);
   else
-    hipLaunchKernelGGL((gn_act_pool_fwd_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x, coef, (const f16*)residual, (f16*)z, (f16*)pooled, n, d, h, w, c, act, mode);
+    hipLaunchKernelGGL((gn_act_pool_fwd_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, coef, (const float*)residual, (float*)z, (float*)pooled, n, d, h, w, c, act, mode);
   return check_launch("gn_act_pool_fwd");
 }
 

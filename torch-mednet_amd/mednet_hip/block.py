@@ -224,7 +224,7 @@ def res_block(x, convs, norms, groups, eps, act, pool_mode=None):
     output (`_mednet_pooled`)."""
     (k1, k2, k3), (n1, n2, n3) = convs, norms
     hook = ops.GN3Hook() if (ops.FUSE_GN3 and torch.is_grad_enabled()) else None  # (training only)
-    stash = PoolStash(pool_mode) if (pool_mode is not None and FUSE_POOL and config.is_half_mode()) else None
+    stash = PoolStash(pool_mode) if (pool_mode is not None and FUSE_POOL) else None
     out = ResBlockFn.apply(x, k1.weight, n1.weight, n1.bias, k2.weight, n2.weight, n2.bias, k3.weight, n3.weight, n3.bias,
                            k1._packed(), k2._packed(), k3._packed(), groups, eps, act, hook, stash)
     if hook is not None:
