@@ -203,6 +203,14 @@ int mednet_gn_act_bwd_fused_res(const void* dz, const void* x, const void* z, co
                                 const float* gamma, const float* fused_partial, int rows, void* dx, void* dres,
                                 float* dgamma, float* dbeta, int n, size_t spatial, int c, int groups, int act, int dtype,
                                 void* ws, size_t ws_bytes, mednet_stream stream);
+/* ... when dz is the pooling backward + skip join of an encoder level and was NOT materialised: mednet_pool2_bwd_gn called with
+ * dx = NULL takes the sums only, and this apply pass rebuilds dz per 2x2x2 window from the pooled gradient dy_pool, the arg-max of
+ * the block output z (read for act' anyway) and the skip gradient (nullable), rounded as the pooling backward would have stored
+ * it.  dx (= dy3) and dres are bit-identical to mednet_pool2_bwd_gn + mednet_gn_act_bwd_fused_res.  Even d, h, w; C % 8 == 0. */
+int mednet_gn_act_bwd_fused_res_pool(const void* dy_pool, const void* skip_grad, const void* x, const void* z, const float* stats,
+                                     const float* gamma, const float* fused_partial, int rows, void* dx, void* dres, float* dgamma,
+                                     float* dbeta, int n, int d, int h, int w, int c, int groups, int act, int pool_mode, int dtype,
+                                     void* ws, size_t ws_bytes, mednet_stream stream);
 /* stand-alone activation (orders such as 'cr', 'crg'); in-place allowed (x == z). */
 int mednet_act_fwd(const void* x, void* z, size_t count, int act, int dtype, mednet_stream stream);
 int mednet_act_bwd(const void* dz, const void* z, void* dx, size_t count, int act, int dtype,

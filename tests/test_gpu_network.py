@@ -1075,3 +1075,53 @@ def test_pooling_inside_the_block_output_pass_changes_nothing(mode):
         finally:
             block.FUSE_POOL = old
         assert res[True][0] == res[False][0] and torch.equal(res[True][1], res[False][1]), shape
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("pool", ["max", "avg"])
+def test_the_unwritten_gradient_of_an_encoder_level_changes_nothing(mode, pool):
+    """The pooling backward of an encoder level takes GroupNorm-3's sums WITHOUT storing the gradient of the block output; the block's
+    apply pass rebuilds it (ops.SkipPool2Fn lazy, mednet_gn_act_bwd_fused_res_pool; model.py:194-205 gives the level's output to the
+    pooling and to the skip join only): loss and every gradient bit-identical to the step that materialises it."""
+    from mednet_hip.train import SegmentationStep
+    from mednet_hip import ops
+    ctor = dict(in_channels=1, out_channels=3, final_sigmoid=False, f_maps=[32, 64, 96])
+    res = {}
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(2, 1, (16, 24, 32), 3, 0, seed=5).items()}
+    old = ops.LAZY_POOL
+    try:
+        for lazy in (False, True):
+            ops.LAZY_POOL = lazy
+            for k in ops.GN3_COUNT:
+                ops.GN3_COUNT[k] = 0
+            with mednet_hip.precision(mode):
+                net = O.keyed_init_(HM.ResidualUNet3D(**ctor))
+                if pool == "avg":  # (components.py:206-214: Encoder's pool_type; the U-Net classes never pass it)
+                    for enc in net.encoders[1:]:
+                        enc.pooling = hnn.AvgPool3d(kernel_size=(2, 2, 2))
+                step = SegmentationStep(net.to(DEV), loss_weight=None, lr=1e-3)
+                (loss,) = step._fwd_bwd(batch)
+                torch.cuda.synchronize()
+                res[lazy] = (float(loss), step.flat.grad.clone(), dict(ops.GN3_COUNT))
+                step.flat.release()
+    finally:
+        ops.LAZY_POOL = old
+    assert res[True][2] == res[False][2] and res[True][2]["declined"] == 0, res[True][2]
+    assert res[True][0] == res[False][0] and torch.equal(res[True][1], res[False][1])
+
+
+def test_a_second_consumer_of_a_sole_consumer_output_is_an_error():
+    """skip_pool2(sole_consumer=True) is a contract of the caller; breaking it must not yield a silently wrong gradient."""
+    from mednet_hip import ops, _lib as L
+    from mednet_hip.unet.components import ExtResNetBlock
+    with mednet_hip.precision("bf16"):
+        blk = ExtResNetBlock(8, 16).to(DEV)
+        x = torch.randn(1, 8, 8, 8, 8, device=DEV)
+        out = blk(x)
+        skip, pooled = ops.skip_pool2(out, L.POOL_MAX, sole_consumer=True)
+        loss = pooled.float().sum() + skip.float().sum() + out.float().sum()  # `out` used again: the contract is broken
+        with pytest.raises(RuntimeError, match="another consumer"):
+            loss.backward()
+        out = blk(x)  # ... and the honest use of the same call works and matches the materialised form
+        skip, pooled = ops.skip_pool2(out, L.POOL_MAX, sole_consumer=True)
+        (pooled.float().square().sum() + skip.float().sum()).backward()

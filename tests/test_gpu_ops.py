@@ -1145,3 +1145,57 @@ def test_groupnorm_apply_fused_with_the_pooling_that_follows(mode, n, c, shape, 
                                        pm, L.dt_of(dt), L.stream()), "gn_act_pool_fwd")
     assert torch.equal(z0, z1) and torch.equal(p0, p1)
     assert not lib.mednet_gn_act_pool_supported(5, h, w, c, L.dt_of(dt))  # odd extents keep the two launches
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("n,c,groups,shape,pool,skip", [(2, 32, 8, (8, 12, 16), "max", True), (1, 64, 8, (6, 4, 10), "avg", True),
+                                                        (2, 16, 2, (4, 8, 6), "max", False), (1, 128, 8, (4, 4, 4), "max", True)])
+def test_groupnorm_backward_rebuilds_the_pooled_gradient_it_was_not_given(mode, n, c, groups, shape, pool, skip):
+    """mednet_pool2_bwd_gn(dx = NULL) + mednet_gn_act_bwd_fused_res_pool (the gradient of an encoder block's output is never in
+    memory; components.py:177-178 <- :222-224) against mednet_pool2_bwd_gn + mednet_gn_act_bwd_fused_res: the sums, dy3, dres,
+    dgamma and dbeta bit-identical, max pooling with ties in the windows.  (The 128-channel case runs the two-launch reducer.)"""
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[mode]
+    d, h, w = shape
+    sp = d * h * w
+    lib = L.lib()
+    pm = L.POOL_MAX if pool == "max" else L.POOL_AVG
+    y3 = ops.to_cl(rnd("lp_y", n, c, *shape).to(dt).to(DEV))
+    out = ops.to_cl((rnd("lp_o", n, c, *shape) * 2).round().div(2).to(dt).to(DEV))  # block output: coarse values, ties
+    dyp = ops.to_cl(rnd("lp_g", n, c, d // 2, h // 2, w // 2).to(dt).to(DEV))
+    dsk = ops.to_cl(rnd("lp_s", n, c, *shape).to(dt).to(DEV)) if skip else None
+    gamma = (1 + 0.1 * rnd("lp_ga", c)).to(DEV)
+    stats = torch.stack((0.1 * rnd("lp_m", n, groups), 1 + 0.1 * rnd("lp_r", n, groups).abs()), dim=-1).to(DEV).contiguous()
+    coef = torch.stack((torch.ones(n, c), torch.zeros(n, c)), dim=-1).to(DEV).contiguous()
+    rows = lib.mednet_pool2_bwd_gn_rows(n, d, h, w, c, L.dt_of(dt))
+    assert rows > 0
+    ws = L.workspace(lib.mednet_gn_ws_bytes(n, c, sp), DEV)
+    res = []
+    lib.mednet_set_option(b"gn_bwd_one_launch", 0 if c == 128 else 1)
+    for lazy in (False, True):
+        part = torch.full((n, rows, c, 2), float("nan"), device=DEV)
+        dx = torch.full_like(out, float("nan"))
+        L.check(lib.mednet_pool2_bwd_gn(dyp.data_ptr(), out.data_ptr(), L.ptr(dsk), None if lazy else dx.data_ptr(), y3.data_ptr(),
+                                        L.ACT_ELU, part.data_ptr(), n, d, h, w, c, pm, L.dt_of(dt), L.stream()), "pool2_bwd_gn")
+        dy3, dres = torch.full_like(out, float("nan")), torch.full_like(out, float("nan"))
+        dg, db = torch.full((c,), float("nan"), device=DEV), torch.full((c,), float("nan"), device=DEV)
+        if lazy:
+            L.check(lib.mednet_gn_act_bwd_fused_res_pool(dyp.data_ptr(), L.ptr(dsk), y3.data_ptr(), out.data_ptr(), stats.data_ptr(),
+                                                         gamma.data_ptr(), part.data_ptr(), rows, dy3.data_ptr(), dres.data_ptr(),
+                                                         dg.data_ptr(), db.data_ptr(), n, d, h, w, c, groups, L.ACT_ELU, pm,
+                                                         L.dt_of(dt), ws.data_ptr(), ws.numel(), L.stream()), "fused_res_pool")
+            assert torch.isnan(dx.float()).all()  # nothing wrote the gradient tensor
+        else:
+            L.check(lib.mednet_gn_act_bwd_fused_res(dx.data_ptr(), y3.data_ptr(), out.data_ptr(), coef.data_ptr(), stats.data_ptr(),
+                                                    gamma.data_ptr(), part.data_ptr(), rows, dy3.data_ptr(), dres.data_ptr(),
+                                                    dg.data_ptr(), db.data_ptr(), n, sp, c, groups, L.ACT_ELU, L.dt_of(dt),
+                                                    ws.data_ptr(), ws.numel(), L.stream()), "fused_res")
+        torch.cuda.synchronize()
+        res.append((part, dy3, dres, dg, db))
+    lib.mednet_set_option(b"gn_bwd_one_launch", 1)
+    for name, a, b in zip(("partial", "dy3", "dres", "dgamma", "dbeta"), *res):
+        assert not torch.isnan(a.float()).any(), name
+        if not torch.equal(a, b):
+            bad = (a != b).nonzero()
+            i = tuple(bad[0].tolist())
+            raise AssertionError(f"{name}: {len(bad)} of {a.numel()} differ, first at {i}: {a[i].item()!r} vs {b[i].item()!r}; "
+                                 f"max |diff| {(a.float() - b.float()).abs().max().item():.3e}")

@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256) void pool2_bwd_gn_kernel(const T* __restrict__
       }
 #pragma unroll
       for (int k = 0; k < VEC; ++k) o.v[k] = (float)(T)o.v[k];  // the stored value is what GroupNorm-3's second pass reads
-      VecIO<T, VEC>::store(dx, dst, o);
+      if (dx) VecIO<T, VEC>::store(dx, dst, o);  // (dx == nullptr: statistics only, gn_bwd_apply_pool_kernel rebuilds the rows)
       const F8 yv = VecIO<T, VEC>::load(gy, dst);
       act_grad_n<VEC>(o.v, xv[t].v, act);
 #pragma unroll
@@ -901,6 +901,103 @@ __global__ __launch_bounds__(256) void pool2_bwd_gn_kernel(const T* __restrict__
   }
   float* out = partial + (((size_t)nn * gridDim.x + blockIdx.x) * 4) * c * 2;
   column_reduce_lds_free<2 * VEC>(acc, cv, cc, true, out, c * 2);
+}
+
+// GroupNorm-3's backward apply pass of an encoder block whose output gradient is the pooling backward + skip join above, WITHOUT
+// that gradient in memory: a thread owns one pooled voxel x VEC channels, rebuilds the 8 gradient rows of its window from the
+// pooled gradient, the arg-max of the block output (which it reads anyway for act') and the skip gradient -- rounded to T exactly
+// as pool2_bwd_gn_kernel rounds what it would have stored -- and applies gn_bwd_apply_kernel's closed form:
+//   du = dz * act'(out);  dy3 = k1 * du + k2 * y3 + k3;  dres = du.
+// The 537 MB gradient tensor of a 32-channel 128^3 batch is neither written (pooling backward) nor read (this pass).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gn_bwd_apply_pool_kernel(const T* __restrict__ dyp, const T* __restrict__ add,
+                                                                const T* __restrict__ x, const T* __restrict__ z,
+                                                                const float* __restrict__ bcoef, T* __restrict__ dx,
+                                                                T* __restrict__ dres, int n, int d, int h, int w, int c, int act,
+                                                                int mode, GnParamGrad pg) {
+  if (pg.csum && blockIdx.x == 0) {  // pass 2b (gn_bwd_params_kernel) without a launch of its own
+    for (int cc = threadIdx.x; cc < c; cc += 256) {
+      double a = 0.0, b = 0.0;
+      for (int i = 0; i < pg.n; ++i) {
+        a += (double)pg.csum[((size_t)i * c + cc) * 2];
+        b += (double)pg.csum[((size_t)i * c + cc) * 2 + 1];
+      }
+      if (pg.dbeta) pg.dbeta[cc] = (float)a;
+      if (pg.dgamma) pg.dgamma[cc] = (float)b;
+    }
+  }
+  const int od = d / 2, oh = h / 2, ow = w / 2, cv = c / VEC;
+  const size_t total = (size_t)n * od * oh * ow * cv;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cc = (int)(i % cv);
+  size_t v = i / cv;
+  const int ox = (int)(v % ow);
+  v /= ow;
+  const int oy = (int)(v % oh);
+  v /= oh;
+  const int oz = (int)(v % od);
+  const int nn = (int)(v / od);
+  float k1[VEC], k2[VEC], k3[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const float* o = bcoef + ((size_t)nn * c + cc * VEC + k) * 3;
+    k1[k] = o[0];
+    k2[k] = o[1];
+    k3[k] = o[2];
+  }
+  const F8 g = VecIO<T, VEC>::load(dyp, i * VEC);
+  size_t src[8];
+  F8 zv[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int iz = 2 * oz + (t >> 2), iy = 2 * oy + ((t >> 1) & 1), ix = 2 * ox + (t & 1);
+    src[t] = ((((size_t)nn * d + iz) * h + iy) * w + ix) * c + (size_t)cc * VEC;
+    zv[t] = VecIO<T, VEC>::load(z, src[t]);
+  }
+  int arg[VEC];
+  float best[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    best[k] = -INFINITY;
+    arg[k] = 0;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+      if (zv[t].v[k] > best[k] || zv[t].v[k] != zv[t].v[k]) {  // first maximum in scan order, NaN propagates (ATen)
+        best[k] = zv[t].v[k];
+        arg[k] = t;
+      }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const F8 xv = VecIO<T, VEC>::load(x, src[t]);
+    F8 g1;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) g1.v[k] = mode == MEDNET_POOL_MAX ? (arg[k] == t ? g.v[k] : 0.f) : 0.125f * g.v[k];
+    if (add) {
+      const F8 a = VecIO<T, VEC>::load(add, src[t]);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) g1.v[k] += a.v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) g1.v[k] = (float)(T)g1.v[k];  // the value pool2_bwd_gn_kernel would have stored (and summed)
+    act_grad_n<VEC>(g1.v, zv[t].v, act);
+    F8 o;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      // plain fp32 FMAs on converted operands, THEN the rounding to T, as gn_bwd_apply_kernel has them: left alone the compiler
+      // folds the conversions of the fp16 form into v_fma_mix_f32 / v_fma_mixlo_f16, whose results are not those of v_fma_f32 +
+      // v_cvt (measured: about 4 % of the exact fp16 ties of dy3 then round the other way, a handful of elements per 10^6)
+      float xf = xv.v[k];
+      if (sizeof(T) == 2) asm volatile("" : "+v"(xf));
+      o.v[k] = fmaf(k1[k], g1.v[k], fmaf(k2[k], xf, k3[k]));
+      if (sizeof(T) == 2) asm volatile("" : "+v"(o.v[k]));
+    }
+    VecIO<T, VEC>::store(dx, src[t], o);
+    VecIO<T, VEC>::store(dres, src[t], g1);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- upsample + concat
@@ -1266,6 +1363,54 @@ extern "C" int mednet_gn_act_bwd_fused_res(const void* dz, const void* x, const 
   MEDNET_REQUIRE(z && dres, MEDNET_E_SHAPE, "gn_act_bwd_fused_res: z and dres are required");
   return gn_act_bwd_fused_impl(dz, x, z, coef, stats, gamma, fused_partial, rows, dx, dres, dgamma, dbeta, n, spatial, c, groups,
                                act, MEDNET_ACT_NONE, dtype, ws, ws_bytes, stream);
+}
+
+// ... for the residual layer of an ENCODER block whose output gradient dz = pooling backward(dy_pool) + skip gradient was not
+// materialised (mednet_pool2_bwd_gn with dx = NULL took the sums): the apply pass rebuilds dz per pooling window.
+extern "C" int mednet_gn_act_bwd_fused_res_pool(const void* dy_pool, const void* skip_grad, const void* x, const void* z,
+                                                const float* stats, const float* gamma, const float* fused_partial, int rows,
+                                                void* dx, void* dres, float* dgamma, float* dbeta, int n, int d, int h, int w, int c,
+                                                int groups, int act, int pool_mode, int dtype, void* ws, size_t ws_bytes,
+                                                mednet_stream stream) {
+  MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "gn_act_bwd_fused_res_pool: bad dtype");
+  MEDNET_REQUIRE(c % groups == 0 && rows > 0 && fused_partial && dy_pool && x && z && dx && dres, MEDNET_E_SHAPE,
+                 "gn_act_bwd_fused_res_pool: bad arguments");
+  MEDNET_REQUIRE(d % 2 == 0 && h % 2 == 0 && w % 2 == 0 && c % 8 == 0, MEDNET_E_UNSUPPORTED,
+                 "gn_act_bwd_fused_res_pool: even extents and C %% 8 == 0 (%dx%dx%d, C=%d)", d, h, w, c);
+  const size_t spatial = (size_t)d * h * w;
+  MEDNET_REQUIRE(ws_bytes >= mednet_gn_ws_bytes(n, c, spatial), MEDNET_E_WORKSPACE, "gn_act_bwd_fused_res_pool: workspace too small");
+  float* bcoef = (float*)ws + (size_t)n * gn_partial_rows_max(c) * c * 2;
+  float* csum = bcoef + (size_t)n * c * 3;
+  hipStream_t s = (hipStream_t)stream;
+  GnParamGrad pg;
+  int rc;
+  if (gn_bwd_one_launch(c, groups)) {
+    hipLaunchKernelGGL(gn_bwd_reduce_finalize_kernel<true>, dim3(n * groups), dim3(256), 0, s, fused_partial, stats, gamma, csum, bcoef,
+                       c, groups, rows, (double)spatial * (c / groups));
+    rc = check_launch("gn_bwd_reduce_finalize");
+    if (rc) return rc;
+    if (dgamma || dbeta) pg = GnParamGrad{csum, dgamma, dbeta, n};
+  } else {
+    hipLaunchKernelGGL(reduce_partials_dux_kernel, dim3(n * c), dim3(64), 0, s, fused_partial, stats, csum, c, groups, rows);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, stats, gamma, bcoef, c, groups,
+                       (double)spatial * (c / groups));
+    rc = check_launch("gn_bwd_finalize");
+    if (rc) return rc;
+    if (dgamma || dbeta) {
+      hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((c + 255) / 256), dim3(256), 0, s, csum, dgamma, dbeta, n, c);
+      rc = check_launch("gn_bwd_params");
+      if (rc) return rc;
+    }
+  }
+  const int vec = dtype == MEDNET_F32 ? 4 : 8;
+  const size_t total = (size_t)n * (d / 2) * (h / 2) * (w / 2) * (c / vec);
+  const dim3 grid((unsigned)((total + 255) / 256));
+#define GO(T, V) hipLaunchKernelGGL((gn_bwd_apply_pool_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy_pool, (const T*)skip_grad, (const T*)x, (const T*)z, bcoef, (T*)dx, (T*)dres, n, d, h, w, c, act, pool_mode, pg)
+  if (dtype == MEDNET_F32) GO(float, 4);
+  else if (dtype == MEDNET_BF16) GO(bf16, 8);
+  else GO(f16, 8);
+#undef GO
+  return check_launch("gn_bwd_apply_pool");
 }
 
 extern "C" int mednet_act_fwd(const void* x, void* z, size_t count, int act, int dtype, mednet_stream stream) {

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mednet_conv3d_dgrad_gn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 8 + [_vp]),
     "mednet_gn_act_bwd_fused": (_i, [_vp] * 6 + [_i, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mednet_gn_act_bwd_fused_res": (_i, [_vp] * 7 + [_i, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mednet_gn_act_bwd_fused_res_pool": (_i, [_vp] * 7 + [_i, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp, _sz, _vp]),
     "mednet_head_dgrad_gn_rows": (_i, [_i] * 6),
     "mednet_head_dgrad_gn": (_i, [_vp] * 5 + [_i, _vp] + [_i] * 7 + [_vp]),
     "mednet_pool2_bwd_gn_rows": (_i, [_i] * 6),

@@ -67,7 +67,7 @@ def _gn_fwd(y, partial, gamma, beta, groups, eps, act, residual, pool_mode=None)
     return (z, stats, coef, None) if pool_mode is not None else (z, stats, coef)
 
 
-def _gn_bwd(dz, dz2, y, z, coef, stats, gamma_p, beta_p, groups, act, want_dres, partial=None):
+def _gn_bwd(dz, dz2, y, z, coef, stats, gamma_p, beta_p, groups, act, want_dres, partial=None, lazy=None):
     """Returns (dy, dres, dgamma, dbeta).  `partial`: the first pass ({sum du, sum du*y} per channel) already taken by the
     data-gradient kernel that produced dz (mednet_conv3d_dgrad_gn)."""
     n, c, d, h, w = y.shape
@@ -78,6 +78,17 @@ def _gn_bwd(dz, dz2, y, z, coef, stats, gamma_p, beta_p, groups, act, want_dres,
     dgamma, dg_direct = ops._grad_target(gamma_p, (c,))
     dbeta, db_direct = ops._grad_target(beta_p, (c,))
     ws = L.workspace(lib.mednet_gn_ws_bytes(n, c, spatial), y.device)
+    if partial is not None and z is not None and lazy is not None:
+        # residual layer of an encoder block; dz = pooling backward + skip join was NOT written (ops.SkipPool2Fn, lazy): the
+        # apply pass rebuilds its rows from the pooled gradient, the arg-max of the block output and the skip gradient
+        dy_pool, dskip, pool_mode = lazy
+        assert dz2 is None and want_dres
+        L.check(lib.mednet_gn_act_bwd_fused_res_pool(dy_pool.data_ptr(), L.ptr(dskip), y.data_ptr(), z.data_ptr(), stats.data_ptr(),
+                                                     gamma_p.data_ptr(), partial.data_ptr(), partial.shape[1], dy.data_ptr(),
+                                                     dres.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), n, d, h, w, c, groups,
+                                                     act, pool_mode, L.dt(y), ws.data_ptr(), ws.numel(), L.stream()),
+                "gn_act_bwd_fused_res_pool")
+        return dy, dres, (None if dg_direct else dgamma), (None if db_direct else dbeta)
     if partial is not None and z is not None:  # residual layer: sums taken by the producer of dz (ops.GN3Hook)
         assert dz2 is None and want_dres
         L.check(lib.mednet_gn_act_bwd_fused_res(dz.data_ptr(), y.data_ptr(), z.data_ptr(), coef.data_ptr(), stats.data_ptr(),
@@ -191,9 +202,13 @@ class ResBlockFn(Function):
         w1, g1, b1, w2, g2, b2, w3, g3, b3 = ctx.params
         groups, act = ctx.meta
         part3 = ctx.gn3.take(dout) if ctx.gn3 is not None else None  # (before any conversion: identity matters)
-        dout = ops.to_cl(dout.to(out.dtype))
+        lazy = None
+        if ctx.gn3 is not None and part3 is not None:
+            lazy, ctx.gn3.lazy = ctx.gn3.lazy, None  # dout is an unwritten placeholder: see ops.SkipPool2Fn / GN3Hook.take
+        if lazy is None:
+            dout = ops.to_cl(dout.to(out.dtype))
         # GN3 + residual + activation: act' from the block output; dres = gradient of the residual branch (into z1)
-        dy3, dres, dg3, db3 = _gn_bwd(dout, None, y3, out, c3, s3, g3, b3, groups, act, True, partial=part3)
+        dy3, dres, dg3, db3 = _gn_bwd(dout, None, y3, out, c3, s3, g3, b3, groups, act, True, partial=part3, lazy=lazy)
         dz2, dw3, part2 = _conv_bwd(z2, dy3, pk3, w3, True, gnb=(y2, c2, act))
         dy2, _, dg2, db2 = _gn_bwd(dz2, None, y2, None, c2, s2, g2, b2, groups, act, False, partial=part2)
         # z1 feeds conv2 AND the residual add: the two gradients are summed in the epilogue of conv2's data gradient (bf16
@@ -205,7 +220,7 @@ class ResBlockFn(Function):
         dy1, _, dg1, db1 = _gn_bwd(dz1, None if fuse else dres, y1, None, c1, s1, g1, b1, groups, act, False, partial=part1)
         dx, dw1, _ = _conv_bwd(xin, dy1, pk1, w1, ctx.needs_input_grad[0])
         if debug.TRACE is not None:
-            debug.trace("resblock.bwd", dout, part3, dy3, dres, dz2, part2, dy2, dz1, part1, dy1, dx)
+            debug.trace("resblock.bwd", None if lazy is not None else dout, part3, dy3, dres, dz2, part2, dy2, dz1, part1, dy1, dx)
         return (dx, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + (None,) * 8
 
 

@@ -154,23 +154,31 @@ class GN3Hook:
     output gradient (mednet_head_dgrad_gn / mednet_pool2_bwd_gn).  The block's backward uses the sums only if the gradient it
     receives IS that tensor, untouched (same object, same version counter): any other consumer of `out` makes autograd
     accumulate into / replace it, and the block falls back to its stand-alone pass."""
-    __slots__ = ("gn_in", "act", "partial", "dx", "version")
+    __slots__ = ("gn_in", "act", "partial", "dx", "version", "lazy")
 
     def __init__(self):
         self.gn_in = None  # the GroupNorm's input (y3 of an ExtResNetBlock; x of a plain GroupNorm)
         self.act = 0
         self.partial = self.dx = None
         self.version = -1
+        self.lazy = None  # (dy_pool, skip gradient, pool mode): `dx` was NOT written, the block's apply pass rebuilds it
 
-    def offer(self, dx, partial):
-        self.dx, self.partial, self.version = dx, partial, dx._version
+    def offer(self, dx, partial, lazy=None):
+        self.dx, self.partial, self.version, self.lazy = dx, partial, dx._version, lazy
 
     def take(self, dout):
-        """The sums, if `dout` is exactly the tensor they were taken from; releases the references either way."""
-        partial, dx, version = self.partial, self.dx, self.version
-        self.partial = self.dx = None
+        """The sums, if `dout` is exactly the tensor they were taken from; releases the references either way.  A LAZY offer (the
+        gradient tensor is a placeholder nobody wrote: SkipPool2Fn with sole_consumer) cannot be declined -- the caller asserted
+        that the block output has no other consumer; a violated contract is an error, not a silent wrong gradient."""
+        partial, dx, version, lazy = self.partial, self.dx, self.version, self.lazy
+        self.partial = self.dx = self.lazy = None
         ok = partial is not None and dout is dx and dout._version == version
+        if lazy is not None and not ok:
+            raise RuntimeError("mednet_hip: the block output handed to skip_pool2(sole_consumer=True) has another consumer (or its "
+                               "gradient was replaced by a hook): the pooling backward did not materialise its gradient (MEDNET_LAZY_POOL=0 turns "
+                               "the optimisation off)")
         GN3_COUNT["taken" if ok else ("declined" if partial is not None else "absent")] += 1
+        self.lazy = lazy if ok else None  # (read and cleared by the block's backward)
         return partial if ok else None
 
 
@@ -711,7 +719,7 @@ class SkipPool2Fn(Function):
     backward kernel, instead of autograd adding two full-resolution tensors with a separate kernel."""
 
     @staticmethod
-    def forward(ctx, x, mode):
+    def forward(ctx, x, mode, sole_consumer=False):
         L.require_gpu(x, "pool3d")
         x0 = x
         x = to_cl(_as_act(x))
@@ -725,6 +733,11 @@ class SkipPool2Fn(Function):
         ctx.save_for_backward(x)
         ctx.mode = mode
         ctx.gn3 = _gn3_hook_of(x0, x.dtype) if x is x0 else None
+        # sole_consumer: the caller (the U-Net's own forward) hands x to nothing else, so the gradient of x goes to the producing
+        # block and nowhere else -- the backward may then leave it unwritten and let the block's apply pass rebuild it (LAZY_POOL)
+        # (a tensor hook or retain_grad() on x would READ that gradient: then it is written as before)
+        ctx.lazy_ok = (bool(sole_consumer) and LAZY_POOL and ctx.gn3 is not None and not x0._backward_hooks
+                       and not getattr(x0, "retains_grad", False))
         if debug.TRACE is not None:
             debug.trace(f"skip_pool2.fwd c{c}", y)
         return x.view_as(x), y
@@ -734,7 +747,7 @@ class SkipPool2Fn(Function):
         (x,) = ctx.saved_tensors
         n, c, d, h, w = x.shape
         if dy is None:
-            return dskip, None
+            return dskip, None, None
         dy = to_cl(dy.to(x.dtype))
         if dskip is not None:
             dskip = to_cl(dskip.to(x.dtype))
@@ -743,22 +756,30 @@ class SkipPool2Fn(Function):
         rows = L.lib().mednet_pool2_bwd_gn_rows(n, d, h, w, c, L.dt(x)) if hook is not None else 0
         if rows > 0:  # + the first pass of the producing block's GroupNorm-3 backward (x IS that block's output)
             partial = torch.empty((n, rows, c, 2), dtype=torch.float32, device=x.device)
-            L.check(L.lib().mednet_pool2_bwd_gn(dy.data_ptr(), x.data_ptr(), L.ptr(dskip), dx.data_ptr(), hook.gn_in.data_ptr(),
-                                                hook.act, partial.data_ptr(), n, d, h, w, c, ctx.mode, L.dt(x), L.stream()),
-                    "pool2_bwd_gn")
-            hook.offer(dx, partial)
+            lazy = ctx.lazy_ok and bool(L.lib().mednet_gn_act_pool_supported(d, h, w, c, L.dt(x)))
+            # lazy: sums only -- dx stays an unwritten placeholder (autograd needs a tensor of the right shape to hand on), the
+            # block's GroupNorm-3 apply pass rebuilds its rows from dy, the arg-max of x and dskip (mednet_gn_act_bwd_fused_res_pool)
+            L.check(L.lib().mednet_pool2_bwd_gn(dy.data_ptr(), x.data_ptr(), L.ptr(dskip), None if lazy else dx.data_ptr(),
+                                                hook.gn_in.data_ptr(), hook.act, partial.data_ptr(), n, d, h, w, c, ctx.mode, L.dt(x),
+                                                L.stream()), "pool2_bwd_gn")
+            hook.offer(dx, partial, (dy, dskip, ctx.mode) if lazy else None)
             if debug.TRACE is not None:
-                debug.trace(f"skip_pool2.bwd c{c}", dx, partial)
-            return dx, None
+                debug.trace(f"skip_pool2.bwd c{c}", None if lazy else dx, partial)
+            return dx, None, None
         L.check(L.lib().mednet_pool2_bwd(dy.data_ptr(), x.data_ptr(), L.ptr(dskip), dx.data_ptr(), n, d, h, w, c, ctx.mode,
                                          L.dt(x), L.stream()), "pool2_bwd")
         if debug.TRACE is not None:
             debug.trace(f"skip_pool2.bwd c{c}", dx)
-        return dx, None
+        return dx, None, None
 
 
-def skip_pool2(x, mode=L.POOL_MAX):
-    return SkipPool2Fn.apply(x, mode)
+LAZY_POOL = os.environ.get("MEDNET_LAZY_POOL", "1") == "1"  # A/B knob
+
+
+def skip_pool2(x, mode=L.POOL_MAX, sole_consumer=False):
+    """(skip, pooled).  `sole_consumer`: the caller guarantees that x -- a block output -- is used by nothing but this call (the
+    returned `skip` IS the tensor to use as x from here on); the backward then need not materialise the gradient of x."""
+    return SkipPool2Fn.apply(x, mode, sole_consumer)
 
 
 # ------------------------------------------------------------------------------------------------- nearest upsample + concat

@@ -214,7 +214,7 @@ class Encoder(nn.Module):
         self.basic_module = basic_module(in_channels, out_channels, encoder=True, kernel_size=conv_kernel_size,
                                          order=conv_layer_order, num_groups=num_groups)
 
-    def forward(self, x, with_skip=False, pool_next=None):
+    def forward(self, x, with_skip=False, pool_next=None, sole_consumer=False):
         """forward(x) is the reference's Encoder.forward (components.py:222-226).  `with_skip=True` -> (skip, out): `skip` is
         x as the decoder will use it, `out` = forward(x).  With the 2x2x2 pooling of this package the split is one autograd
         node (ops.SkipPool2Fn), so the two gradients of x meet inside the pooling backward kernel; any other pooling module
@@ -231,7 +231,8 @@ class Encoder(nn.Module):
                 x = self.pooling(x)
             return body(x)
         if _FUSE_SKIP_POOL and isinstance(self.pooling, hnn._Pool2) and torch.is_tensor(x) and x.is_cuda and x.requires_grad:
-            skip, pooled = ops.skip_pool2(x, self.pooling.mode)
+            # sole_consumer: the caller uses the returned skip tensor from here on and x nowhere else (ops.skip_pool2)
+            skip, pooled = ops.skip_pool2(x, self.pooling.mode, sole_consumer=sole_consumer)
             return skip, body(pooled)
         return x, self.forward(x, pool_next=pool_next)
 

@@ -122,7 +122,9 @@ class _UNetCore(*((_Base,) if _Base is not nn.Module else (_CheckpointCompat, nn
             if i == 0:
                 x = enc(x, pool_next=pool_next)
             else:  # x is both the previous level's skip tensor and this level's pooling input (model.py:194-199)
-                skips[0], x = enc(x, with_skip=True, pool_next=pool_next)
+                # (x is re-bound to the level's output and skips[0] to the returned skip tensor: the previous output has no
+                #  other consumer, which lets the pooling backward leave its gradient unwritten, ops.SkipPool2Fn)
+                skips[0], x = enc(x, with_skip=True, pool_next=pool_next, sole_consumer=True)
             skips.insert(0, x)
         for dec, skip in zip(self.decoders, skips[1:]):
             x = dec(skip, x)
