@@ -23,7 +23,7 @@ struct Option {
   char name[32];
   int value;
 };
-static Option g_options[16];
+static Option g_options[48];
 static int g_noptions = 0;
 int mednet_internal_tuning_option(const char* name, int default_value) {
   for (int i = 0; i < g_noptions; ++i)
@@ -65,7 +65,7 @@ extern "C" int mednet_set_option(const char* name, int value) {
       g_options[i].value = value;
       return MEDNET_OK;
     }
-  MEDNET_REQUIRE(g_noptions < 16 && strlen(name) < 32, MEDNET_E_UNSUPPORTED, "set_option: table full or name too long");
+  MEDNET_REQUIRE(g_noptions < 48 && strlen(name) < 32, MEDNET_E_UNSUPPORTED, "set_option: table full or name too long");
   strcpy(g_options[g_noptions].name, name);
   g_options[g_noptions++].value = value;
   return MEDNET_OK;

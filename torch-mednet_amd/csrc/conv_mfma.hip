@@ -893,6 +893,11 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
   }
   STAMP(1);
   int buf = 0;
+  // (GNB) per-wave copy of the current sample's GroupNorm coefficients: 256 bytes inside the spare-slot area, of which only the
+  // slots of threads 224..255 are ever written (spare_slot above)
+  [[maybe_unused]] int coef_n = -1;
+  [[maybe_unused]] char* cf_lds = smem + (size_t)2 * BUF_PIECES * 16 + 4 * 4096 + wv_s * 256;
+  static_assert(4 * 256 <= 224 * 16, "the coefficient copies stay clear of the spare slots in use");
   while (true) {
     int n, tz0, ty0, tx0;
     origin(seq, n, tz0, ty0, tx0);
@@ -906,6 +911,19 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
       while (acc_n < n) {
         flush(acc_n);
         ++acc_n;
+      }
+    }
+    if constexpr (GNB) {
+      // ... and the sample's GroupNorm coefficients (32 channels x {a, b}: 256 bytes) come in, into this wave's own copy in LDS.
+      // Fetched per brick from global memory, as until round 4, the four loads sat between the tap loop and the epilogue with
+      // nothing to hide their latency behind (one wave per SIMD).
+      if (n != coef_n) {
+        coef_n = n;
+        const auto rsrc_cf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_coef + (size_t)n * 64), 0, 256u, 0x00020000);
+        const u32x4 c4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc_cf, (unsigned)(lane * 16), 0, 0);  // (lanes >= 16: zeros)
+        wave_lds_fence();  // the previous brick's epilogue has read the old copy
+        if (lane < 16) *reinterpret_cast<u32x4*>(cf_lds + lane * 16) = c4;
+        wave_lds_fence();
       }
     }
     int n2, tz2, ty2, tx2;  // brick j + 2
@@ -1051,10 +1069,9 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
     }
     float ca[GNB ? 8 : 1], cbf[GNB ? 8 : 1];
     if constexpr (GNB) {  // (after the accumulators are gone: the register file is full until then)
-      const auto rsrc_cf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.gnb_coef + (size_t)n * 64), 0, 256u, 0x00020000);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 c4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_cf, (unsigned)(pj * 64 + q * 16), 0, 0));
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(cf_lds + pj * 64 + q * 16);
         ca[2 * q] = c4[0];
         cbf[2 * q] = c4[1];
         ca[2 * q + 1] = c4[2];
@@ -1082,14 +1099,24 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
         // one-wave-per-SIMD kernel is exposed, instruction for instruction.
         typedef __attribute__((ext_vector_type(2))) float f32x2;
         const eltx8 vz = ok ? v : eltx8{};
+        // MEDNET_C32_EPI_PROBE (measurement builds only, `make epi_probe`, profiles/r04_ab.md section 10; results are WRONG):
+        // bit 0 drops the 64 v_exp_f32 per lane and brick, bit 1 the whole block -- what act' from a stored activation (bit 0) or
+        // an epilogue overlapped with the next tap loop (bit 1) could save at most
+#ifndef MEDNET_C32_EPI_PROBE
+#define MEDNET_C32_EPI_PROBE 0
+#endif
 #pragma unroll
-        for (int p2 = 0; p2 < 4; ++p2) {
+        for (int p2 = 0; p2 < ((MEDNET_C32_EPI_PROBE & 2) ? 0 : 4); ++p2) {
           const f32x2 yy = {(float)yrw[j][2 * p2], (float)yrw[j][2 * p2 + 1]};
           const f32x2 g = {(float)vz[2 * p2], (float)vz[2 * p2 + 1]};
           const f32x2 ca2 = {ca[2 * p2], ca[2 * p2 + 1]}, cb2 = {cbf[2 * p2], cbf[2 * p2 + 1]};
           const f32x2 u = ca2 * yy + cb2;
           const f32x2 ul = u * 1.44269504088896340736f;  // exp(u) = 2^(u * log2 e), as __expf
+#if MEDNET_C32_EPI_PROBE & 1
+          const f32x2 e = ul;
+#else
           const f32x2 e = {__builtin_amdgcn_exp2f(ul[0]), __builtin_amdgcn_exp2f(ul[1])};
+#endif
           const f32x2 negc = {gnb_neg, gnb_neg};
           const f32x2 gn = g * (gnb_elu ? e : negc);
           const f32x2 du = {u[0] > 0.f ? g[0] : gn[0], u[1] > 0.f ? g[1] : gn[1]};
@@ -2252,7 +2279,10 @@ static void wgrad2_plan(int n, int d, int h, int w, int ka, int kb, Wg2Args& a) 
   a.nab = (ka + 31) / 32;  // a 16-channel operand is zero-padded to a 32-wide block by the buffer loads
   a.nbb = (kb + 31) / 32;
   const int pairs = a.nab * a.nbb;
-  const int target = tuning_option("wgrad_wgs", 256);  // workgroups per launch (256 = one per CU)
+  // workgroups per launch: one per CU when the launch has the chip to itself; the trainer asks for HALF of them when the weight
+  // gradients run on their own stream beside the main one (train.use_side_stream): a workgroup takes a CU's whole
+  // register file, so 256 of them lock every kernel of the main stream out until they retire
+  const int asked = tuning_option("wgrad_wgs", 0), target = asked > 0 ? asked : 256;
   int splits = (target + pairs - 1) / pairs;
   if (splits > a.ntiles) splits = a.ntiles;
   if (splits < 1) splits = 1;
@@ -2800,7 +2830,8 @@ static void ct2_plan(int n, int d, int h, int w, int ka, int kb, Ct2Args& a) {
   a.nab = (ka + 31) / 32;
   a.nbb = (kb + 31) / 32;
   const int pairs = a.nab * a.nbb;
-  int splits = (256 + pairs - 1) / pairs;  // one workgroup per CU
+  const int asked = tuning_option("wgrad_wgs", 0);
+  int splits = ((asked > 0 ? asked : 256) + pairs - 1) / pairs;  // one workgroup per CU (or per second CU: wgrad2_plan)
   if (splits > a.ntiles) splits = a.ntiles;
   if (splits < 1) splits = 1;
   a.splits = splits;

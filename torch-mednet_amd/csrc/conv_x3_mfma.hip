@@ -422,6 +422,12 @@ static int x3_grid() {
   if (cus <= 0) cus = 256;
   return (cus + 7) / 8 * 8;
 }
+// workgroups of a weight-gradient launch: about one per CU, or what the trainer asks for when the launch runs beside the main
+// stream (option wgrad_wgs, see wgrad2_plan in conv_mfma.hip)
+static int x3_wgrad_target() {
+  const int asked = tuning_option("wgrad_wgs", 0);
+  return asked > 0 ? asked : x3_grid();
+}
 
 bool conv_x3_enabled() { return tuning_option("x3", 1) != 0; }
 bool conv_x3_supported(int cin, int cout, int ksize) { return ksize == 3 && cin % 16 == 0 && cout % 16 == 0; }
@@ -1084,7 +1090,7 @@ static void wgx3_plan(int n, int d, int h, int w, int ka, int kb, WgX3Args& a) {
   a.nab = (ka + 31) / 32;
   a.nbb = (kb + 31) / 32;
   const int pairs = a.nab * a.nbb;
-  int splits = (x3_grid() + pairs - 1) / pairs;  // about one workgroup per CU
+  int splits = (x3_wgrad_target() + pairs - 1) / pairs;  // about one workgroup per CU (or per second CU beside the main stream)
   if (splits > a.ntiles) splits = a.ntiles;
   if (splits < 1) splits = 1;
   a.splits = splits;
@@ -1467,7 +1473,7 @@ static void ctwg_plan(int n, int d, int h, int w, int cin, int cout, CtWgX3Args&
   a.nab = (cin + ca32 - 1) / ca32;
   a.nbb = (cout + 31) / 32;
   const int pairs = a.nab * a.nbb;
-  int splits = (x3_grid() + pairs - 1) / pairs;
+  int splits = (x3_wgrad_target() + pairs - 1) / pairs;
   if (splits > a.ntiles) splits = a.ntiles;
   if (splits < 1) splits = 1;
   a.splits = splits;

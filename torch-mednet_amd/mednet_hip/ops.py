@@ -26,7 +26,12 @@ PROFILE = {"enabled": False, "events": [], "match": None}
 # Adam), while the data gradient -> GroupNorm backward chain is HBM-bound.  When the trainer provides in-place gradient
 # targets, weight-gradient kernels are launched on a second HIP stream so the matrix-core work overlaps the bandwidth
 # work of the main stream.  train.py joins the streams before the gradient exchange.
-SIDE = {"enabled": False, "stream": None, "keepalive": []}
+# Workgroups of a weight-gradient launch on the side stream: HALF the CUs.  A weight-gradient workgroup takes a CU's whole
+# register file; with one per CU nothing of the main stream -- not even the 32-workgroup reducer in front of a GroupNorm backward
+# pass -- starts before they retire, and the two streams merely take turns.  With 128 the other 128 CUs run the bandwidth-bound
+# GroupNorm passes of the main stream beside them, and the main stream's persistent kernels (256 / 512 workgroups) still divide
+# evenly over what is left (profiles/r04_ab.md section 9: 144 or 192 are worse than 128 AND than 256).  0: the library's default.
+SIDE = {"enabled": False, "stream": None, "keepalive": [], "wgrad_wgs": int(os.environ.get("MEDNET_SIDE_WGRAD_WGS", "128"))}
 
 
 def side_stream(device):
@@ -63,10 +68,14 @@ class _OnSide:
                     SIDE["keepalive"].append(t)
             self.ctx = torch.cuda.stream(side)
             self.ctx.__enter__()
+            if SIDE["wgrad_wgs"] > 0:  # (scoped: a weight gradient launched on the main stream keeps the whole chip)
+                L.lib().mednet_set_option(b"wgrad_wgs", SIDE["wgrad_wgs"])
         return self
 
     def __exit__(self, *exc):
         if self.active:
+            if SIDE["wgrad_wgs"] > 0:
+                L.lib().mednet_set_option(b"wgrad_wgs", 0)
             self.ctx.__exit__(*exc)
         return False
 

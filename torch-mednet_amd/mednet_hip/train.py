@@ -352,6 +352,11 @@ class _GraphedStep:
         return self._out
 
 
+def use_side_stream():
+    """Weight gradients on their own stream (ops.SIDE) for every step class: MEDNET_SIDE_STREAM=0 turns it off."""
+    ops.SIDE["enabled"] = os.environ.get("MEDNET_SIDE_STREAM", "1") == "1"
+
+
 class SegmentationStep(_GraphedStep):
     """One data-parallel training step of SegmentationNet (segmentation.py:58-65) on the MI355X path."""
 
@@ -364,7 +369,7 @@ class SegmentationStep(_GraphedStep):
         self.opt = FlatAdam(self.flat, lr=lr)
         self.repack = BatchedRepack(model)
         self.world = world_size
-        ops.SIDE["enabled"] = os.environ.get("MEDNET_SIDE_STREAM", "1") == "1"
+        use_side_stream()
         self.scaler = make_scaler(dev)  # fp16 storage only
         self._init_graph(graph)
         self._exchange = None
@@ -453,6 +458,7 @@ class LandmarkStep(_GraphedStep):
         self.opt = FlatAdam(self.flat, lr=lr)
         self.repack = BatchedRepack(model)
         self.world = world_size
+        use_side_stream()
         self.scaler = make_scaler(dev)
         self._init_graph(graph)
         self._exchange = BucketedExchange(model, self.flat, world_size)
