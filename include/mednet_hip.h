@@ -52,6 +52,8 @@ const char* mednet_last_error(void);
 int mednet_device_ok(void);
 /* Kernel-variant knobs for in-process A/B measurements (e.g. "conv_pipe" 0|1); results never depend on them. */
 int mednet_set_option(const char* name, int value);
+/* the value a launcher would read now (default_value when the option was never set); tests and tools */
+int mednet_get_option(const char* name, int default_value);
 
 /* ---- nn.Conv3d(k=3,p=1 | k=1,p=0, stride 1)  components.py:8-9,44 ; model.py:77,179 ------------------------ */
 /* Weight packing: PyTorch (Cout,Cin,k,k,k) [or ConvTranspose3d's (Cin,Cout,k,k,k) when transposed_src=1] ->

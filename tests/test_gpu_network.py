@@ -1125,3 +1125,32 @@ def test_a_second_consumer_of_a_sole_consumer_output_is_an_error():
         out = blk(x)  # ... and the honest use of the same call works and matches the materialised form
         skip, pooled = ops.skip_pool2(out, L.POOL_MAX, sole_consumer=True)
         (pooled.float().square().sum() + skip.float().sum()).backward()
+
+
+def test_side_stream_weight_gradients_ask_for_half_the_chip_and_give_it_back():
+    """A weight gradient launched on the side stream is planned for 128 workgroups (ops._OnSide sets option wgrad_wgs for the
+    launch and clears it again: profiles/r04_ab.md section 9); one on the main stream, and every workspace query outside a
+    side-stream scope, keeps the one-per-CU plan.  Both step classes switch the side stream on (train.use_side_stream)."""
+    from mednet_hip import ops, _lib as L
+    from mednet_hip.train import SegmentationStep, LandmarkStep
+    lib = L.lib()
+    q = lambda: lib.mednet_get_option(b"wgrad_wgs", 0)  # (0: the launchers' own default, one workgroup per CU)
+    full = q()
+    with ops._OnSide(True, torch.device(DEV)):
+        half = q()
+    assert q() == full == 0 and half == 128 == ops.SIDE["wgrad_wgs"]
+    with ops._OnSide(False, torch.device(DEV)):
+        assert q() == full
+    ops.join_side_stream()
+    for make, nlab, nhm in ((lambda net: SegmentationStep(net, loss_weight=None, lr=1e-3), 3, 0),
+                            (lambda net: LandmarkStep(net, [0.05, 1.0], [0.015] * 2, "L2"), 2, 2)):
+        ops.SIDE["enabled"] = False
+        with mednet_hip.precision("bf16"):
+            net = O.keyed_init_(HM.ResidualUNet3D(1, nlab + nhm, False, f_maps=[32, 64])).to(DEV)
+            step = make(net)
+            assert ops.SIDE["enabled"]
+            batch = {k: v.to(DEV) for k, v in O.synthetic_batch(2, 1, (16, 16, 32), nlab, nhm, seed=11).items()}
+            out = step._fwd_bwd(batch)
+            torch.cuda.synchronize()
+            assert all(torch.isfinite(torch.as_tensor(float(v))) for v in out) and q() == full
+            step.flat.release()

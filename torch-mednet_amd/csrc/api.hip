@@ -71,6 +71,8 @@ extern "C" int mednet_set_option(const char* name, int value) {
   return MEDNET_OK;
 }
 
+extern "C" int mednet_get_option(const char* name, int default_value) { return mednet_internal_tuning_option(name, default_value); }
+
 extern "C" int mednet_abi_version(void) { return 1; }
 extern "C" const char* mednet_last_error(void) { return g_err; }
 extern "C" int mednet_device_ok(void) {

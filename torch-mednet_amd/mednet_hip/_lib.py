@@ -33,6 +33,7 @@ SIGNATURES = {
     "mednet_last_error": (C.c_char_p, []),
     "mednet_device_ok": (_i, []),
     "mednet_set_option": (_i, [C.c_char_p, _i]),
+    "mednet_get_option": (_i, [C.c_char_p, _i]),
     "mednet_conv3d_pack_bytes": (_sz, [_i, _i, _i]),
     "mednet_conv3d_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mednet_conv3d_pack_elt": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
