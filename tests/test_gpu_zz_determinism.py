@@ -2,8 +2,8 @@
 steps at the sizes that are benchmarked, and insensitivity of the step to what free memory holds.
 
 Round 3's GPU run went red on one of these (two bf16 steps of config 5 three fp32 ulp apart in the loss) 30 tests into an
-`-x` run, which left 287 parity tests unreached.  The deviation has not been seen again in ~2 700 forward passes and ~600 full
-steps on four other MI355X, so these tests now (a) sit behind the parity tests and (b) localise a
+`-x` run, which left 287 parity tests unreached.  The deviation has not been seen again in ~2 100 forward passes and ~670 full
+steps on five other MI355X, so these tests now (a) sit behind the parity tests and (b) localise a
 failure themselves: on a mismatch the step is re-run with mednet_hip.debug's trace open and the assertion names the first
 tensor that differs."""
 import numpy as np
