@@ -8,7 +8,8 @@
 #include "common.h"
 
 #ifndef GN_NT
-#define GN_NT 1  // GroupNorm backward's apply pass reads dz and y for the last time: non-temporal loads
+#define GN_NT 1  // GroupNorm backward's apply pass reads dz and y for the last time: non-temporal loads.  (Non-temporal STORES of
+                 // the streaming kernels' outputs were measured too: +0.13 ms per step, profiles/r04_ab.md section 12.)
 #endif
 #ifndef GN_WAVES
 #define GN_WAVES 3  // waves per SIMD the streaming GroupNorm kernels are compiled for (register cap 512 / GN_WAVES).  At 4
@@ -242,18 +243,19 @@ __global__ __launch_bounds__(64) void reduce_partials_dux_kernel(const float* __
   }
 }
 
-// one 256-thread workgroup per (n, g): its 4 waves split the group's channels, each wave sums a channel's per-chunk
-// partials (fp64, fixed order); then mean, rstd and the per-channel affine the apply kernel uses.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ stats,
-                                                          float* __restrict__ coef, int c, int groups, int chunks,
-                                                          double count, float eps) {
-  __shared__ double sh[2][4];
+// one workgroup per (n, g) -- 256 threads, or 1024 when there are thousands of rows (the first layer writes 16 384 per sample: a
+// thread's chain of dependent round trips, four rows in flight, was 46 us of exposed latency) --: a thread walks rows t, t + NT,
+// ... and adds the group's cg {sum, sumsq} pairs of each row (32 contiguous bytes when cg = 4); fp64, fixed order => bitwise
+// reproducible; then mean, rstd and the per-channel affine the apply kernel uses.
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ partial,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ stats,
+                                                           float* __restrict__ coef, int c, int groups, int chunks,
+                                                           double count, float eps) {
+  __shared__ double sh[2][16];
   const int n = blockIdx.x / groups, g = blockIdx.x % groups;
   const int cg = c / groups, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // a thread walks chunk rows t, t+256, ... and adds the group's cg {sum, sumsq} pairs of each row (32 contiguous bytes
-  // when cg = 4), four rows in flight; fp64, fixed order => bitwise reproducible
+  const int nt = (int)blockDim.x, nwv = nt >> 6;
   double s = 0.0, q = 0.0;
   const float* base = partial + (size_t)n * chunks * c * 2 + (size_t)g * cg * 2;
   const size_t row = (size_t)c * 2;
@@ -267,17 +269,17 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     };
     double s1 = 0.0, q1 = 0.0, s2 = 0.0, q2 = 0.0, s3 = 0.0, q3 = 0.0;
     int ch = threadIdx.x;
-    for (; ch + 768 < chunks; ch += 1024) {
+    for (; ch + 3 * nt < chunks; ch += 4 * nt) {
       add_row(base + (size_t)ch * row, s, q);
-      add_row(base + (size_t)(ch + 256) * row, s1, q1);
-      add_row(base + (size_t)(ch + 512) * row, s2, q2);
-      add_row(base + (size_t)(ch + 768) * row, s3, q3);
+      add_row(base + (size_t)(ch + nt) * row, s1, q1);
+      add_row(base + (size_t)(ch + 2 * nt) * row, s2, q2);
+      add_row(base + (size_t)(ch + 3 * nt) * row, s3, q3);
     }
-    for (; ch < chunks; ch += 256) add_row(base + (size_t)ch * row, s, q);
+    for (; ch < chunks; ch += nt) add_row(base + (size_t)ch * row, s, q);
     s = (s + s1) + (s2 + s3);
     q = (q + q1) + (q2 + q3);
   } else {
-    for (int ch = threadIdx.x; ch < chunks; ch += 256) {
+    for (int ch = threadIdx.x; ch < chunks; ch += nt) {
       const float* p = base + (size_t)ch * row;
       for (int i = 0; i < cg; ++i) {
         s += (double)p[2 * i];
@@ -292,8 +294,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     sh[1][wv] = q;
   }
   __syncthreads();
-  s = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-  q = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  s = q = 0.0;
+  for (int k = 0; k < nwv; ++k) {  // (fixed order)
+    s += sh[0][k];
+    q += sh[1][k];
+  }
   const double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     stats[((size_t)n * groups + g) * 2] = (float)mean;
     stats[((size_t)n * groups + g) * 2 + 1] = rstd;
   }
-  for (int i = threadIdx.x; i < cg; i += 256) {
+  for (int i = threadIdx.x; i < cg; i += nt) {
     const int cc = g * cg + i;
     const float ga = gamma ? gamma[cc] : 1.f, be = beta ? beta[cc] : 0.f;
     const float a = ga * rstd;
@@ -479,22 +484,38 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_finalize_kernel(const float
   const int i = t % cg, r0 = t / cg, rstep = 256 / cg;
   const float* base = partial + (size_t)n * rows * c * 2 + (size_t)(g * cg + i) * 2;
   const size_t rs = (size_t)c * 2;
-  double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+  // (16 rows in flight per thread: with 4, the 2 048 rows a ConvTranspose data gradient writes per sample were 16 dependent round
+  //  trips, 45 us of a kernel that otherwise takes 7)
+  constexpr int U = 16;
+  double a[U], b[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) a[k] = b[k] = 0.0;
   int r = r0;
-  for (; r + 3 * rstep < rows; r += 4 * rstep) {
-    const float2 p0 = *reinterpret_cast<const float2*>(base + r * rs), p1 = *reinterpret_cast<const float2*>(base + (r + rstep) * rs);
-    const float2 p2 = *reinterpret_cast<const float2*>(base + (r + 2 * rstep) * rs), p3 = *reinterpret_cast<const float2*>(base + (r + 3 * rstep) * rs);
-    a0 += (double)p0.x; b0 += (double)p0.y;
-    a1 += (double)p1.x; b1 += (double)p1.y;
-    a2 += (double)p2.x; b2 += (double)p2.y;
-    a3 += (double)p3.x; b3 += (double)p3.y;
+  for (; r + (U - 1) * rstep < rows; r += U * rstep) {
+    float2 p[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) p[k] = *reinterpret_cast<const float2*>(base + (size_t)(r + k * rstep) * rs);
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      a[k] += (double)p[k].x;
+      b[k] += (double)p[k].y;
+    }
   }
   for (; r < rows; r += rstep) {
-    const float2 p0 = *reinterpret_cast<const float2*>(base + r * rs);
-    a0 += (double)p0.x; b0 += (double)p0.y;
+    const float2 p0 = *reinterpret_cast<const float2*>(base + (size_t)r * rs);
+    a[0] += (double)p0.x;
+    b[0] += (double)p0.y;
   }
-  sha[t] = (a0 + a1) + (a2 + a3);
-  shb[t] = (b0 + b1) + (b2 + b3);
+#pragma unroll
+  for (int w = 1; w < U; w *= 2) {  // fixed pairwise order
+#pragma unroll
+    for (int k = 0; k < U; k += 2 * w) {
+      a[k] += a[k + w];
+      b[k] += b[k + w];
+    }
+  }
+  sha[t] = a[0];
+  shb[t] = b[0];
   __syncthreads();
   const double mean = stats[((size_t)n * groups + g) * 2], rstd = stats[((size_t)n * groups + g) * 2 + 1];
   if (t < cg) {  // channel t of the group: its 256 / cg row classes, in order
@@ -1208,7 +1229,7 @@ extern "C" int mednet_gn_stats(const void* x, const float* gamma, const float* b
 #undef GO
   int rc = check_launch("gn_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n * groups), dim3(256), 0, s, partial, gamma, beta, stats, coef, c, groups,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n * groups), dim3(chunks >= 4096 ? 1024 : 256), 0, s, partial, gamma, beta, stats, coef, c, groups,
                      (int)chunks, (double)spatial * (c / groups), eps);
   return check_launch("gn_finalize");
 }
@@ -1220,7 +1241,7 @@ extern "C" int mednet_gn_finalize(const float* partial, int chunks, const float*
   (void)ws;
   (void)ws_bytes;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n * groups), dim3(256), 0, s, partial, gamma, beta, stats, coef, c, groups, chunks,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n * groups), dim3(chunks >= 4096 ? 1024 : 256), 0, s, partial, gamma, beta, stats, coef, c, groups, chunks,
                      (double)spatial * (c / groups), eps);
   return check_launch("gn_finalize");
 }
