@@ -233,6 +233,10 @@ int mednet_gn_act_pool_fwd(const void* x, const float* coef, const void* residua
                            int w, int c, int act, int mode, int dtype, mednet_stream stream);
 int mednet_pool2_bwd(const void* dy, const void* x, const void* add, void* dx, int n, int d, int h, int w, int c,
                      int mode, int dtype, mednet_stream stream);
+/* ... with the derivative of the activation whose OUTPUT x is (a fused conv -> activation layer, components.py:57-63) folded into
+ * dx = (pooling backward + add) * act'(x), rounded like the stand-alone join followed by mednet_act_bwd.  Even d, h, w. */
+int mednet_pool2_bwd_act(const void* dy, const void* x, const void* add, void* dx, int n, int d, int h, int w, int c, int mode,
+                         int in_act, int dtype, mednet_stream stream);
 
 /* ---- F.interpolate(nearest, size=enc) + torch.cat((enc, x), 1)  components.py:277-280 (UNet3D decoder) ------- */
 int mednet_upcat_fwd(const void* enc, const void* x, void* out, int n, int d, int h, int w, int c_enc, int xd,
@@ -271,7 +275,9 @@ int mednet_dice_bwd_lt(const float* logits, const void* labels, int label_dtype,
  * labels: MEDNET_I64 or MEDNET_U8, N x spatial with element stride label_stride_n between samples (the last channel of a
  * uint8 label volume is consumed where it lies).  packed: the head's pack buffer (mednet_conv3d_pack, ksize 1).
  * Logits, loss, dz and the GroupNorm sums are bit-identical to mednet_conv3d_fwd + mednet_dice_fwd / mednet_dice_bwd +
- * mednet_head_dgrad_gn; dW / dbias are summed in another fixed order than mednet_conv3d_wgrad's. */
+ * mednet_head_dgrad_gn; dW / dbias are summed in another fixed order than mednet_conv3d_wgrad's.
+ * mednet_head_dice_bwd with gn_y == NULL and gn_act != MEDNET_ACT_NONE: z is the OUTPUT of a fused conv -> activation layer
+ * (UNet3D's last block); dz is stored as (head data gradient) * act'(z), rounded like mednet_act_bwd applied to the stored form. */
 int mednet_head_dice_supported(int cin, int cout, int dtype, int label_dtype);
 size_t mednet_head_dice_ws_bytes(int n, size_t spatial, int cin, int cout);
 int mednet_head_dice_gn_rows(int n, size_t spatial, int cin);

@@ -1154,3 +1154,31 @@ def test_side_stream_weight_gradients_ask_for_half_the_chip_and_give_it_back():
             torch.cuda.synchronize()
             assert all(torch.isfinite(torch.as_tensor(float(v))) for v in out) and q() == full
             step.flat.release()
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_relu_mask_inside_the_pooling_join_and_the_head_changes_nothing(mode):
+    """UNet3D ('gcr', components.py:57-63): an encoder level's output is the output of a fused conv -> ReLU layer; the join of its
+    two gradients (next level's pooling backward + the decoder's skip gradient, model.py:194-205) folds ReLU' in and the layer's
+    backward skips its activation pass (mednet_pool2_bwd_act, ops.ActMaskHook); the fused head + Dice backward does the same for
+    the last decoder block (mednet_head_dice_bwd): loss and every gradient bit-identical."""
+    from mednet_hip import ops
+    from mednet_hip.train import SegmentationStep
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(2, 1, (16, 24, 32), 3, 0, seed=7).items()}
+    res = {}
+    old = ops.POOL_ACT_MASK
+    try:
+        for fused in (False, True):
+            ops.POOL_ACT_MASK = fused
+            ops.GN3_COUNT["masked"] = 0
+            with mednet_hip.precision(mode):
+                net = O.keyed_init_(HM.UNet3D(1, 3, False, f_maps=[32, 64, 128])).to(DEV)
+                step = SegmentationStep(net, loss_weight=None, lr=1e-3)
+                (loss,) = step._fwd_bwd(batch)
+                torch.cuda.synchronize()
+                res[fused] = (float(loss), step.flat.grad.clone(), ops.GN3_COUNT["masked"])
+                step.flat.release()
+    finally:
+        ops.POOL_ACT_MASK = old
+    assert res[True][2] == res[False][2] + 3, (res[True][2], res[False][2])  # two encoder levels that feed a pooling + the head
+    assert res[True][0] == res[False][0] and torch.equal(res[True][1], res[False][1])

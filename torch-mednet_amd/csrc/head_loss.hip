@@ -147,8 +147,10 @@ __global__ __launch_bounds__(256) void head_dice_fwd_kernel(const TI* __restrict
 
 // ---- backward: K/8 lanes per voxel, each owns 8 channels of the voxel's row; two voxels per trip --------------------------
 // wpart[n][block][wave][m * K + m]: this wave's partial of dW (row-major [class][channel]) and, behind it, of db
-template <typename TO, int K, typename TL>
-__global__ __launch_bounds__(256, sizeof(TO) == 2 ? 3 : 2) void head_dice_bwd_kernel(const float* __restrict__ lgs, const TL* __restrict__ lab, int64_t lab_sn,
+// FOLD: z is the output of a fused conv -> activation layer and there are no GroupNorm sums to take (UNet3D's last block): the
+// stored gradient carries act'(z).  Its own instantiation: as a runtime branch it cost the main form its third wave per SIMD.
+template <typename TO, int K, typename TL, bool FOLD = false>
+__global__ __launch_bounds__(256, (sizeof(TO) == 2 && !FOLD) ? 3 : 2) void head_dice_bwd_kernel(const float* __restrict__ lgs, const TL* __restrict__ lab, int64_t lab_sn,
                                                             const float* __restrict__ Pb /*[m][K]*/, const float* __restrict__ weight,
                                                             const float* __restrict__ saved, const float* __restrict__ dloss,
                                                             float eps, int sigmoid, int ignore, TO* __restrict__ dz,
@@ -271,9 +273,22 @@ __global__ __launch_bounds__(256, sizeof(TO) == 2 ? 3 : 2) void head_dice_bwd_ke
       t.v[j] = (float)(TO)t.v[j];
       u.v[j] = (float)(TO)u.v[j];
     }
+    if constexpr (FOLD) {
+      // x is the OUTPUT of a fused conv -> activation layer (UNet3D's last block, components.py:57-63): its derivative is folded
+      // into the stored gradient -- on the rounded value, as mednet_act_bwd would read it -- and that layer's backward skips its
+      // activation pass (ops.ActMaskHook)
+      float za[8], zb[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        za[j] = zva.at(j);
+        zb[j] = zvb.at(j);
+      }
+      act_grad_n<8>(t.v, za, act);
+      act_grad_n<8>(u.v, zb, act);
+    }
     st8(dz, rowa, t);
     if (hb) st8(dz, rowb, u);
-    if (gy) {
+    if (!FOLD && gy) {
       float za[8], zb[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -422,7 +437,9 @@ extern "C" int mednet_head_dice_bwd(const float* logits, const void* labels, int
   const unsigned nb = hl_bwd_blocks(spatial, cin);
   float* wpart = (float*)ws;
   const dim3 grid(nb, n);
-#define HB(TO_, K_, TL_) hipLaunchKernelGGL((head_dice_bwd_kernel<TO_, K_, TL_>), grid, dim3(256), 0, s, logits, (const TL_*)labels, label_stride_n, Pb, weight, saved, dloss, eps, sigmoid, ignore_index, (TO_*)dz, (const TO_*)gn_y, (const TO_*)z, gn_act, gn_partial, wpart, spatial, cout)
+  const bool fold = gn_y == nullptr && gn_act != MEDNET_ACT_NONE;
+#define HB_(TO_, K_, TL_, F_) hipLaunchKernelGGL((head_dice_bwd_kernel<TO_, K_, TL_, F_>), grid, dim3(256), 0, s, logits, (const TL_*)labels, label_stride_n, Pb, weight, saved, dloss, eps, sigmoid, ignore_index, (TO_*)dz, (const TO_*)gn_y, (const TO_*)z, gn_act, gn_partial, wpart, spatial, cout)
+#define HB(TO_, K_, TL_) do { if (fold) HB_(TO_, K_, TL_, true); else HB_(TO_, K_, TL_, false); } while (0)
 #define HB_L(TO_, K_) do { if (label_dtype == MEDNET_U8) HB(TO_, K_, uint8_t); else HB(TO_, K_, int64_t); } while (0)
 #define HB_K(TO_) do { if (cin == 16) HB_L(TO_, 16); else if (cin == 32) HB_L(TO_, 32); else HB_L(TO_, 64); } while (0)
   if (z_dtype == MEDNET_F32) HB_K(float);
@@ -430,6 +447,7 @@ extern "C" int mednet_head_dice_bwd(const float* logits, const void* labels, int
   else HB_K(f16);
 #undef HB_K
 #undef HB_L
+#undef HB_
 #undef HB
   int rc = check_launch("head_dice_bwd");
   if (rc) return rc;

@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) void gn_act_pool_fwd_kernel(const T* __restric
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void pool2_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                         const T* __restrict__ add, T* __restrict__ dx, int n, int d,
-                                                        int h, int w, int c, int mode) {
+                                                        int h, int w, int c, int mode, int in_act) {
   const int od = d / 2, oh = h / 2, ow = w / 2, cv = c / VEC;
   const size_t total = (size_t)n * od * oh * ow * cv;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -842,6 +842,15 @@ __global__ __launch_bounds__(256) void pool2_bwd_kernel(const T* __restrict__ dy
       const F8 a = VecIO<T, VEC>::load(add, dst);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) o.v[k] += a.v[k];
+    }
+    // x is the OUTPUT of a fused conv -> activation layer (UNet3D's 'gcr' blocks, components.py:57-63): its derivative is folded in
+    // here, on the value a stand-alone join would have stored, and the conv layer's backward skips its activation pass
+    // (ops.ActMaskHook) -- 3 passes over the level's output less
+    if (in_act != MEDNET_ACT_NONE) {
+      const F8 xv = VecIO<T, VEC>::load(x, dst);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) o.v[k] = (float)(T)o.v[k];
+      act_grad_n<VEC>(o.v, xv.v, in_act);
     }
     VecIO<T, VEC>::store(dx, dst, o);
   }
@@ -1499,9 +1508,11 @@ extern "C" int mednet_gn_act_pool_fwd(const void* x, const float* coef, const vo
   return check_launch("gn_act_pool_fwd");
 }
 
-extern "C" int mednet_pool2_bwd(const void* dy, const void* x, const void* add, void* dx, int n, int d, int h, int w,
-                                int c, int mode, int dtype, mednet_stream stream) {
+extern "C" int mednet_pool2_bwd_act(const void* dy, const void* x, const void* add, void* dx, int n, int d, int h, int w,
+                                    int c, int mode, int in_act, int dtype, mednet_stream stream) {
   MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "pool2_bwd: bad dtype");
+  MEDNET_REQUIRE(in_act == MEDNET_ACT_NONE || !((d | h | w) & 1), MEDNET_E_UNSUPPORTED,
+                 "pool2_bwd_act: the activation derivative is folded in for even extents only (%dx%dx%d)", d, h, w);
   hipStream_t s = (hipStream_t)stream;
   if ((d | h | w) & 1) {  // odd tails are never pooled: their gradient is zero (or just `add`)
     const size_t bytes = (size_t)n * d * h * w * c * dtype_size(dtype);
@@ -1511,12 +1522,16 @@ extern "C" int mednet_pool2_bwd(const void* dy, const void* x, const void* add, 
   const int vec = c % 8 == 0 ? 8 : 1;
   const size_t total = (size_t)n * (d / 2) * (h / 2) * (w / 2) * (c / vec);
   const dim3 grid((unsigned)((total + 255) / 256));
-#define GO(T, V) hipLaunchKernelGGL((pool2_bwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, n, d, h, w, c, mode)
+#define GO(T, V) hipLaunchKernelGGL((pool2_bwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, n, d, h, w, c, mode, in_act)
   if (dtype == MEDNET_F32) { if (vec == 4) GO(float, 4); else if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
   return check_launch("pool2_bwd");
+}
+extern "C" int mednet_pool2_bwd(const void* dy, const void* x, const void* add, void* dx, int n, int d, int h, int w,
+                                int c, int mode, int dtype, mednet_stream stream) {
+  return mednet_pool2_bwd_act(dy, x, add, dx, n, d, h, w, c, mode, MEDNET_ACT_NONE, dtype, stream);
 }
 
 static bool pool2_gn_ok(int d, int h, int w, int c, int dtype) {

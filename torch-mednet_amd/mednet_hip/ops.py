@@ -742,6 +742,9 @@ class SkipPool2Fn(Function):
         ctx.save_for_backward(x)
         ctx.mode = mode
         ctx.gn3 = _gn3_hook_of(x0, x.dtype) if x is x0 else None
+        # x is the output of a fused conv -> activation layer (UNet3D's blocks): the join below folds act'(x) into the gradient it
+        # produces and that layer's backward skips its activation pass (ActMaskHook) -- for even extents (mednet_pool2_bwd_act)
+        ctx.inmask = getattr(x0, "_mednet_actmask", None) if (x is x0 and FUSE_GN3 and POOL_ACT_MASK and not ((d | h | w) & 1)) else None
         # sole_consumer: the caller (the U-Net's own forward) hands x to nothing else, so the gradient of x goes to the producing
         # block and nowhere else -- the backward may then leave it unwritten and let the block's apply pass rebuild it (LAZY_POOL)
         # (a tensor hook or retain_grad() on x would READ that gradient: then it is written as before)
@@ -775,13 +778,17 @@ class SkipPool2Fn(Function):
             if debug.TRACE is not None:
                 debug.trace(f"skip_pool2.bwd c{c}", None if lazy else dx, partial)
             return dx, None, None
-        L.check(L.lib().mednet_pool2_bwd(dy.data_ptr(), x.data_ptr(), L.ptr(dskip), dx.data_ptr(), n, d, h, w, c, ctx.mode,
-                                         L.dt(x), L.stream()), "pool2_bwd")
+        mask = ctx.inmask
+        L.check(L.lib().mednet_pool2_bwd_act(dy.data_ptr(), x.data_ptr(), L.ptr(dskip), dx.data_ptr(), n, d, h, w, c, ctx.mode,
+                                             L.ACT_NONE if mask is None else mask.act, L.dt(x), L.stream()), "pool2_bwd")
+        if mask is not None:
+            mask.offer(dx)
         if debug.TRACE is not None:
             debug.trace(f"skip_pool2.bwd c{c}", dx)
         return dx, None, None
 
 
+POOL_ACT_MASK = os.environ.get("MEDNET_POOL_ACT_MASK", "1") == "1"  # A/B knob
 LAZY_POOL = os.environ.get("MEDNET_LAZY_POOL", "1") == "1"  # A/B knob
 
 
@@ -949,6 +956,9 @@ class HeadDiceFn(Function):
         ctx.meta = (eps, int(sigmoid), ii, lab_sn, lab_dt, cin, cout)
         ctx.params = (weight, bias)
         ctx.gn3 = _gn3_hook_of(x, x.dtype)
+        # x is the output of a fused conv -> activation layer (UNet3D's last block): the backward folds act'(x) into the feature
+        # gradient it stores and that layer skips its activation pass (ActMaskHook), as SkipPool2Fn does for the encoder levels
+        ctx.inmask = getattr(x, "_mednet_actmask", None) if (ctx.gn3 is None and FUSE_GN3 and POOL_ACT_MASK) else None
         ctx.mark_non_differentiable(logits)
         if debug.TRACE is not None:
             debug.trace("head_dice.fwd", logits, loss, saved)
@@ -974,10 +984,13 @@ class HeadDiceFn(Function):
         L.check(lib.mednet_head_dice_bwd(logits.data_ptr(), lab.data_ptr(), lab_dt, lab_sn, packed.data_ptr(), L.ptr(wt),
                                          saved.data_ptr(), dl.data_ptr(), dx.data_ptr(),
                                          None if hook is None else hook.gn_in.data_ptr(), x.data_ptr(),
-                                         0 if hook is None else hook.act, L.ptr(partial), dw.data_ptr(), L.ptr(db), n, spatial, cin,
+                                         hook.act if hook is not None else (ctx.inmask.act if ctx.inmask is not None else 0),
+                                         L.ptr(partial), dw.data_ptr(), L.ptr(db), n, spatial, cin,
                                          cout, eps, sigmoid, ii, L.dt(x), ws.data_ptr(), ws.numel(), L.stream()), "head_dice_bwd")
         if hook is not None:
             hook.offer(dx, partial)
+        elif ctx.inmask is not None:
+            ctx.inmask.offer(dx)
         if debug.TRACE is not None:
             debug.trace("head_dice.bwd", dx, partial, dw, db)
         return dx, (None if direct_w else dw), (None if (bias is None or direct_b) else db), None, None, None, None, None, None
