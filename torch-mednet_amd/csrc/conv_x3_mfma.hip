@@ -38,6 +38,19 @@ struct HiLo {
 };
 // 8 fp32 (two 16-byte loads) -> 8 high + 8 low bf16
 __device__ __forceinline__ HiLo split8(u32x4 ua, u32x4 ub) {
+#ifdef MEDNET_X3_SPLIT_PROBE  // (measurement build, `make x3_probe`: what operands that ARRIVE split would cost at most -- the high
+  {                           //  halves by one conversion each (sane magnitudes: the matrix cores' power depends on the operands),
+    const f4 a = __builtin_bit_cast(f4, ua), b = __builtin_bit_cast(f4, ub);  // the low halves a copy; results are wrong)
+    HiLo p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      p.hi[j] = (bf16)a[j];
+      p.hi[j + 4] = (bf16)b[j];
+    }
+    p.lo = p.hi;
+    return p;
+  }
+#endif
   const f4 a = __builtin_bit_cast(f4, ua), b = __builtin_bit_cast(f4, ub);
   HiLo r;
 #pragma unroll
