@@ -339,7 +339,11 @@ def main():
                                    f"fwd+DiceLoss+bwd+allreduce+Adam (BASELINE config {'2' if world == 1 else '3'})",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "loss": round(final_loss, 6),
                        "graph_replay": bool(a.graph),
-                       "gradient_exchange": step._exchange.describe() if step._exchange is not None else "none"},
+                       "gradient_exchange": step._exchange.describe() if step._exchange is not None else "none",
+                       # does the weight-gradient stream run beside the compute stream (its own hardware queue)?  ops.side_stream
+                       "side_stream": {"enabled": bool(ops.SIDE["enabled"]), "overlaps": ops.SIDE.get("overlaps"),
+                                       "candidates_tried": ops.SIDE.get("candidates_tried"),
+                                       "wgrad_workgroups": ops.SIDE["wgrad_wgs"] or "one per CU"}},
             "host_enqueue_ms_per_step": round(1e3 * t_issue / n_issue, 3),
         }
         if P == 128 and a.precision == "bf16":

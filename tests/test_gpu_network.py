@@ -1138,6 +1138,7 @@ def test_side_stream_weight_gradients_ask_for_half_the_chip_and_give_it_back():
     full = q()
     with ops._OnSide(True, torch.device(DEV)):
         half = q()
+    assert ops.SIDE.get("overlaps") is True, ops.SIDE  # a stream with a hardware queue of its own was found (ops.side_stream)
     assert q() == full == 0 and half == 128 == ops.SIDE["wgrad_wgs"]
     with ops._OnSide(False, torch.device(DEV)):
         assert q() == full

@@ -34,9 +34,43 @@ PROFILE = {"enabled": False, "events": [], "match": None}
 SIDE = {"enabled": False, "stream": None, "keepalive": [], "wgrad_wgs": int(os.environ.get("MEDNET_SIDE_WGRAD_WGS", "128"))}
 
 
+def _runs_beside(main, cand, device) -> bool:
+    """Does work queued on `cand` execute while `main` is busy?  HIP multiplexes its streams onto a few hardware queues (4 by
+    default) in creation order; two streams that land on the same queue take turns whatever the program says."""
+    x = torch.zeros(64, device=device)
+    e0, em, ec = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    torch.cuda.synchronize(device)
+    with torch.cuda.stream(main):
+        e0.record(main)
+        torch.cuda._sleep(3_000_000)  # main is busy for a millisecond or two
+        em.record(main)
+    with torch.cuda.stream(cand):
+        x.add_(1.0)
+        ec.record(cand)
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(ec) < 0.5 * e0.elapsed_time(em)
+
+
 def side_stream(device):
+    """The weight-gradient stream: a stream that really runs beside the current one.  With a process group up (RCCL and c10d have
+    taken streams of their own by then) the first new stream shared the compute stream's hardware queue: the one-rank rehearsal
+    of the data-parallel step ran every kernel on one queue, 23.7 ms instead of 20.5 (profiles/r04_ab.md section 15).  So the
+    candidates are TESTED, once, at the first use (an eager warm-up step): up to 8 new streams, the first that overlaps wins."""
     if SIDE["stream"] is None:
-        SIDE["stream"] = torch.cuda.Stream(device=device)
+        main = torch.cuda.current_stream(device)
+        probe = os.environ.get("MEDNET_SIDE_PROBE", "1") == "1" and not torch.cuda.is_current_stream_capturing()
+        cands, chosen = [], None
+        for _ in range(8 if probe else 1):
+            c = torch.cuda.Stream(device=device)
+            cands.append(c)  # (kept alive until the choice is made: a released stream's slot would be handed out again)
+            if not probe or _runs_beside(main, c, device):
+                chosen = c
+                break
+        SIDE["stream"] = chosen if chosen is not None else cands[0]
+        SIDE["overlaps"] = chosen is not None
+        SIDE["candidates_tried"] = len(cands)
+        if chosen is None:  # no queue to itself: one workgroup per CU again (half the chip for twice as long gains nothing in turns)
+            SIDE["wgrad_wgs"] = 0
     return SIDE["stream"]
 
 
