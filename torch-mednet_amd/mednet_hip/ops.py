@@ -39,6 +39,8 @@ def _runs_beside(main, cand, device) -> bool:
     default) in creation order; two streams that land on the same queue take turns whatever the program says."""
     x = torch.zeros(64, device=device)
     e0, em, ec = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    with torch.cuda.stream(cand):
+        x.add_(1.0)  # (a stream's first launch creates its hardware queue: milliseconds that would read as "did not overlap")
     torch.cuda.synchronize(device)
     with torch.cuda.stream(main):
         e0.record(main)
