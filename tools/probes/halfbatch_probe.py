@@ -1,6 +1,6 @@
 """Would two half-batch pipelines on two streams hide the forward's GroupNorm apply passes under the convolutions?
-conv32_mfma_kernel leaves half of every SIMD's registers free (one wave of 256 VGPRs per SIMD) and the apply kernel uses no LDS, so
-the two can share a CU -- unlike the weight gradient, which fills the register file (profiles/r04_ab.md section 9).
+(They do not: conv32_mfma_kernel holds 483-494 of a lane's 512 registers, accumulation registers included, so nothing shares a CU
+with it and the streams take turns -- profiles/r04_ab.md section 11.)
 Chain per stream: [conv 32->32 (+ fused statistics) -> GroupNorm apply + ELU] x ROUNDS at 128^3.
   serial: one stream, the whole batch (N = 4) per launch: what the step does today
   halves: two streams, N = 2 each, launches issued alternately"""
