@@ -260,12 +260,14 @@ class BucketedExchange:
     def __init__(self, model, flat: FlatParams, world_size: int, force: bool = False, levels: int = 2):
         self.flat, self.world, self.work, self.force = flat, world_size, None, bool(force)
         self.split = late_bucket_split(model, flat, levels) if (world_size > 1 or force) else None
-        # The overlapped form is OPT-IN (MEDNET_BUCKETS=1) until a multi-GPU measurement exists: the only measurement taken,
-        # the one-rank RCCL rehearsal on an MI355X, had the collective launched inside backward cost the compute stream
-        # 0.6 ms -- four times the single 35 MB all-reduce of cfg3 after backward (0.14 ms; its ring time over xGMI is ~0.4 ms
-        # of a 22 ms step).  For cfg5 (565 MB, ~6.5 ms single-ring against a 49 ms step) hiding the
-        # exchange under the backward of the full-resolution encoders is the obvious candidate, to be switched on by a
-        # scaling run, not by a guess.
+        # The overlapped form is OPT-IN (MEDNET_BUCKETS=1) until a multi-GPU measurement exists.  One-rank RCCL rehearsal on an
+        # MI355X, round 4 (profiles/r04_ab.md section 15, after the side stream got a hardware queue of its own under a
+        # process group): one all-reduce after backward 20.55 ms per step, two buckets 20.69 ms, no process group 20.58 -- the
+        # collective inside backward costs the compute stream ~0.14 ms there, against a ring time over xGMI of ~0.4-1.2 ms
+        # for cfg3's 35 MB that it would hide (the round-3 figure of 0.6 ms was taken with both streams on one queue).  For
+        # cfg5 (565 MB, ~6.5 ms single-ring against a 47 ms step) hiding the exchange under the backward
+        # of the full-resolution encoders is the obvious candidate -- to be switched on by a scaling run, not by a guess
+        # (ADVICE r3).
         self.enabled = self.split is not None and self.overlap_selected(flat.total * 4)
         if self.enabled:
             list(model.encoders)[levels - 1].register_forward_hook(self._on_forward)
