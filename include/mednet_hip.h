@@ -241,6 +241,12 @@ int mednet_pool2_bwd_act(const void* dy, const void* x, const void* add, void* d
 /* ---- F.interpolate(nearest, size=enc) + torch.cat((enc, x), 1)  components.py:277-280 (UNet3D decoder) ------- */
 int mednet_upcat_fwd(const void* enc, const void* x, void* out, int n, int d, int h, int w, int c_enc, int xd,
                      int xh, int xw, int c_x, int dtype, mednet_stream stream);
+/* mednet_upcat_fwd that also takes the GroupNorm partial sums of the tensor it writes (UNet3D's decoder opens with a GroupNorm over
+ * the concatenation, components.py:46-57 after :277-280): partial[n][mednet_upcat_stats_chunks][c_enc + c_x][2] = {sum, sum of
+ * squares}, to be finalised by mednet_gn_finalize.  chunks == 0: not for this shape (channel counts must be multiples of 8). */
+int mednet_upcat_stats_chunks(int n, int d, int h, int w, int c_enc, int c_x, int dtype);
+int mednet_upcat_fwd_stats(const void* enc, const void* x, void* out, float* partial, int n, int d, int h, int w, int c_enc, int xd,
+                           int xh, int xw, int c_x, int dtype, mednet_stream stream);
 int mednet_upcat_bwd(const void* dout, void* denc, void* dx, int n, int d, int h, int w, int c_enc, int xd, int xh,
                      int xw, int c_x, int dtype, mednet_stream stream);
 

@@ -1199,3 +1199,40 @@ def test_groupnorm_backward_rebuilds_the_pooled_gradient_it_was_not_given(mode, 
             i = tuple(bad[0].tolist())
             raise AssertionError(f"{name}: {len(bad)} of {a.numel()} differ, first at {i}: {a[i].item()!r} vs {b[i].item()!r}; "
                                  f"max |diff| {(a.float() - b.float()).abs().max().item():.3e}")
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("n,ce,cx,shape,xshape", [(2, 32, 64, (8, 12, 16), (4, 6, 8)), (1, 64, 128, (6, 6, 10), (3, 3, 5)),
+                                                  (2, 16, 32, (9, 7, 11), (4, 3, 5))])
+def test_concatenation_kernel_takes_the_groupnorm_sums_of_what_it_writes(mode, n, ce, cx, shape, xshape):
+    """mednet_upcat_fwd_stats (UNet3D's decoder: interpolate + cat, components.py:277-280, followed by the GroupNorm that opens its
+    'gcr' block, :46-57) against mednet_upcat_fwd + the stand-alone statistics pass: the concatenated tensor bit-identical, the
+    finalised statistics and coefficients equal to 1e-6 (the sums run in another order), odd sizes included."""
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[mode]
+    groups, eps = 8, 1e-5
+    d, h, w = shape
+    sp = d * h * w
+    ct = ce + cx
+    enc = ops.to_cl(rnd("uc_e", n, ce, *shape).to(dt).to(DEV))
+    x = ops.to_cl(rnd("uc_x", n, cx, *xshape).to(dt).to(DEV))
+    gamma, beta = (1 + 0.1 * rnd("uc_g", ct)).to(DEV), (0.1 * rnd("uc_b", ct)).to(DEV)
+    lib = L.lib()
+    out0, out1 = (ops.empty_cl(n, ct, d, h, w, dt, DEV) for _ in range(2))
+    L.check(lib.mednet_upcat_fwd(enc.data_ptr(), x.data_ptr(), out0.data_ptr(), n, d, h, w, ce, *xshape, cx, L.dt_of(dt), L.stream()), "upcat")
+    chunks = lib.mednet_upcat_stats_chunks(n, d, h, w, ce, cx, L.dt_of(dt))
+    assert chunks > 0
+    part = torch.full((n, chunks, ct, 2), float("nan"), device=DEV)
+    L.check(lib.mednet_upcat_fwd_stats(enc.data_ptr(), x.data_ptr(), out1.data_ptr(), part.data_ptr(), n, d, h, w, ce, *xshape, cx,
+                                       L.dt_of(dt), L.stream()), "upcat_stats")
+    assert torch.equal(out0, out1) and not torch.isnan(part).any()
+    ws = L.workspace(lib.mednet_gn_ws_bytes(n, ct, sp), DEV)
+    st0, cf0, st1, cf1 = (torch.empty(n, groups, 2, device=DEV), torch.empty(n, ct, 2, device=DEV),
+                          torch.empty(n, groups, 2, device=DEV), torch.empty(n, ct, 2, device=DEV))
+    L.check(lib.mednet_gn_stats(out0.data_ptr(), gamma.data_ptr(), beta.data_ptr(), st0.data_ptr(), cf0.data_ptr(), n, sp, ct, groups, eps,
+                                L.dt_of(dt), ws.data_ptr(), ws.numel(), L.stream()), "gn_stats")
+    L.check(lib.mednet_gn_finalize(part.data_ptr(), chunks, gamma.data_ptr(), beta.data_ptr(), st1.data_ptr(), cf1.data_ptr(), n, sp, ct,
+                                   groups, eps, ws.data_ptr(), ws.numel(), L.stream()), "gn_finalize")
+    torch.cuda.synchronize()
+    assert_close(st1, st0, 1e-6, "statistics")
+    assert_close(cf1, cf0, 1e-6, "coefficients")
+    assert lib.mednet_upcat_stats_chunks(n, d, h, w, ce + 4, cx, L.dt_of(dt)) == 0  # channel counts that are not multiples of 8

@@ -1061,6 +1061,65 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ en
   VecIO<T, VEC>::store(out, v * ct + cc,
                        VecIO<T, VEC>::load(x, ((((size_t)nn * xd + sz) * xh + sy) * xw + sx) * cx + (cc - ce)));
 }
+// The same concatenation in the column-persistent layout of the GroupNorm kernels, with the statistics of what it writes: UNet3D's
+// decoder opens with a GroupNorm over the concatenated tensor ('gcr', components.py:46-57 after :277-280), whose stand-alone
+// statistics pass read all of it again (1.6 GB at 96 channels x 128^3 x 4).  A thread keeps its VEC channels -- from `enc` or from
+// the low-resolution `x` -- walks the chunk's voxels four at a time, stores the pieces and sums them: partial[n][chunk][ct][2] =
+// {sum v, sum v^2}, the layout of gn_partial_kernel (finalize: mednet_gn_finalize).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void upcat_stats_fwd_kernel(const T* __restrict__ enc, const T* __restrict__ x, T* __restrict__ out,
+                                                              float* __restrict__ partial, int d, int h, int w, int ce, int xd, int xh,
+                                                              int xw, int cx, size_t chunk_vox) {
+  __shared__ float lds[256 * 2 * VEC];
+  const int ct = ce + cx;
+  const Cols<VEC> L(ct);
+  const int n = blockIdx.y;
+  const size_t spatial = (size_t)d * h * w;
+  const size_t v0 = (size_t)blockIdx.x * chunk_vox;
+  const size_t v1 = v0 + chunk_vox < spatial ? v0 + chunk_vox : spatial;
+  float acc[2 * VEC];
+#pragma unroll
+  for (int k = 0; k < 2 * VEC; ++k) acc[k] = 0.f;
+  if (L.active) {
+    const int cc = L.col * VEC;
+    const bool from_enc = cc < ce;
+    const T* src = from_enc ? enc + (size_t)n * spatial * ce + cc : x + (size_t)n * xd * xh * xw * cx + (cc - ce);
+    T* dst = out + (size_t)n * spatial * ct + cc;
+    auto src_index = [&](size_t v) -> size_t {
+      if (from_enc) return v * ce;
+      const int ox = (int)(v % w);
+      const size_t r = v / w;
+      const int oy = (int)(r % h), oz = (int)(r / h);
+      return ((size_t)(nearest_src(oz, xd, d) * xh + nearest_src(oy, xh, h)) * xw + nearest_src(ox, xw, w)) * cx;
+    };
+    size_t v = v0 + L.row;
+    for (; v + 3 * (size_t)L.rows < v1; v += 4 * (size_t)L.rows) {
+      F8 xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv[u] = VecIO<T, VEC>::load(src, src_index(v + (size_t)u * L.rows));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        VecIO<T, VEC>::store(dst, (v + (size_t)u * L.rows) * ct, xv[u]);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          acc[2 * k] += xv[u].v[k];
+          acc[2 * k + 1] = fmaf(xv[u].v[k], xv[u].v[k], acc[2 * k + 1]);
+        }
+      }
+    }
+    for (; v < v1; v += L.rows) {
+      const F8 xv = VecIO<T, VEC>::load(src, src_index(v));
+      VecIO<T, VEC>::store(dst, v * ct, xv);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        acc[2 * k] += xv.v[k];
+        acc[2 * k + 1] = fmaf(xv.v[k], xv.v[k], acc[2 * k + 1]);
+      }
+    }
+  }
+  float* rows = partial + ((size_t)n * gridDim.x + blockIdx.x) * ct * 2;
+  column_reduce<2 * VEC>(acc, L.cols, L.rows, L.col, L.row, L.active, lds, rows);
+}
 // denc = dout[..., :ce]; dx[src] = sum over the destination voxels that map to src
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void upcat_bwd_enc_kernel(const T* __restrict__ dout, T* __restrict__ denc,
@@ -1577,6 +1636,32 @@ extern "C" int mednet_upcat_fwd(const void* enc, const void* x, void* out, int n
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
 #undef GO
   return check_launch("upcat_fwd");
+}
+// ... with the GroupNorm partial sums of the concatenated tensor: partial[n][mednet_upcat_stats_chunks][c_enc + c_x][2]
+extern "C" int mednet_upcat_stats_chunks(int n, int d, int h, int w, int c_enc, int c_x, int dtype) {
+  (void)n;
+  const int ct = c_enc + c_x;
+  if (!dtype_ok(dtype) || c_enc % 8 || c_x % 8 || ct / 8 > 256 || !tuning_option("upcat_stats", 1)) return 0;
+  size_t cv;
+  unsigned chunks;
+  chunk_plan((size_t)d * h * w, ct, 8, cv, chunks);
+  return (int)chunks;
+}
+extern "C" int mednet_upcat_fwd_stats(const void* enc, const void* x, void* out, float* partial, int n, int d, int h, int w,
+                                      int c_enc, int xd, int xh, int xw, int c_x, int dtype, mednet_stream stream) {
+  MEDNET_REQUIRE(mednet_upcat_stats_chunks(n, d, h, w, c_enc, c_x, dtype) > 0 && partial, MEDNET_E_UNSUPPORTED,
+                 "upcat_fwd_stats: %d + %d channels, dtype %d", c_enc, c_x, dtype);
+  size_t cv;
+  unsigned chunks;
+  chunk_plan((size_t)d * h * w, c_enc + c_x, 8, cv, chunks);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(chunks, n);
+#define GO(T) hipLaunchKernelGGL((upcat_stats_fwd_kernel<T, 8>), grid, dim3(256), 0, s, (const T*)enc, (const T*)x, (T*)out, partial, d, h, w, c_enc, xd, xh, xw, c_x, cv)
+  if (dtype == MEDNET_F32) GO(float);
+  else if (dtype == MEDNET_BF16) GO(bf16);
+  else GO(f16);
+#undef GO
+  return check_launch("upcat_fwd_stats");
 }
 extern "C" int mednet_upcat_bwd(const void* dout, void* denc, void* dx, int n, int d, int h, int w, int c_enc, int xd,
                                 int xh, int xw, int c_x, int dtype, mednet_stream stream) {

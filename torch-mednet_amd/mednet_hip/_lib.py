@@ -79,6 +79,8 @@ SIGNATURES = {
     "mednet_pool2_bwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
     "mednet_pool2_bwd_act": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "mednet_upcat_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
+    "mednet_upcat_stats_chunks": (_i, [_i] * 7),
+    "mednet_upcat_fwd_stats": (_i, [_vp, _vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "mednet_upcat_bwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "mednet_loss_ws_bytes": (_sz, [_i, _i, _sz]),
     "mednet_dice_fwd": (_i, [_vp] * 6 + [_i, _i, _sz, _i64, _i64, _f, _i, _i, _vp, _sz, _vp]),

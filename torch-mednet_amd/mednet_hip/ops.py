@@ -839,31 +839,46 @@ class UpCatFn(Function):
     """F.interpolate(x, size=enc.shape[2:], mode='nearest') ; torch.cat((enc, x), 1)  -- components.py:277-280."""
 
     @staticmethod
-    def forward(ctx, enc, x):
+    def forward(ctx, enc, x, want_stats=False):
         L.require_gpu(x, "upsample_concat")
         enc = to_cl(_as_act(enc))
         x = to_cl(_as_act(x)).to(enc.dtype)
         n, ce, d, h, w = enc.shape
         _, cx, xd, xh, xw = x.shape
         out = empty_cl(n, ce + cx, d, h, w, enc.dtype, enc.device)
-        L.check(L.lib().mednet_upcat_fwd(enc.data_ptr(), x.data_ptr(), out.data_ptr(), n, d, h, w, ce, xd, xh, xw, cx,
+        lib = L.lib()
+        chunks = lib.mednet_upcat_stats_chunks(n, d, h, w, ce, cx, L.dt(enc)) if want_stats else 0
+        if chunks > 0:  # + the GroupNorm partial sums of the concatenated tensor (the 'g c r' block that follows opens with one)
+            partial = torch.empty((n, chunks, ce + cx, 2), dtype=torch.float32, device=enc.device)
+            L.check(lib.mednet_upcat_fwd_stats(enc.data_ptr(), x.data_ptr(), out.data_ptr(), partial.data_ptr(), n, d, h, w, ce, xd, xh,
+                                               xw, cx, L.dt(enc), L.stream()), "upcat_fwd_stats")
+        else:
+            partial = torch.empty(0, device=enc.device)
+            L.check(lib.mednet_upcat_fwd(enc.data_ptr(), x.data_ptr(), out.data_ptr(), n, d, h, w, ce, xd, xh, xw, cx,
                                          L.dt(enc), L.stream()), "upcat_fwd")
         ctx.dims = (n, ce, d, h, w, cx, xd, xh, xw)
-        return out
+        if not want_stats:
+            return out
+        ctx.mark_non_differentiable(partial)
+        return out, partial
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dpartial=None):
         n, ce, d, h, w, cx, xd, xh, xw = ctx.dims
         dout = to_cl(dout)
         denc = empty_cl(n, ce, d, h, w, dout.dtype, dout.device)
         dx = empty_cl(n, cx, xd, xh, xw, dout.dtype, dout.device)
         L.check(L.lib().mednet_upcat_bwd(dout.data_ptr(), denc.data_ptr(), dx.data_ptr(), n, d, h, w, ce, xd, xh, xw, cx,
                                          L.dt(dout), L.stream()), "upcat_bwd")
-        return denc, dx
+        return denc, dx, None
 
 
-def upsample_concat(enc, x):
-    return UpCatFn.apply(enc, x)
+def upsample_concat(enc, x, want_stats=False):
+    """cat((enc, nearest-upsampled x), 1); with want_stats -> (tensor, GroupNorm partial sums of it or None)."""
+    if not want_stats:
+        return UpCatFn.apply(enc, x)
+    out, partial = UpCatFn.apply(enc, x, True)
+    return out, (partial if partial.numel() else None)
 
 
 # ------------------------------------------------------------------------------------------------- losses

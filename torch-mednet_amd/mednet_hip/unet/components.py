@@ -137,15 +137,17 @@ class DoubleConv(nn.Sequential):
         self.add_module("SingleConv1", SingleConv(c1_in, c1_out, kernel_size, order, num_groups))
         self.add_module("SingleConv2", SingleConv(c2_in, c2_out, kernel_size, order, num_groups))
 
-    def forward(self, x):
+    def forward(self, x, partial=None):
         """SingleConv1 -> SingleConv2 (components.py:93-133).  When SingleConv2 opens with a GroupNorm ('gcr'), the kernel
-        that ends SingleConv1 (conv + activation) also produces that GroupNorm's partial sums."""
+        that ends SingleConv1 (conv + activation) also produces that GroupNorm's partial sums.  `partial` (not part of the
+        reference's signature): GroupNorm partial sums of x from the kernel that wrote it, for a SingleConv1 that opens with a
+        GroupNorm (the decoder's concatenation kernel, Decoder.forward)."""
         sc1, sc2 = self.SingleConv1, self.SingleConv2
         first2 = next(iter(sc2._modules.values()))
         if isinstance(first2, hnn.GroupNorm) and torch.is_tensor(x) and x.is_cuda:
-            x, partial = sc1(x, stats_for=first2)
-            return sc2(x, partial=partial)
-        return sc2(sc1(x))
+            x, p2 = sc1(x, partial=partial, stats_for=first2)
+            return sc2(x, partial=p2)
+        return sc2(sc1(x, partial=partial))
 
 
 class ExtResNetBlock(nn.Module):
@@ -256,6 +258,12 @@ class Decoder(nn.Module):
     def forward(self, encoder_features, x):
         with config.exact_products(_module_kinked(self.basic_module)):  # (the upsampling follows its block)
             if self.upsample is None:
+                bm = self.basic_module
+                first = next(iter(bm.SingleConv1._modules.values())) if isinstance(bm, DoubleConv) else None
+                if isinstance(first, hnn.GroupNorm) and torch.is_tensor(x) and x.is_cuda and first.num_channels % (2 * first.num_groups) == 0:
+                    # 'g c r': the block opens with a GroupNorm over the concatenation -- the kernel that writes it takes the sums
+                    x, partial = ops.upsample_concat(encoder_features, x, want_stats=True)
+                    return bm(x, partial=partial)
                 x = ops.upsample_concat(encoder_features, x)
             else:
                 x = self.upsample(x, skip=encoder_features)
