@@ -234,9 +234,11 @@ int mednet_gn_act_pool_fwd(const void* x, const float* coef, const void* residua
 int mednet_pool2_bwd(const void* dy, const void* x, const void* add, void* dx, int n, int d, int h, int w, int c,
                      int mode, int dtype, mednet_stream stream);
 /* ... with the derivative of the activation whose OUTPUT x is (a fused conv -> activation layer, components.py:57-63) folded into
- * dx = (pooling backward + add) * act'(x), rounded like the stand-alone join followed by mednet_act_bwd.  Even d, h, w. */
-int mednet_pool2_bwd_act(const void* dy, const void* x, const void* add, void* dx, int n, int d, int h, int w, int c, int mode,
-                         int in_act, int dtype, mednet_stream stream);
+ * dx = (pooling backward + add) * act'(x), rounded like the stand-alone join followed by mednet_act_bwd.  Even d, h, w.
+ * add_channels (0 or c: dense): `add` points at the first of c channels inside voxel rows of add_channels channels -- the leading
+ * slice of the gradient of UNet3D's concatenation (components.py:277-280), read where it lies. */
+int mednet_pool2_bwd_act(const void* dy, const void* x, const void* add, int add_channels, void* dx, int n, int d, int h, int w, int c,
+                         int mode, int in_act, int dtype, mednet_stream stream);
 
 /* ---- F.interpolate(nearest, size=enc) + torch.cat((enc, x), 1)  components.py:277-280 (UNet3D decoder) ------- */
 int mednet_upcat_fwd(const void* enc, const void* x, void* out, int n, int d, int h, int w, int c_enc, int xd,
@@ -247,6 +249,7 @@ int mednet_upcat_fwd(const void* enc, const void* x, void* out, int n, int d, in
 int mednet_upcat_stats_chunks(int n, int d, int h, int w, int c_enc, int c_x, int dtype);
 int mednet_upcat_fwd_stats(const void* enc, const void* x, void* out, float* partial, int n, int d, int h, int w, int c_enc, int xd,
                            int xh, int xw, int c_x, int dtype, mednet_stream stream);
+/* (denc == NULL: only dx; the caller reads the encoder part of dout where it lies) */
 int mednet_upcat_bwd(const void* dout, void* denc, void* dx, int n, int d, int h, int w, int c_enc, int xd, int xh,
                      int xw, int c_x, int dtype, mednet_stream stream);
 

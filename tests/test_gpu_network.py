@@ -1186,3 +1186,28 @@ def test_relu_mask_inside_the_pooling_join_and_the_head_changes_nothing(mode):
         ops.POOL_ACT_MASK = old
     assert res[True][2] == res[False][2] + 3, (res[True][2], res[False][2])  # two encoder levels that feed a pooling + the head
     assert res[True][0] == res[False][0] and torch.equal(res[True][1], res[False][1])
+
+
+@pytest.mark.parametrize("shape", [(16, 24, 32), (12, 20, 18)])
+def test_skip_gradient_read_inside_the_concatenation_gradient_changes_nothing(shape):
+    """UNet3D: the gradient of a skip tensor is the leading channels of the gradient of the decoder's concatenation
+    (components.py:277-280); the pooling join of the encoder level reads it there (mednet_pool2_bwd_act, add_channels) instead
+    of from a copy.  Loss and every gradient bit-identical; sizes whose deeper levels are odd take the dense path."""
+    from mednet_hip import ops
+    from mednet_hip.train import SegmentationStep
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(2, 1, shape, 3, 0, seed=9).items()}
+    res = {}
+    old = ops.UPCAT_VIEW
+    try:
+        for view in (False, True):
+            ops.UPCAT_VIEW = view
+            with mednet_hip.precision("bf16"):
+                net = O.keyed_init_(HM.UNet3D(1, 3, False, f_maps=[32, 64, 128])).to(DEV)
+                step = SegmentationStep(net, loss_weight=None, lr=1e-3)
+                (loss,) = step._fwd_bwd(batch)
+                torch.cuda.synchronize()
+                res[view] = (float(loss), step.flat.grad.clone())
+                step.flat.release()
+    finally:
+        ops.UPCAT_VIEW = old
+    assert res[True][0] == res[False][0] and torch.equal(res[True][1], res[False][1])

@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) void gn_act_pool_fwd_kernel(const T* __restric
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void pool2_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                         const T* __restrict__ add, T* __restrict__ dx, int n, int d,
-                                                        int h, int w, int c, int mode, int in_act) {
+                                                        int h, int w, int c, int mode, int in_act, int add_c) {
   const int od = d / 2, oh = h / 2, ow = w / 2, cv = c / VEC;
   const size_t total = (size_t)n * od * oh * ow * cv;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -839,7 +839,9 @@ __global__ __launch_bounds__(256) void pool2_bwd_kernel(const T* __restrict__ dy
     for (int k = 0; k < VEC; ++k)
       o.v[k] = mode == MEDNET_POOL_MAX ? (arg[k] == t ? g.v[k] : 0.f) : 0.125f * g.v[k];
     if (add) {  // the other consumer's gradient of the same tensor (the decoder's skip join): one pass instead of an add kernel
-      const F8 a = VecIO<T, VEC>::load(add, dst);
+      // (add_c: channels per voxel of the tensor `add` is a channel slice of -- the gradient of UNet3D's concatenation, read where
+      //  it lies instead of being copied out first)
+      const F8 a = VecIO<T, VEC>::load(add, (dst / c) * add_c + dst % c);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) o.v[k] += a.v[k];
     }
@@ -1567,9 +1569,12 @@ extern "C" int mednet_gn_act_pool_fwd(const void* x, const float* coef, const vo
   return check_launch("gn_act_pool_fwd");
 }
 
-extern "C" int mednet_pool2_bwd_act(const void* dy, const void* x, const void* add, void* dx, int n, int d, int h, int w,
-                                    int c, int mode, int in_act, int dtype, mednet_stream stream) {
+extern "C" int mednet_pool2_bwd_act(const void* dy, const void* x, const void* add, int add_channels, void* dx, int n, int d, int h,
+                                    int w, int c, int mode, int in_act, int dtype, mednet_stream stream) {
   MEDNET_REQUIRE(dtype_ok(dtype), MEDNET_E_DTYPE, "pool2_bwd: bad dtype");
+  if (add_channels <= 0) add_channels = c;
+  MEDNET_REQUIRE(add_channels == c || (add && add_channels > c && add_channels % 8 == 0 && c % 8 == 0 && !((d | h | w) & 1)), MEDNET_E_UNSUPPORTED,
+                 "pool2_bwd_act: a strided second gradient needs channel counts that are multiples of 8 and even extents");
   MEDNET_REQUIRE(in_act == MEDNET_ACT_NONE || !((d | h | w) & 1), MEDNET_E_UNSUPPORTED,
                  "pool2_bwd_act: the activation derivative is folded in for even extents only (%dx%dx%d)", d, h, w);
   hipStream_t s = (hipStream_t)stream;
@@ -1581,7 +1586,7 @@ extern "C" int mednet_pool2_bwd_act(const void* dy, const void* x, const void* a
   const int vec = c % 8 == 0 ? 8 : 1;
   const size_t total = (size_t)n * (d / 2) * (h / 2) * (w / 2) * (c / vec);
   const dim3 grid((unsigned)((total + 255) / 256));
-#define GO(T, V) hipLaunchKernelGGL((pool2_bwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, n, d, h, w, c, mode, in_act)
+#define GO(T, V) hipLaunchKernelGGL((pool2_bwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, (const T*)add, (T*)dx, n, d, h, w, c, mode, in_act, add_channels)
   if (dtype == MEDNET_F32) { if (vec == 4) GO(float, 4); else if (vec == 8) GO(float, 8); else GO(float, 1); }
   else if (dtype == MEDNET_BF16) { if (vec == 8) GO(bf16, 8); else GO(bf16, 1); }
   else { if (vec == 8) GO(f16, 8); else GO(f16, 1); }
@@ -1590,7 +1595,7 @@ extern "C" int mednet_pool2_bwd_act(const void* dy, const void* x, const void* a
 }
 extern "C" int mednet_pool2_bwd(const void* dy, const void* x, const void* add, void* dx, int n, int d, int h, int w,
                                 int c, int mode, int dtype, mednet_stream stream) {
-  return mednet_pool2_bwd_act(dy, x, add, dx, n, d, h, w, c, mode, MEDNET_ACT_NONE, dtype, stream);
+  return mednet_pool2_bwd_act(dy, x, add, 0, dx, n, d, h, w, c, mode, MEDNET_ACT_NONE, dtype, stream);
 }
 
 static bool pool2_gn_ok(int d, int h, int w, int c, int dtype) {
@@ -1675,7 +1680,7 @@ extern "C" int mednet_upcat_bwd(const void* dout, void* denc, void* dx, int n, i
   const dim3 g2((unsigned)((tx + 255) / 256));
 #define GO(T, V)                                                                                                        \
   do {                                                                                                                  \
-    hipLaunchKernelGGL((upcat_bwd_enc_kernel<T, V>), g1, dim3(256), 0, s, (const T*)dout, (T*)denc, nvox, c_enc, ct);   \
+    if (denc) hipLaunchKernelGGL((upcat_bwd_enc_kernel<T, V>), g1, dim3(256), 0, s, (const T*)dout, (T*)denc, nvox, c_enc, ct); \
     hipLaunchKernelGGL((upcat_bwd_x_kernel<T, V>), g2, dim3(256), 0, s, (const T*)dout, (T*)dx, n, d, h, w, c_enc, xd,  \
                        xh, xw, c_x);                                                                                    \
   } while (0)

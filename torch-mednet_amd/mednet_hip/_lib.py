@@ -77,7 +77,7 @@ SIGNATURES = {
     "mednet_gn_act_pool_supported": (_i, [_i] * 5),
     "mednet_gn_act_pool_fwd": (_i, [_vp] * 5 + [_i] * 8 + [_vp]),
     "mednet_pool2_bwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
-    "mednet_pool2_bwd_act": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
+    "mednet_pool2_bwd_act": (_i, [_vp, _vp, _vp, _i, _vp] + [_i] * 8 + [_vp]),
     "mednet_upcat_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "mednet_upcat_stats_chunks": (_i, [_i] * 7),
     "mednet_upcat_fwd_stats": (_i, [_vp, _vp, _vp, _vp] + [_i] * 10 + [_vp]),

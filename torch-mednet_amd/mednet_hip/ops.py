@@ -797,10 +797,15 @@ class SkipPool2Fn(Function):
         if dy is None:
             return dskip, None, None
         dy = to_cl(dy.to(x.dtype))
-        if dskip is not None:
-            dskip = to_cl(dskip.to(x.dtype))
-        dx = torch.empty_like(x, memory_format=CL)
         hook = ctx.gn3
+        add_c = 0
+        if dskip is not None:
+            # (UNet3D: the skip gradient is the leading channels of the concatenation's gradient -- read in place by the plain join)
+            add_c = _channel_slice_of_cl(dskip, c) if (hook is None and dskip.dtype == x.dtype and c % 8 == 0 and not ((d | h | w) & 1)) else 0
+            if add_c == 0 or add_c % 8:
+                add_c = 0
+                dskip = to_cl(dskip.to(x.dtype))
+        dx = torch.empty_like(x, memory_format=CL)
         rows = L.lib().mednet_pool2_bwd_gn_rows(n, d, h, w, c, L.dt(x)) if hook is not None else 0
         if rows > 0:  # + the first pass of the producing block's GroupNorm-3 backward (x IS that block's output)
             partial = torch.empty((n, rows, c, 2), dtype=torch.float32, device=x.device)
@@ -815,7 +820,7 @@ class SkipPool2Fn(Function):
                 debug.trace(f"skip_pool2.bwd c{c}", None if lazy else dx, partial)
             return dx, None, None
         mask = ctx.inmask
-        L.check(L.lib().mednet_pool2_bwd_act(dy.data_ptr(), x.data_ptr(), L.ptr(dskip), dx.data_ptr(), n, d, h, w, c, ctx.mode,
+        L.check(L.lib().mednet_pool2_bwd_act(dy.data_ptr(), x.data_ptr(), L.ptr(dskip), add_c, dx.data_ptr(), n, d, h, w, c, ctx.mode,
                                              L.ACT_NONE if mask is None else mask.act, L.dt(x), L.stream()), "pool2_bwd")
         if mask is not None:
             mask.offer(dx)
@@ -866,11 +871,29 @@ class UpCatFn(Function):
     def backward(ctx, dout, _dpartial=None):
         n, ce, d, h, w, cx, xd, xh, xw = ctx.dims
         dout = to_cl(dout)
-        denc = empty_cl(n, ce, d, h, w, dout.dtype, dout.device)
+        # the encoder part of the gradient is a VIEW of dout (its leading channels): the pooling join that consumes it reads it
+        # where it lies (SkipPool2Fn, mednet_pool2_bwd_act's add_channels); any other consumer makes it dense itself
+        view = UPCAT_VIEW and ce % 8 == 0 and cx % 8 == 0
+        denc = dout.narrow(1, 0, ce) if view else empty_cl(n, ce, d, h, w, dout.dtype, dout.device)
         dx = empty_cl(n, cx, xd, xh, xw, dout.dtype, dout.device)
-        L.check(L.lib().mednet_upcat_bwd(dout.data_ptr(), denc.data_ptr(), dx.data_ptr(), n, d, h, w, ce, xd, xh, xw, cx,
-                                         L.dt(dout), L.stream()), "upcat_bwd")
+        L.check(L.lib().mednet_upcat_bwd(dout.data_ptr(), None if view else denc.data_ptr(), dx.data_ptr(), n, d, h, w, ce, xd, xh,
+                                         xw, cx, L.dt(dout), L.stream()), "upcat_bwd")
         return denc, dx, None
+
+
+UPCAT_VIEW = os.environ.get("MEDNET_UPCAT_VIEW", "1") == "1"  # A/B knob
+
+
+def _channel_slice_of_cl(t, c):
+    """Channels per voxel of the channels-last tensor `t` is a leading-channel slice of (0: `t` is not such a view)."""
+    if t.dim() != 5 or t.shape[1] != c:
+        return 0
+    n, _, d, h, w = t.shape
+    sn, sc, sd, sh, sw = t.stride()
+    ct = sw
+    if sc == 1 and ct > c and sh == w * ct and sd == h * w * ct and sn == d * h * w * ct:
+        return ct
+    return 0
 
 
 def upsample_concat(enc, x, want_stats=False):
