@@ -115,3 +115,30 @@ def test_the_step_does_not_read_memory_nobody_wrote(cfg):
         assert got[0] == ref[0], f"{cfg}: loss {got[0]!r} with poisoned memory (pattern {pattern:#x}), {ref[0]!r} without"
         assert torch.equal(got[1], ref[1]), f"{cfg}: gradients change with what free memory holds (pattern {pattern:#x})"
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("which", ["landmark", "unet3d"])
+def test_the_other_step_classes_are_bitwise_repeatable(which):
+    """LandmarkStep (config 4's path: 16 heat maps + 2 classes, its weight gradients on the side stream since round 4) and a
+    SegmentationStep over UNet3D (the 'gcr' blocks: fused concatenation statistics, ReLU' folded into the pooling join and the
+    head, the skip gradient read inside the concatenation's gradient) at 64^3, N = 2: two fresh runs agree bit for bit."""
+    from mednet_hip.train import LandmarkStep, SegmentationStep
+    nh = 16 if which == "landmark" else 0
+    ncls = 2 if which == "landmark" else 4
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(2, 1, (64, 64, 64), ncls, nh, seed=77).items()}
+    runs = []
+    for _ in range(2):
+        with mednet_hip.precision("bf16"):
+            if which == "landmark":
+                net = O.keyed_init_(HM.ResidualUNet3D(1, 18, False, f_maps=[32, 64, 128])).to(DEV)
+                step = LandmarkStep(net, [0.05, 1.0], [0.015] * 16, "L2")
+            else:
+                net = O.keyed_init_(HM.UNet3D(1, 4, False, f_maps=[32, 64, 128])).to(DEV)
+                step = SegmentationStep(net, loss_weight=[0.05, 1.0, 1.0, 1.0], lr=1e-3)
+            out = step._fwd_bwd(batch)
+            torch.cuda.synchronize()
+            runs.append(([float(v) for v in out], step.flat.grad.clone()))
+            step.flat.release()
+            del net, step
+    assert all(np.isfinite(v) for v in runs[0][0]) and float(runs[0][1].abs().max()) > 0
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]), which
