@@ -34,6 +34,9 @@ PROFILE = {"enabled": False, "events": [], "match": None}
 SIDE = {"enabled": False, "stream": None, "keepalive": [], "wgrad_wgs": int(os.environ.get("MEDNET_SIDE_WGRAD_WGS", "128"))}
 
 
+SIDE_MIN_VOXELS = int(os.environ.get("MEDNET_SIDE_MIN_VOXELS", "0"))  # (A/B knob: half-chip weight gradients from this layer size on)
+
+
 def _runs_beside(main, cand, device) -> bool:
     """Does work queued on `cand` execute while `main` is busy?  HIP multiplexes its streams onto a few hardware queues (4 by
     default) in creation order; two streams that land on the same queue take turns whatever the program says."""
@@ -104,13 +107,16 @@ class _OnSide:
                     SIDE["keepalive"].append(t)
             self.ctx = torch.cuda.stream(side)
             self.ctx.__enter__()
-            if SIDE["wgrad_wgs"] > 0:  # (scoped: a weight gradient launched on the main stream keeps the whole chip)
+            t = self.tensors[-1] if self.tensors else None
+            vox = (t.shape[0] * t[0, 0].numel()) if (t is not None and t.dim() == 5) else 1 << 40
+            self.half = SIDE["wgrad_wgs"] > 0 and vox >= SIDE_MIN_VOXELS
+            if self.half:  # (scoped: a weight gradient launched on the main stream keeps the whole chip)
                 L.lib().mednet_set_option(b"wgrad_wgs", SIDE["wgrad_wgs"])
         return self
 
     def __exit__(self, *exc):
         if self.active:
-            if SIDE["wgrad_wgs"] > 0:
+            if self.half:
                 L.lib().mednet_set_option(b"wgrad_wgs", 0)
             self.ctx.__exit__(*exc)
         return False
