@@ -7,8 +7,13 @@
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator); nothing is allocated,
  *     freed or synchronised inside; launches go on `stream` (a hipStream_t passed as void*).
- *   - activations are NDHWC ("channels_last_3d") unless a layout argument says otherwise; dtype arguments are
- *     MEDNET_F32 / MEDNET_BF16; parameters and their gradients are always fp32 in PyTorch layout.
+ *   - activations are NDHWC ("channels_last_3d") unless a layout argument says otherwise; dtype arguments name the STORAGE
+ *     type of a tensor: MEDNET_F32, MEDNET_BF16 or MEDNET_F16 for activations and their gradients (arithmetic is fp32
+ *     accumulation in every mode), MEDNET_U8 / MEDNET_I64 for labels and MEDNET_U8 / MEDNET_F16 for resident volumes where
+ *     an entry point says so; parameters and their gradients are always fp32 in PyTorch layout.
+ *   - no global state: everything a launch depends on is an argument.  The one exception is mednet_set_option, a table of
+ *     integer A/B knobs for measurements; it never carries pointers, results never depend on it, and the product path
+ *     (the mednet_hip Python package) sets none.
  *   - return value: MEDNET_OK or a negative MEDNET_E_*; mednet_last_error() gives the text.  The Python shim
  *     raises RuntimeError, matching the reference's assert/exception convention (components.py:30-31,56,65;
  *     loss.py:28,66).
@@ -50,7 +55,8 @@ int mednet_abi_version(void);
 const char* mednet_last_error(void);
 /* 1 if a gfx950 device is visible to this process, 0 otherwise (never throws). */
 int mednet_device_ok(void);
-/* Kernel-variant knobs for in-process A/B measurements (e.g. "conv_pipe" 0|1); results never depend on them. */
+/* Kernel-variant knobs for in-process A/B measurements (e.g. "conv32" 0|1); integers only, results never depend on them,
+ * and the table is read without a lock: set them from one thread while no launch is being planned (tools/, tests/). */
 int mednet_set_option(const char* name, int value);
 /* the value a launcher would read now (default_value when the option was never set); tests and tools */
 int mednet_get_option(const char* name, int default_value);
@@ -153,11 +159,17 @@ int mednet_convt3d_dgrad_gn(const void* dy, const void* packed, void* dx, const 
 int mednet_pool2_bwd_gn_rows(int n, int d, int h, int w, int c, int dtype);
 int mednet_pool2_bwd_gn(const void* dy, const void* x, const void* add, void* dx, const void* gn_y, int gn_act,
                         float* gn_partial, int n, int d, int h, int w, int c, int mode, int dtype, mednet_stream stream);
-size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize);
-/* dw[co,ci,tap] = sum_{n,v} dy[n,v,co] * x[n,v+tap,ci]; dbias[co] = sum dy (nullable). */
+/* dw[co,ci,tap] = sum_{n,v} dy[n,v,co] * x[n,v+tap,ci]; dbias[co] = sum dy (nullable).
+ * `workgroups` (>= 0) is part of the launch plan and therefore an ARGUMENT of the call and of its workspace query (the same
+ * value to both): 0 = the library's plan, one persistent workgroup per CU; N > 0 = about N workgroups -- the trainer passes
+ * half the CUs for launches that run on a second stream beside the main one (a weight-gradient workgroup takes a CU's whole
+ * register file; mednet_hip/ops.py _OnSide).  Results are deterministic for a fixed value (fixed-order reduce of the
+ * per-workgroup partial slabs); another value changes the rounding of the sums, once.  Kernels that do not split their work
+ * this way (first layer, 1x1x1 head, direct kernels) ignore it. */
+size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize, int workgroups);
 int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
                         int cin, int cout, int ksize, int x_dtype, int x_layout, int dy_dtype, int dy_layout,
-                        int algo, void* ws, size_t ws_bytes, mednet_stream stream);
+                        int algo, int workgroups, void* ws, size_t ws_bytes, mednet_stream stream);
 
 /* ---- nn.ConvTranspose3d(k=3,s=2,p=1,output_padding=1,bias) + `x += encoder_features`  components.py:259-264,283-284 */
 /* (n,d,h,w) are the INPUT dims; output is (2d,2h,2w).  `skip` (nullable, y's dtype/shape) is added in the epilogue. */
@@ -166,10 +178,11 @@ int mednet_convt3d_fwd(const void* x, const void* packed, const float* bias, con
                        mednet_stream stream);
 int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx, int n, int d, int h, int w, int cin,
                          int cout, int dy_dtype, int dx_dtype, int algo, mednet_stream stream);
-size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+/* (`workgroups`: as for mednet_conv3d_wgrad) */
+size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int workgroups);
 int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
-                         int cin, int cout, int x_dtype, int dy_dtype, int algo, void* ws, size_t ws_bytes,
-                         mednet_stream stream);
+                         int cin, int cout, int x_dtype, int dy_dtype, int algo, int workgroups, void* ws,
+                         size_t ws_bytes, mednet_stream stream);
 
 /* ---- nn.GroupNorm(G,C,eps) fused with the following activation and the residual add
  *      components.py:57 (GroupNorm), :36-40 (ReLU/LeakyReLU(0.1)/ELU), :177-178 (out += residual; non_linearity) */

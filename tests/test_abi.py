@@ -34,7 +34,7 @@ def test_ctypes_table_matches_header():
     from mednet_hip import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     lib = _lib.lib()
-    assert lib.mednet_abi_version() == 1
+    assert lib.mednet_abi_version() == 2
     assert lib.mednet_device_ok() in (0, 1)
 
 
@@ -56,4 +56,4 @@ def test_size_queries_work_without_gpu():
     assert lib.mednet_conv3d_pack_bytes(32, 32, 3) >= 2 * 27 * 32 * 32 * 4
     assert lib.mednet_gn_ws_bytes(4, 32, 128 ** 3) > 0
     assert lib.mednet_loss_ws_bytes(4, 4, 128 ** 3) > 0
-    assert lib.mednet_conv3d_wgrad_ws_bytes(1, 16, 16, 16, 32, 32, 3) > 0
+    assert lib.mednet_conv3d_wgrad_ws_bytes(1, 16, 16, 16, 32, 32, 3, 0) > 0

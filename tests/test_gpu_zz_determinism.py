@@ -38,6 +38,30 @@ def _fresh_step_run(ctor, mode, batch, traced=False):
     return out
 
 
+def _describe_difference(ctor, mode, a, b, limit=12):
+    """Where two flat gradient buffers differ: per parameter (train.FlatParams lays the parameters out in named_parameters()
+    order, each padded to the buffer's alignment) the count, first index and values; plus the caching allocator's counters."""
+    from mednet_hip.train import FlatParams
+    with mednet_hip.precision(mode):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+        flat = FlatParams(net)
+        spans = [(k, int(p._mednet_grad.data_ptr() - flat.grad.data_ptr()) // 4, p.numel()) for k, p in net.named_parameters()]
+        flat.release()
+    diff = (a[1] != b[1]).nonzero().flatten()
+    lines = []
+    for k, off, cnt in spans:
+        idx = diff[(diff >= off) & (diff < off + cnt)]
+        if idx.numel():
+            i = int(idx[0])
+            lines.append(f"{k}: {idx.numel()} of {cnt} (first at {i - off}: {float(a[1][i])!r} vs {float(b[1][i])!r})")
+        if len(lines) >= limit:
+            lines.append("...")
+            break
+    st = torch.cuda.memory_stats()
+    mem = {k: st.get(k) for k in ("allocated_bytes.all.current", "reserved_bytes.all.current", "num_alloc_retries", "segment.all.current")}
+    return f"differing parameters: {lines or 'none (loss only)'}; allocator {mem}"
+
+
 def _assert_step_is_bitwise_repeatable(ctor, mode, batch, what):
     """Two fresh runs of the same step must agree bit for bit (no atomics, fixed-order reductions, two streams).  If they do
     not, the step is run twice more with mednet_hip.debug's trace open -- a checksum of every tensor the ops produce -- so
@@ -49,11 +73,14 @@ def _assert_step_is_bitwise_repeatable(ctor, mode, batch, what):
     assert float(a[1].abs().max()) > 0
     if a[0] == b[0] and torch.equal(a[1], b[1]):
         return a
+    # what the failing pair already holds goes on record BEFORE anything is re-run (a rare event will not show in the re-runs):
+    # the differing flat-gradient elements mapped to parameter names, and the allocator's state
+    evidence = _describe_difference(ctor, mode, a, b)
     t0 = _fresh_step_run(ctor, mode, batch, traced=True)
     t1 = _fresh_step_run(ctor, mode, batch, traced=True)
     where = debug.first_difference(t0[2], t1[2])
     raise AssertionError(f"{what}: two runs differ -- loss {a[0]!r} vs {b[0]!r}, {int((a[1] != b[1]).sum())} of {a[1].numel()} "
-                         f"gradient values; traced re-runs: losses {t0[0]!r} / {t1[0]!r}, first differing trace point: {where}")
+                         f"gradient values; {evidence}; traced re-runs: losses {t0[0]!r} / {t1[0]!r}, first differing trace point: {where}")
 
 
 @pytest.mark.parametrize("MODE16", ["fp16", "bf16"])

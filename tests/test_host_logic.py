@@ -314,3 +314,29 @@ def test_optimizer_and_scaler_state_round_trip():
     assert sc.state.tolist() == [1024.0, 5.0, 40.0, 0.0, 0.0, 0.0, 0.0, 0.0] and sc.growth_interval == 100
     with pytest.raises(ValueError):
         sc.load_state_dict({"state": torch.zeros(9), "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 100})
+
+
+def test_algo_mfma_is_satisfied_by_the_fp32_mode_matrix_core_kernels():
+    """include/mednet_hip.h: MEDNET_ALGO_MFMA = "a matrix-core path is required"; in fp32 storage that is the split-bf16
+    contraction, with MEDNET_ALGO_EXACT_BIT the fp32 matrix instruction.  Until round 4 the C side rejected both (its gate only
+    knew the 16-bit kernels: ADVICE r4).  Host-only: without a device the call fails where it prepares the LAUNCH (MEDNET_E_HIP,
+    naming the kernel it chose), not at the algorithm gate (MEDNET_E_UNSUPPORTED)."""
+    from mednet_hip import _lib as L
+    lib = L.lib()
+    if lib.mednet_device_ok():
+        pytest.skip("host-logic check: needs the no-device error path")
+    chosen = {}
+    for algo in (L.ALGO_AUTO, L.ALGO_MFMA, L.ALGO_EXACT, L.ALGO_MFMA | 4):
+        rc = lib.mednet_conv3d_fwd(None, None, None, None, 1, 8, 8, 16, 32, 32, 3, L.F32, L.NDHWC, L.F32, L.NDHWC, 0, algo, None, None)
+        msg = lib.mednet_last_error().decode()
+        assert rc == -4 and "does not take" not in msg, (algo, rc, msg)
+        chosen[algo] = msg.split(":")[0]
+    assert chosen[L.ALGO_MFMA] == chosen[L.ALGO_AUTO] == "conv_x3"                    # split-bf16 contraction
+    assert chosen[L.ALGO_MFMA | 4] == chosen[L.ALGO_EXACT] == "conv_f32_mfma"         # exact fp32 products
+    # the 16-bit gate is unchanged: a channel count the matrix-core kernels do not take is still refused under ALGO_MFMA
+    rc = lib.mednet_conv3d_fwd(None, None, None, None, 1, 8, 8, 16, 12, 20, 3, L.BF16, L.NDHWC, L.BF16, L.NDHWC, 0, L.ALGO_MFMA, None, None)
+    assert rc == -5 and "does not take" in lib.mednet_last_error().decode()
+    # and the weight-gradient plan is an argument: a negative workgroup count is a shape error before anything else happens
+    rc = lib.mednet_conv3d_wgrad(None, None, None, None, 1, 8, 8, 16, 32, 32, 3, L.BF16, L.NDHWC, L.BF16, L.NDHWC, L.ALGO_AUTO, -1, None, 0, None)
+    assert rc == -1 and "workgroups" in lib.mednet_last_error().decode()
+    assert lib.mednet_get_option(b"wgrad_wgs", -7) == -7 and lib.mednet_abi_version() == 2

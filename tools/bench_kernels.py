@@ -32,7 +32,7 @@ def conv_case(cin, cout, s):
     pk = ops.pack_conv_weight(w, 3, False)
     y = torch.empty(N, cout, s, s, s, device=dev, dtype=torch.bfloat16).contiguous(memory_format=CL)
     dw = torch.empty(cout, cin, 3, 3, 3, device=dev)
-    ws = torch.empty(lib.mednet_conv3d_wgrad_ws_bytes(N, s, s, s, cin, cout, 3), dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.mednet_conv3d_wgrad_ws_bytes(N, s, s, s, cin, cout, 3, 0), dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     flop = 2.0 * N * s ** 3 * cin * cout * 27
 
@@ -46,7 +46,7 @@ def conv_case(cin, cout, s):
         L.check(lib.mednet_conv3d_fwd(x.data_ptr(), pk.data_ptr(), None, y.data_ptr(), N, s, s, s, cin, cout, 3, 1, 0, 1, 0, 0, 2, part.data_ptr(), st), "fwd")
 
     def wg():
-        L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, N, s, s, s, cin, cout, 3, 1, 0, 1, 0, 2,
+        L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, N, s, s, s, cin, cout, 3, 1, 0, 1, 0, 2, 0,
                                         ws.data_ptr(), ws.numel(), st), "wgrad")
 
     res = []
@@ -57,13 +57,6 @@ def conv_case(cin, cout, s):
     ts = min(timeit(fwd_stats) for _ in range(3))
     print(f"   fwd + fused GroupNorm partials: {ts*1e3:6.1f} us {flop/ts/1e9:6.1f} TF/s")
     tw = timeit(wg)
-    wres = {}
-    for rnd in range(3):
-        for av in (0, 1):
-            lib.mednet_set_option(b"wgrad_v2", av)
-            wres[av] = min(wres.get(av, 1e9), timeit(wg))
-    lib.mednet_set_option(b"wgrad_v2", 1)
-    print("   wgrad v1/v2: " + " | ".join(f"v{k+1}: {v*1e3:6.1f} us {flop/v/1e9:6.1f} TF/s" for k, v in wres.items()))
     txt = " | ".join(f" {min(t for p, t in res if p == pv)*1e3:6.1f} us {flop/min(t for p, t in res if p == pv)/1e9:6.1f} TF/s" for pv in variants)
     print(f"conv {cin:3d}->{cout:3d} @{s:3d}^3 N={N}: fwd {txt} | wgrad {tw*1e3:7.1f} us {flop/tw/1e9:7.1f} TF/s", flush=True)
 
@@ -100,20 +93,16 @@ def convt_case(cin, cout, s):
     y = torch.empty_like(skip)
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
-    ws = torch.empty(lib.mednet_convt3d_wgrad_ws_bytes(N, s, s, s, cin, cout), dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.mednet_convt3d_wgrad_ws_bytes(N, s, s, s, cin, cout, 0), dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     flop = 2.0 * N * s ** 3 * cin * cout * 27
     f = lambda: L.check(lib.mednet_convt3d_fwd(x.data_ptr(), pk.data_ptr(), b.data_ptr(), skip.data_ptr(), y.data_ptr(), N, s, s, s, cin, cout, 1, 1, 2, st), "ctf")
     d = lambda: L.check(lib.mednet_convt3d_dgrad(y.data_ptr(), pk.data_ptr(), dx.data_ptr(), N, s, s, s, cin, cout, 1, 1, 2, st), "ctd")
-    g = lambda: L.check(lib.mednet_convt3d_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, N, s, s, s, cin, cout, 1, 1, 2, ws.data_ptr(), ws.numel(), st), "ctw")
+    g = lambda: L.check(lib.mednet_convt3d_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, N, s, s, s, cin, cout, 1, 1, 2, 0, ws.data_ptr(), ws.numel(), st), "ctw")
     tf, td = min(timeit(f) for _ in range(3)), min(timeit(d) for _ in range(3))
-    res = {}
-    for v in (0, 1):
-        lib.mednet_set_option(b"convt_wgrad_v2", v)
-        res[v] = min(timeit(g) for _ in range(3))
-    lib.mednet_set_option(b"convt_wgrad_v2", 1)
+    tg = min(timeit(g) for _ in range(3))
     print(f"convT {cin:3d}->{cout:3d} @{s:3d}^3->{2*s}^3 N={N}: fwd {tf*1e3:6.1f} us {flop/tf/1e9:6.1f} TF/s | dgrad {td*1e3:6.1f} us {flop/td/1e9:6.1f} TF/s"
-          f" | wgrad v1 {res[0]*1e3:6.1f} us {flop/res[0]/1e9:6.1f} TF/s  v2 {res[1]*1e3:6.1f} us {flop/res[1]/1e9:6.1f} TF/s", flush=True)
+          f" | wgrad {tg*1e3:6.1f} us {flop/tg/1e9:6.1f} TF/s", flush=True)
 
 
 if "convt" in which:

@@ -41,7 +41,7 @@ def conv_case(cin, cout, s):
     y = torch.empty(N, cout, s, s, s, device=dev).contiguous(memory_format=CL)
     dx = torch.empty_like(x)
     dw = torch.empty(cout, cin, 3, 3, 3, device=dev)
-    ws = torch.empty(lib.mednet_conv3d_wgrad_ws_bytes(N, s, s, s, cin, cout, 3), dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.mednet_conv3d_wgrad_ws_bytes(N, s, s, s, cin, cout, 3, 0), dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     flop = 2.0 * N * s ** 3 * cin * cout * 27
     rows = lib.mednet_conv3d_fused_stats_chunks(N, s, s, s, cin, cout, 3, F32, F32, AUTO)
@@ -53,7 +53,7 @@ def conv_case(cin, cout, s):
     dg = lambda: L.check(lib.mednet_conv3d_fwd(y.data_ptr(), pk.data_ptr(), None, dx.data_ptr(), N, s, s, s, cout, cin, 3, F32, NDHWC,
                                                F32, NDHWC, 1, AUTO, None, st), "dgrad")
     wg = lambda: L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, N, s, s, s, cin, cout, 3, F32, NDHWC,
-                                                 F32, NDHWC, AUTO, ws.data_ptr(), ws.numel(), st), "wgrad")
+                                                 F32, NDHWC, AUTO, 0, ws.data_ptr(), ws.numel(), st), "wgrad")
     out = []
     for x3 in (1, 0):
         lib.mednet_set_option(b"x3", x3)
@@ -76,13 +76,13 @@ def convt_case(cin, cout, s):
     y = torch.empty_like(skip)
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
-    ws = torch.empty(lib.mednet_convt3d_wgrad_ws_bytes(N, s, s, s, cin, cout), dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.mednet_convt3d_wgrad_ws_bytes(N, s, s, s, cin, cout, 0), dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     flop = 2.0 * N * s ** 3 * cin * cout * 27
     f = lambda: L.check(lib.mednet_convt3d_fwd(x.data_ptr(), pk.data_ptr(), b.data_ptr(), skip.data_ptr(), y.data_ptr(), N, s, s, s, cin,
                                                cout, F32, F32, AUTO, st), "ctf")
     d = lambda: L.check(lib.mednet_convt3d_dgrad(y.data_ptr(), pk.data_ptr(), dx.data_ptr(), N, s, s, s, cin, cout, F32, F32, AUTO, st), "ctd")
-    g = lambda: L.check(lib.mednet_convt3d_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, N, s, s, s, cin, cout, F32, F32, AUTO,
+    g = lambda: L.check(lib.mednet_convt3d_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, N, s, s, s, cin, cout, F32, F32, AUTO, 0,
                                                  ws.data_ptr(), ws.numel(), st), "ctw")
     out = []
     for x3 in (1, 0):

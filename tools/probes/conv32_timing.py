@@ -1,8 +1,7 @@
-"""Phase timing of conv32_mfma_kernel (the 32 -> 32 channel specialisation) with s_memtime stamps; needs the instrumented
-build:  make -C torch-mednet_amd/csrc timing  ->  mednet_hip/libmednet_hip_timing.so; run with MEDNET_LIB_PATH set to it.
-Stamps of wave 0 of every workgroup: 0 start, 1 weights in registers + first brick committed, and for the workgroup's 5th
-brick: 3 barrier passed, 5 the 216 MFMAs issued, 6 epilogue done; 15 end of the workgroup.  Also prints plain event timings of
-the specialised and the general kernel (option conv32=0) with and without the fused statistics."""
+"""Stand-alone event timings of conv32_mfma_kernel (the 32 -> 32 channel specialisation) against the general kernel (option
+conv32=0): forward with and without the fused statistics, and the data-gradient variants.  (The s_memtime phase stamps this
+tool printed until round 4 needed an instrumented build of conv_mfma.hip; that scaffolding left the product source in round 5,
+the numbers it produced are in profiles/r02_* / r04_ab.md.)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "torch-mednet_amd")]
@@ -68,22 +67,3 @@ for special in (1, 0):
         torch.cuda.synchronize()
         print(f"conv32={special} {name:14s}: {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us")
 lib.mednet_set_option(b"conv32", 1)
-if "timing" in os.environ.get("MEDNET_LIB_PATH", ""):
-    dbg = torch.zeros(256, 16, dtype=torch.int64, device=dev)
-    p = dbg.data_ptr()
-    lib.mednet_set_option(b"conv_dbg_lo", (p & 0xFFFFFFFF) - (1 << 32) if (p & 0x80000000) else (p & 0xFFFFFFFF))
-    lib.mednet_set_option(b"conv_dbg_hi", p >> 32)
-    for _ in range(2):
-        dbg.zero_()
-        launch(None)
-        torch.cuda.synchronize()
-    lib.mednet_set_option(b"conv_dbg_lo", 0)
-    lib.mednet_set_option(b"conv_dbg_hi", 0)
-    t = dbg.cpu().double()
-    nitem = N * (s // 4) * (s // 8) * (s // 16) / 256
-    print(f"{nitem:.0f} bricks per workgroup; ticks of s_memtime (100 MHz):")
-    for nm, a_, b_ in (("prologue (weights, first brick)", 0, 1), ("5th brick: tap loop", 3, 5), ("5th brick: epilogue", 5, 6),
-                       ("whole workgroup", 0, 15)):
-        d = t[:, b_] - t[:, a_]
-        print(f"   {nm:34s} mean {d.mean():9.1f}  p10 {d.quantile(0.1):9.1f}  p90 {d.quantile(0.9):9.1f}")
-    print(f"   per brick {((t[:, 15] - t[:, 1]).mean() / nitem):.1f} ticks")

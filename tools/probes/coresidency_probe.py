@@ -15,7 +15,7 @@ CL = torch.channels_last_3d
 x = torch.randn(N, c, s, s, s, device=dev).bfloat16().contiguous(memory_format=CL)
 dy = torch.randn(N, c, s, s, s, device=dev).bfloat16().contiguous(memory_format=CL)
 dw = torch.empty(c, c, 3, 3, 3, device=dev)
-ws = torch.empty(lib.mednet_conv3d_wgrad_ws_bytes(N, s, s, s, c, c, 3), dtype=torch.uint8, device=dev)
+ws = torch.empty(lib.mednet_conv3d_wgrad_ws_bytes(N, s, s, s, c, c, 3, 0), dtype=torch.uint8, device=dev)
 side = torch.cuda.Stream()
 main = torch.cuda.current_stream()
 small = torch.zeros(64, device=dev)
@@ -25,7 +25,7 @@ dbl = torch.zeros(2048, device=dev, dtype=torch.float64)
 
 def wgrad():
     with torch.cuda.stream(side):
-        L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, N, s, s, s, c, c, 3, 1, 0, 1, 0, 0,
+        L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, N, s, s, s, c, c, 3, 1, 0, 1, 0, 0, 0,
                                         ws.data_ptr(), ws.numel(), side.cuda_stream), "wgrad")
 
 

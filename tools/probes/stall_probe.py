@@ -17,7 +17,7 @@ x, dy, y_prev, dx, dyo = mk(), mk(), mk(), mk(), mk()
 w = torch.randn(c, c, 3, 3, 3, device=dev) * 0.05
 pk = ops.pack_conv_weight(w, 3, False)
 dw = torch.empty(c, c, 3, 3, 3, device=dev)
-ws = torch.empty(lib.mednet_conv3d_wgrad_ws_bytes(N, s, s, s, c, c, 3), dtype=torch.uint8, device=dev)
+ws = torch.empty(lib.mednet_conv3d_wgrad_ws_bytes(N, s, s, s, c, c, 3, 0), dtype=torch.uint8, device=dev)
 rows = lib.mednet_conv3d_dgrad_gn_rows(N, s, s, s, c, c, 0)
 part = torch.empty(N, rows, c, 2, device=dev)
 coef = torch.randn(N, c, 2, device=dev)
@@ -46,7 +46,7 @@ def scenario(name, cand, wgrad_after_dgrad=False):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             w0.record()
-            L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, N, s, s, s, c, c, 3, 1, 0, 1, 0, 0,
+            L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, N, s, s, s, c, c, 3, 1, 0, 1, 0, 0, 0,
                                             ws.data_ptr(), ws.numel(), side.cuda_stream), "wgrad")
             w1.record()
 

@@ -73,7 +73,7 @@ extern "C" int mednet_set_option(const char* name, int value) {
 
 extern "C" int mednet_get_option(const char* name, int default_value) { return mednet_internal_tuning_option(name, default_value); }
 
-extern "C" int mednet_abi_version(void) { return 1; }
+extern "C" int mednet_abi_version(void) { return 2; }  // 2: `workgroups` argument of the weight-gradient calls (round 5)
 extern "C" const char* mednet_last_error(void) { return g_err; }
 extern "C" int mednet_device_ok(void) {
   int count = 0;
@@ -201,7 +201,12 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
   hipStream_t s = (hipStream_t)stream;
   const bool mfma_ok = ELT_CALL(y_dtype, conv_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, x_layout, y_layout, bias != nullptr) &&
                        conv_mfma_fits(n, d, h, w, cin);
-  if (algo_base(algo) == MEDNET_ALGO_MFMA && !mfma_ok)
+  // fp32 storage (the 1e-3 parity mode): 3x3x3 forward / data gradient on the matrix cores -- the split-bf16 contraction (three
+  // bf16 MFMAs per product; the pack must hold the low images: mednet_conv3d_pack_elt(MEDNET_F32)) or, for shapes it does not
+  // take and under ALGO_EXACT, the fp32 matrix instruction.  Both satisfy MEDNET_ALGO_MFMA ("a matrix-core path is required").
+  const bool f32_mode = algo_base(algo) != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 &&
+                        y_dtype == MEDNET_F32 && (x_layout == MEDNET_NDHWC || cin == 1) && y_layout == MEDNET_NDHWC;
+  if (algo_base(algo) == MEDNET_ALGO_MFMA && !mfma_ok && !f32_mode)
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_fwd: MFMA path does not take cin=%d cout=%d k=%d dtypes %d->%d", cin, cout,
                 ksize, x_dtype, y_dtype);
   if (mfma_ok && algo_base(algo) != MEDNET_ALGO_DIRECT)
@@ -211,10 +216,7 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
   if (!dgrad && algo_base(algo) != MEDNET_ALGO_DIRECT && x_layout == MEDNET_NDHWC &&
       ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, y_layout, bias != nullptr))
     return ELT_CALL(y_dtype, launch_conv_c1_mfma, x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, gn_partial, s, x_dtype);
-  // fp32 storage (the 1e-3 parity mode): 3x3x3 forward / data gradient as a split-bf16 contraction on the bf16 matrix cores
-  // (three MFMAs per product; the pack must hold the low images: mednet_conv3d_pack_elt(MEDNET_F32)) ...
-  const bool f32_mode = algo_base(algo) != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && ksize == 3 && x_dtype == MEDNET_F32 &&
-                        y_dtype == MEDNET_F32 && (x_layout == MEDNET_NDHWC || cin == 1) && y_layout == MEDNET_NDHWC;
+  // fp32 storage: the split-bf16 contraction ...
   if (f32_mode && (!algo_exact(algo) && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin))
     return launch_conv_x3(x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), L.lo_delta, bias, y, n, d, h, w, cin, cout, gn_partial, s);
   if (f32_mode && !dgrad && !algo_exact(algo) && conv_x3_enabled() && conv_c1_x3_supported(cin, cout, ksize))  // first layer
@@ -239,13 +241,14 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
                                  y_dtype, s);
 }
 
-extern "C" size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize) {
+extern "C" size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize, int workgroups) {
   const size_t a = wgrad_direct_ws_bytes((size_t)n * d * h * w, cout, cin, ksize);
-  const size_t b = wgrad_mfma_ws_bytes(n, d, h, w, cin, cout, ksize);
+  // (the 16-bit element types share one plan; `workgroups`: see mednet_conv3d_wgrad)
+  const size_t b = wgrad_mfma_ws_bytes(n, d, h, w, cin, cout, ksize, workgroups);
   const size_t c1 = cin == 1 ? wgrad_c1_ws_bytes(n, d, h, w, cout) : 0;
   const size_t c2 = ksize == 1 ? wgrad_1x1_ws_bytes(n, (size_t)d * h * w, cin, cout) : 0;
   const size_t f = ksize == 3 ? wgrad_f32_mfma_ws_bytes(n, d, h, w, cout, cin, 0) : 0;
-  const size_t f3 = conv_x3_supported(cin, cout, ksize) ? wgrad_x3_ws_bytes(n, d, h, w, cin, cout) : 0;
+  const size_t f3 = conv_x3_supported(cin, cout, ksize) ? wgrad_x3_ws_bytes(n, d, h, w, cin, cout, workgroups) : 0;
   size_t m = a > b ? a : b;
   if (f > m) m = f;
   if (f3 > m) m = f3;
@@ -257,7 +260,8 @@ extern "C" size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int c
 
 extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
                                    int cin, int cout, int ksize, int x_dtype, int x_layout, int dy_dtype, int dy_layout,
-                                   int algo, void* ws, size_t ws_bytes, mednet_stream stream) {
+                                   int algo, int workgroups, void* ws, size_t ws_bytes, mednet_stream stream) {
+  MEDNET_REQUIRE(workgroups >= 0, MEDNET_E_SHAPE, "conv3d_wgrad: workgroups %d (0 = one per CU)", workgroups);
   int rc = conv_common_checks("conv3d_wgrad", n, d, h, w, cin, cout, ksize, x_dtype, dy_dtype);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -277,7 +281,7 @@ extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, flo
       (x_layout == MEDNET_NDHWC || cin == 1) && dy_layout == MEDNET_NDHWC) {
     const int cmax = cin > cout ? cin : cout;
     if ((!algo_exact(algo) && conv_x3_enabled()) && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cmax))
-      return launch_wgrad_x3(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);  // split-bf16 contraction over the voxels
+      return launch_wgrad_x3(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s, workgroups);  // split-bf16 contraction over the voxels
     return launch_wgrad_f32_mfma(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
   }
   const bool mfma_ok = ELT_CALL(dy_dtype, wgrad_mfma_supported, cin, cout, ksize, x_dtype, dy_dtype, x_layout, dy_layout) &&
@@ -285,7 +289,7 @@ extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, flo
   if (algo_base(algo) == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_wgrad: MFMA path does not take cin=%d cout=%d k=%d", cin, cout, ksize);
   if (mfma_ok && algo_base(algo) != MEDNET_ALGO_DIRECT)
-    return ELT_CALL(dy_dtype, launch_wgrad_mfma, x, dy, dw, n, d, h, w, cin, cout, x_dtype, ws, ws_bytes, s);
+    return ELT_CALL(dy_dtype, launch_wgrad_mfma, x, dy, dw, n, d, h, w, cin, cout, x_dtype, ws, ws_bytes, s, workgroups);
   WgradGeom g;
   g.n = n; g.ad = d; g.ah = h; g.aw = w; g.bd = d; g.bh = h; g.bw = w;
   g.ka = cout; g.kb = cin; g.ks = ksize; g.stride2 = 0;
@@ -408,7 +412,8 @@ extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float
   if (rc) return rc;
   const PackLayout L = pack_layout(cin, cout, 3);
   const bool mfma_ok = L.mfma_bytes && cin % 32 == 0 && cout % 32 == 0 && is16(x_dtype) && y_dtype == x_dtype;
-  if (algo_base(algo) == MEDNET_ALGO_MFMA && !mfma_ok)
+  const bool f32_mfma = conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32;  // (fp32 storage: see conv3d_fwd)
+  if (algo_base(algo) == MEDNET_ALGO_MFMA && !mfma_ok && !f32_mfma)
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_fwd: MFMA path does not take cin=%d cout=%d", cin, cout);
   if (mfma_ok && algo_base(algo) != MEDNET_ALGO_DIRECT)
     return ELT_CALL(x_dtype, launch_convt_fwd_mfma, x, (const char*)packed + L.mfma_fwd, bias, skip, y, n, d, h, w, cin, cout,
@@ -434,7 +439,8 @@ extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx
   const PackLayout L = pack_layout(cin, cout, 3);
   const bool mfma_ok = L.mfma_bytes && cin % 32 == 0 && cout % 32 == 0 && is16(dy_dtype) && dx_dtype == dy_dtype &&
                        conv_mfma_fits(n, 2 * d, 2 * h, 2 * w, cout);
-  if (algo_base(algo) == MEDNET_ALGO_MFMA && !mfma_ok)
+  const bool f32_mfma = conv_f32_mfma_enabled() && dy_dtype == MEDNET_F32 && dx_dtype == MEDNET_F32;
+  if (algo_base(algo) == MEDNET_ALGO_MFMA && !mfma_ok && !f32_mfma)
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_dgrad: MFMA path does not take cin=%d cout=%d", cin, cout);
   if (mfma_ok && algo_base(algo) != MEDNET_ALGO_DIRECT)
     return ELT_CALL(dy_dtype, launch_convt_dgrad_mfma, dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cin, cout,
@@ -473,19 +479,20 @@ extern "C" int mednet_convt3d_dgrad_gn(const void* dy, const void* packed, void*
                   h, w, cin, cout, (hipStream_t)stream);
 }
 
-extern "C" size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+extern "C" size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int workgroups) {
   const size_t a = wgrad_direct_ws_bytes((size_t)n * d * h * w, cin, cout, 3);
-  size_t b = convt_wgrad_mfma_ws_bytes(n, d, h, w, cin, cout);
+  size_t b = convt_wgrad_mfma_ws_bytes(n, d, h, w, cin, cout, workgroups);
   const size_t f = wgrad_f32_mfma_ws_bytes(n, d, h, w, cin, cout, 1);
   if (f > b) b = f;
-  const size_t f3 = conv_x3_supported(cin, cout, 3) ? convt_wgrad_x3_ws_bytes(n, d, h, w, cin, cout) : 0;
+  const size_t f3 = conv_x3_supported(cin, cout, 3) ? convt_wgrad_x3_ws_bytes(n, d, h, w, cin, cout, workgroups) : 0;
   if (f3 > b) b = f3;
   return align_up(a > b ? a : b, 256) + channel_sum_ws_bytes(n, (size_t)8 * d * h * w, cout) + 256;
 }
 
 extern "C" int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
-                                    int cin, int cout, int x_dtype, int dy_dtype, int algo, void* ws, size_t ws_bytes,
-                                    mednet_stream stream) {
+                                    int cin, int cout, int x_dtype, int dy_dtype, int algo, int workgroups, void* ws,
+                                    size_t ws_bytes, mednet_stream stream) {
+  MEDNET_REQUIRE(workgroups >= 0, MEDNET_E_SHAPE, "convt3d_wgrad: workgroups %d (0 = one per CU)", workgroups);
   int rc = conv_common_checks("convt3d_wgrad", n, d, h, w, cin, cout, 3, x_dtype, dy_dtype);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -500,7 +507,7 @@ extern "C" int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, fl
   if (algo_base(algo) != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && dy_dtype == MEDNET_F32) {
     if (!algo_exact(algo) && conv_x3_enabled() && tuning_option("x3_convt_wgrad", 1) && conv_x3_supported(cin, cout, 3) &&
         conv_x3_fits(2 * d, 2 * h, 2 * w, cout) && conv_x3_fits(d, h, w, cin))
-      return launch_convt_wgrad_x3(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);  // split-bf16, output-parity planes
+      return launch_convt_wgrad_x3(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s, workgroups);  // split-bf16, output-parity planes
     return launch_convt_wgrad_f32_mfma(x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
   }
   const bool mfma_ok = cin % 32 == 0 && cout % 32 == 0 && is16(x_dtype) && dy_dtype == x_dtype &&
@@ -508,7 +515,7 @@ extern "C" int mednet_convt3d_wgrad(const void* x, const void* dy, float* dw, fl
   if (algo_base(algo) == MEDNET_ALGO_MFMA && !mfma_ok)
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_wgrad: MFMA path does not take cin=%d cout=%d", cin, cout);
   if (mfma_ok && algo_base(algo) != MEDNET_ALGO_DIRECT)
-    return ELT_CALL(x_dtype, launch_convt_wgrad_mfma, x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s);
+    return ELT_CALL(x_dtype, launch_convt_wgrad_mfma, x, dy, dw, n, d, h, w, cin, cout, ws, ws_bytes, s, workgroups);
   WgradGeom g;
   g.n = n; g.ad = d; g.ah = h; g.aw = w; g.bd = 2 * d; g.bh = 2 * h; g.bw = 2 * w;
   g.ka = cin; g.kb = cout; g.ks = 3; g.stride2 = 1; g.a_planar = 0; g.b_planar = 0; g.chunk = 0;

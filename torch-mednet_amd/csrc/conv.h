@@ -88,15 +88,15 @@ int launch_convt_dgrad_x3(const void* dy, const void* sec_hi, size_t lo_delta, v
                           int cout, hipStream_t s);
 int launch_convt_fwd_x3(const void* x, const void* sec_hi, size_t lo_delta, const float* bias, const void* skip, void* y, int n,
                         int d, int h, int w, int cin, int cout, hipStream_t s);
-size_t wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+size_t wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout, int workgroups);
 bool wgrad_c1_x3_supported(int cout, int x_dtype, int dy_dtype);
 int wgrad_c1_x3_blocks(int n, int d, int h, int w);
 int launch_wgrad_c1_x3(const void* x, const void* dy, float* part, int n, int d, int h, int w, hipStream_t s);
 int launch_wgrad_x3(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, void* ws,
-                    size_t ws_bytes, hipStream_t s);
+                    size_t ws_bytes, hipStream_t s, int workgroups);
 
-size_t convt_wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+size_t convt_wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout, int workgroups);
 int launch_convt_wgrad_x3(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, void* ws,
-                          size_t ws_bytes, hipStream_t s);
+                          size_t ws_bytes, hipStream_t s, int workgroups);
 
 }  // namespace mednet

@@ -107,29 +107,13 @@ struct FwdArgs {
   const elt* gnb_z;       // nullable: the layer in front is the RESIDUAL layer of an ExtResNetBlock (GroupNorm-3, components.py:
                           // 170-178): this kernel's output is the block's output gradient, the activation derivative comes from
                           // the block OUTPUT z (shape of this kernel's output) and gnb_coef is not used
-  const float* xf_coef;   // conv_mfma_kernel<1, false, 1> (measurement probe, option conv_xform_probe): [n][cin][2] = {ca, cb} of the
-                          // GroupNorm in front; the kernel reads the conv OUTPUT y of the previous layer and applies
-                          // z = ELU(ca * y + cb) while it commits the staged pieces to LDS (profiles/r04_ab.md)
   int xcd_chunk;          // conv32_mfma_kernel: bricks per XCD when the brick count divides by 8 (each XCD then works through a
                           // CONTIGUOUS part of the volume, so neighbouring bricks' halos meet in its L2), else 0
   int zslab;              // conv32_mfma_kernel: z-layers of bricks per XCD (> 0: the x-z-y walk of origin(); implies xcd_chunk)
   unsigned rcp_zslab;
-#ifdef MEDNET_CONV_TIMING
-  long long* dbg;  // [workgroup][16] s_memtime stamps of wave 0 (tools/probes/conv_timing.py)
-#endif
 };
-#ifdef MEDNET_CONV_TIMING
-// (stamps 3..14 are taken for ONE item of a workgroup: the 9th when it has that many, else its first)
-#define STAMP(i)                                                                  \
-  do {                                                                            \
-    if (a.dbg && threadIdx.x == 0 && ((i) < 3 || (i) == 15 || stamp_item))        \
-      a.dbg[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
 
-template <int STRIDE, bool GNB = false, int XF = 0>
+template <int STRIDE, bool GNB = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   using G = FwdTile<STRIDE>;
   constexpr int TZ = G::TZ, TY = G::TY, TX = G::TX;
@@ -147,11 +131,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-#ifdef MEDNET_CONV_TIMING
-  bool stamp_item = false;
-  int item_no = 0;
-#endif
-  STAMP(0);
 
   // ---- work items: (brick, channel block), numbered so that all channel blocks of a brick run on the same XCD (ids 8
   //      apart share an L2).  A workgroup takes items blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8, so it
@@ -212,10 +191,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   };
 
   u32x4 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
-  [[maybe_unused]] u32x4 cf_reg[XF ? 4 : 1];  // XF: {ca, cb} of this thread's 8 channels (k-half tid & 1) of the chunk in flight
-  auto cf_rsrc = [&]() {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(a.xf_coef + (size_t)pn * a.cin * 2), 0, (unsigned)a.cin * 8u, 0x00020000);
-  };
   auto prefetch = [&](int cb, int kc) {  // 15 loads issued back to back, nothing waits on them until commit()
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)pn * a.id * a.ih * a.iw * a.cin), 0, a.bytes_x, 0x00020000);
 #pragma unroll
@@ -225,27 +200,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + ((size_t)cb * a.nkc + kc) * (W_CHUNKS * 8)), 0, W_CHUNKS * 16, 0x00020000);
 #pragma unroll
     for (int it = 0; it < W_ROUNDS; ++it) w_reg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16 + it * 4096, 0, 0);
-    if constexpr (XF != 0) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) cf_reg[q] = __builtin_amdgcn_raw_buffer_load_b128(cf_rsrc(), (unsigned)((kc * 16 + hh * 8) * 8 + q * 16), 0, 0);
-    }
   };
   auto commit = [&]() {
 #pragma unroll
     for (int it = 0; it < IN_ROUNDS; ++it) {
       const int p = it * 256 + tid;
-      if constexpr (XF != 0) {  // z = ELU(ca * y + cb) per channel, zero outside the volume (the padding is of z, not of y)
-        const eltx8 yv = __builtin_bit_cast(eltx8, in_reg[it]);
-        eltx8 zv;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const f32x4 c4 = __builtin_bit_cast(f32x4, cf_reg[k >> 1]);
-          const float u = fmaf(c4[(k & 1) * 2], (float)yv[k], c4[(k & 1) * 2 + 1]);
-          const float e = __builtin_amdgcn_exp2f(u * 1.44269504088896340736f) - 1.f;
-          zv[k] = (elt)(u > 0.f ? u : e);
-        }
-        in_reg[it] = goff[it] != OOB ? __builtin_bit_cast(u32x4, zv) : u32x4{0u, 0u, 0u, 0u};
-      }
       if (p < 2 * NV) in_lds[(p & 1) * NV + (p >> 1)] = in_reg[it];
     }
 #pragma unroll
@@ -266,7 +225,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   }
   const eltx2 ones = {(elt)1.0f, (elt)1.0f};
   const size_t ovol = (size_t)a.od * a.oh * a.ow;
-  STAMP(1);
 
   // fused GroupNorm statistics (see the epilogue): per channel PAIR, kept across the items of one sample when stats_accum
   float gs[4], gq[4];
@@ -360,16 +318,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 
   plan(ctile);
   prefetch(ccb, 0);
-  STAMP(2);
   while (true) {
     int n, tz0, ty0, tx0;
     origin(ctile, n, tz0, ty0, tx0);
     const int tis = ctile - n * tiles_per_sample;
     const int cb = ccb;
-#ifdef MEDNET_CONV_TIMING
-    stamp_item = item_no == 8 || (item_no == 0 && (int)blockIdx.x + 8 * (int)gridDim.x >= a.nitems);
-    ++item_no;
-#endif
     // the item after this one
     const int nbid = cur_bid + (int)gridDim.x;
     int ntile = 0, ncb2 = 0;
@@ -387,9 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 
     for (int kc = 0; kc < a.nkc; ++kc) {
       __syncthreads();  // every wave is done reading the previous LDS image (MFMA operands or the epilogue's rows)
-      if (kc < 2) STAMP(3 + 4 * kc);
       commit();
-      if (kc < 2) STAMP(4 + 4 * kc);
       __syncthreads();
       // What flies while chunk kc is on the matrix cores: the next chunk of this item, or the first chunk of the next
       // item.  Its 15 loads are NOT issued in one burst (measured: a burst blocks the wave's issue for ~3000 cycles
@@ -407,7 +358,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       const unsigned kill = do_pf ? 0u : OOB;
       const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)pn * a.id * a.ih * a.iw * a.cin), 0, a.bytes_x, 0x00020000);
       const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + ((size_t)pf_cb * a.nkc + pf_kc) * (W_CHUNKS * 8)), 0, W_CHUNKS * 16, 0x00020000);
-      if (kc < 2) STAMP(5 + 4 * kc);
       // Software-pipelined over the 27 taps: the fragments of tap t+1 (1 weight + NTW input ds_read_b128) are in flight
       // while tap t is on the matrix cores; sched_group_barrier pins that interleave (hipcc otherwise sinks each read to
       // just in front of its MFMA and exposes the LDS latency 108 times per chunk).
@@ -439,16 +389,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
           in_reg[tap] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, goff[tap] | kill, pf_kc * 32, 0);
         else if (tap < IN_ROUNDS + W_ROUNDS)
           w_reg[tap - IN_ROUNDS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(tid * 16 + (tap - IN_ROUNDS) * 4096) | kill, 0, 0);
-        else if (XF != 0 && tap < IN_ROUNDS + W_ROUNDS + 4)
-          cf_reg[XF ? tap - IN_ROUNDS - W_ROUNDS : 0] = __builtin_amdgcn_raw_buffer_load_b128(cf_rsrc(), (unsigned)((pf_kc * 16 + hh * 8) * 8 + (tap - IN_ROUNDS - W_ROUNDS) * 16) | kill, 0, 0);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[t] = MEDNET_MFMA_32x32x16(wa[cur], xb[cur][t], acc[t], 0, 0, 0);
         if (tap + PD < 27) __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);  // DS reads of tap+PD first ...
-        if (tap < IN_ROUNDS + W_ROUNDS + (XF ? 4 : 0)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // ... one staging load ...
+        if (tap < IN_ROUNDS + W_ROUNDS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // ... one staging load ...
         __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                          // ... then the MFMAs of tap
       }
       __builtin_amdgcn_s_setprio(0);
-      if (kc < 2) STAMP(6 + 4 * kc);
     }
 
     // ---- epilogue through LDS.  D[row = co][col = voxel]: the accumulator layout gives every lane four 8-byte pieces of
@@ -458,7 +405,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     // wave instruction when Cout = 32.  The GroupNorm partial sums come from the same LDS image (8 channels per lane).
     elt* out_lds = reinterpret_cast<elt*>(smem);  // [TZ*TY*TX voxels][32 co], reuses the input image
     __syncthreads();                                // every wave is done with the MFMA reads of the last chunk
-    STAMP(11);
     // (an opaque copy of the thread id: without it the compiler hoists the epilogue's ~30 addresses, which are the same
     //  for every item, out of the item loop and pays for that with spills in the tap loop)
     int etid = tid;
@@ -482,7 +428,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       }
     }
     __syncthreads();
-    STAMP(12);
     // GroupNorm partials are kept per channel PAIR (v_dot2c_f32_bf16: two exact elt products + fp32 add per
     // instruction, 8 instructions per 8-channel piece instead of 24): entry 2j of the partial row gets the sums of
     // channels 2j and 2j+1, entry 2j+1 is zero.  GroupNorm only ever adds the channels of a group, so this is exact
@@ -623,11 +568,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
         park[(8 + k) * 256] = ebq[k];
       }
     }
-    STAMP(13);
     // GroupNorm statistics fused into the producer (components.py:57 follows every conv of the 'c g .' orders): one row
     // per wave and brick, or -- accumulate mode -- nothing here: the sums stay in registers until the sample changes
     if (a.gn_partial && !a.stats_accum) flush_any(n, tis * 4 + e_wv, cb);
-    STAMP(14);
     if (!has_next) {
       if (a.gn_partial && a.stats_accum) {
         while (acc_n < a.n) {  // the last sample of this wave, then zero rows for the samples after it
@@ -641,10 +584,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     ctile = ntile;
     ccb = ncb2;
   }
-#ifdef MEDNET_CONV_TIMING
-  __builtin_amdgcn_s_waitcnt(0);  // all stores of this wave acknowledged
-  STAMP(15);
-#endif
 }
 
 // ================================================================================================== 32 -> 32 channels
@@ -677,11 +616,6 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u32x4* in_lds = reinterpret_cast<u32x4*>(smem);                           // [2 buffers][4 pieces][NVP]
   elt* wlds = reinterpret_cast<elt*>(smem + (size_t)2 * BUF_PIECES * 16) + (threadIdx.x >> 6) * 2048;  // 4 KB per wave
-#ifdef MEDNET_CONV_TIMING
-  bool stamp_item = false;
-  int item_no = 0;
-#endif
-  STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wv_s = __builtin_amdgcn_readfirstlane(wv);
@@ -891,7 +825,6 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
 #pragma unroll
     for (int it = 0; it < IN_ROUNDS; ++it) load_round(it, -1, n0, tz0, ty0, tx0, valid1);
   }
-  STAMP(1);
   int buf = 0;
   // (GNB) per-wave copy of the current sample's GroupNorm coefficients: 256 bytes inside the spare-slot area, of which only the
   // slots of threads 224..255 are ever written (spare_slot above)
@@ -903,10 +836,6 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
     origin(seq, n, tz0, ty0, tx0);
     const bool has_next = seq + seq_step < seq_end;
     const bool has_next2 = seq + 2 * seq_step < seq_end;
-#ifdef MEDNET_CONV_TIMING
-    stamp_item = item_no == 4;
-    ++item_no;
-#endif
     if constexpr (GNB || STATS) {  // a new sample: the sums so far go out (here, where no accumulator is alive)
       while (acc_n < n) {
         flush(acc_n);
@@ -929,7 +858,6 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
     int n2, tz2, ty2, tx2;  // brick j + 2
     origin(has_next2 ? seq + 2 * seq_step : 0, n2, tz2, ty2, tx2);
     __syncthreads();  // the brick is complete, and every wave is done reading the other buffer (the previous brick)
-    STAMP(3);
 
     // ---- output rows of this wave (its z-plane of the brick, 8 x-rows of 16 voxels)
     const int pj = lane & 3, ev = lane >> 2;  // row reads: voxel ev of 16 in an x-row, 16-byte piece pj
@@ -1003,9 +931,7 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
           // of its neighbours) until THEIR step 26.  This wave is past its own (the MFMAs of step 26 have consumed them), but
           // waves of a workgroup are not in lockstep: one barrier here -- every wave arrives within a few hundred cycles of
           // the others, one wave per SIMD -- makes "dead from step 27 on" true for the workgroup, not only for this wave.
-#ifndef MEDNET_C32_NO_MIDBARRIER  // (A/B builds only: profiles/r04_ab.md)
           if (t == 2 && s54 == 27) __builtin_amdgcn_s_barrier();
-#endif
           if (t == 2 && s54 >= 27 && s54 < 35) {  // GroupNorm input row s54 - 27 -> LDS (row planned at step 24 + row)
             const int j = s54 - 27;
             // (the resource is built here, not by the row_rsrc lambda: handed a lambda's return value, hipcc 7.2 silently drops
@@ -1021,7 +947,6 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    STAMP(5);
 
     // ---- epilogue: two halves of 64 voxels (4 x-rows) through the wave's private 4 KB of LDS -- no barrier
     if constexpr (ACT) {
@@ -1099,24 +1024,14 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
         // one-wave-per-SIMD kernel is exposed, instruction for instruction.
         typedef __attribute__((ext_vector_type(2))) float f32x2;
         const eltx8 vz = ok ? v : eltx8{};
-        // MEDNET_C32_EPI_PROBE (measurement builds only, `make epi_probe`, profiles/r04_ab.md section 10; results are WRONG):
-        // bit 0 drops the 64 v_exp_f32 per lane and brick, bit 1 the whole block -- what act' from a stored activation (bit 0) or
-        // an epilogue overlapped with the next tap loop (bit 1) could save at most
-#ifndef MEDNET_C32_EPI_PROBE
-#define MEDNET_C32_EPI_PROBE 0
-#endif
 #pragma unroll
-        for (int p2 = 0; p2 < ((MEDNET_C32_EPI_PROBE & 2) ? 0 : 4); ++p2) {
+        for (int p2 = 0; p2 < 4; ++p2) {
           const f32x2 yy = {(float)yrw[j][2 * p2], (float)yrw[j][2 * p2 + 1]};
           const f32x2 g = {(float)vz[2 * p2], (float)vz[2 * p2 + 1]};
           const f32x2 ca2 = {ca[2 * p2], ca[2 * p2 + 1]}, cb2 = {cbf[2 * p2], cbf[2 * p2 + 1]};
           const f32x2 u = ca2 * yy + cb2;
           const f32x2 ul = u * 1.44269504088896340736f;  // exp(u) = 2^(u * log2 e), as __expf
-#if MEDNET_C32_EPI_PROBE & 1
-          const f32x2 e = ul;
-#else
           const f32x2 e = {__builtin_amdgcn_exp2f(ul[0]), __builtin_amdgcn_exp2f(ul[1])};
-#endif
           const f32x2 negc = {gnb_neg, gnb_neg};
           const f32x2 gn = g * (gnb_elu ? e : negc);
           const f32x2 du = {u[0] > 0.f ? g[0] : gn[0], u[1] > 0.f ? g[1] : gn[1]};
@@ -1138,7 +1053,6 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
         }
       }
     }
-    STAMP(6);
     if (!has_next) {
       if constexpr (GNB || STATS) {
         while (acc_n < a.n) {
@@ -1151,7 +1065,6 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
     seq += seq_step;
     buf ^= 1;
   }
-  STAMP(15);
 }
 
 // ================================================================================================== ConvTranspose3d forward
@@ -1769,9 +1682,6 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   MEDNET_REQUIRE(!use_gnb || (gn_partial && (gnb.z ? STRIDE == 2 : (STRIDE == 1 && gnb.coef))), MEDNET_E_UNSUPPORTED,
                  "conv_mfma: fused GroupNorm-backward sums need a partial buffer and the forward affine (stride 1) or the block "
                  "output (stride 2)");
-#ifdef MEDNET_CONV_TIMING
-  a.dbg = (long long*)(((unsigned long long)(unsigned)tuning_option("conv_dbg_hi", 0) << 32) | (unsigned)tuning_option("conv_dbg_lo", 0));
-#endif
   a.x = (const elt*)x;
   a.wpk = (const elt*)sec;
   a.y = (elt*)y;
@@ -1797,7 +1707,6 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   a.stats_rows = 4 * a.tiles_z * a.tiles_y * a.tiles_x;
   if (gn_partial && STRIDE == 1) conv_stats_plan(n, od, oh, ow, cin, cout, a.stats_rows, a.stats_accum, use_gnb);
   a.xcd_chunk = 0;
-  a.xf_coef = nullptr;
   if constexpr (STRIDE == 1) {
     if (conv32_takes(a.ntiles, cin, cout, use_gnb)) {
       constexpr size_t lds32 = (size_t)2 * 4 * (HZ * HY * HX + 4) * 16 + 4 * 4096 + 256 * 16;
@@ -1881,23 +1790,6 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
       return check_launch("conv_mfma(gnb, stride 2)");
     }
   }
-#ifdef MEDNET_XFORM_PROBE  // (`make probe`: libmednet_hip_probe.so; the shipped library does not carry this instantiation)
-  if constexpr (STRIDE == 1) {
-    if (tuning_option("conv_xform_probe", 0) && !use_gnb && !add && act == MEDNET_ACT_NONE) {
-      // measurement probe (tools/probes/xform_probe.py): the GroupNorm apply + ELU of the layer in front inside commit()
-      a.xf_coef = (const float*)(((unsigned long long)(unsigned)tuning_option("conv_xf_hi", 0) << 32) | (unsigned)tuning_option("conv_xf_lo", 0));
-      MEDNET_REQUIRE(a.xf_coef != nullptr, MEDNET_E_SHAPE, "conv_xform_probe: set conv_xf_hi / conv_xf_lo to the coefficient tensor");
-      static bool attr_xf = false;
-      if (!attr_xf) {
-        if (hipFuncSetAttribute((const void*)conv_mfma_kernel<1, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-          return fail(MEDNET_E_HIP, "conv_mfma: cannot raise dynamic LDS to %zu", lds);
-        attr_xf = true;
-      }
-      hipLaunchKernelGGL((conv_mfma_kernel<1, false, 1>), dim3(grid), dim3(256), lds, s, a);
-      return check_launch("conv_mfma(xform probe)");
-    }
-  }
-#endif
   hipLaunchKernelGGL((conv_mfma_kernel<STRIDE>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_mfma");
 }
@@ -1968,139 +1860,6 @@ int launch_convt_dgrad_gn_mfma(const void* dy, const void* packed_section, void*
 }
 
 // ================================================================================================== weight gradient
-template <int STRIDE>
-struct WgTile;
-template <>
-struct WgTile<1> {
-  static constexpr int TZ = 2, TY = 8, TX = 16;
-};
-template <>
-struct WgTile<2> {
-  static constexpr int TZ = 1, TY = 4, TX = 16;
-};
-
-struct WgArgs {
-  const elt* A;  // loop grid tensor (ad,ah,aw; ka channels)
-  const elt* B;  // shifted tensor   (bd,bh,bw; kb channels)
-  float* part;    // [wg][27][32][32]
-  int n, ad, ah, aw, bd, bh, bw, ka, kb;
-  int tiles_z, tiles_y, tiles_x, ntiles;
-  int nab, nbb, splits;
-  int ablate;  // timing-only experiments ("wgrad_ablate"): 1 stage only the first brick, 2 skip the MFMA loop
-  unsigned bytesA, bytesB;  // buffer-resource sizes (tensors < 4 GB)
-};
-
-template <int STRIDE>
-__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
-  using G = WgTile<STRIDE>;
-  constexpr int TZ = G::TZ, TY = G::TY, TX = G::TX;
-  constexpr int HZ = STRIDE * (TZ - 1) + 3, HY = STRIDE * (TY - 1) + 3, HX = STRIDE * (TX - 1) + 3;
-  constexpr int NA = TZ * TY * TX, NB = HZ * HY * HX;
-  constexpr int A_ROUNDS = (NA * 4 + 255) / 256, B_ROUNDS = (NB * 4 + 255) / 256;
-  constexpr int KSTEPS = NA / 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  elt* A_lds = reinterpret_cast<elt*>(smem);            // [NA][32]
-  elt* B_lds = reinterpret_cast<elt*>(smem) + NA * 32;  // [NB][32]
-
-  const int pair = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
-  const int ab = pair / a.nbb, bb = pair % a.nbb;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, hk = lane >> 5;
-  // byte offset inside a 64-byte voxel row of the 4 channels this lane addresses in a transposing read
-  const int coloff = (16 * (g & 1) + 4 * p) * 2;
-
-  f32x16 acc[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-
-  for (int tile = split; tile < a.ntiles; tile += a.splits) {
-    int tt = tile;
-    const int tx0 = (tt % a.tiles_x) * TX;
-    tt /= a.tiles_x;
-    const int ty0 = (tt % a.tiles_y) * TY;
-    tt /= a.tiles_y;
-    const int tz0 = (tt % a.tiles_z) * TZ;
-    const int n = tt / a.tiles_z;
-    __syncthreads();  // previous brick fully consumed
-    // ---- stage A brick (zero outside the volume) and B halo brick
-#pragma unroll 4
-    for (int it = 0; it < A_ROUNDS; ++it) {
-      const int c = it * 256 + tid;
-      if (c < NA * 4) {
-        const int v = c >> 2, part = c & 3;
-        const int lx = v % TX, ly = (v / TX) % TY, lz = v / (TX * TY);
-        const int gz = tz0 + lz, gy = ty0 + ly, gx = tx0 + lx;
-        eltx8 val = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (gz < a.ad && gy < a.ah && gx < a.aw)
-          val = *reinterpret_cast<const eltx8*>(a.A + ((((size_t)n * a.ad + gz) * a.ah + gy) * a.aw + gx) * a.ka + ab * 32 + part * 8);
-        *reinterpret_cast<eltx8*>(A_lds + v * 32 + part * 8) = val;
-      }
-    }
-#pragma unroll 4
-    for (int it = 0; it < B_ROUNDS; ++it) {
-      const int c = it * 256 + tid;
-      if (c < NB * 4) {
-        const int v = c >> 2, part = c & 3;
-        const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
-        const int gz = STRIDE * tz0 - 1 + hz, gy = STRIDE * ty0 - 1 + hy, gx = STRIDE * tx0 - 1 + hx;
-        eltx8 val = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (gz >= 0 && gz < a.bd && gy >= 0 && gy < a.bh && gx >= 0 && gx < a.bw)
-          val = *reinterpret_cast<const eltx8*>(a.B + ((((size_t)n * a.bd + gz) * a.bh + gy) * a.bw + gx) * a.kb + bb * 32 + part * 8);
-        *reinterpret_cast<eltx8*>(B_lds + v * 32 + part * 8) = val;
-      }
-    }
-    __syncthreads();
-    // ---- contraction over the brick's voxels, 16 x-consecutive voxels per MFMA k-step.  Two operand sets: the 16
-    // transposing reads of k-step s+1 are in flight while the 7 MFMAs of k-step s run (sched_group_barrier pins it).
-    // Wave 3 has only 6 taps: its 7th slot recomputes tap 26 and is discarded at write-out.
-    const char* Ab = reinterpret_cast<const char*>(A_lds) + coloff;
-    const char* Bb = reinterpret_cast<const char*>(B_lds) + coloff;
-    int toff[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int tap = wv + 4 * i < 27 ? wv + 4 * i : 26;
-      toff[i] = (((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3) * 64;
-    }
-    auto load_set = [&](int ks, eltx8& fa, eltx8 (&fb)[7]) {
-      fa = tr_operand(Ab + (ks * TX + 8 * hk + q) * 64, 4 * 64);
-      const char* brow = Bb + (((STRIDE * (ks / TY)) * HY + STRIDE * (ks % TY)) * HX + STRIDE * (8 * hk + q)) * 64;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) fb[i] = tr_operand(brow + toff[i], 4 * STRIDE * 64);
-    };
-    eltx8 fa0, fa1, fb0[7], fb1[7];
-    load_set(0, fa0, fb0);
-    static_assert(KSTEPS % 2 == 0, "k-steps are consumed in pairs");
-    for (int ks = 0; ks < KSTEPS; ks += 2) {
-      load_set(ks + 1, fa1, fb1);
-#pragma unroll
-      for (int i = 0; i < 7; ++i) acc[i] = MEDNET_MFMA_32x32x16(fa0, fb0[i], acc[i], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
-      load_set(ks + 2 < KSTEPS ? ks + 2 : ks, fa0, fb0);  // (the last pair re-reads a valid step; result unused)
-#pragma unroll
-      for (int i = 0; i < 7; ++i) acc[i] = MEDNET_MFMA_32x32x16(fa1, fb1[i], acc[i], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
-    }
-  }
-  // ---- partial[wg][tap][a][b]: row a = (j&3) + 8*(j>>2) + 4*hk, col b = lane & 31
-  float* out = a.part + (size_t)blockIdx.x * 27 * 1024;
-  const int col = lane & 31;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int tap = wv + 4 * i;
-    if (tap < 27) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int row = (j & 3) + 8 * (j >> 2) + 4 * hk;
-        out[((size_t)tap * 32 + row) * 32 + col] = acc[i][j];
-      }
-    }
-  }
-}
-
 // ---- weight gradient, second generation (stride 1): 8 waves, one workgroup per CU, 4x8x16 bricks ---------------------
 // Measured on the first kernel: its time is the per-brick staging (2.8x halo at 2x8x16, no overlap inside the
 // workgroup), not the MFMAs.  Here the brick is twice as deep (halo 2.1x, half the fixed cost per MFMA), the 32 k-steps
@@ -2269,7 +2028,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
   }
 }
 
-static void wgrad2_plan(int n, int d, int h, int w, int ka, int kb, Wg2Args& a) {
+static void wgrad2_plan(int n, int d, int h, int w, int ka, int kb, int workgroups, Wg2Args& a) {
   a.tiles_z = (d + 3) / 4;
   a.tiles_y = (h + 7) / 8;
   a.tiles_x = (w + 15) / 16;
@@ -2279,18 +2038,18 @@ static void wgrad2_plan(int n, int d, int h, int w, int ka, int kb, Wg2Args& a) 
   a.nab = (ka + 31) / 32;  // a 16-channel operand is zero-padded to a 32-wide block by the buffer loads
   a.nbb = (kb + 31) / 32;
   const int pairs = a.nab * a.nbb;
-  // workgroups per launch: one per CU when the launch has the chip to itself; the trainer asks for HALF of them when the weight
-  // gradients run on their own stream beside the main one (train.use_side_stream): a workgroup takes a CU's whole
-  // register file, so 256 of them lock every kernel of the main stream out until they retire
-  const int asked = tuning_option("wgrad_wgs", 0), target = asked > 0 ? asked : 256;
+  // workgroups per launch (the caller's `workgroups` argument, 0 = one per CU: the launch has the chip to itself); the trainer
+  // asks for HALF of them when the weight gradients run on their own stream beside the main one (train.use_side_stream, DESIGN
+  // 12.4): a workgroup takes a CU's whole register file, so 256 of them lock every kernel of the main stream out until they retire
+  const int target = workgroups > 0 ? workgroups : 256;
   int splits = (target + pairs - 1) / pairs;
   if (splits > a.ntiles) splits = a.ntiles;
   if (splits < 1) splits = 1;
   a.splits = splits;
 }
-static size_t wgrad2_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+static size_t wgrad2_ws_bytes(int n, int d, int h, int w, int cin, int cout, int workgroups) {
   Wg2Args a;
-  wgrad2_plan(n, d, h, w, cout, cin, a);
+  wgrad2_plan(n, d, h, w, cout, cin, workgroups, a);
   return (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
 }
 
@@ -2352,83 +2111,22 @@ bool wgrad_mfma_fits(int n, int d, int h, int w, int cmax, int scale) {
   return (double)d * h * w * scale * cmax * 2.0 < 4294960000.0;
 }
 
-template <int STRIDE>
-static void wgrad_plan(int n, int ad, int ah, int aw, int ka, int kb, WgArgs& a) {
-  using G = WgTile<STRIDE>;
-  a.tiles_z = (ad + G::TZ - 1) / G::TZ;
-  a.tiles_y = (ah + G::TY - 1) / G::TY;
-  a.tiles_x = (aw + G::TX - 1) / G::TX;
-  a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
-  a.nab = ka / 32;
-  a.nbb = kb / 32;
-  const int pairs = a.nab * a.nbb;
-  int splits = (512 + pairs - 1) / pairs;  // ~2 workgroups per CU resident: one wave of workgroups, 56 MB of partials
-  if (splits > a.ntiles) splits = a.ntiles;
-  if (splits < 1) splits = 1;
-  a.splits = splits;
-}
-
-size_t wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize) {
+size_t wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize, int workgroups) {
   if (ksize != 3 || cin % 16 || cout % 16) return 0;
-  size_t v1 = 0;
-  if (cin % 32 == 0 && cout % 32 == 0) {  // the first-generation kernel (option wgrad_v2=0) has no channel padding
-    WgArgs a;
-    wgrad_plan<1>(n, d, h, w, cout, cin, a);
-    v1 = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
-  }
-  const size_t v2 = wgrad2_ws_bytes(n, d, h, w, cin, cout);
-  return v1 > v2 ? v1 : v2;
-}
-
-template <int STRIDE>
-static int launch_wg(const void* A, const void* B, float* dw, int n, int ad, int ah, int aw, int bd, int bh, int bw,
-                     int ka, int kb, void* ws, size_t ws_bytes, hipStream_t s) {
-  using G = WgTile<STRIDE>;
-  constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
-  constexpr size_t lds = ((size_t)G::TZ * G::TY * G::TX + (size_t)HZ * HY * HX) * 64;
-  static_assert(lds <= 80 * 1024, "two workgroups must fit one CU");
-  WgArgs a;
-  a.A = (const elt*)A;
-  a.B = (const elt*)B;
-  a.part = (float*)ws;
-  a.n = n; a.ad = ad; a.ah = ah; a.aw = aw; a.bd = bd; a.bh = bh; a.bw = bw; a.ka = ka; a.kb = kb;
-  wgrad_plan<STRIDE>(n, ad, ah, aw, ka, kb, a);
-  a.ablate = tuning_option("wgrad_ablate", 0);
-  a.bytesA = (unsigned)((size_t)n * ad * ah * aw * ka * 2);
-  a.bytesB = (unsigned)((size_t)n * bd * bh * bw * kb * 2);
-  const size_t need = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
-  MEDNET_REQUIRE(ws_bytes >= need, MEDNET_E_WORKSPACE, "wgrad_mfma: workspace %zu < %zu", ws_bytes, need);
-  static bool attr_set[3] = {false, false, false};
-  if (!attr_set[STRIDE]) {
-    if (hipFuncSetAttribute((const void*)wgrad_mfma_kernel<STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
-      return fail(MEDNET_E_HIP, "wgrad_mfma: cannot raise dynamic LDS to %zu", lds);
-    attr_set[STRIDE] = true;
-  }
-  hipLaunchKernelGGL((wgrad_mfma_kernel<STRIDE>), dim3(a.nab * a.nbb * a.splits), dim3(256), lds, s, a);
-  int rc = check_launch("wgrad_mfma");
-  if (rc) return rc;
-  const size_t total = (size_t)a.nab * a.nbb * 1024 * 27;
-  if (a.splits < 4) hipLaunchKernelGGL(wgrad_mfma_reduce_kernel_few, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, ka, kb,
-                     a.nbb, a.splits);
-  else hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.part, dw, ka, kb,
-                     a.nbb, a.splits);
-  return check_launch("wgrad_mfma_reduce");
+  return wgrad2_ws_bytes(n, d, h, w, cin, cout, workgroups);
 }
 
 int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, int dtype,
-                      void* ws, size_t ws_bytes, hipStream_t s) {
+                      void* ws, size_t ws_bytes, hipStream_t s, int workgroups) {
   (void)dtype;
   // conv: A = dy (Cout rows), B = x (Cin cols) shifted by tap - 1
-  if (!tuning_option("wgrad_v2", 1) && cin % 32 == 0 && cout % 32 == 0)
-    return launch_wg<1>(dy, x, dw, n, d, h, w, d, h, w, cout, cin, ws, ws_bytes, s);
   constexpr size_t lds = ((size_t)4 * 8 * 16 + 6 * 10 * 18) * 64;
   Wg2Args a;
   a.A = (const elt*)dy;
   a.B = (const elt*)x;
   a.part = (float*)ws;
   a.n = n; a.d = d; a.h = h; a.w = w; a.ka = cout; a.kb = cin;
-  wgrad2_plan(n, d, h, w, cout, cin, a);
+  wgrad2_plan(n, d, h, w, cout, cin, workgroups, a);
   a.bytesA = (unsigned)((size_t)d * h * w * cout * 2);  // per sample
   a.bytesB = (unsigned)((size_t)d * h * w * cin * 2);
   const size_t need = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
@@ -2820,7 +2518,7 @@ __global__ __launch_bounds__(512, 2) void convt_wgrad_mfma2_kernel(Ct2Args a) {
   }
 }
 
-static void ct2_plan(int n, int d, int h, int w, int ka, int kb, Ct2Args& a) {
+static void ct2_plan(int n, int d, int h, int w, int ka, int kb, int workgroups, Ct2Args& a) {
   a.tiles_z = (d + 1) / 2;
   a.tiles_y = (h + 3) / 4;
   a.tiles_x = (w + 15) / 16;
@@ -2830,36 +2528,29 @@ static void ct2_plan(int n, int d, int h, int w, int ka, int kb, Ct2Args& a) {
   a.nab = (ka + 31) / 32;
   a.nbb = (kb + 31) / 32;
   const int pairs = a.nab * a.nbb;
-  const int asked = tuning_option("wgrad_wgs", 0);
-  int splits = ((asked > 0 ? asked : 256) + pairs - 1) / pairs;  // one workgroup per CU (or per second CU: wgrad2_plan)
+  int splits = ((workgroups > 0 ? workgroups : 256) + pairs - 1) / pairs;  // one workgroup per CU (or what the caller asks for: wgrad2_plan)
   if (splits > a.ntiles) splits = a.ntiles;
   if (splits < 1) splits = 1;
   a.splits = splits;
 }
 
-size_t convt_wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+size_t convt_wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int workgroups) {
   if (cin % 32 || cout % 32) return 0;
-  WgArgs a;
-  wgrad_plan<2>(n, d, h, w, cin, cout, a);
-  const size_t v1 = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
   Ct2Args b;
-  ct2_plan(n, d, h, w, cin, cout, b);
-  const size_t v2 = (size_t)b.nab * b.nbb * b.splits * 27 * 1024 * sizeof(float);
-  return v1 > v2 ? v1 : v2;
+  ct2_plan(n, d, h, w, cin, cout, workgroups, b);
+  return (size_t)b.nab * b.nbb * b.splits * 27 * 1024 * sizeof(float);
 }
 
 int launch_convt_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout,
-                            void* ws, size_t ws_bytes, hipStream_t s) {
+                            void* ws, size_t ws_bytes, hipStream_t s, int workgroups) {
   // convT: A = x (Cin rows) on the (d,h,w) grid, B = dy (Cout cols) on the (2d,2h,2w) grid at 2v - 1 + tap
-  if (!tuning_option("convt_wgrad_v2", 1))
-    return launch_wg<2>(x, dy, dw, n, d, h, w, 2 * d, 2 * h, 2 * w, cin, cout, ws, ws_bytes, s);
   constexpr size_t lds = 16384 + 8 * 128 * 64;
   Ct2Args a;
   a.A = (const elt*)x;
   a.B = (const elt*)dy;
   a.part = (float*)ws;
   a.n = n; a.d = d; a.h = h; a.w = w; a.ka = cin; a.kb = cout;
-  ct2_plan(n, d, h, w, cin, cout, a);
+  ct2_plan(n, d, h, w, cin, cout, workgroups, a);
   a.bytesA = (unsigned)((size_t)d * h * w * cin * 2);
   a.bytesB = (unsigned)((size_t)8 * d * h * w * cout * 2);
   const size_t need = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);

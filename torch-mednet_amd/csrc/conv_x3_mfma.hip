@@ -38,19 +38,6 @@ struct HiLo {
 };
 // 8 fp32 (two 16-byte loads) -> 8 high + 8 low bf16
 __device__ __forceinline__ HiLo split8(u32x4 ua, u32x4 ub) {
-#ifdef MEDNET_X3_SPLIT_PROBE  // (measurement build, `make x3_probe`: what operands that ARRIVE split would cost at most -- the high
-  {                           //  halves by one conversion each (sane magnitudes: the matrix cores' power depends on the operands),
-    const f4 a = __builtin_bit_cast(f4, ua), b = __builtin_bit_cast(f4, ub);  // the low halves a copy; results are wrong)
-    HiLo p;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      p.hi[j] = (bf16)a[j];
-      p.hi[j + 4] = (bf16)b[j];
-    }
-    p.lo = p.hi;
-    return p;
-  }
-#endif
   const f4 a = __builtin_bit_cast(f4, ua), b = __builtin_bit_cast(f4, ub);
   HiLo r;
 #pragma unroll
@@ -435,12 +422,9 @@ static int x3_grid() {
   if (cus <= 0) cus = 256;
   return (cus + 7) / 8 * 8;
 }
-// workgroups of a weight-gradient launch: about one per CU, or what the trainer asks for when the launch runs beside the main
-// stream (option wgrad_wgs, see wgrad2_plan in conv_mfma.hip)
-static int x3_wgrad_target() {
-  const int asked = tuning_option("wgrad_wgs", 0);
-  return asked > 0 ? asked : x3_grid();
-}
+// workgroups of a weight-gradient launch: about one per CU, or what the caller asks for (`workgroups` > 0: the trainer, when the
+// launch runs beside the main stream; see wgrad2_plan in conv_mfma.hip)
+static int x3_wgrad_target(int workgroups) { return workgroups > 0 ? workgroups : x3_grid(); }
 
 bool conv_x3_enabled() { return tuning_option("x3", 1) != 0; }
 bool conv_x3_supported(int cin, int cout, int ksize) { return ksize == 3 && cin % 16 == 0 && cout % 16 == 0; }
@@ -1094,7 +1078,7 @@ __global__ __launch_bounds__(256) void wgrad_x3_reduce_kernel(const float* __res
     dw[((size_t)(ab * 32 + a32) * kb + bb * 32 + b32) * 27 + tap] = (sh[threadIdx.x] + sh[64 + threadIdx.x]) + (sh[128 + threadIdx.x] + sh[192 + threadIdx.x]);
 }
 
-static void wgx3_plan(int n, int d, int h, int w, int ka, int kb, WgX3Args& a) {
+static void wgx3_plan(int n, int d, int h, int w, int ka, int kb, int workgroups, WgX3Args& a) {
   a.tiles_z = (d + 3) / 4;
   a.tiles_y = (h + 3) / 4;
   a.tiles_x = (w + 15) / 16;
@@ -1103,15 +1087,15 @@ static void wgx3_plan(int n, int d, int h, int w, int ka, int kb, WgX3Args& a) {
   a.nab = (ka + 31) / 32;
   a.nbb = (kb + 31) / 32;
   const int pairs = a.nab * a.nbb;
-  int splits = (x3_wgrad_target() + pairs - 1) / pairs;  // about one workgroup per CU (or per second CU beside the main stream)
+  int splits = (x3_wgrad_target(workgroups) + pairs - 1) / pairs;  // about one workgroup per CU (or per second CU beside the main stream)
   if (splits > a.ntiles) splits = a.ntiles;
   if (splits < 1) splits = 1;
   a.splits = splits;
 }
 
-size_t wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+size_t wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout, int workgroups) {
   WgX3Args a;
-  wgx3_plan(n, d, h, w, cout, cin, a);
+  wgx3_plan(n, d, h, w, cout, cin, workgroups, a);
   return (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
 }
 
@@ -1262,7 +1246,7 @@ int launch_wgrad_c1_x3(const void* x, const void* dy, float* part, int n, int d,
 }
 
 int launch_wgrad_x3(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, void* ws,
-                    size_t ws_bytes, hipStream_t s) {
+                    size_t ws_bytes, hipStream_t s, int workgroups) {
   constexpr size_t lds = ((size_t)4 * 4 * 16 + 6 * 6 * 18) * 64 * 2;
   static_assert(lds <= 160 * 1024, "one workgroup per CU");
   MEDNET_REQUIRE(cin % 16 == 0 && cout % 16 == 0, MEDNET_E_UNSUPPORTED, "wgrad_x3: channels %d -> %d", cin, cout);
@@ -1271,7 +1255,7 @@ int launch_wgrad_x3(const void* x, const void* dy, float* dw, int n, int d, int 
   a.B = (const float*)x;
   a.part = (float*)ws;
   a.n = n; a.d = d; a.h = h; a.w = w; a.ka = cout; a.kb = cin;
-  wgx3_plan(n, d, h, w, cout, cin, a);
+  wgx3_plan(n, d, h, w, cout, cin, workgroups, a);
   a.bytesA = (unsigned)((size_t)d * h * w * cout * 4);
   a.bytesB = (unsigned)((size_t)d * h * w * cin * 4);
   const size_t need = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
@@ -1476,7 +1460,7 @@ __global__ __launch_bounds__(256) void convt_wgrad_x3_reduce_kernel(const float*
 }
 
 static int ctwg_ca(int cin) { return cin % 64 == 0 ? 2 : 1; }
-static void ctwg_plan(int n, int d, int h, int w, int cin, int cout, CtWgX3Args& a) {
+static void ctwg_plan(int n, int d, int h, int w, int cin, int cout, int workgroups, CtWgX3Args& a) {
   const int ca32 = ctwg_ca(cin) * 32;
   a.tiles_z = (d + 1) / 2;
   a.tiles_y = (h + 1) / 2;
@@ -1486,23 +1470,23 @@ static void ctwg_plan(int n, int d, int h, int w, int cin, int cout, CtWgX3Args&
   a.nab = (cin + ca32 - 1) / ca32;
   a.nbb = (cout + 31) / 32;
   const int pairs = a.nab * a.nbb;
-  int splits = (x3_wgrad_target() + pairs - 1) / pairs;
+  int splits = (x3_wgrad_target(workgroups) + pairs - 1) / pairs;
   if (splits > a.ntiles) splits = a.ntiles;
   if (splits < 1) splits = 1;
   a.splits = splits;
 }
-size_t convt_wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+size_t convt_wgrad_x3_ws_bytes(int n, int d, int h, int w, int cin, int cout, int workgroups) {
   CtWgX3Args a;
-  ctwg_plan(n, d, h, w, cin, cout, a);
+  ctwg_plan(n, d, h, w, cin, cout, workgroups, a);
   return (size_t)a.nab * a.nbb * a.splits * 27 * ctwg_ca(cin) * 1024 * sizeof(float);
 }
 int launch_convt_wgrad_x3(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, void* ws,
-                          size_t ws_bytes, hipStream_t s) {
+                          size_t ws_bytes, hipStream_t s, int workgroups) {
   MEDNET_REQUIRE(cin % 16 == 0 && cout % 16 == 0, MEDNET_E_UNSUPPORTED, "convt_wgrad_x3: channels %d -> %d", cin, cout);
   CtWgX3Args a;
   a.x = (const float*)x; a.dy = (const float*)dy; a.part = (float*)ws;
   a.n = n; a.d = d; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
-  ctwg_plan(n, d, h, w, cin, cout, a);
+  ctwg_plan(n, d, h, w, cin, cout, workgroups, a);
   a.bytes_x = (unsigned)((size_t)d * h * w * cin * 4);
   a.bytes_dy = (unsigned)((size_t)d * h * w * 8 * cout * 4);
   const int ca = ctwg_ca(cin);

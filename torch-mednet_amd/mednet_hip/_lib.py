@@ -60,12 +60,12 @@ SIGNATURES = {
     "mednet_convt3d_dgrad_gn_rows": (_i, [_i] * 8),
     "mednet_convt3d_dgrad_gn": (_i, [_vp] * 5 + [_i, _vp] + [_i] * 8 + [_vp]),
     "mednet_pool2_bwd_gn": (_i, [_vp] * 5 + [_i, _vp] + [_i] * 7 + [_vp]),
-    "mednet_conv3d_wgrad_ws_bytes": (_sz, [_i] * 7),
-    "mednet_conv3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp, _sz, _vp]),
+    "mednet_conv3d_wgrad_ws_bytes": (_sz, [_i] * 8),
+    "mednet_conv3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _sz, _vp]),
     "mednet_convt3d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "mednet_convt3d_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 9 + [_vp]),
-    "mednet_convt3d_wgrad_ws_bytes": (_sz, [_i] * 6),
-    "mednet_convt3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 9 + [_vp, _sz, _vp]),
+    "mednet_convt3d_wgrad_ws_bytes": (_sz, [_i] * 7),
+    "mednet_convt3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 10 + [_vp, _sz, _vp]),
     "mednet_gn_ws_bytes": (_sz, [_i, _i, _sz]),
     "mednet_gn_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _f, _i, _vp, _sz, _vp]),
     "mednet_gn_act_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _vp]),

@@ -154,11 +154,11 @@ def _conv_bwd(x, dy, packed, weight_p, need_dx, add=None, gnb=None):
     if not WGRAD_FIRST:
         dgrad()
     dw, direct = ops._grad_target(weight_p, (cout, cin, 3, 3, 3))
-    with ops._OnSide(ops.SIDE["enabled"] and direct, dy.device, x, dy):
-        ws = L.workspace(lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, 3), dy.device)
+    with ops._OnSide(ops.SIDE["enabled"] and direct, dy.device, x, dy) as side:
+        ws = L.workspace(lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, 3, side.workgroups), dy.device)
         L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, n, d, h, w, cin, cout, 3, L.dt(x),
-                                        L.NDHWC, L.dt(dy), L.NDHWC, config.conv_algo(), ws.data_ptr(), ws.numel(), L.stream()),
-                "conv3d_wgrad")
+                                        L.NDHWC, L.dt(dy), L.NDHWC, config.conv_algo(), side.workgroups, ws.data_ptr(), ws.numel(),
+                                        L.stream()), "conv3d_wgrad")
     if WGRAD_FIRST:
         dgrad()
     return dx, (None if direct else dw), partial
@@ -227,10 +227,10 @@ class ResBlockFn(Function):
 class PoolStash:
     """Carried by a block output whose consumer is a 2x2x2 pooling of `mode`: the pooled tensor the block's last apply pass wrote
     beside the output (or None when the shape did not allow it).  ops.SkipPool2Fn / Pool2Fn take it instead of launching."""
-    __slots__ = ("mode", "pooled")
+    __slots__ = ("mode", "pooled", "version")
 
     def __init__(self, mode):
-        self.mode, self.pooled = mode, None
+        self.mode, self.pooled, self.version = mode, None, -1  # version: the output's `_version` when the stash was attached
 
 
 def res_block(x, convs, norms, groups, eps, act, pool_mode=None):
@@ -245,5 +245,6 @@ def res_block(x, convs, norms, groups, eps, act, pool_mode=None):
     if hook is not None:
         out._mednet_gn3 = hook  # see ops.GN3Hook: the consumer of `out` may take GroupNorm-3's first backward pass
     if stash is not None and stash.pooled is not None:
+        stash.version = out._version
         out._mednet_pooled = stash
     return out

@@ -72,9 +72,11 @@ def side_stream(device):
                 chosen = c
                 break
         SIDE["stream"] = chosen if chosen is not None else cands[0]
-        SIDE["overlaps"] = chosen is not None
+        # True / False: MEASURED; None: the probe did not run (hipGraph capture, MEDNET_SIDE_PROBE=0) -- the first new stream is
+        # taken on trust and may share the compute stream's hardware queue (bench.py reports the tri-state)
+        SIDE["overlaps"] = (chosen is not None) if probe else None
         SIDE["candidates_tried"] = len(cands)
-        if chosen is None:  # no queue to itself: one workgroup per CU again (half the chip for twice as long gains nothing in turns)
+        if probe and chosen is None:  # no queue to itself: one workgroup per CU again (half the chip for twice as long gains nothing in turns)
             SIDE["wgrad_wgs"] = 0
     return SIDE["stream"]
 
@@ -90,6 +92,9 @@ class _OnSide:
 
     def __init__(self, active, device, *tensors):
         self.active, self.device, self.tensors = active, device, tensors
+        # the `workgroups` argument of the weight-gradient launch AND its workspace query inside this context (0: the library's
+        # plan, one workgroup per CU -- a weight gradient launched on the main stream keeps the whole chip)
+        self.workgroups = 0
 
     def __enter__(self):
         if self.active:
@@ -109,15 +114,12 @@ class _OnSide:
             self.ctx.__enter__()
             t = self.tensors[-1] if self.tensors else None
             vox = (t.shape[0] * t[0, 0].numel()) if (t is not None and t.dim() == 5) else 1 << 40
-            self.half = SIDE["wgrad_wgs"] > 0 and vox >= SIDE_MIN_VOXELS
-            if self.half:  # (scoped: a weight gradient launched on the main stream keeps the whole chip)
-                L.lib().mednet_set_option(b"wgrad_wgs", SIDE["wgrad_wgs"])
+            if SIDE["wgrad_wgs"] > 0 and vox >= SIDE_MIN_VOXELS:
+                self.workgroups = SIDE["wgrad_wgs"]
         return self
 
     def __exit__(self, *exc):
         if self.active:
-            if self.half:
-                L.lib().mednet_set_option(b"wgrad_wgs", 0)
             self.ctx.__exit__(*exc)
         return False
 
@@ -355,13 +357,13 @@ class Conv3dFn(Function):
             if has_bias and ctx.needs_input_grad[2]:
                 db, direct_b = _grad_target(bias, (cout,))
             on_side = SIDE["enabled"] and direct_w and (db is None or direct_b)
-            with _OnSide(on_side, dy.device, xin, dy):
-                nbytes = lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, ksize)
+            with _OnSide(on_side, dy.device, xin, dy) as side:
+                nbytes = lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, ksize, side.workgroups)
                 ws = L.workspace(nbytes, dy.device)
                 L.check(lib.mednet_conv3d_wgrad(xin.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), n, d, h, w, cin,
                                                 cout, ksize, L.dt(xin), L.NDHWC, L.dt(dy),
-                                                L.NCDHW if out_planar else L.NDHWC, config.conv_algo(), ws.data_ptr(),
-                                                ws.numel(), L.stream()), "conv3d_wgrad")
+                                                L.NCDHW if out_planar else L.NDHWC, config.conv_algo(), side.workgroups,
+                                                ws.data_ptr(), ws.numel(), L.stream()), "conv3d_wgrad")
         return dx, (None if direct_w else dw), (None if direct_b else db), None, None, None, None, None
 
 
@@ -506,11 +508,11 @@ class ConvT3dFn(Function):
             if has_bias and ctx.needs_input_grad[2]:
                 db, direct_b = _grad_target(bias, (cout,))
             on_side = SIDE["enabled"] and direct_w and (db is None or direct_b)
-            with _OnSide(on_side, dy.device, x, dy):
-                ws = L.workspace(lib.mednet_convt3d_wgrad_ws_bytes(n, d, h, w, cin, cout), dy.device)
+            with _OnSide(on_side, dy.device, x, dy) as side:
+                ws = L.workspace(lib.mednet_convt3d_wgrad_ws_bytes(n, d, h, w, cin, cout, side.workgroups), dy.device)
                 L.check(lib.mednet_convt3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), n, d, h, w, cin, cout,
-                                                 L.dt(x), L.dt(dy), config.conv_algo(), ws.data_ptr(), ws.numel(), L.stream()),
-                        "convt3d_wgrad")
+                                                 L.dt(x), L.dt(dy), config.conv_algo(), side.workgroups, ws.data_ptr(), ws.numel(),
+                                                 L.stream()), "convt3d_wgrad")
         if has_skip and ctx.needs_input_grad[3]:
             dskip = dy if dy.dtype == skip_dtype else dy.to(skip_dtype)
         if debug.TRACE is not None:
@@ -740,7 +742,10 @@ class Pool2Fn(Function):
         x = to_cl(_as_act(x))
         n, c, d, h, w = x.shape
         stash = getattr(x0, "_mednet_pooled", None) if x is x0 else None
-        if stash is not None and stash.mode == mode and stash.pooled is not None and stash.pooled.dtype == x.dtype:
+        # (the stash pooled the values the block WROTE: an in-place change of the output since then -- a forward hook's clamp_(),
+        #  user code between the levels -- shows in the version counter, and the pooling kernel runs on the current values)
+        if (stash is not None and stash.mode == mode and stash.pooled is not None and stash.pooled.dtype == x.dtype
+                and stash.version == x0._version):
             y, stash.pooled = stash.pooled, None  # written by the producing block's last apply pass (block.PoolStash)
         else:
             y = empty_cl(n, c, d // 2, h // 2, w // 2, x.dtype, x.device)
@@ -776,7 +781,10 @@ class SkipPool2Fn(Function):
         x = to_cl(_as_act(x))
         n, c, d, h, w = x.shape
         stash = getattr(x0, "_mednet_pooled", None) if x is x0 else None
-        if stash is not None and stash.mode == mode and stash.pooled is not None and stash.pooled.dtype == x.dtype:
+        # (the stash pooled the values the block WROTE: an in-place change of the output since then -- a forward hook's clamp_(),
+        #  user code between the levels -- shows in the version counter, and the pooling kernel runs on the current values)
+        if (stash is not None and stash.mode == mode and stash.pooled is not None and stash.pooled.dtype == x.dtype
+                and stash.version == x0._version):
             y, stash.pooled = stash.pooled, None  # written by the producing block's last apply pass (block.PoolStash)
         else:
             y = empty_cl(n, c, d // 2, h // 2, w // 2, x.dtype, x.device)

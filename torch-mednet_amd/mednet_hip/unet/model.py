@@ -124,11 +124,21 @@ class _UNetCore(*((_Base,) if _Base is not nn.Module else (_CheckpointCompat, nn
             else:  # x is both the previous level's skip tensor and this level's pooling input (model.py:194-199)
                 # (x is re-bound to the level's output and skips[0] to the returned skip tensor: the previous output has no
                 #  other consumer, which lets the pooling backward leave its gradient unwritten, ops.SkipPool2Fn)
-                skips[0], x = enc(x, with_skip=True, pool_next=pool_next, sole_consumer=True)
+                # ... provided nobody else SAW that output: a forward hook on the level that produced it (or a global module
+                # hook) may have handed it to an auxiliary / deep-supervision loss, and then its gradient must be materialised
+                skips[0], x = enc(x, with_skip=True, pool_next=pool_next, sole_consumer=not _has_forward_hooks(self.encoders[i - 1]))
             skips.insert(0, x)
         for dec, skip in zip(self.decoders, skips[1:]):
             x = dec(skip, x)
         return x
+
+
+def _has_forward_hooks(module) -> bool:
+    """Could anything but this package's own forward have received `module`'s output (or that of one of its children)?"""
+    import torch.nn.modules.module as M
+    if getattr(M, "_global_forward_hooks", None) or getattr(M, "_global_forward_hooks_always_called", None):
+        return True
+    return any(m._forward_hooks for m in module.modules())
 
 
 class UNet3D(_UNetCore):
