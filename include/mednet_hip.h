@@ -167,6 +167,10 @@ int mednet_pool2_bwd_gn(const void* dy, const void* x, const void* add, void* dx
  * per-workgroup partial slabs); another value changes the rounding of the sums, once.  Kernels that do not split their work
  * this way (first layer, 1x1x1 head, direct kernels) ignore it. */
 size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize, int workgroups);
+/* 1 if this weight gradient runs on the co-resident kernel (wgrad_mfma4_kernel: 4 waves of < 256 registers, 104 KB of LDS --
+ * bandwidth-bound kernels of another stream run on the same CUs beside it); 0 if it takes its CUs whole.  A caller that runs
+ * weight gradients on a second stream passes workgroups = 0 (all CUs) in the first case and about half the CUs in the second. */
+int mednet_conv3d_wgrad_coresident(int n, int d, int h, int w, int cin, int cout, int ksize, int x_dtype, int dy_dtype, int algo);
 int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
                         int cin, int cout, int ksize, int x_dtype, int x_layout, int dy_dtype, int dy_layout,
                         int algo, int workgroups, void* ws, size_t ws_bytes, mednet_stream stream);

@@ -702,6 +702,50 @@ def test_conv3d_mfma_fwd_dgrad_wgrad(n, cin, cout, shape):
     assert_close(dw, dwd, 2e-4, "dw vs direct kernel")
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("n,cin,cout,shape,wgs", [
+    (1, 32, 32, (8, 8, 16), 0),        # one column, one slab
+    (2, 32, 32, (9, 11, 21), 0),       # ragged in every dimension, two samples
+    (1, 32, 32, (40, 16, 32), 0),      # two z-slabs (20 planes each)
+    (2, 64, 64, (16, 16, 32), 0),      # four channel-block pairs
+    (1, 16, 48, (12, 9, 17), 0),       # 16-channel sides: half-filled channel blocks
+    (4, 32, 32, (32, 32, 64), 128),    # the trainer's side-stream plan
+    (2, 64, 32, (24, 24, 48), 24),     # a workgroup count that does not divide the items (and not a multiple of 8)
+    (1, 128, 96, (8, 8, 16), 0),       # more pairs than items per pair: one workgroup per pair
+])
+def test_co_resident_weight_gradient_kernel(mode, n, cin, cout, shape, wgs):
+    """wgrad_mfma4_kernel (round 5: one wave per SIMD, z-columns through an LDS-DMA ring, option wgrad_v4) against ATen in fp32 on
+    the same 16-bit inputs and against wgrad_mfma2_kernel (same products, another summation order; wgrad_v4=0 selects it)."""
+    from mednet_hip import _lib as L
+    lib = L.lib()
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[mode]
+    code = {"bf16": L.BF16, "fp16": L.F16}[mode]
+    tag = f"wg4{n}{cin}{cout}{shape}"
+    x = rnd(tag + "x", n, cin, *shape).to(dt)
+    dy = rnd(tag + "g", n, cout, *shape).to(dt)
+    xr = x.float()
+    wr = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    (F.conv3d(xr, wr, None, padding=1) * dy.float()).sum().backward()
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    dyg = dy.to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    d, h, w = shape
+    out = {}
+    try:
+        for v4 in (1, 0):
+            lib.mednet_set_option(b"wgrad_v4", v4)
+            ws = torch.empty(lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, 3, wgs), dtype=torch.uint8, device=DEV)
+            ws.fill_(0xFF)  # (NaN pattern: a slab element nobody wrote would show)
+            dw = torch.full((cout, cin, 3, 3, 3), float("nan"), device=DEV)
+            L.check(lib.mednet_conv3d_wgrad(xg.data_ptr(), dyg.data_ptr(), dw.data_ptr(), None, n, d, h, w, cin, cout, 3, code, L.NDHWC,
+                                            code, L.NDHWC, L.ALGO_MFMA, wgs, ws.data_ptr(), ws.numel(), L.stream()), "conv3d_wgrad")
+            torch.cuda.synchronize()
+            out[v4] = dw.cpu()
+    finally:
+        lib.mednet_set_option(b"wgrad_v4", 1)  # (the default)
+    assert_close(out[1], wr.grad, 1e-4, "dw (co-resident kernel) vs ATen fp32")
+    assert_close(out[1], out[0], 2e-5, "dw (co-resident kernel) vs wgrad_mfma2_kernel")
+
+
 def _fuzz_cases_ct(k, seed):
     rng = np.random.default_rng(seed)
     return [(int(rng.integers(1, 3)), int(rng.choice([32, 64, 96])), int(rng.choice([32, 64])),

@@ -258,6 +258,17 @@ extern "C" size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int c
   return align_up(m, 256) + channel_sum_ws_bytes(n, (size_t)d * h * w, cout) + 256;
 }
 
+// Does this weight gradient run on the kernel that leaves half of every CU (registers, wave slots, 60 KB of LDS) to other streams?
+// A caller that launches weight gradients beside its main stream asks for all CUs then (workgroups = 0) instead of half of them.
+extern "C" int mednet_conv3d_wgrad_coresident(int n, int d, int h, int w, int cin, int cout, int ksize, int x_dtype, int dy_dtype,
+                                              int algo) {
+  if (algo_base(algo) == MEDNET_ALGO_DIRECT || !is16(dy_dtype) || x_dtype != dy_dtype || ksize != 3) return 0;
+  if (!ELT_CALL(dy_dtype, wgrad_mfma_supported, cin, cout, ksize, x_dtype, dy_dtype, MEDNET_NDHWC, MEDNET_NDHWC) ||
+      !wgrad_mfma_fits(n, d, h, w, cin > cout ? cin : cout, 1))
+    return 0;
+  return ELT_CALL(dy_dtype, wgrad_mfma_coresident, d, h, w) ? 1 : 0;
+}
+
 extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
                                    int cin, int cout, int ksize, int x_dtype, int x_layout, int dy_dtype, int dy_layout,
                                    int algo, int workgroups, void* ws, size_t ws_bytes, mednet_stream stream) {

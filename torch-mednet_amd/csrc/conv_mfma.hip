@@ -2101,6 +2101,255 @@ __global__ __launch_bounds__(256) void wgrad_mfma_reduce_kernel(const float* __r
     dw[((size_t)(ab * 32 + a32) * kb + bb * 32 + b32) * 27 + tap] = (sh[threadIdx.x] + sh[64 + threadIdx.x]) + (sh[128 + threadIdx.x] + sh[192 + threadIdx.x]);
 }
 
+// ---- weight gradient, fourth generation: ONE wave per SIMD, half a CU's registers, z-ring through LDS-DMA -----------------
+// wgrad_mfma2_kernel takes a CU whole (8 waves x 244 registers), so nothing of the main stream -- not even a bandwidth-bound
+// GroupNorm pass that would use none of the matrix pipe -- runs on a CU while a weight gradient is resident.
+// This kernel computes the same sums with 4 waves (one per SIMD) of < 256 registers: the other half of every SIMD's register
+// file, 28 wave slots and 60 KB of LDS stay free for kernels of another stream.
+//   * a wave owns 7 of the 27 taps (7 x 16 accumulators) and EVERY k-step of its workgroup (the lean variant of round 3 split
+//     the taps over 8 waves, 3-4 each, and became LDS-read-bound: 1.25 transposing reads per MFMA; here 16 reads per 7 MFMAs);
+//   * work items are z-COLUMNS: an 8 x 16 (y, x) tile walked plane by plane.  One "tick" = one plane of dy (8 k-steps of 16
+//     voxels) against the three planes z-1, z, z+1 of x: the halo in z is never re-fetched, a tick needs ONE new plane of each
+//     operand (8 KB + 11.25 KB for 56 MFMAs per wave; the 4x8x16 brick of wgrad_mfma2 fetches 101 KB per 224);
+//   * the planes arrive by LDS-DMA (buffer_load ... lds, 1 KB per wave instruction, no staging registers, no commit phase) into
+//     rings of RB / RA slots, DEPTH ticks ahead of their use; one s_barrier per tick, one counted s_waitcnt vmcnt in front of it;
+//   * the operands of k-step s+1 are read (ds_read_b64_tr_b16) while the MFMAs of k-step s run, across the tick boundary too:
+//     the barrier that publishes tick t+1's planes sits in front of the LAST k-step of tick t.
+// An item = (sample, z-slab of ZS planes, y tile, x tile) costs ZS + 2 ticks (the slab's ZS + 2 planes of x); the two extra
+// ticks issue loads only.  Per-workgroup partial slabs and the fixed-order reduce are those of wgrad_mfma2_kernel.
+struct Wg4Args {
+  const elt* A;  // dy (ka = Cout channels)
+  const elt* B;  // x  (kb = Cin channels)
+  float* part;   // [wg][27][32][32]
+  int n, d, h, w, ka, kb;
+  int tiles_y, tiles_x, zslabs, zs, nitems;
+  int nab, nbb, splits, xcd_remap;
+  unsigned rcp_tiles_x, rcp_tiles_y, rcp_zslabs;
+  unsigned bytesA, bytesB;  // one sample
+};
+
+constexpr int WG4_DEPTH = 3;                            // ticks between a plane's LDS-DMA and its first use
+constexpr int WG4_RB = WG4_DEPTH + 3, WG4_RA = WG4_DEPTH + 1;
+constexpr int WG4_BSLOT = 12 * 1024, WG4_ASLOT = 8 * 1024;  // 10 x 18 voxel rows = 11.25 DMA pieces, padded to 12; 8 x 16 = 8
+constexpr size_t WG4_LDS = (size_t)WG4_RB * WG4_BSLOT + (size_t)WG4_RA * WG4_ASLOT;
+
+__global__ __launch_bounds__(256, 2) void wgrad_mfma4_kernel(Wg4Args a) {
+  constexpr int TY = 8, TX = 16, HX = 18;
+  constexpr int D = WG4_DEPTH, RB = WG4_RB, RA = WG4_RA, BSLOT = WG4_BSLOT, ASLOT = WG4_ASLOT;
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [RB slots of x planes][RA slots of dy planes]
+
+  const int pair = blockIdx.x / a.splits, split = blockIdx.x % a.splits;
+  const int ab = pair / a.nbb, bb = pair % a.nbb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int tw = __builtin_amdgcn_readfirstlane(tid >> 6);  // tap wave (provably wave-uniform)
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, hk = lane >> 5;
+  const int lanepart = (8 * hk + q) * 64 + (16 * (g & 1) + 4 * p) * 2;  // see tr_operand / wgrad_mfma2_kernel
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  int tap_dz[7], tap_off[7];  // wave-uniform (SGPRs): tap = tw + 4 i; the wave with 6 taps recomputes tap 26 (discarded)
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = tw + 4 * i < 27 ? tw + 4 * i : 26;
+    tap_dz[i] = tap / 9;
+    tap_off[i] = (((tap / 3) % 3) * HX + tap % 3) * 64;
+  }
+
+  // ---- this workgroup's items: split, split + splits, ... (with xcd_remap the 32 workgroups of an XCD -- ids 8 apart -- work
+  //      on 32 NEIGHBOURING columns at a time, whose x / y halos then meet in that XCD's L2)
+  const int first = a.xcd_remap ? (split & 7) * (a.splits >> 3) + (split >> 3) : split;
+  const int my_items = first < a.nitems ? (a.nitems - first + a.splits - 1) / a.splits : 0;
+  const int TPI = a.zs + 2;  // ticks per item
+  const int load_ticks = my_items * TPI, total_ticks = my_items > 0 ? load_ticks + D : 0;
+
+  // load stage state
+  int li = 0, lt = 0;                      // item counter, tick inside the item
+  int it_z0 = 0, it_y0 = 0;
+  const elt* it_A = a.A;
+  const elt* it_B = a.B;
+  unsigned voffA = OOB, voffB[3] = {OOB, OOB, OOB};
+  auto open_item = [&](int k) {  // decode item `first + k * splits`, make the per-lane parts of its plane loads
+    int t = first + k * a.splits;
+    int qd = fastdiv(t, a.tiles_x, a.rcp_tiles_x);
+    const int x0 = (t - qd * a.tiles_x) * TX;
+    t = qd;
+    qd = fastdiv(t, a.tiles_y, a.rcp_tiles_y);
+    it_y0 = (t - qd * a.tiles_y) * TY;
+    t = qd;
+    qd = fastdiv(t, a.zslabs, a.rcp_zslabs);
+    it_z0 = (t - qd * a.zslabs) * a.zs;
+    const size_t svox = (size_t)qd * a.d * a.h * a.w;  // one buffer resource per sample: 32-bit offsets span a single sample
+    it_A = a.A + svox * a.ka;
+    it_B = a.B + svox * a.kb;
+    {  // A: row r of the plane is one DMA: lane = (voxel x 4 + 16-byte part); the row's offset is the load's scalar offset
+      const int gx = x0 + (lane >> 2), part = lane & 3;
+      const bool ok = (gx < a.w) & (ab * 32 + part * 8 < a.ka);
+      voffA = ok ? ((unsigned)gx * (unsigned)a.ka + ab * 32 + part * 8) * 2u : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {  // B: pieces 64 k .. 64 k + 63 of the plane's 720 (10 rows x 18 voxels x 4), k = tw + 4 j
+      const int pc = (tw + 4 * j) * 64 + lane, v = pc >> 2, part = pc & 3;
+      const int row = v / HX, hx = v - row * HX;
+      const int gy = it_y0 - 1 + row, gx = x0 - 1 + hx;
+      const bool ok = (pc < 720) & ((unsigned)gy < (unsigned)a.h) & ((unsigned)gx < (unsigned)a.w) & (bb * 32 + part * 8 < a.kb);
+      voffB[j] = ok ? ((unsigned)(gy * a.w + gx) * (unsigned)a.kb + bb * 32 + part * 8) * 2u : OOB;
+    }
+  };
+  // DMA j (0..4) of the load tick: 0..2 pieces tw, tw + 4, tw + 8 of x's plane z0 + lt - 1; 3, 4 rows tw, tw + 4 of dy's plane
+  // z0 + lt - 2.  Planes outside the slab / the volume (and every load past the last item) get a resource of 0 bytes: the
+  // hardware returns zeros, and every wave issues exactly 5 DMAs per tick whatever happens (the vmcnt arithmetic relies on it).
+  int sBw = 0, sAw = 0;  // ring slots the load tick writes
+  // One LDS-DMA (1 KB: lane l's 16 bytes land at lds_byte + 16 l).  Hand-written because hipcc (ROCm 7.2) orders EVERY later LDS
+  // read of the kernel behind an LDS-DMA it knows about with s_waitcnt vmcnt(0) -- it cannot tell that the ring slot being filled
+  // is not the one being read -- which would drain the DEPTH ticks of loads in flight at every k-step.  The kernel keeps its own
+  // vmcnt arithmetic instead (one counted wait per tick).  M0 = the LDS byte address, written in the same statement that uses it.
+  const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto lds_dma = [&](const elt* base, unsigned num_records, unsigned voff, unsigned soff, unsigned lds_byte) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const unsigned long long ba = (unsigned long long)base;
+    u32x4 rs;
+    rs[0] = (unsigned)ba;
+    rs[1] = (unsigned)(ba >> 32) & 0xFFFFu;
+    rs[2] = num_records;
+    rs[3] = 0x00020000u;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(smem_base + lds_byte), "v"(voff), "s"(rs), "s"(soff)
+                 : "memory");
+  };
+  auto dma = [&](int j, bool live) {
+    if (j < 3) {
+      const int z = it_z0 + lt - 1;
+      const bool ok = live & ((unsigned)z < (unsigned)a.d);
+      const unsigned soff = (unsigned)z * (unsigned)(a.h * a.w) * (unsigned)a.kb * 2u;  // (anything for an invalid plane)
+      lds_dma(it_B, a.bytesB & (0u - (unsigned)ok), voffB[j], soff, (unsigned)(sBw * BSLOT + (tw + 4 * j) * 1024));
+    } else {
+      const int z = it_z0 + lt - 2, row = tw + 4 * (j - 3);
+      const bool ok = live & (lt >= 2) & (z < a.d) & (it_y0 + row < a.h);  // (lt - 2 < zs by construction: lt < zs + 2)
+      const unsigned soff = (unsigned)((z * a.h + it_y0 + row) * a.w) * (unsigned)a.ka * 2u;
+      lds_dma(it_A, a.bytesA & (0u - (unsigned)ok), voffA, soff, (unsigned)(RB * BSLOT + sAw * ASLOT + row * 1024));
+    }
+  };
+
+  // compute stage: at tick T the planes of load tick T - D are complete: dy plane in A slot (T - D) % RA, x planes z-1, z, z+1
+  // in B slots (T - D - 2 .. T - D) % RB.  Operand addresses of a tick: one register for dy, one per tap for x.
+  int vA = 0, vB[7];
+  auto bases = [&](int cA, int cB0) {  // cB0: slot of plane z - 1
+    vA = lanepart + RB * BSLOT + cA * ASLOT;
+    int sb[3];
+    sb[0] = cB0;
+    sb[1] = cB0 + 1 >= RB ? cB0 + 1 - RB : cB0 + 1;
+    sb[2] = cB0 + 2 >= RB ? cB0 + 2 - RB : cB0 + 2;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) vB[i] = lanepart + (tap_dz[i] == 0 ? sb[0] : (tap_dz[i] == 1 ? sb[1] : sb[2])) * BSLOT + tap_off[i];
+  };
+  eltx4 opA[2][2], opB[2][7][2];  // two operand sets x (dy, 7 taps of x) x two transposing reads
+  auto rd = [&](int set, int idx, int ks) {  // read number idx (0..15) of the operands of k-step ks (row ks of the plane)
+    const int o = idx >> 1, second = (idx & 1) * 256;
+    if (o == 0) opA[set][idx & 1] = MEDNET_DS_READ_TR16(smem + vA + ks * 1024 + second);
+    else opB[set][o - 1][idx & 1] = MEDNET_DS_READ_TR16(smem + vB[o - 1] + ks * (HX * 64) + second);
+  };
+
+  int T = 0, ct = -D;         // global tick; tick inside the item of the compute stage (negative: pipeline filling)
+  int cA = 0, cB0 = RB - 2;   // compute-stage slots at tick T = D: A slot 0, B slots (RB - 2, RB - 1, 0)
+  // (slots advance only from tick D on, see the loop's tail)
+  bases(cA, cB0);
+  auto tick = [&](auto compute_tag) {
+    constexpr bool COMPUTE = decltype(compute_tag)::value;
+    const bool live = T < load_ticks;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks == 7) {
+        // the planes of load tick T + 1 - D are needed from here on (the reads below fetch the first operands of tick T + 1):
+        // of this wave's DMAs only those of the D - 1 youngest ticks may still be in flight; then the barrier makes that true
+        // for every wave's share, and tells everybody that the slots tick T + 1 overwrites are no longer read
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 5) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int nA = cA + 1 >= RA ? 0 : cA + 1, nB = cB0 + 1 >= RB ? 0 : cB0 + 1;
+        if (T + 1 >= D) bases(T + 1 == D ? cA : nA, T + 1 == D ? cB0 : nB);
+      }
+      const int nks = ks == 7 ? 0 : ks + 1;
+      // issue order written out: one MFMA, then up to three transposing reads of the NEXT k-step's operands (front-loaded: the
+      // last reads must be back before the next k-step's first MFMA), the tick's five DMAs one per k-step
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (COMPUTE) {
+          const eltx8 fa = __builtin_shufflevector(opA[cur][0], opA[cur][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          const eltx8 fb = __builtin_shufflevector(opB[cur][i][0], opB[cur][i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[i] = MEDNET_MFMA_32x32x16(fa, fb, acc[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int first_rd[8] = {0, 3, 6, 9, 12, 14, 16, 16};
+        for (int idx = first_rd[i]; idx < first_rd[i + 1]; ++idx) rd(nxt, idx, nks);
+        if (i == 5 && ks < 5) dma(ks, live);
+      }
+    }
+  };
+  if (my_items > 0) open_item(0);
+  for (; T < total_ticks; ++T) {
+    if (ct >= 2) tick(std::true_type{});
+    else tick(std::false_type{});
+    // advance the load stage ...
+    sBw = sBw + 1 >= RB ? 0 : sBw + 1;
+    sAw = sAw + 1 >= RA ? 0 : sAw + 1;
+    if (++lt == TPI) {
+      lt = 0;
+      ++li;
+      if (li < my_items) open_item(li);
+    }
+    // ... and the compute stage (D ticks behind; the slots were advanced for the prefetch inside tick())
+    if (T + 1 > D) {
+      cA = cA + 1 >= RA ? 0 : cA + 1;
+      cB0 = cB0 + 1 >= RB ? 0 : cB0 + 1;
+    }
+    ct = ct + 1 == TPI ? 0 : ct + 1;
+  }
+  // ---- partial[wg][tap][a][b]: row a = (j&3) + 8*(j>>2) + 4*hk, col b = lane & 31 (the layout wgrad_mfma_reduce_kernel reads)
+  float* out = a.part + (size_t)blockIdx.x * 27 * 1024;
+  const int col = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = tw + 4 * i;
+    if (tap < 27) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) out[((size_t)tap * 32 + (j & 3) + 8 * (j >> 2) + 4 * hk) * 32 + col] = acc[i][j];
+    }
+  }
+}
+
+// (volumes below one 8 x 16 tile or a few planes stay with wgrad_mfma2_kernel: a column's ring needs 2 + DEPTH ticks to fill)
+static bool wgrad4_applies(int d, int h, int w) { return tuning_option("wgrad_v4", 1) != 0 && d >= 8 && h >= 8 && w >= 16; }
+bool wgrad_mfma_coresident(int d, int h, int w) { return wgrad4_applies(d, h, w); }
+static void wgrad4_plan(int n, int d, int h, int w, int ka, int kb, int workgroups, Wg4Args& a) {
+  const int slabs = (d + 31) / 32;  // z-slabs of at most 32 planes, equal depth
+  a.zslabs = slabs;
+  a.zs = (d + slabs - 1) / slabs;
+  a.tiles_y = (h + 7) / 8;
+  a.tiles_x = (w + 15) / 16;
+  a.nitems = n * slabs * a.tiles_y * a.tiles_x;
+  auto rcp = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+  a.rcp_tiles_x = rcp(a.tiles_x); a.rcp_tiles_y = rcp(a.tiles_y); a.rcp_zslabs = rcp(a.zslabs);
+  a.nab = (ka + 31) / 32;
+  a.nbb = (kb + 31) / 32;
+  const int pairs = a.nab * a.nbb;
+  const int target = workgroups > 0 ? workgroups : 256;
+  int splits = (target + pairs - 1) / pairs;
+  if (splits > a.nitems) splits = a.nitems;
+  if (splits < 1) splits = 1;
+  a.splits = splits;
+  a.xcd_remap = splits % 8 == 0 ? 1 : 0;
+}
+static size_t wgrad4_ws_bytes(int n, int d, int h, int w, int cin, int cout, int workgroups) {
+  Wg4Args a;
+  wgrad4_plan(n, d, h, w, cout, cin, workgroups, a);
+  return (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+}
+
 bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtype, int x_layout, int dy_layout) {
   return ksize == 3 && cin % 16 == 0 && cout % 16 == 0 && x_dtype == ELT_DTYPE && dy_dtype == ELT_DTYPE &&
          x_layout == MEDNET_NDHWC && dy_layout == MEDNET_NDHWC;
@@ -2113,13 +2362,41 @@ bool wgrad_mfma_fits(int n, int d, int h, int w, int cmax, int scale) {
 
 size_t wgrad_mfma_ws_bytes(int n, int d, int h, int w, int cin, int cout, int ksize, int workgroups) {
   if (ksize != 3 || cin % 16 || cout % 16) return 0;
-  return wgrad2_ws_bytes(n, d, h, w, cin, cout, workgroups);
+  const size_t v2 = wgrad2_ws_bytes(n, d, h, w, cin, cout, workgroups), v4 = wgrad4_ws_bytes(n, d, h, w, cin, cout, workgroups);
+  return v2 > v4 ? v2 : v4;
 }
 
 int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cin, int cout, int dtype,
                       void* ws, size_t ws_bytes, hipStream_t s, int workgroups) {
   (void)dtype;
   // conv: A = dy (Cout rows), B = x (Cin cols) shifted by tap - 1
+  if (wgrad4_applies(d, h, w)) {
+    Wg4Args a;
+    a.A = (const elt*)dy;
+    a.B = (const elt*)x;
+    a.part = (float*)ws;
+    a.n = n; a.d = d; a.h = h; a.w = w; a.ka = cout; a.kb = cin;
+    wgrad4_plan(n, d, h, w, cout, cin, workgroups, a);
+    a.bytesA = (unsigned)((size_t)d * h * w * cout * 2);  // per sample
+    a.bytesB = (unsigned)((size_t)d * h * w * cin * 2);
+    const size_t need = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
+    MEDNET_REQUIRE(ws_bytes >= need, MEDNET_E_WORKSPACE, "wgrad_mfma4: workspace %zu < %zu", ws_bytes, need);
+    static bool attr4 = false;
+    if (!attr4) {
+      if (hipFuncSetAttribute((const void*)wgrad_mfma4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG4_LDS) != hipSuccess)
+        return fail(MEDNET_E_HIP, "wgrad_mfma4: cannot raise dynamic LDS to %zu", WG4_LDS);
+      attr4 = true;
+    }
+    hipLaunchKernelGGL(wgrad_mfma4_kernel, dim3(a.nab * a.nbb * a.splits), dim3(256), WG4_LDS, s, a);
+    int rc4 = check_launch("wgrad_mfma4");
+    if (rc4) return rc4;
+    const size_t total4 = (size_t)a.nab * a.nbb * 1024 * 27;
+    if (a.splits < 4) hipLaunchKernelGGL(wgrad_mfma_reduce_kernel_few, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, a.part, dw, cout, cin,
+                       a.nbb, a.splits);
+    else hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, a.part, dw, cout, cin,
+                       a.nbb, a.splits);
+    return check_launch("wgrad_mfma_reduce");
+  }
   constexpr size_t lds = ((size_t)4 * 8 * 16 + 6 * 10 * 18) * 64;
   Wg2Args a;
   a.A = (const elt*)dy;

@@ -35,6 +35,11 @@ SIDE = {"enabled": False, "stream": None, "keepalive": [], "wgrad_wgs": int(os.e
 
 
 SIDE_MIN_VOXELS = int(os.environ.get("MEDNET_SIDE_MIN_VOXELS", "0"))  # (A/B knob: half-chip weight gradients from this layer size on)
+SIDE_CORESIDENT = os.environ.get("MEDNET_SIDE_CORESIDENT", "1") == "1"  # (A/B knob: 0 = half the CUs for the co-resident kernel too)
+
+
+def wgrad_coresident(n, d, h, w, cin, cout, ksize, x, dy) -> bool:
+    return bool(L.lib().mednet_conv3d_wgrad_coresident(n, d, h, w, cin, cout, ksize, L.dt(x), L.dt(dy), config.conv_algo()))
 
 
 def _runs_beside(main, cand, device) -> bool:
@@ -90,8 +95,10 @@ def join_side_stream():
 class _OnSide:
     """Context: run the enclosed launches on the side stream after everything queued so far on the main stream."""
 
-    def __init__(self, active, device, *tensors):
-        self.active, self.device, self.tensors = active, device, tensors
+    def __init__(self, active, device, *tensors, coresident=False):
+        # coresident: the enclosed launch leaves half of every CU free (mednet_conv3d_wgrad_coresident): it gets ALL the CUs, and
+        # the main stream's bandwidth-bound passes run on the same CUs beside it (round 5; profiles/r05_ab.md)
+        self.active, self.device, self.tensors, self.coresident = active, device, tensors, bool(coresident) and SIDE_CORESIDENT
         # the `workgroups` argument of the weight-gradient launch AND its workspace query inside this context (0: the library's
         # plan, one workgroup per CU -- a weight gradient launched on the main stream keeps the whole chip)
         self.workgroups = 0
@@ -114,7 +121,7 @@ class _OnSide:
             self.ctx.__enter__()
             t = self.tensors[-1] if self.tensors else None
             vox = (t.shape[0] * t[0, 0].numel()) if (t is not None and t.dim() == 5) else 1 << 40
-            if SIDE["wgrad_wgs"] > 0 and vox >= SIDE_MIN_VOXELS:
+            if SIDE["wgrad_wgs"] > 0 and vox >= SIDE_MIN_VOXELS and not self.coresident:
                 self.workgroups = SIDE["wgrad_wgs"]
         return self
 
@@ -357,7 +364,8 @@ class Conv3dFn(Function):
             if has_bias and ctx.needs_input_grad[2]:
                 db, direct_b = _grad_target(bias, (cout,))
             on_side = SIDE["enabled"] and direct_w and (db is None or direct_b)
-            with _OnSide(on_side, dy.device, xin, dy) as side:
+            cores = on_side and not out_planar and wgrad_coresident(n, d, h, w, cin, cout, ksize, xin, dy)
+            with _OnSide(on_side, dy.device, xin, dy, coresident=cores) as side:
                 nbytes = lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, ksize, side.workgroups)
                 ws = L.workspace(nbytes, dy.device)
                 L.check(lib.mednet_conv3d_wgrad(xin.data_ptr(), dy.data_ptr(), dw.data_ptr(), L.ptr(db), n, d, h, w, cin,
