@@ -181,6 +181,37 @@ def pmc_traffic(batch: int, patch: int):
                   (", ".join(stale) if stale else "every profile under profiles/") + "; re-run tools/gpu_profile.sh")
 
 
+def wgrad_alone_ms(dev, batch: int, patch: int, precision: str) -> float:
+    """Weight gradient of a 32 -> 32 layer at full resolution alone on the chip (through the C ABI, HIP events on the launch
+    stream), on operands with the statistics the step's own tensors have (post-ELU activations, small zero-mean gradients: the
+    clock the chip holds under matrix load depends on the operands)."""
+    from mednet_hip import _lib as L
+    lib = L.lib()
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(precision)
+    if dt is None:
+        return float("nan")
+    code = L.BF16 if dt == torch.bfloat16 else L.F16
+    c = F_MAPS[0]
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.nn.functional.elu(torch.randn(batch, c, patch, patch, patch, device=dev, generator=g)).to(dt).contiguous(memory_format=torch.channels_last_3d)
+    dy = (torch.randn(batch, c, patch, patch, patch, device=dev, generator=g) * 1e-3).to(dt).contiguous(memory_format=torch.channels_last_3d)
+    dw = torch.empty(c, c, 3, 3, 3, device=dev)
+    ws = torch.empty(lib.mednet_conv3d_wgrad_ws_bytes(batch, patch, patch, patch, c, c, 3, 0), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    run = lambda: L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, batch, patch, patch, patch, c, c, 3, code,
+                                                  L.NDHWC, code, L.NDHWC, L.ALGO_AUTO, 0, ws.data_ptr(), ws.numel(), st), "conv3d_wgrad")
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 20
+
+
 def fp32_parity_mode(dev, batch: int, patch: int, steps: int):
     """The SAME step in the fp32 storage mode -- the mode that meets the north star's 1e-3 on logits and gradients
     (tests: test_cfg2_128_against_reference_golden) -- timed the same way, as a sub-record."""
@@ -311,7 +342,7 @@ def main():
     if not a.no_roofline:
         # dominant kernel: the 3x3x3 conv at full resolution with f0 -> f0 channels (forward launches; the data
         # gradient runs the same kernel).  HIP events on the launch stream (= torch's current stream).
-        ops.PROFILE.update(enabled=True, events=[],
+        ops.PROFILE.update(enabled=True, events=[], wgrad_events=[],
                            match=lambda k, ci, co, d, h, w: k == 3 and ci == F_MAPS[0] and co == F_MAPS[0] and d == P)
     t0 = time.perf_counter()
     t_issue, n_issue = 0.0, min(a.steps, 5)
@@ -360,6 +391,23 @@ def main():
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "traffic_source": traffic_source, "launches": len(ms),
                                "avg_ms": round(avg, 4), "flop_per_launch": flops}
+        if not a.no_roofline and ops.PROFILE.get("wgrad_events"):
+            # the kernel with the largest share of the step's kernel time: the weight gradient of the same layers.  In the step it
+            # runs on the second stream, on all CUs, BESIDE the main stream's bandwidth-bound GroupNorm-backward passes (which is
+            # what it was rebuilt for in round 5), so its in-step duration includes that sharing; `alone` is the same launch by
+            # itself on the chip, on the step's own operands (timed after the loop, 20 launches).
+            ev = ops.PROFILE["wgrad_events"]
+            ms = [e0.elapsed_time(e1) for e0, e1, _ in ev]
+            flops = ev[0][2]
+            avg = sum(ms) / len(ms)
+            peak = MFMA_PEAK_TFLOPS[a.precision]
+            alone = wgrad_alone_ms(dev, a.batch, P, a.precision)
+            out["roofline_wgrad"] = {"kernel": "wgrad_mfma4_kernel: weight gradient of conv3d 3x3x3 32->32 @128^3", "bound": "mfma",
+                                     "achieved": round(flops / (alone * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                                     "frac": round(flops / (alone * 1e-3) / 1e12 / peak, 4), "avg_ms": round(alone, 4),
+                                     "launches": 20, "flop_per_launch": flops,
+                                     "in_step_beside_the_main_stream": {"avg_ms": round(avg, 4), "launches": len(ms),
+                                                                        "achieved": round(flops / (avg * 1e-3) / 1e12, 2)}}
         if a.fp32_steps > 0 and world == 1 and a.precision == "bf16":
             del step, model
             torch.cuda.empty_cache()

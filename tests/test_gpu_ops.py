@@ -669,6 +669,9 @@ def _conv_case(n, cin, cout, shape, tag):
     (1, 32, 16, (8, 8, 16)),
     (1, 16, 16, (5, 9, 17)),
     (1, 48, 80, (4, 8, 16)),      # any multiple of 16: the last channel block is half full
+    (2, 64, 96, (10, 10, 6)),     # config 5's deepest level: 8-wide bricks (FwdTile<3>, wgrad_mfma2_kernel<8>), 39 % instead of 10 % filled
+    (1, 32, 64, (12, 20, 24)),    # 24 columns: three 8-wide bricks instead of two 16-wide ones
+    (2, 32, 32, (7, 9, 40)),      # 40 columns: 16 + 16 + 8
 ])
 def test_conv3d_mfma_fwd_dgrad_wgrad(n, cin, cout, shape):
     """The bf16 MFMA kernels (forced) against the fp32 oracle AND against the direct kernels on identical bf16 inputs
@@ -700,6 +703,35 @@ def test_conv3d_mfma_fwd_dgrad_wgrad(n, cin, cout, shape):
     assert_close(y, yd, 5e-3, "y vs direct kernel")
     assert_close(dx, dxd, 5e-3, "dx vs direct kernel")
     assert_close(dw, dwd, 2e-4, "dw vs direct kernel")
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("n,cin,cout,shape", [(2, 64, 64, (10, 10, 6)), (1, 32, 64, (12, 20, 24)), (2, 32, 32, (7, 9, 40)), (1, 128, 64, (5, 6, 7))])
+def test_narrow_bricks_change_no_bit_of_the_convolution(mode, n, cin, cout, shape):
+    """8-wide bricks (FwdTile<3>, option conv_narrow; round 5) only re-partition the output voxels: every output element is the same
+    chain of MFMA accumulations (K chunk outer, tap inner) as with 16-wide bricks, so forward and data gradient are bit-identical;
+    the weight gradient (wgrad_mfma2_kernel<8>: other partial slabs) agrees to fp32 summation order."""
+    lib = L.lib()
+    tag = f"narrow{n}{cin}{cout}{shape}"
+    x, w, cot = _conv_case(n, cin, cout, shape, tag)
+    res = {}
+    try:
+        for narrow in (2, 0):  # (2: 8-wide bricks wherever they need fewer voxel slots; the default 1 takes them up to 8 columns only)
+            lib.mednet_set_option(b"conv_narrow", narrow)
+            mednet_hip.set_conv_algo("mfma")
+            with mednet_hip.precision(mode):
+                conv = hnn.Conv3d(cin, cout, 3, bias=False).to(DEV)
+                with torch.no_grad():
+                    conv.weight.copy_(w)
+                xg = x.to(DEV).to(mednet_hip.config.act_dtype()).requires_grad_(True)
+                y = conv(xg)
+                y.backward(cot.to(DEV).to(y.dtype))
+                res[narrow] = (y.detach().clone(), xg.grad.clone(), conv.weight.grad.clone())
+    finally:
+        lib.mednet_set_option(b"conv_narrow", 1)
+        mednet_hip.set_conv_algo("auto")
+    assert torch.equal(res[2][0], res[0][0]) and torch.equal(res[2][1], res[0][1])
+    assert_close(res[2][2], res[0][2], 2e-5, "dw narrow vs wide bricks")
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
@@ -997,7 +1029,8 @@ def test_conv3d_mfma_batch_larger_than_4GB():
         mednet_hip.set_conv_algo("auto")
 
 
-@pytest.mark.parametrize("n,cout,shape", [(1, 32, (4, 8, 16)), (2, 32, (9, 11, 21)), (1, 64, (5, 6, 7))])
+@pytest.mark.parametrize("n,cout,shape", [(1, 32, (4, 8, 16)), (2, 32, (9, 11, 21)), (1, 64, (5, 6, 7)),
+                                          (2, 16, (9, 11, 21)), (1, 48, (4, 8, 16))])  # 16 / 48: half-filled channel block (UNet3D: 1 -> 16)
 def test_first_layer_mfma_keeps_fp32_input_precision(n, cout, shape):
     """Cin=1 forward on the matrix cores (contraction over the 27 taps, x split into bf16 hi+lo): with bf16-representable
     weights the only rounding left is the bf16 store of the output; x itself is NOT rounded to 8 bits."""
@@ -1015,7 +1048,8 @@ def test_first_layer_mfma_keeps_fp32_input_precision(n, cout, shape):
     assert_close(y, bf16_round(yr), 4e-4, "y vs correctly rounded reference")
 
 
-@pytest.mark.parametrize("n,cout,shape", [(1, 32, (4, 8, 16)), (2, 32, (9, 11, 21)), (2, 64, (5, 6, 7)), (1, 32, (20, 24, 40))])
+@pytest.mark.parametrize("n,cout,shape", [(1, 32, (4, 8, 16)), (2, 32, (9, 11, 21)), (2, 64, (5, 6, 7)), (1, 32, (20, 24, 40)),
+                                          (2, 16, (9, 11, 21))])  # 16: UNet3D's first DoubleConv (components.py:119-121)
 def test_first_layer_weight_gradient_on_matrix_cores(n, cout, shape):
     """Cin=1 weight gradient: contraction over voxels with x gathered per tap and split into bf16 hi+lo.  The cotangent is
     bf16-representable, so the result must match the fp32 oracle to fp32-accumulation accuracy, and the VALU kernel."""

@@ -89,7 +89,7 @@ if "unet3d" in which:
         PEAK["fp32"] = 2500.0 / 3
 if "cfg5" in which:
     b = {k: v.to(dev) for k, v in synthetic_batch(2, 1, (160, 160, 96), 4, 0, seed=1234).items()}
-    for prec in ["fp16"] + precs:
+    for prec in (precs if "cfg5only" in which else ["fp16"] + precs):
         run(f"cfg5: ResidualUNet3D [64,128,256,512,1024] 4-class, 160x160x96, batch 2, {prec} storage"
             + (" + dynamic loss scaling (the mode BASELINE names)" if prec == "fp16" else ""),
             lambda: SegmentationStep(keyed_init_(ResidualUNet3D(1, 4, False, f_maps=[64, 128, 256, 512, 1024])).to(dev), [0.05, 1, 1, 1.0]),

@@ -60,16 +60,31 @@ __device__ __forceinline__ eltx8 tr_operand(const char* base, int second_read_by
 }
 
 // ================================================================================================== geometry
-template <int STRIDE>
+// Brick KINDS of the forward / data-gradient kernel (the template parameter of conv_mfma_kernel and launch_fwd):
+template <int KIND>
 struct FwdTile;
 template <>
 struct FwdTile<1> {  // conv forward / data gradient
-  static constexpr int TZ = 4, TY = 8, TX = 16;
+  static constexpr int TZ = 4, TY = 8, TX = 16, STRIDE = 1;
 };
 template <>
 struct FwdTile<2> {  // ConvTranspose3d data gradient: in = 2*out - 1 + tap
-  static constexpr int TZ = 2, TY = 4, TX = 16;
+  static constexpr int TZ = 2, TY = 4, TX = 16, STRIDE = 2;
 };
+template <>
+struct FwdTile<3> {  // conv forward / data gradient on NARROW volumes (round 5): half as wide.  The deep levels of BASELINE config 5
+  // (f_maps [64 .. 1024] on 160 x 160 x 96 patches: ... 20 x 20 x 12, 10 x 10 x 6 voxels) fill 16-wide bricks badly in x -- 6 of 16
+  // columns at the deepest level -- and every padded column costs its MFMAs; with 8-wide bricks a 10 x 10 x 6 volume is 39 % real
+  // voxels instead of 10 %.  A wave then has two N-tiles (4 x-rows of 8 voxels each) per weight fragment instead of four.
+  static constexpr int TZ = 4, TY = 8, TX = 8, STRIDE = 1;
+};
+// 8-wide bricks for volumes at most 8 voxels wide.  (Measured, profiles/r05_ab.md: for wider volumes whose last 16-wide brick is at
+// most half full -- 24 = 16 + 8 columns, config 5's level 2 -- 8-wide bricks do 25 % fewer MFMAs and are 10 % SLOWER: with two N-tiles
+// per weight fragment instead of four the kernel is LDS-bound; option conv_narrow=2 selects them there too.)
+static bool narrow_bricks(int w) {
+  const int mode = tuning_option("conv_narrow", 1);
+  return mode != 0 && (w <= 8 || (mode == 2 && (w + 7) / 8 < 2 * ((w + 15) / 16)));
+}
 
 // x / d for launch constants d: the host passes ceil(2^32 / d); exact while x * d < 2^32 (checked by the launcher).
 // d == 1 has no 32-bit reciprocal and is passed through.
@@ -113,10 +128,11 @@ struct FwdArgs {
   unsigned rcp_zslab;
 };
 
-template <int STRIDE, bool GNB = false>
+template <int KIND, bool GNB = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
-  using G = FwdTile<STRIDE>;
-  constexpr int TZ = G::TZ, TY = G::TY, TX = G::TX;
+  using G = FwdTile<KIND>;
+  constexpr int TZ = G::TZ, TY = G::TY, TX = G::TX, STRIDE = G::STRIDE;
+  constexpr int RPT = 32 / TX;  // x-rows of an N-tile (32 voxels): 2 rows of 16 or 4 rows of 8
   constexpr int HZ = STRIDE * (TZ - 1) + 3, HY = STRIDE * (TY - 1) + 3, HX = STRIDE * (TX - 1) + 3;
   constexpr int NV = HZ * HY * HX;
   constexpr int NTW = TZ * TY * TX / 32 / 4;  // N-tiles per wave
@@ -219,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const int g = wv * NTW + t;
-    const int lz = g / (TY / 2), ly = (g % (TY / 2)) * 2 + (r >> 4);
-    const int lx = STRIDE == 1 ? (((r & 15) - (r >> 4) * HX) & 15) : (r & 15);
+    const int lz = g / (TY / RPT), ly = (g % (TY / RPT)) * RPT + r / TX;
+    const int lx = TX == 8 ? (r & 7) : (STRIDE == 1 ? (((r & 15) - (r >> 4) * HX) & 15) : (r & 15));
     lbase[t] = ((STRIDE * lz) * HY + STRIDE * ly) * HX + STRIDE * lx + h * NV;
   }
   const eltx2 ones = {(elt)1.0f, (elt)1.0f};
@@ -415,8 +431,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int g = e_wv * NTW + t;
-      const int lz = g / (TY / 2), ly = (g % (TY / 2)) * 2 + (e_r >> 4);
-      const int lx = STRIDE == 1 ? (((e_r & 15) - (e_r >> 4) * HX) & 15) : (e_r & 15);
+      const int lz = g / (TY / RPT), ly = (g % (TY / RPT)) * RPT + e_r / TX;
+      const int lx = TX == 8 ? (e_r & 7) : (STRIDE == 1 ? (((e_r & 15) - (e_r >> 4) * HX) & 15) : (e_r & 15));
       const int vl = (lz * TY + ly) * TX + lx;
       const int sw = (vl >> 1) & 7;
 #pragma unroll
@@ -443,8 +459,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
     // the per-round part of the address is a SCALAR (soffset of a buffer store whose resource is this sample) and the
     // lane part is computed once; lanes outside the volume / past Cout get an out-of-range voffset and the hardware
     // drops the store.
-    static_assert(TX == 16 && TY % 4 == 0, "row decomposition of the epilogue");
-    const int et = etid >> 2, ex = et & 15, ey = et >> 4;
+    constexpr int RPR = 64 / TX;  // x-rows per round of 64 voxels
+    static_assert((TX == 16 || TX == 8) && TY % RPR == 0, "row decomposition of the epilogue");
+    const int et = etid >> 2, ex = et & (TX - 1), ey = et / TX;
     const bool lane_ok = (tx0 + ex < a.ow) & (cb * 32 + pj * 8 < a.cout);  // (a 16-channel layer fills half a block)
     const unsigned vbase = (unsigned)((ey * a.ow + ex) * a.cout + pj * 8) * 2u;
     const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)n * ovol * a.cout), 0, a.bytes_y, 0x00020000);
@@ -499,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 #pragma unroll
       for (int itl = 0; itl < RG; ++itl) {
         const int it = it0 + itl;
-        const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
+        const int oz = tz0 + (it * RPR) / TY, oyb = ty0 + (it * RPR) % TY;
         const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
         const unsigned soff = (unsigned)(((oz * a.oh + oyb) * a.ow + tx0) * a.cout + cb * 32) * 2u;
         yrow[itl] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_gy, ok ? vbase : OOB, soff, 0));
@@ -511,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       const int it = it0 + itl;
       eltx8 v = rows[itl];
       if (swl & 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
-      const int oz = tz0 + (it * 4) / TY, oyb = ty0 + (it * 4) % TY;
+      const int oz = tz0 + (it * RPR) / TY, oyb = ty0 + (it * RPR) % TY;
       const bool ok = lane_ok & (oz < a.od) & (oyb + ey < a.oh);
       const unsigned soff = (unsigned)(((oz * a.oh + oyb) * a.ow + tx0) * a.cout + cb * 32) * 2u;
       if (a.add) {  // (wave-uniform) y += add: 16-byte row pieces at the same offsets, out-of-range lanes read zeros
@@ -1319,7 +1336,7 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int tap = ks * 16 + 8 * h + j;
-      wa[ks][j] = (elt)(tap < 27 ? a.w[(size_t)tap * a.cout + cb * 32 + r] : 0.f);
+      wa[ks][j] = (elt)(tap < 27 && cb * 32 + r < a.cout ? a.w[(size_t)tap * a.cout + cb * 32 + r] : 0.f);  // (a 16-channel layer fills half a block)
     }
   // LDS offsets of this lane's 8 taps per k-step
   int toff[2][8];
@@ -1398,7 +1415,7 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
     for (int i = 0; i < 2; ++i) {
       const int v = i * 16 + (lane >> 2);
       const int sy = ty0 + (g % (TY / 2)) * 2 + (v >> 4), sx = tx0 + (v & 15);
-      if (oz_t < a.d && sy < a.h && sx < a.w_)
+      if (oz_t < a.d && sy < a.h && sx < a.w_ && cb * 32 + (lane & 3) * 8 < a.cout)
         __builtin_nontemporal_store(rows2[i], reinterpret_cast<eltx8*>(a.y + ((size_t)n * vol + ((size_t)oz_t * a.h + sy) * a.w_ + sx) * a.cout + cb * 32 + (lane & 3) * 8));
     }
   }
@@ -1417,6 +1434,7 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+          if (cb * 32 + 8 * q + 4 * h + j >= a.cout) continue;
           dst[(8 * q + 4 * h + j) * 2] = ssum[q * 4 + j];
           dst[(8 * q + 4 * h + j) * 2 + 1] = ssq[q * 4 + j];
         }
@@ -1425,7 +1443,7 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
 }
 
 bool conv_c1_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dtype, int y_layout, bool bias) {
-  return cin == 1 && ksize == 3 && cout % 32 == 0 && (x_dtype == MEDNET_F32 || x_dtype == ELT_DTYPE) && y_dtype == ELT_DTYPE &&
+  return cin == 1 && ksize == 3 && cout % 16 == 0 && (x_dtype == MEDNET_F32 || x_dtype == ELT_DTYPE) && y_dtype == ELT_DTYPE &&
          y_layout == MEDNET_NDHWC && !bias;
 }
 int conv_c1_stats_chunks(int d, int h, int w) { return 4 * ((d + 3) / 4) * ((h + 7) / 8) * ((w + 15) / 16); }
@@ -1442,7 +1460,7 @@ int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d,
   a.tiles_y = (h + 7) / 8;
   a.tiles_x = (w + 15) / 16;
   a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
-  a.ncb = cout / 32;
+  a.ncb = (cout + 31) / 32;
   hipLaunchKernelGGL(conv_c1_mfma_kernel, dim3((unsigned)a.ntiles * a.ncb), dim3(256), 0, s, a);
   return check_launch("conv_c1_mfma");
 }
@@ -1633,11 +1651,19 @@ static bool conv32_applies(int ntiles, int cin, int cout) {
 static bool conv32_takes(int ntiles, int cin, int cout, bool gnb) {
   return conv32_applies(ntiles, cin, cout) && (!gnb || tuning_option("conv32_gnb", 1));
 }
-static void conv_stats_plan(int n, int d, int h, int w, int cin, int cout, int& rows, int& accum, bool gnb = false) {
+// Brick kind of a stride-1 launch: 3 (8-wide bricks) where that covers the volume with fewer voxel slots, unless the 32 -> 32
+// specialisation (16-wide bricks only) takes the call
+static int conv_fwd_kind(int n, int d, int h, int w, int cin, int cout, bool gnb) {
   using G = FwdTile<1>;
-  const int tps = ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
+  const int ntiles16 = n * ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
+  return narrow_bricks(w) && !conv32_takes(ntiles16, cin, cout, gnb) ? 3 : 1;
+}
+static void conv_stats_plan(int n, int d, int h, int w, int cin, int cout, int& rows, int& accum, bool gnb = false) {
+  const int tx = conv_fwd_kind(n, d, h, w, cin, cout, gnb) == 3 ? FwdTile<3>::TX : FwdTile<1>::TX;
+  using G = FwdTile<1>;
+  const int tps = ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + tx - 1) / tx);
   const int ncb = (cout + 31) / 32, ntiles = n * tps;
-  if (conv32_takes(ntiles, cin, cout, gnb)) {  // always accumulating: one row per wave of the 256 workgroups
+  if (tx == G::TX && conv32_takes(ntiles, cin, cout, gnb)) {  // always accumulating: one row per wave of the 256 workgroups
     accum = 1;
     rows = 256 * 4;
     return;
@@ -1662,11 +1688,12 @@ struct GnbSpec {  // fused first pass of a GroupNorm backward (see FwdArgs::gnb_
   const void* z = nullptr;  // residual-layer form (FwdArgs::gnb_z)
 };
 
-template <int STRIDE>
+template <int KIND>
 static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, int oh, int ow, int id, int ih, int iw,
                       int cin, int cout, float* gn_partial, hipStream_t s, int act = MEDNET_ACT_NONE,
                       const void* add = nullptr, GnbSpec gnb = GnbSpec(), FwdPlanProbe* probe = nullptr) {
-  using G = FwdTile<STRIDE>;
+  using G = FwdTile<KIND>;
+  constexpr int STRIDE = G::STRIDE;
   constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
   constexpr size_t lds = ((size_t)2 * HZ * HY * HX + 27 * 2 * 32) * 16;
   static_assert(lds <= 80 * 1024, "two workgroups must fit one CU");
@@ -1707,7 +1734,7 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   a.stats_rows = 4 * a.tiles_z * a.tiles_y * a.tiles_x;
   if (gn_partial && STRIDE == 1) conv_stats_plan(n, od, oh, ow, cin, cout, a.stats_rows, a.stats_accum, use_gnb);
   a.xcd_chunk = 0;
-  if constexpr (STRIDE == 1) {
+  if constexpr (KIND == 1) {
     if (conv32_takes(a.ntiles, cin, cout, use_gnb)) {
       constexpr size_t lds32 = (size_t)2 * 4 * (HZ * HY * HX + 4) * 16 + 4 * 4096 + 256 * 16;
       static_assert(lds32 <= 160 * 1024, "two bricks of whole rows + the waves' epilogue areas + spare slots");
@@ -1758,23 +1785,23 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
                           a.stats_accum, a.stats_rows, 0, 0, a.tiles_x, a.tiles_y, a.tiles_z};
     return MEDNET_OK;
   }
-  static bool attr_set[3] = {false, false, false};
-  if (!attr_set[STRIDE]) {
-    if (hipFuncSetAttribute((const void*)conv_mfma_kernel<STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  static bool attr_set[4] = {false, false, false, false};
+  if (!attr_set[KIND]) {
+    if (hipFuncSetAttribute((const void*)conv_mfma_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(MEDNET_E_HIP, "conv_mfma: cannot raise dynamic LDS to %zu", lds);
-    attr_set[STRIDE] = true;
+    attr_set[KIND] = true;
   }
   if constexpr (STRIDE == 1) {
     if (use_gnb) {
       constexpr size_t lds_gnb = lds + 16 * 256 * sizeof(float);  // + the parked GroupNorm-backward sums (16 per thread)
       static_assert(lds_gnb <= 80 * 1024, "two workgroups must fit one CU");
-      static bool attr_gnb = false;
-      if (!attr_gnb) {
-        if (hipFuncSetAttribute((const void*)conv_mfma_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gnb) != hipSuccess)
+      static bool attr_gnb[4] = {false, false, false, false};
+      if (!attr_gnb[KIND]) {
+        if (hipFuncSetAttribute((const void*)conv_mfma_kernel<KIND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gnb) != hipSuccess)
           return fail(MEDNET_E_HIP, "conv_mfma: cannot raise dynamic LDS to %zu", lds_gnb);
-        attr_gnb = true;
+        attr_gnb[KIND] = true;
       }
-      hipLaunchKernelGGL((conv_mfma_kernel<1, true>), dim3(grid), dim3(256), lds_gnb, s, a);
+      hipLaunchKernelGGL((conv_mfma_kernel<KIND, true>), dim3(grid), dim3(256), lds_gnb, s, a);
       return check_launch("conv_mfma(gnb)");
     }
   }
@@ -1790,7 +1817,7 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
       return check_launch("conv_mfma(gnb, stride 2)");
     }
   }
-  hipLaunchKernelGGL((conv_mfma_kernel<STRIDE>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<KIND>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("conv_mfma");
 }
 
@@ -1798,6 +1825,8 @@ int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, 
                      int x_dtype, int y_dtype, float* gn_partial, hipStream_t s, int act, const void* add) {
   (void)x_dtype;
   (void)y_dtype;
+  if (conv_fwd_kind(n, d, h, w, cin, cout, false) == 3)
+    return launch_fwd<3>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, gn_partial, s, act, add);
   return launch_fwd<1>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, gn_partial, s, act, add);
 }
 // data gradient + the first pass of the GroupNorm backward its output feeds (gn_partial: per-channel {sum du, sum du*y})
@@ -1807,6 +1836,8 @@ int launch_conv_mfma_gnb(const void* dy, const void* packed_section, void* dx, i
   g.y = gn_y;
   g.coef = gn_coef;
   g.act = gn_act;
+  if (conv_fwd_kind(n, d, h, w, cin, cout, true) == 3)
+    return launch_fwd<3>(dy, packed_section, dx, n, d, h, w, d, h, w, cin, cout, gn_partial, s, MEDNET_ACT_NONE, add, g);
   return launch_fwd<1>(dy, packed_section, dx, n, d, h, w, d, h, w, cin, cout, gn_partial, s, MEDNET_ACT_NONE, add, g);
 }
 // plan of launch_conv_mfma / launch_conv_mfma_gnb (stride 1) or launch_convt_dgrad_gn_mfma (stride 2; d, h, w = the LOW-resolution
@@ -1825,7 +1856,9 @@ int conv_mfma_plan(int n, int d, int h, int w, int cin, int cout, bool gnb, int 
       g.y = &dummy_partial;
       g.coef = &dummy_partial;
     }
-    rc = launch_fwd<1>(nullptr, nullptr, nullptr, n, d, h, w, d, h, w, cin, cout, &dummy_partial, nullptr, MEDNET_ACT_NONE, nullptr, g, &p);
+    rc = conv_fwd_kind(n, d, h, w, cin, cout, gnb) == 3
+             ? launch_fwd<3>(nullptr, nullptr, nullptr, n, d, h, w, d, h, w, cin, cout, &dummy_partial, nullptr, MEDNET_ACT_NONE, nullptr, g, &p)
+             : launch_fwd<1>(nullptr, nullptr, nullptr, n, d, h, w, d, h, w, cin, cout, &dummy_partial, nullptr, MEDNET_ACT_NONE, nullptr, g, &p);
   }
   if (rc) return rc;
   const int v[13] = {p.kind, p.grid, p.nitems, p.ncb, p.ntiles, p.tiles_per_sample, p.accum, p.rows, p.xcd_chunk, p.zslab,
@@ -1877,8 +1910,11 @@ struct Wg2Args {
   unsigned bytesA, bytesB;
 };
 
+// TX = 16, or 8 on narrow volumes (see FwdTile<3>): a k-step's 16 voxels are then two x-rows of 8.
+template <int TX>
 __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
-  constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+  constexpr int TZ = 4, TY = 8, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+  static_assert(TX == 16 || TX == 8, "brick widths");
   constexpr int NA = TZ * TY * TX, NB = HZ * HY * HX;
   constexpr int A_ROUNDS = NA * 4 / 512, B_ROUNDS = (NB * 4 + 511) / 512;
   constexpr int KSTEPS = NA / 16;
@@ -1983,8 +2019,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
 #pragma unroll
     for (int k2 = 0; k2 < KSTEPS / 2; ++k2) {
       const int ks = 2 * k2 + kgrp;  // the two wave groups interleave the brick's k-steps
-      const eltx8 fa = tr_operand(Ab + (ks * TX + 8 * hk + q) * 64, 4 * 64);
-      const char* brow = Bb + (((ks / TY) * HY + ks % TY) * HX + 8 * hk + q) * 64;
+      const eltx8 fa = tr_operand(Ab + (ks * 16 + 8 * hk + q) * 64, 4 * 64);  // (dy brick: voxels in x, y, z order, no halo)
+      // x: the k-step's voxels in the halo brick -- one x-row of 16 (lanes hk = 1 hold its second half), or the x-rows 2 ks and
+      // 2 ks + 1 of 8 (TY is even: both lie in the same z-plane)
+      const int krow = TX == 16 ? ks : 2 * ks;
+      const char* brow = Bb + (((krow / TY) * HY + krow % TY) * HX + (TX == 16 ? 8 * hk : hk * HX) + q) * 64;
       eltx8 fb[7];
 #pragma unroll
       for (int i = 0; i < 7; ++i) fb[i] = tr_operand(brow + toff[i], 4 * 64);
@@ -2028,10 +2067,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_mfma2_kernel(Wg2Args a) {
   }
 }
 
+static int wgrad2_tx(int w) { return narrow_bricks(w) ? 8 : 16; }
 static void wgrad2_plan(int n, int d, int h, int w, int ka, int kb, int workgroups, Wg2Args& a) {
+  const int tx = wgrad2_tx(w);
   a.tiles_z = (d + 3) / 4;
   a.tiles_y = (h + 7) / 8;
-  a.tiles_x = (w + 15) / 16;
+  a.tiles_x = (w + tx - 1) / tx;
   a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
   auto rcp = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
   a.rcp_tiles_x = rcp(a.tiles_x); a.rcp_tiles_y = rcp(a.tiles_y); a.rcp_tiles_z = rcp(a.tiles_z);
@@ -2054,19 +2095,32 @@ static size_t wgrad2_ws_bytes(int n, int d, int h, int w, int cin, int cout, int
 }
 
 // dw[(a*KB + b)*27 + tap] = sum_split part[(pair*splits + split)][tap][a%32][b%32]
-// (few slabs per output -- deep layers, where the channel-block pairs alone fill the chip: one thread per output)
+// (few slabs per output -- deep layers, where the channel-block pairs alone fill the chip.  For one row a of a pair the 32 x 27
+//  outputs are CONTIGUOUS in dw: a workgroup takes 8 rows of a pair, sums the slabs with coalesced reads (thread = (row, b), the
+//  27 taps in turn), turns the tile to [row][b][tap] in LDS and writes each row's run of 864 floats in order.  The element-per-
+//  thread form it replaces wrote 4-byte pieces 108 bytes apart: 136 us for the 113 MB of config 5's 1024 -> 1024 layers, 0.65 ms
+//  of its step.)
 __global__ __launch_bounds__(256) void wgrad_mfma_reduce_kernel_few(const float* __restrict__ part, float* __restrict__ dw, int ka, int kb, int nbb,
                                                int splits) {
-  const size_t total = (size_t)((ka + 31) / 32) * nbb * 1024 * 27;
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  const int b32 = (int)(e % 32), a32 = (int)((e / 32) % 32), tap = (int)((e / 1024) % 27);
-  const int pair = (int)(e / (1024 * 27));
+  __shared__ float tile[8][32 * 27 + 1];
+  const int pair = (int)blockIdx.x >> 2, a0 = ((int)blockIdx.x & 3) * 8;
   const int ab = pair / nbb, bb = pair % nbb;
-  const float* src = part + ((size_t)pair * splits) * 27 * 1024 + (size_t)tap * 1024 + a32 * 32 + b32;
-  float s0 = 0.f;
-  for (int k = 0; k < splits; ++k) s0 += src[(size_t)k * 27 * 1024];
-  if (ab * 32 + a32 < ka && bb * 32 + b32 < kb) dw[((size_t)(ab * 32 + a32) * kb + bb * 32 + b32) * 27 + tap] = s0;
+  const int tr = threadIdx.x >> 5, tb = threadIdx.x & 31;
+  const float* src = part + ((size_t)pair * splits) * 27 * 1024 + (size_t)(a0 + tr) * 32 + tb;
+#pragma unroll 3
+  for (int tap = 0; tap < 27; ++tap) {
+    float s0 = 0.f;
+    for (int k = 0; k < splits; ++k) s0 += src[((size_t)k * 27 + tap) * 1024];
+    tile[tr][tb * 27 + tap] = s0;
+  }
+  __syncthreads();
+  const int nb = kb - bb * 32 < 32 ? kb - bb * 32 : 32;  // valid columns of this block: the row's run is nb * 27 floats
+  for (int r = 0; r < 8; ++r) {
+    const int arow = ab * 32 + a0 + r;
+    if (arow >= ka) break;
+    float* dst = dw + ((size_t)arow * kb + bb * 32) * 27;
+    for (int e = threadIdx.x; e < nb * 27; e += 256) dst[e] = tile[r][e];
+  }
 }
 __global__ __launch_bounds__(256) void wgrad_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int ka, int kb,
                                                               int nbb, int splits) {
@@ -2391,13 +2445,15 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
     int rc4 = check_launch("wgrad_mfma4");
     if (rc4) return rc4;
     const size_t total4 = (size_t)a.nab * a.nbb * 1024 * 27;
-    if (a.splits < 4) hipLaunchKernelGGL(wgrad_mfma_reduce_kernel_few, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, a.part, dw, cout, cin,
+    if (a.splits < 4) hipLaunchKernelGGL(wgrad_mfma_reduce_kernel_few, dim3((unsigned)(a.nab * a.nbb * 4)), dim3(256), 0, s, a.part, dw, cout, cin,
                        a.nbb, a.splits);
     else hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, a.part, dw, cout, cin,
                        a.nbb, a.splits);
     return check_launch("wgrad_mfma_reduce");
   }
-  constexpr size_t lds = ((size_t)4 * 8 * 16 + 6 * 10 * 18) * 64;
+  const int tx = wgrad2_tx(w);
+  size_t lds = ((size_t)4 * 8 * tx + 6 * 10 * (tx + 2)) * 64;
+  if (lds < 65536) lds = 65536;  // (the k-groups' merge area at the end: 4 tap waves x 4 slots x 16 x 64 floats)
   Wg2Args a;
   a.A = (const elt*)dy;
   a.B = (const elt*)x;
@@ -2408,17 +2464,19 @@ int launch_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int d, in
   a.bytesB = (unsigned)((size_t)d * h * w * cin * 2);
   const size_t need = (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
   MEDNET_REQUIRE(ws_bytes >= need, MEDNET_E_WORKSPACE, "wgrad_mfma2: workspace %zu < %zu", ws_bytes, need);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wgrad_mfma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(MEDNET_E_HIP, "wgrad_mfma2: cannot raise dynamic LDS to %zu", lds);
-    attr_set = true;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[tx == 8]) {
+    const hipError_t e = tx == 8 ? hipFuncSetAttribute((const void*)wgrad_mfma2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                 : hipFuncSetAttribute((const void*)wgrad_mfma2_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(MEDNET_E_HIP, "wgrad_mfma2: cannot raise dynamic LDS to %zu", lds);
+    attr_set[tx == 8] = true;
   }
-  hipLaunchKernelGGL(wgrad_mfma2_kernel, dim3(a.nab * a.nbb * a.splits), dim3(512), lds, s, a);
+  if (tx == 8) hipLaunchKernelGGL(wgrad_mfma2_kernel<8>, dim3(a.nab * a.nbb * a.splits), dim3(512), lds, s, a);
+  else hipLaunchKernelGGL(wgrad_mfma2_kernel<16>, dim3(a.nab * a.nbb * a.splits), dim3(512), lds, s, a);
   int rc = check_launch("wgrad_mfma2");
   if (rc) return rc;
   const size_t total = (size_t)a.nab * a.nbb * 1024 * 27;
-  if (a.splits < 4) hipLaunchKernelGGL(wgrad_mfma_reduce_kernel_few, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, cout, cin,
+  if (a.splits < 4) hipLaunchKernelGGL(wgrad_mfma_reduce_kernel_few, dim3((unsigned)(a.nab * a.nbb * 4)), dim3(256), 0, s, a.part, dw, cout, cin,
                      a.nbb, a.splits);
   else hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.part, dw, cout, cin,
                      a.nbb, a.splits);
@@ -2484,7 +2542,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_mfma_kernel(Wc1Args a) {
       const int c = it * 256 + tid;
       const int part = c % (4 * NB), v = c / (4 * NB);
       const int gz = tz0 + v / (TX * TY), gy = ty0 + (v / TX) % TY, gx = tx0 + v % TX;
-      const bool in_vol = (gz < a.d) & (gy < a.h) & (gx < a.w);
+      const bool in_vol = (gz < a.d) & (gy < a.h) & (gx < a.w) & (part * 8 < a.cout);  // (16 channels: the row's second half is zeros)
       const unsigned off = ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.cout + part * 8) * 2u;
       rdy[it] = __builtin_amdgcn_raw_buffer_load_b128(rD, in_vol ? off : OOB, 0, 0);
     }
@@ -2561,13 +2619,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_mfma_kernel(Wc1Args a) {
         const float s = (red[((0 * NB + b) * 16 + j) * 64 + lane] + red[((1 * NB + b) * 16 + j) * 64 + lane]) +
                         (red[((2 * NB + b) * 16 + j) * 64 + lane] + red[((3 * NB + b) * 16 + j) * 64 + lane]);
         const int tap = (j & 3) + 8 * (j >> 2) + 4 * hk, co = b * 32 + (lane & 31);
-        if (tap < 27) a.part[((size_t)blockIdx.x * a.cout + co) * 27 + tap] = s;
+        if (tap < 27 && co < a.cout) a.part[((size_t)blockIdx.x * a.cout + co) * 27 + tap] = s;
       }
   }
 }
 
 bool wgrad_c1_mfma_supported(int cout, int x_dtype, int dy_dtype) {
-  return (cout == 32 || cout == 64) && (x_dtype == MEDNET_F32 || x_dtype == ELT_DTYPE) && dy_dtype == ELT_DTYPE;
+  return (cout == 16 || cout == 32 || cout == 64) && (x_dtype == MEDNET_F32 || x_dtype == ELT_DTYPE) && dy_dtype == ELT_DTYPE;
 }
 int wgrad_c1_mfma_blocks(int n, int d, int h, int w) {
   const int nt = n * ((d + 3) / 4) * ((h + 7) / 8) * ((w + 15) / 16);
@@ -2589,7 +2647,7 @@ int launch_wgrad_c1_mfma(const void* x, const void* dy, float* part, int n, int 
   a.bytes_x = (unsigned)((size_t)d * h * w * (a.x16 ? 2 : 4));
   a.bytes_dy = (unsigned)((size_t)d * h * w * cout * 2);
   const int blocks = wgrad_c1_mfma_blocks(n, d, h, w);
-  const int nb = cout / 32;
+  const int nb = (cout + 31) / 32;
   const size_t stage = 4352 + (size_t)512 * 64 * nb, red = (size_t)4 * nb * 16 * 64 * 4;
   const size_t lds = stage > red ? stage : red;
   if (nb == 1) hipLaunchKernelGGL(wgrad_c1_mfma_kernel<1>, dim3(blocks), dim3(256), lds, s, a);
@@ -2842,7 +2900,7 @@ int launch_convt_wgrad_mfma(const void* x, const void* dy, float* dw, int n, int
   int rc = check_launch("convt_wgrad_mfma2");
   if (rc) return rc;
   const size_t total = (size_t)a.nab * a.nbb * 1024 * 27;
-  if (a.splits < 4) hipLaunchKernelGGL(wgrad_mfma_reduce_kernel_few, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.part, dw, cin, cout,
+  if (a.splits < 4) hipLaunchKernelGGL(wgrad_mfma_reduce_kernel_few, dim3((unsigned)(a.nab * a.nbb * 4)), dim3(256), 0, s, a.part, dw, cin, cout,
                      a.nbb, a.splits);
   else hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.part, dw, cin, cout,
                      a.nbb, a.splits);

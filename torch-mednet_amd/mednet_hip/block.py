@@ -157,9 +157,10 @@ def _conv_bwd(x, dy, packed, weight_p, need_dx, add=None, gnb=None):
     on_side = ops.SIDE["enabled"] and direct
     with ops._OnSide(on_side, dy.device, x, dy, coresident=on_side and ops.wgrad_coresident(n, d, h, w, cin, cout, 3, x, dy)) as side:
         ws = L.workspace(lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, 3, side.workgroups), dy.device)
-        L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, n, d, h, w, cin, cout, 3, L.dt(x),
-                                        L.NDHWC, L.dt(dy), L.NDHWC, config.conv_algo(), side.workgroups, ws.data_ptr(), ws.numel(),
-                                        L.stream()), "conv3d_wgrad")
+        with ops.profiled_wgrad(3, cin, cout, n, d, h, w):
+            L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, n, d, h, w, cin, cout, 3, L.dt(x),
+                                            L.NDHWC, L.dt(dy), L.NDHWC, config.conv_algo(), side.workgroups, ws.data_ptr(),
+                                            ws.numel(), L.stream()), "conv3d_wgrad")
     if WGRAD_FIRST:
         dgrad()
     return dx, (None if direct else dw), partial

@@ -151,6 +151,22 @@ class profiled_conv:
         return False
 
 
+class profiled_wgrad(profiled_conv):
+    """The same for the weight gradient of matching layers (bench.py's second roofline object): the events go on the stream the
+    launch runs on -- inside _OnSide that is the weight-gradient stream, where the kernel shares the CUs with the main stream's
+    bandwidth-bound passes."""
+
+    def __init__(self, ksize, cin, cout, n, d, h, w):
+        super().__init__(ksize, cin, cout, n, d, h, w)
+        self.on = self.on and PROFILE.get("wgrad_events") is not None
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            PROFILE["wgrad_events"].append((self.e0, self.e1, self.flops))
+        return False
+
+
 def _with_algo(backward):
     """backward of a conv-family Function: replays the algorithm choice (config.conv_algo()) captured at forward."""
     def wrapped(ctx, *grads):
