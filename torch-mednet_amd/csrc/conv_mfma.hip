@@ -2182,7 +2182,10 @@ struct Wg4Args {
   unsigned bytesA, bytesB;  // one sample
 };
 
-constexpr int WG4_DEPTH = 3;                            // ticks between a plane's LDS-DMA and its first use
+#ifndef MEDNET_WG4_DEPTH
+#define MEDNET_WG4_DEPTH 3
+#endif
+constexpr int WG4_DEPTH = MEDNET_WG4_DEPTH;             // ticks between a plane's LDS-DMA and its first use
 constexpr int WG4_RB = WG4_DEPTH + 3, WG4_RA = WG4_DEPTH + 1;
 constexpr int WG4_BSLOT = 12 * 1024, WG4_ASLOT = 8 * 1024;  // 10 x 18 voxel rows = 11.25 DMA pieces, padded to 12; 8 x 16 = 8
 constexpr size_t WG4_LDS = (size_t)WG4_RB * WG4_BSLOT + (size_t)WG4_RA * WG4_ASLOT;
@@ -2380,7 +2383,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma4_kernel(Wg4Args a) {
 static bool wgrad4_applies(int d, int h, int w) { return tuning_option("wgrad_v4", 1) != 0 && d >= 8 && h >= 8 && w >= 16; }
 bool wgrad_mfma_coresident(int d, int h, int w) { return wgrad4_applies(d, h, w); }
 static void wgrad4_plan(int n, int d, int h, int w, int ka, int kb, int workgroups, Wg4Args& a) {
-  const int slabs = (d + 31) / 32;  // z-slabs of at most 32 planes, equal depth
+  const int zmax = tuning_option("wgrad4_zs", 32);
+  const int slabs = (d + zmax - 1) / zmax;  // z-slabs of at most 32 planes, equal depth
   a.zslabs = slabs;
   a.zs = (d + slabs - 1) / slabs;
   a.tiles_y = (h + 7) / 8;
