@@ -171,6 +171,11 @@ size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cou
  * bandwidth-bound kernels of another stream run on the same CUs beside it); 0 if it takes its CUs whole.  A caller that runs
  * weight gradients on a second stream passes workgroups = 0 (all CUs) in the first case and about half the CUs in the second. */
 int mednet_conv3d_wgrad_coresident(int n, int d, int h, int w, int cin, int cout, int ksize, int x_dtype, int dy_dtype, int algo);
+/* Launch plan of the 3x3x3 weight gradient (16-bit matrix-core path) made by the launcher's own planning code, for audits without
+ * a device (tests/test_plan_audit.py): out10 = {kind (4: wgrad_mfma4_kernel, z-columns; 2: wgrad_mfma2_kernel, bricks), workgroups,
+ * channel-block pairs, workgroups per pair, work items per pair, tiles_x, tiles_y, z-slabs (kind 4) or tiles_z (kind 2), planes
+ * per slab (kind 4) or brick width (kind 2), XCD remap of the item order (kind 4)}. */
+int mednet_conv3d_wgrad_plan(int n, int d, int h, int w, int cin, int cout, int dtype, int workgroups, int* out10);
 int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
                         int cin, int cout, int ksize, int x_dtype, int x_layout, int dy_dtype, int dy_layout,
                         int algo, int workgroups, void* ws, size_t ws_bytes, mednet_stream stream);

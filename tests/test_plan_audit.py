@@ -165,3 +165,75 @@ def test_ragged_shapes(shape, n, chan):
         check(n, d, h, w, chan[0], chan[1], BF16, gnb, 1)
     if chan[0] % 32 == 0 and chan[1] % 32 == 0:
         check(n, d, h, w, chan[0], chan[1], BF16, True, 2)
+
+
+# ---- weight-gradient plans (round 5: wgrad_mfma4_kernel's z-columns, wgrad_mfma2_kernel<8>'s narrow bricks) -----------------------
+def wgrad_plan(n, d, h, w, cin, cout, dtype, workgroups):
+    lib = L.lib()
+    out = (C.c_int * 10)()
+    rc = lib.mednet_conv3d_wgrad_plan(n, d, h, w, cin, cout, dtype, workgroups, C.addressof(out))
+    assert rc == 0, lib.mednet_last_error().decode()
+    keys = ("kind", "grid", "pairs", "splits", "nitems", "tiles_x", "tiles_y", "tz_or_slabs", "zs_or_tx", "xcd_remap")
+    return dict(zip(keys, out))
+
+
+def audit_wgrad(n, d, h, w, p):
+    """Every voxel of every sample must be contracted exactly once per channel-block pair: walk the item lists of a pair's
+    workgroups with the kernels' own rules (first item, stride, XCD remap) and mark the voxels of each item."""
+    import numpy as np
+    seen = np.zeros((n, d, h, w), dtype=np.int32)
+    splits, nitems = p["splits"], p["nitems"]
+    assert p["grid"] == p["pairs"] * splits and 1 <= splits <= max(nitems, 1)
+    for split in range(splits):
+        first = (split & 7) * (splits >> 3) + (split >> 3) if p["xcd_remap"] else split
+        if p["xcd_remap"]:
+            assert splits % 8 == 0
+        for item in range(first, nitems, splits):
+            t = item
+            tx, t = t % p["tiles_x"], t // p["tiles_x"]
+            ty, t = t % p["tiles_y"], t // p["tiles_y"]
+            tz, nn = t % p["tz_or_slabs"], t // p["tz_or_slabs"]
+            assert nn < n
+            if p["kind"] == 4:
+                zs = p["zs_or_tx"]
+                z0, z1, y0, x0, ey, ex = tz * zs, min(d, (tz + 1) * zs), ty * 8, tx * 16, 8, 16
+            else:
+                z0, z1, y0, x0, ey, ex = tz * 4, min(d, tz * 4 + 4), ty * 8, tx * p["zs_or_tx"], 8, p["zs_or_tx"]
+            seen[nn, z0:z1, y0:min(h, y0 + ey), x0:min(w, x0 + ex)] += 1
+    assert seen.min() == 1 and seen.max() == 1, (p, int(seen.min()), int(seen.max()))
+
+
+@pytest.mark.parametrize("workgroups", [0, 128, 24])
+@pytest.mark.parametrize("cfg", sorted(CFG))
+def test_weight_gradient_plans_cover_every_voxel_once(cfg, workgroups):
+    f_maps, size, n = CFG[cfg]
+    convs, _ = unet_layers(f_maps, size, n)
+    kinds = set()
+    for (nn, d, h, w, cin, cout) in convs:
+        p = wgrad_plan(nn, d, h, w, cin, cout, BF16, workgroups)
+        audit_wgrad(nn, d, h, w, p)
+        kinds.add((p["kind"], p["zs_or_tx"] if p["kind"] == 2 else 0))
+        if p["kind"] == 4:  # slabs of at most 32 planes that cover the depth
+            assert p["zs_or_tx"] <= 32 and p["zs_or_tx"] * p["tz_or_slabs"] >= d > p["zs_or_tx"] * (p["tz_or_slabs"] - 1)
+    if cfg == "cfg5":  # levels 0 - 2 on the co-resident kernel, 20 x 20 x 12 on 16-wide bricks, 10 x 10 x 6 on 8-wide ones
+        assert kinds == {(4, 0), (2, 16), (2, 8)}, kinds
+    if cfg == "cfg2":
+        assert kinds == {(4, 0)}, kinds
+
+
+@pytest.mark.parametrize("shape", [(9, 11, 21), (4, 8, 16), (10, 10, 6), (7, 9, 40), (33, 8, 16), (64, 20, 17), (5, 300, 7)])
+@pytest.mark.parametrize("chan", [(16, 16), (32, 64), (96, 32), (256, 512)])
+def test_weight_gradient_plans_ragged(shape, chan):
+    d, h, w = shape
+    for n in (1, 3):
+        for wgs in (0, 128, 1000):
+            audit_wgrad(n, d, h, w, wgrad_plan(n, d, h, w, chan[0], chan[1], F16, wgs))
+
+
+def test_narrow_brick_plans():
+    """8-wide bricks (FwdTile<3>) for volumes up to 8 voxels wide: the forward / data-gradient plans of config 5's deepest level."""
+    for gnb in (False, True):
+        p = check(2, 10, 10, 6, 1024, 1024, BF16, gnb, 1)
+        assert (p["tiles_x"], p["tiles_y"], p["tiles_z"]) == (1, 2, 3) and p["kind"] == 2
+        check(3, 7, 13, 8, 64, 96, F16, gnb, 1)
+        check(1, 4, 4, 4, 256, 256, BF16, gnb, 1)

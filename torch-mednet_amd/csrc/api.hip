@@ -258,6 +258,14 @@ extern "C" size_t mednet_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int c
   return align_up(m, 256) + channel_sum_ws_bytes(n, (size_t)d * h * w, cout) + 256;
 }
 
+// Launch plan of a 3x3x3 weight gradient on the 16-bit matrix-core path, from the launcher's own planning code (no device needed)
+extern "C" int mednet_conv3d_wgrad_plan(int n, int d, int h, int w, int cin, int cout, int dtype, int workgroups, int* out10) {
+  MEDNET_REQUIRE(out10 && n > 0 && d > 0 && h > 0 && w > 0 && workgroups >= 0, MEDNET_E_SHAPE, "conv3d_wgrad_plan: bad arguments");
+  MEDNET_REQUIRE(is16(dtype) && cin % 16 == 0 && cout % 16 == 0, MEDNET_E_UNSUPPORTED,
+                 "conv3d_wgrad_plan: the 16-bit matrix-core kernels only (dtype %d, %d -> %d)", dtype, cin, cout);
+  return ELT_CALL(dtype, wgrad_mfma_plan, n, d, h, w, cin, cout, workgroups, out10);
+}
+
 // Does this weight gradient run on the kernel that leaves half of every CU (registers, wave slots, 60 KB of LDS) to other streams?
 // A caller that launches weight gradients beside its main stream asks for all CUs then (workgroups = 0) instead of half of them.
 extern "C" int mednet_conv3d_wgrad_coresident(int n, int d, int h, int w, int cin, int cout, int ksize, int x_dtype, int dy_dtype,

@@ -2408,6 +2408,24 @@ static size_t wgrad4_ws_bytes(int n, int d, int h, int w, int cin, int cout, int
   return (size_t)a.nab * a.nbb * a.splits * 27 * 1024 * sizeof(float);
 }
 
+// Launch plan of the 3x3x3 weight gradient for audits without a device (mednet_conv3d_wgrad_plan, tests/test_plan_audit.py):
+// out[10] = {kind (4: wgrad_mfma4_kernel, z-columns; 2: wgrad_mfma2_kernel, bricks), workgroups, pairs, splits, items per pair,
+//            tiles_x, tiles_y, tiles_z or z-slabs, planes per slab (kind 4) or brick width (kind 2), xcd_remap}
+int wgrad_mfma_plan(int n, int d, int h, int w, int cin, int cout, int workgroups, int* out) {
+  if (wgrad4_applies(d, h, w)) {
+    Wg4Args a;
+    wgrad4_plan(n, d, h, w, cout, cin, workgroups, a);
+    const int v[10] = {4, a.nab * a.nbb * a.splits, a.nab * a.nbb, a.splits, a.nitems, a.tiles_x, a.tiles_y, a.zslabs, a.zs, a.xcd_remap};
+    for (int i = 0; i < 10; ++i) out[i] = v[i];
+  } else {
+    Wg2Args a;
+    wgrad2_plan(n, d, h, w, cout, cin, workgroups, a);
+    const int v[10] = {2, a.nab * a.nbb * a.splits, a.nab * a.nbb, a.splits, a.ntiles, a.tiles_x, a.tiles_y, a.tiles_z, wgrad2_tx(w), 0};
+    for (int i = 0; i < 10; ++i) out[i] = v[i];
+  }
+  return MEDNET_OK;
+}
+
 bool wgrad_mfma_supported(int cin, int cout, int ksize, int x_dtype, int dy_dtype, int x_layout, int dy_layout) {
   return ksize == 3 && cin % 16 == 0 && cout % 16 == 0 && x_dtype == ELT_DTYPE && dy_dtype == ELT_DTYPE &&
          x_layout == MEDNET_NDHWC && dy_layout == MEDNET_NDHWC;

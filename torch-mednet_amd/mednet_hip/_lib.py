@@ -62,6 +62,7 @@ SIGNATURES = {
     "mednet_pool2_bwd_gn": (_i, [_vp] * 5 + [_i, _vp] + [_i] * 7 + [_vp]),
     "mednet_conv3d_wgrad_ws_bytes": (_sz, [_i] * 8),
     "mednet_conv3d_wgrad_coresident": (_i, [_i] * 10),
+    "mednet_conv3d_wgrad_plan": (_i, [_i] * 8 + [_vp]),
     "mednet_conv3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _sz, _vp]),
     "mednet_convt3d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "mednet_convt3d_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 9 + [_vp]),
