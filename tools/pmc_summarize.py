@@ -97,6 +97,25 @@ def main():
                 res["mfma_busy_fraction_of_SQ_BUSY_CYCLES_x_simds"] = "see DESIGN.md: busy cycles / (kernel cycles x 1024 SIMDs)"
             json.dump(res, open(os.path.join(ROOT, "profiles", f"{ROUND}_pmc_sq_dominant_kernel.json"), "w"), indent=1)
             print("SQ:", res["counters_avg_per_launch"])
+    if sq:  # the same for the weight gradient of the same layers (round 5: wgrad_mfma4_kernel; the longest launches = 32 -> 32 @128^3)
+        rows = list(csv.DictReader(open(sq)))
+        wg = [r for r in rows if "wgrad_mfma4_kernel" in r["Kernel_Name"] and "mednet_f16" not in r["Kernel_Name"]]
+        byd = collections.defaultdict(dict)
+        for r in wg:
+            byd[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+            byd[r["Dispatch_Id"]]["_dur"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        dmax = max((d["_dur"] for d in byd.values()), default=0)
+        big = [d for d in byd.values() if d["_dur"] >= 0.6 * dmax]
+        if big:
+            avg = {k: sum(d[k] for d in big) / len(big) for k in big[0]}
+            mf = 2 * 27 * 32 * 32 * 4 * 128 ** 3 / (2 * 32 * 32 * 16) * 28 / 27  # (a wave with 6 taps issues a 7th, discarded)
+            res = {"kernel": "mednet::wgrad_mfma4_kernel weight gradient of conv3d 32->32@128^3 (the step's longest launches; beside the "
+                             "main stream's GroupNorm-backward passes unless MEDNET_SIDE_STREAM=0)",
+                   "launches": len(big), "avg_duration_us_under_pmc": round(avg.pop("_dur") / 1e3, 1),
+                   "counters_avg_per_launch": {k: round(v, 1) for k, v in sorted(avg.items())},
+                   "mfma_instructions_per_launch": mf, "_meta": out["_meta"]}
+            json.dump(res, open(os.path.join(ROOT, "profiles", f"{ROUND}_pmc_sq_wgrad_kernel.json"), "w"), indent=1)
+            print("SQ wgrad:", res["counters_avg_per_launch"])
     fs, wsl = per_slot(f), per_slot(w)
     slots = {k: [int((2 * a + b) * 1024) for a, b in zip(fs[k], wsl[k])] for k in fs if k in wsl and len(fs[k]) == len(wsl[k])}
     json.dump(slots, open(os.path.join(ROOT, "profiles", f"{ROUND}_pmc_hbm_slots.json"), "w"))
