@@ -200,16 +200,19 @@ def wgrad_alone_ms(dev, batch: int, patch: int, precision: str) -> float:
     st = torch.cuda.current_stream().cuda_stream
     run = lambda: L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, batch, patch, patch, patch, c, c, 3, code,
                                                   L.NDHWC, code, L.NDHWC, L.ALGO_AUTO, 0, ws.data_ptr(), ws.numel(), st), "conv3d_wgrad")
+    for _ in range(20):  # (the chip idled while the host assembled the record: bring the clocks back before timing)
+        run()
+    torch.cuda.synchronize()
+    rounds = []
     for _ in range(3):
-        run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        rounds.append(e0.elapsed_time(e1) / 20)
+    return sorted(rounds)[1]  # median of three rounds of 20 launches (each launch = the kernel + its fixed-order reduce)
 
 
 def fp32_parity_mode(dev, batch: int, patch: int, steps: int):
@@ -405,7 +408,7 @@ def main():
             out["roofline_wgrad"] = {"kernel": "wgrad_mfma4_kernel: weight gradient of conv3d 3x3x3 32->32 @128^3", "bound": "mfma",
                                      "achieved": round(flops / (alone * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
                                      "frac": round(flops / (alone * 1e-3) / 1e12 / peak, 4), "avg_ms": round(alone, 4),
-                                     "launches": 20, "flop_per_launch": flops,
+                                     "launches": 60, "flop_per_launch": flops,
                                      "in_step_beside_the_main_stream": {"avg_ms": round(avg, 4), "launches": len(ms),
                                                                         "achieved": round(flops / (avg * 1e-3) / 1e12, 2)}}
         if a.fp32_steps > 0 and world == 1 and a.precision == "bf16":
