@@ -2343,7 +2343,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma4_kernel(Wg4Args a) {
         __builtin_amdgcn_sched_barrier(0);
         constexpr int first_rd[8] = {0, 3, 6, 9, 12, 14, 16, 16};
         for (int idx = first_rd[i]; idx < first_rd[i + 1]; ++idx) rd(nxt, idx, nks);
-        if (i == 5 && ks < 5) dma(ks, live);
+        if (i == 6 && ks < 5) dma(ks, live);  // (the gap without reads: 1 % faster than beside two of them, profiles/r05_ab.md 6)
       }
     }
   };
