@@ -1869,6 +1869,13 @@ int conv_mfma_plan(int n, int d, int h, int w, int cin, int cout, bool gnb, int 
 int conv_mfma_stats_chunks(int n, int d, int h, int w, int cin, int cout, bool gnb) {
   int rows, accum;
   conv_stats_plan(n, d, h, w, cin, cout, rows, accum, gnb);
+  // (A/B knob conv_fuse_gnb_general=0: only the 32 -> 32 specialisation takes the GroupNorm-backward sums in its epilogue; the
+  //  general kernel's data gradients leave them to the stand-alone pass)
+  if (gnb && !tuning_option("conv_fuse_gnb_general", 1)) {
+    using G = FwdTile<1>;
+    const int ntiles16 = n * ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
+    if (!conv32_takes(ntiles16, cin, cout, true)) return 0;
+  }
   return rows;
 }
 
