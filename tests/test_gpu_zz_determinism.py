@@ -169,3 +169,49 @@ def test_the_other_step_classes_are_bitwise_repeatable(which):
             del net, step
     assert all(np.isfinite(v) for v in runs[0][0]) and float(runs[0][1].abs().max()) > 0
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]), which
+
+
+@pytest.mark.parametrize("shape,wgs", [((4, 32, 32, (64, 64, 64)), 0), ((2, 64, 96, (24, 40, 56)), 24)])
+def test_co_resident_weight_gradient_is_timing_independent(shape, wgs):
+    """wgrad_mfma4_kernel's ring protocol (a counted vmcnt wait + one barrier per tick, slots recycled six ticks later, hand-written
+    LDS-DMA the compiler does not see) must not depend on timing: the launch alone, beside a streaming copy on a second stream (memory
+    latencies stretch) and beside a second weight gradient on the same CUs must give the same bits every time.  (The long form:
+    tools/probes/wgrad4_soak.py, profiles/r05_wgrad4_race_screen.log -- 300 launches, none differs.)"""
+    from mednet_hip import _lib as L
+    lib = L.lib()
+    n, cin, cout, (d, h, w) = shape
+    CL = torch.channels_last_3d
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(n, cin, d, h, w, device=DEV, generator=g).bfloat16().contiguous(memory_format=CL)
+    dy = torch.randn(n, cout, d, h, w, device=DEV, generator=g).bfloat16().contiguous(memory_format=CL)
+    big = torch.randn(32 * 1024 * 1024, device=DEV)
+    big2 = torch.empty_like(big)
+    side, main = torch.cuda.Stream(), torch.cuda.current_stream()
+    assert lib.mednet_conv3d_wgrad_coresident(n, d, h, w, cin, cout, 3, L.BF16, L.BF16, L.ALGO_AUTO) == 1
+    nbytes = lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, 3, wgs)
+    ws1, ws2 = (torch.empty(nbytes, dtype=torch.uint8, device=DEV) for _ in range(2))
+
+    def launch(stream, dw, ws):
+        L.check(lib.mednet_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, n, d, h, w, cin, cout, 3, L.BF16, L.NDHWC, L.BF16,
+                                        L.NDHWC, L.ALGO_MFMA, wgs, ws.data_ptr(), ws.numel(), stream.cuda_stream), "conv3d_wgrad")
+
+    ref = torch.empty(cout, cin, 3, 3, 3, device=DEV)
+    launch(main, ref, ws1)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ref).all())
+    for i in range(18):
+        dw, dwb = torch.full_like(ref, float("nan")), torch.full_like(ref, float("nan"))
+        ws1.fill_(0xFF)
+        side.wait_stream(main)
+        if i % 3 == 1:
+            with torch.cuda.stream(side):
+                big2.copy_(big)
+                big.copy_(big2)
+        elif i % 3 == 2:
+            launch(side, dwb, ws2)
+        launch(main, dw, ws1)
+        main.wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(dw, ref), f"launch {i} (mode {i % 3}) differs from the first"
+        if i % 3 == 2:
+            assert torch.equal(dwb, ref), f"the concurrent launch {i} differs from the first"
