@@ -176,6 +176,15 @@ int mednet_conv3d_wgrad_coresident(int n, int d, int h, int w, int cin, int cout
  * channel-block pairs, workgroups per pair, work items per pair, tiles_x, tiles_y, z-slabs (kind 4) or tiles_z (kind 2), planes
  * per slab (kind 4) or brick width (kind 2), XCD remap of the item order (kind 4)}. */
 int mednet_conv3d_wgrad_plan(int n, int d, int h, int w, int cin, int cout, int dtype, int workgroups, int* out10);
+/* The Cin = 1, 3x3x3 weight gradient with GroupNorm's backward apply folded into its staging: dz / y = gradient of, and input
+ * to, act(GroupNorm(y)) (16-bit NDHWC, Cout channels), coef = the forward affine {ca, cb}, bcoef from
+ * mednet_gn_bwd_coefficients.  dw gets what mednet_conv3d_wgrad(x, dy) returns for the dy mednet_gn_act_bwd_fused stores --
+ * bit for bit -- without dy ever reaching memory.  Workspace: mednet_conv3d_wgrad_ws_bytes(n, d, h, w, 1, cout, 3, 0).
+ * _supported: Cout in {16, 32, 64}, 16-bit dtype, x fp32 or that dtype. */
+int mednet_conv3d_wgrad_c1_gn_supported(int cout, int x_dtype, int dtype);
+int mednet_conv3d_wgrad_c1_gn(const void* x, const void* dz, const void* y, const float* coef, const float* bcoef, float* dw,
+                              int n, int d, int h, int w, int cout, int act, int x_dtype, int dtype, void* ws, size_t ws_bytes,
+                              mednet_stream stream);
 int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
                         int cin, int cout, int ksize, int x_dtype, int x_layout, int dy_dtype, int dy_layout,
                         int algo, int workgroups, void* ws, size_t ws_bytes, mednet_stream stream);
@@ -223,6 +232,14 @@ int mednet_gn_act_bwd_fused(const void* dz, const void* x, const float* coef, co
                             const float* partial, int rows, void* dx, float* dgamma, float* dbeta, int n,
                             size_t spatial, int c, int groups, int act, int in_act, int dtype, void* ws, size_t ws_bytes,
                             mednet_stream stream);
+/* Passes 1b + 2 of mednet_gn_act_bwd_fused alone: bcoef[n][c][3] = {k1, k2, k3} with dx = k1 * du + k2 * x + k3
+ * (du = dz * act'(coef_a * x + coef_b)), and dgamma / dbeta.  For a consumer that applies the coefficients while it reads
+ * (dz, x) for its own purpose -- mednet_conv3d_wgrad_c1_gn below -- so the apply pass and its dx tensor disappear.  The first
+ * SingleConv of the network (components.py:57 after model.py:63's first encoder) needs no gradient of the network input:
+ * its GroupNorm backward only feeds the weight gradient. */
+int mednet_gn_bwd_coefficients(const float* stats, const float* gamma, const float* partial, int rows, float* bcoef,
+                               float* dgamma, float* dbeta, int n, size_t spatial, int c, int groups, void* ws,
+                               size_t ws_bytes, mednet_stream stream);
 int mednet_gn_act_bwd_fused_res(const void* dz, const void* x, const void* z, const float* coef, const float* stats,
                                 const float* gamma, const float* fused_partial, int rows, void* dx, void* dres,
                                 float* dgamma, float* dbeta, int n, size_t spatial, int c, int groups, int act, int dtype,

@@ -680,6 +680,39 @@ def test_groupnorm_backward_sums_from_the_data_gradient_epilogue(n, c, shape):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("n,c,shape,act", [(2, 32, (32, 32, 32), "e"), (1, 32, (9, 11, 21), "e"), (2, 64, (16, 24, 32), "l"),
+                                           (1, 16, (8, 8, 16), "r"), (3, 32, (5, 3, 2), "e"), (1, 32, (64, 64, 64), "e")])
+def test_first_layer_groupnorm_backward_inside_its_weight_gradient(mode, n, c, shape, act):
+    """The network's first ExtResNetBlock (model.py:63, Cin = 1, components.py:168-180) needs no gradient of the patch: the
+    backward of its first GroupNorm feeds only the first conv's weight gradient.  mednet_gn_bwd_coefficients +
+    mednet_conv3d_wgrad_c1_gn (the apply pass inside the weight-gradient kernel's staging, dy never stored) against
+    mednet_gn_act_bwd_fused + mednet_conv3d_wgrad on the same tensors: every parameter gradient bit-identical."""
+    from mednet_hip import block, _lib as L, config
+    x = torch.from_numpy(O._rng(f"c1gn{n}{c}{shape}").standard_normal((n, 1) + shape).astype(np.float32))
+    g = torch.from_numpy(O._rng("c1gncot").standard_normal((n, c) + shape).astype(np.float32))
+    res = {}
+    for fused in (True, False):
+        old = block.FUSE_C1GN
+        block.FUSE_C1GN = fused
+        before = block.C1GN_COUNT["fused"]
+        try:
+            with mednet_hip.precision(mode):
+                net = O.keyed_init_(HC.ExtResNetBlock(1, c, order="cg" + act, num_groups=8)).to(DEV)
+                yg = net(x.to(DEV))
+                (yg.float() * g.to(DEV)).sum().backward()
+                res[fused] = [p.grad.clone() for p in net.parameters()]
+        finally:
+            block.FUSE_C1GN = old
+        with mednet_hip.precision(mode):  # (the fused form needs the sums from conv2's data gradient: 32+ channels)
+            rows = L.lib().mednet_conv3d_dgrad_gn_rows_dt(n, *shape, c, c, config.conv_algo(), L.dt(yg))
+        assert block.C1GN_COUNT["fused"] - before == (1 if fused and rows > 0 else 0)
+        assert rows > 0 or c < 32
+    for (k, _), a, b in zip(net.named_parameters(), res[True], res[False]):
+        assert torch.isfinite(a).all(), k
+        assert torch.equal(a, b), f"{k}: fused differs from the two-kernel form by {(a - b).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("consumer,shape", [("head", (16, 24, 32)), ("head", (9, 11, 21)), ("pool", (16, 24, 32)), ("pool", (8, 8, 16)),
                                             ("convt", (8, 12, 16)), ("convt", (3, 5, 9))])
 def test_groupnorm3_backward_sums_from_the_producer_of_the_block_gradient(mode, consumer, shape):

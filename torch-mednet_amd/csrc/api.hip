@@ -277,6 +277,22 @@ extern "C" int mednet_conv3d_wgrad_coresident(int n, int d, int h, int w, int ci
   return ELT_CALL(dy_dtype, wgrad_mfma_coresident, d, h, w) ? 1 : 0;
 }
 
+// First-layer (Cin = 1) 3x3x3 weight gradient taken straight from the gradient dz of the layer's activated GroupNorm output:
+// GroupNorm's backward apply pass (mednet_gn_act_bwd_fused's third kernel) happens while dz and y are staged, so dy is neither
+// written nor read back.  `bcoef` comes from mednet_gn_bwd_coefficients; workspace as mednet_conv3d_wgrad_ws_bytes(.., cin = 1, ..).
+extern "C" int mednet_conv3d_wgrad_c1_gn_supported(int cout, int x_dtype, int dtype) {
+  return is16(dtype) && wgrad_c1_gn_supported(cout, x_dtype, dtype) ? 1 : 0;
+}
+extern "C" int mednet_conv3d_wgrad_c1_gn(const void* x, const void* dz, const void* y, const float* coef, const float* bcoef,
+                                         float* dw, int n, int d, int h, int w, int cout, int act, int x_dtype, int dtype,
+                                         void* ws, size_t ws_bytes, mednet_stream stream) {
+  MEDNET_REQUIRE(x && dz && y && coef && bcoef && dw && ws, MEDNET_E_SHAPE, "conv3d_wgrad_c1_gn: null argument");
+  MEDNET_REQUIRE(is16(dtype), MEDNET_E_DTYPE, "conv3d_wgrad_c1_gn: dz / y must be 16-bit (dtype %d)", dtype);
+  const int rc = conv_common_checks("conv3d_wgrad_c1_gn", n, d, h, w, 1, cout, 3, x_dtype, dtype);
+  if (rc) return rc;
+  return launch_wgrad_c1_gn(x, dz, y, coef, bcoef, act, dw, n, d, h, w, cout, x_dtype, dtype, ws, ws_bytes, (hipStream_t)stream);
+}
+
 extern "C" int mednet_conv3d_wgrad(const void* x, const void* dy, float* dw, float* dbias, int n, int d, int h, int w,
                                    int cin, int cout, int ksize, int x_dtype, int x_layout, int dy_dtype, int dy_layout,
                                    int algo, int workgroups, void* ws, size_t ws_bytes, mednet_stream stream) {

@@ -47,6 +47,9 @@ int launch_wgrad_1x1(const void* z, const void* dy, float* dw, int n, size_t spa
                      void* ws, size_t ws_bytes, hipStream_t s);
 bool wgrad_c1_supported(int cin, int cout, int ksize, int x_layout, int dy_layout);
 size_t wgrad_c1_ws_bytes(int n, int d, int h, int w, int cout);
+bool wgrad_c1_gn_supported(int cout, int x_dtype, int dtype);
+int launch_wgrad_c1_gn(const void* x, const void* dz, const void* y, const float* coef, const float* bcoef, int act, float* dw,
+                       int n, int d, int h, int w, int cout, int x_dtype, int dtype, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cout, int x_dtype,
                     int dy_dtype, void* ws, size_t ws_bytes, hipStream_t s, bool split_bf16 = false);
 int launch_pack_f32(const float* w, float* Pf, float* Pb, int cin, int cout, int T, int transposed_src, hipStream_t s);

@@ -1029,6 +1029,26 @@ size_t wgrad_c1_ws_bytes(int n, int d, int h, int w, int cout) {
   const int b1 = wgrad_c1_blocks(nt), b2 = wgrad_c1_mfma_blocks(n, d, h, w);  // VALU and matrix-core forms
   return (size_t)(b1 > b2 ? b1 : b2) * 27 * cout * sizeof(float);
 }
+// The first layer's weight gradient with GroupNorm's backward applied while dz is staged (16-bit storage, matrix-core
+// kernel only): dy is never materialised.  See Wc1Args in conv_mfma.hip.
+bool wgrad_c1_gn_supported(int cout, int x_dtype, int dtype) {
+  return tuning_option("wgrad_c1_mfma", 1) && (dtype == MEDNET_F16 ? mednet_f16::wgrad_c1_mfma_supported(cout, x_dtype, dtype)
+                                                                  : wgrad_c1_mfma_supported(cout, x_dtype, dtype));
+}
+int launch_wgrad_c1_gn(const void* x, const void* dz, const void* y, const float* coef, const float* bcoef, int act, float* dw,
+                       int n, int d, int h, int w, int cout, int x_dtype, int dtype, void* ws, size_t ws_bytes, hipStream_t s) {
+  MEDNET_REQUIRE(wgrad_c1_gn_supported(cout, x_dtype, dtype), MEDNET_E_UNSUPPORTED,
+                 "wgrad_c1_gn: Cout in {16, 32, 64}, 16-bit dz / y, x fp32 or the same 16-bit type (Cout=%d)", cout);
+  const int blocks = wgrad_c1_mfma_blocks(n, d, h, w);
+  MEDNET_REQUIRE(ws_bytes >= (size_t)blocks * 27 * cout * sizeof(float), MEDNET_E_WORKSPACE, "wgrad_c1_gn: workspace too small");
+  float* part = (float*)ws;
+  const int rc = dtype == MEDNET_F16 ? mednet_f16::launch_wgrad_c1_mfma(x, dz, part, n, d, h, w, cout, s, x_dtype, y, coef, bcoef, act)
+                                     : launch_wgrad_c1_mfma(x, dz, part, n, d, h, w, cout, s, x_dtype, y, coef, bcoef, act);
+  if (rc) return rc;
+  const size_t count = (size_t)27 * cout;
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, s, part, dw, count, blocks);
+  return check_launch("wgrad_c1_reduce");
+}
 int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int h, int w, int cout, int x_dtype,
                     int dy_dtype, void* ws, size_t ws_bytes, hipStream_t s, bool split_bf16) {
   const int tz = (d + W1_TZ - 1) / W1_TZ, ty = (h + W1_TY - 1) / W1_TY, tx = (w + W1_TX - 1) / W1_TX;

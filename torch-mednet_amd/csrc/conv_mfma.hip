@@ -2527,9 +2527,16 @@ struct Wc1Args {
   unsigned rcp_tiles_x, rcp_tiles_y, rcp_tiles_z;
   unsigned bytes_x, bytes_dy;  // per sample
   int x16;                     // 1: x holds elt values, else fp32
+  // GN form: `dy` holds dz (the gradient of the layer's activated, normalised output) and the kernel applies GroupNorm's
+  // backward while it stages:  dy = k1 * dz * act'(ca * y + cb) + k2 * y + k3, rounded to elt -- the value
+  // norm_act.hip's gn_bwd_apply_kernel would have stored, expression for expression -- so dy is never written or re-read
+  const elt* y;        // N x D x H x W x cout: the convolution's output
+  const float* coef;   // [n][cout][2] = {ca, cb}
+  const float* bcoef;  // [n][cout][3] = {k1, k2, k3}
+  int act;
 };
 
-template <int NB>  // 32-channel blocks of dy
+template <int NB, bool GN>  // 32-channel blocks of dy
 __global__ __launch_bounds__(256, 2) void wgrad_c1_mfma_kernel(Wc1Args a) {
   constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
   constexpr int NJ = TZ * TY * TX, NH = HZ * HY * HX;
@@ -2551,7 +2558,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_mfma_kernel(Wc1Args a) {
 
   constexpr unsigned OOB = 0xFFFFFF00u;
   u32x4 rdy[DY_ROUNDS];
+  u32x4 ryy[GN ? DY_ROUNDS : 1];
   float rx[X_ROUNDS];
+  // GN form: this thread's 8 channels are the same in every round (256 % (4 * NB) == 0)
+  float gca[GN ? 8 : 1], gcb[GN ? 8 : 1], gk1[GN ? 8 : 1], gk2[GN ? 8 : 1], gk3[GN ? 8 : 1];
+  unsigned in_mask = 0;  // bit `it`: round `it` of the fetched brick lies inside the volume
+  int coef_n = -1;       // sample the coefficients in registers belong to
   auto fetch = [&](int tile) {
     int tt = tile;
     int qd = fastdiv(tt, a.tiles_x, a.rcp_tiles_x);
@@ -2564,6 +2576,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_mfma_kernel(Wc1Args a) {
     const int tz0 = (tt - qd * a.tiles_z) * TZ;
     const size_t svox = (size_t)qd * a.d * a.h * a.w;
     const auto rD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + svox * a.cout), 0, a.bytes_dy, 0x00020000);
+    const auto rY = __builtin_amdgcn_make_buffer_rsrc((void*)((GN ? a.y : a.dy) + svox * a.cout), 0, a.bytes_dy, 0x00020000);
+    if constexpr (GN) {
+      in_mask = 0;
+      if (qd != coef_n) {  // (workgroup-uniform) first brick of a sample
+        coef_n = qd;
+        const int ch0 = (tid % (4 * NB)) * 8;
+        if (ch0 < a.cout) {
+          const float* pc = a.coef + ((size_t)qd * a.cout + ch0) * 2;
+          const float* pb = a.bcoef + ((size_t)qd * a.cout + ch0) * 3;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            gca[k] = pc[2 * k];
+            gcb[k] = pc[2 * k + 1];
+            gk1[k] = pb[3 * k];
+            gk2[k] = pb[3 * k + 1];
+            gk3[k] = pb[3 * k + 2];
+          }
+        }
+      }
+    }
     const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + svox), 0, a.bytes_x, 0x00020000);
     const auto rX16 = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const elt*>(a.x) + svox), 0, a.bytes_x, 0x00020000);
 #pragma unroll
@@ -2574,6 +2606,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_mfma_kernel(Wc1Args a) {
       const bool in_vol = (gz < a.d) & (gy < a.h) & (gx < a.w) & (part * 8 < a.cout);  // (16 channels: the row's second half is zeros)
       const unsigned off = ((unsigned)((gz * a.h + gy) * a.w + gx) * (unsigned)a.cout + part * 8) * 2u;
       rdy[it] = __builtin_amdgcn_raw_buffer_load_b128(rD, in_vol ? off : OOB, 0, 0);
+      if constexpr (GN) {
+        ryy[it] = __builtin_amdgcn_raw_buffer_load_b128(rY, in_vol ? off : OOB, 0, 0);
+        in_mask |= in_vol ? 1u << it : 0u;
+      }
     }
 #pragma unroll
     for (int it = 0; it < X_ROUNDS; ++it) {
@@ -2591,7 +2627,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_c1_mfma_kernel(Wc1Args a) {
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int it = 0; it < DY_ROUNDS; ++it) *reinterpret_cast<u32x4*>(dyl + (it * 256 + tid) * 16) = rdy[it];
+    for (int it = 0; it < DY_ROUNDS; ++it) {
+      if constexpr (GN) {
+        const eltx8 gz8 = __builtin_bit_cast(eltx8, rdy[it]), yv8 = __builtin_bit_cast(eltx8, ryy[it]);
+        float g[8], u[8], yy[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          yy[k] = (float)yv8[k];
+          g[k] = (float)gz8[k];
+          u[k] = fmaf(gca[k], yy[k], gcb[k]);
+        }
+        act_grad_pre_n<8>(g, u, a.act);
+        eltx8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (elt)fmaf(gk1[k], g[k], fmaf(gk2[k], yy[k], gk3[k]));
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(dyl + (it * 256 + tid) * 16) = (in_mask >> it) & 1u ? __builtin_bit_cast(u32x4, o) : zero;
+      } else {
+        *reinterpret_cast<u32x4*>(dyl + (it * 256 + tid) * 16) = rdy[it];
+      }
+    }
 #pragma unroll
     for (int it = 0; it < X_ROUNDS; ++it) {
       const int v = it * 256 + tid;
@@ -2661,8 +2716,11 @@ int wgrad_c1_mfma_blocks(int n, int d, int h, int w) {
   return nt < 1024 ? nt : 1024;
 }
 int launch_wgrad_c1_mfma(const void* x, const void* dy, float* part, int n, int d, int h, int w, int cout, hipStream_t s,
-                         int x_dtype) {
+                         int x_dtype, const void* gn_y, const float* gn_coef, const float* gn_bcoef, int gn_act) {
   Wc1Args a;
+  const bool gn = gn_y != nullptr;  // dy is dz: GroupNorm's backward applied while staging (Wc1Args)
+  MEDNET_REQUIRE(!gn || (gn_coef && gn_bcoef), MEDNET_E_SHAPE, "wgrad_c1_mfma: the GroupNorm form needs both coefficient tables");
+  a.y = (const elt*)gn_y; a.coef = gn_coef; a.bcoef = gn_bcoef; a.act = gn_act;
   a.x = (const float*)x;
   a.x16 = x_dtype != MEDNET_F32;
   a.dy = (const elt*)dy;
@@ -2679,15 +2737,19 @@ int launch_wgrad_c1_mfma(const void* x, const void* dy, float* part, int n, int 
   const int nb = (cout + 31) / 32;
   const size_t stage = 4352 + (size_t)512 * 64 * nb, red = (size_t)4 * nb * 16 * 64 * 4;
   const size_t lds = stage > red ? stage : red;
-  if (nb == 1) hipLaunchKernelGGL(wgrad_c1_mfma_kernel<1>, dim3(blocks), dim3(256), lds, s, a);
-  else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)wgrad_c1_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  if (nb == 1) {
+    if (gn) hipLaunchKernelGGL((wgrad_c1_mfma_kernel<1, true>), dim3(blocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((wgrad_c1_mfma_kernel<1, false>), dim3(blocks), dim3(256), lds, s, a);
+  } else {
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[gn]) {
+      const void* fn = gn ? (const void*)wgrad_c1_mfma_kernel<2, true> : (const void*)wgrad_c1_mfma_kernel<2, false>;
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return fail(MEDNET_E_HIP, "wgrad_c1_mfma: cannot raise dynamic LDS to %zu", lds);
-      attr_set = true;
+      attr_set[gn] = true;
     }
-    hipLaunchKernelGGL(wgrad_c1_mfma_kernel<2>, dim3(blocks), dim3(256), lds, s, a);
+    if (gn) hipLaunchKernelGGL((wgrad_c1_mfma_kernel<2, true>), dim3(blocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((wgrad_c1_mfma_kernel<2, false>), dim3(blocks), dim3(256), lds, s, a);
   }
   return check_launch("wgrad_c1_mfma");
 }

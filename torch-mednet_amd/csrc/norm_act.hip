@@ -1445,6 +1445,40 @@ extern "C" int mednet_gn_act_bwd_fused(const void* dz, const void* x, const floa
   return gn_act_bwd_fused_impl(dz, x, nullptr, coef, stats, gamma, fused_partial, rows, dx, nullptr, dgamma, dbeta, n, spatial, c,
                                groups, act, in_act, dtype, ws, ws_bytes, stream);
 }
+// Passes 1b + 2 of mednet_gn_act_bwd_fused WITHOUT its apply pass: the per-(sample, channel) coefficients {k1, k2, k3} of
+//   dy = k1 * du + k2 * y + k3        (du = dz * act'(coef_a * y + coef_b))
+// go to `bcoef` ([n][c][3] floats) for a consumer that applies them while it reads (dz, y) for its own purpose
+// (mednet_conv3d_wgrad_c1_gn: the first layer's weight gradient, whose dy is never stored), and the parameter gradients to
+// dgamma / dbeta.  Same kernels, same order of sums as the fused form => the same coefficient bits.
+extern "C" int mednet_gn_bwd_coefficients(const float* stats, const float* gamma, const float* fused_partial, int rows,
+                                          float* bcoef, float* dgamma, float* dbeta, int n, size_t spatial, int c, int groups,
+                                          void* ws, size_t ws_bytes, mednet_stream stream) {
+  MEDNET_REQUIRE(c % groups == 0 && rows > 0 && fused_partial && bcoef && stats && gamma, MEDNET_E_SHAPE,
+                 "gn_bwd_coefficients: bad arguments");
+  MEDNET_REQUIRE(ws_bytes >= mednet_gn_ws_bytes(n, c, spatial), MEDNET_E_WORKSPACE, "gn_bwd_coefficients: workspace too small");
+  float* csum = (float*)ws;  // [n][c][2]
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (gn_bwd_one_launch(c, groups)) {
+    hipLaunchKernelGGL(gn_bwd_reduce_finalize_kernel<true>, dim3(n * groups), dim3(256), 0, s, fused_partial, stats, gamma, csum, bcoef,
+                       c, groups, rows, (double)spatial * (c / groups));
+    rc = check_launch("gn_bwd_reduce_finalize");
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(reduce_partials_dux_kernel, dim3(n * c), dim3(64), 0, s, fused_partial, stats, csum, c, groups, rows);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n * groups), dim3(64), 0, s, csum, stats, gamma, bcoef, c, groups,
+                       (double)spatial * (c / groups));
+    rc = check_launch("gn_bwd_finalize");
+    if (rc) return rc;
+  }
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((c + 255) / 256), dim3(256), 0, s, csum, dgamma, dbeta, n, c);
+    rc = check_launch("gn_bwd_params");
+    if (rc) return rc;
+  }
+  return MEDNET_OK;
+}
+
 // ... for the residual layer of an ExtResNetBlock: the activation derivative comes from the block OUTPUT z, and du is also
 // the gradient of the residual branch (dres)
 extern "C" int mednet_gn_act_bwd_fused_res(const void* dz, const void* x, const void* z, const float* coef, const float* stats,

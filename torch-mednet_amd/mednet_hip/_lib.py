@@ -52,6 +52,7 @@ SIGNATURES = {
     "mednet_conv3d_dgrad_add_supported": (_i, [_i] * 8),
     "mednet_conv3d_dgrad_gn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp] + [_i] * 8 + [_vp]),
     "mednet_gn_act_bwd_fused": (_i, [_vp] * 6 + [_i, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mednet_gn_bwd_coefficients": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _sz, _i, _i, _vp, _sz, _vp]),
     "mednet_gn_act_bwd_fused_res": (_i, [_vp] * 7 + [_i, _vp, _vp, _vp, _vp, _i, _sz, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mednet_gn_act_bwd_fused_res_pool": (_i, [_vp] * 7 + [_i, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp, _sz, _vp]),
     "mednet_head_dgrad_gn_rows": (_i, [_i] * 6),
@@ -63,6 +64,8 @@ SIGNATURES = {
     "mednet_conv3d_wgrad_ws_bytes": (_sz, [_i] * 8),
     "mednet_conv3d_wgrad_coresident": (_i, [_i] * 10),
     "mednet_conv3d_wgrad_plan": (_i, [_i] * 8 + [_vp]),
+    "mednet_conv3d_wgrad_c1_gn_supported": (_i, [_i] * 3),
+    "mednet_conv3d_wgrad_c1_gn": (_i, [_vp] * 6 + [_i] * 8 + [_vp, _sz, _vp]),
     "mednet_conv3d_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 13 + [_vp, _sz, _vp]),
     "mednet_convt3d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "mednet_convt3d_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 9 + [_vp]),

@@ -110,6 +110,39 @@ def _gn_bwd(dz, dz2, y, z, coef, stats, gamma_p, beta_p, groups, act, want_dres,
     return dy, dres, (None if dg_direct else dgamma), (None if db_direct else dbeta)
 
 
+FUSE_C1GN = os.environ.get("MEDNET_FUSE_C1GN", "1") == "1"  # A/B knob: first layer's GroupNorm backward inside its weight gradient
+C1GN_COUNT = {"fused": 0}  # (tests check that the fused form really ran, like ops.GN3_COUNT)
+
+
+def _c1_gn_applies(xin, y, partial, need_dx):
+    """The network's first SingleConv (Cin = 1, no gradient of the input wanted): its GroupNorm backward feeds nothing but the
+    weight gradient, so the apply pass can happen inside that kernel's staging (mednet_conv3d_wgrad_c1_gn)."""
+    return (FUSE_C1GN and partial is not None and not need_dx and xin.shape[1] == 1 and y.dtype != torch.float32
+            and config.conv_algo() != L.ALGO_DIRECT
+            and bool(L.lib().mednet_conv3d_wgrad_c1_gn_supported(y.shape[1], L.dt(xin), L.dt(y))))
+
+
+def _c1_gn_bwd(xin, dz, y, coef, stats, gamma_p, beta_p, weight_p, groups, act, partial):
+    """GroupNorm(+activation) backward and 3x3x3 weight gradient of the first layer without the gradient tensor between them.
+    Returns (dw-or-None, dgamma-or-None, dbeta-or-None) like _gn_bwd / _conv_bwd.  On the caller's stream: the side stream is
+    busy with the second layer's weight gradient at this point, and this kernel is HBM-bound like the pass it replaces."""
+    n, c, d, h, w = y.shape
+    lib = L.lib()
+    C1GN_COUNT["fused"] += 1
+    dgamma, dg_direct = ops._grad_target(gamma_p, (c,))
+    dbeta, db_direct = ops._grad_target(beta_p, (c,))
+    dw, dw_direct = ops._grad_target(weight_p, (c, 1, 3, 3, 3))
+    bcoef = torch.empty((n, c, 3), dtype=torch.float32, device=y.device)
+    ws = L.workspace(max(lib.mednet_gn_ws_bytes(n, c, d * h * w), lib.mednet_conv3d_wgrad_ws_bytes(n, d, h, w, 1, c, 3, 0)), y.device)
+    L.check(lib.mednet_gn_bwd_coefficients(stats.data_ptr(), gamma_p.data_ptr(), partial.data_ptr(), partial.shape[1],
+                                           bcoef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), n, d * h * w, c, groups,
+                                           ws.data_ptr(), ws.numel(), L.stream()), "gn_bwd_coefficients")
+    L.check(lib.mednet_conv3d_wgrad_c1_gn(xin.data_ptr(), dz.data_ptr(), y.data_ptr(), coef.data_ptr(), bcoef.data_ptr(),
+                                          dw.data_ptr(), n, d, h, w, c, act, L.dt(xin), L.dt(y), ws.data_ptr(), ws.numel(),
+                                          L.stream()), "conv3d_wgrad_c1_gn")
+    return (None if dw_direct else dw), (None if dg_direct else dgamma), (None if db_direct else dbeta)
+
+
 FUSE_DRES = os.environ.get("MEDNET_FUSE_DRES", "1") == "1"  # A/B knob: residual gradient summed in conv2's data gradient
 
 
@@ -219,8 +252,12 @@ class ResBlockFn(Function):
         fuse = FUSE_DRES and dres.dtype == dy2.dtype and bool(
             L.lib().mednet_conv3d_dgrad_add_supported(n_, d_, h_, w_, c_, c_, config.conv_algo(), L.dt(dy2)))
         dz1, dw2, part1 = _conv_bwd(z1, dy2, pk2, w2, True, add=dres if fuse else None, gnb=(y1, c1, act) if fuse else None)
-        dy1, _, dg1, db1 = _gn_bwd(dz1, None if fuse else dres, y1, None, c1, s1, g1, b1, groups, act, False, partial=part1)
-        dx, dw1, _ = _conv_bwd(xin, dy1, pk1, w1, ctx.needs_input_grad[0])
+        if fuse and _c1_gn_applies(xin, y1, part1, ctx.needs_input_grad[0]):
+            dy1 = dx = None  # (never materialised)
+            dw1, dg1, db1 = _c1_gn_bwd(xin, dz1, y1, c1, s1, g1, b1, w1, groups, act, part1)
+        else:
+            dy1, _, dg1, db1 = _gn_bwd(dz1, None if fuse else dres, y1, None, c1, s1, g1, b1, groups, act, False, partial=part1)
+            dx, dw1, _ = _conv_bwd(xin, dy1, pk1, w1, ctx.needs_input_grad[0])
         if debug.TRACE is not None:
             debug.trace("resblock.bwd", None if lazy is not None else dout, part3, dy3, dres, dz2, part2, dy2, dz1, part1, dy1, dx)
         return (dx, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + (None,) * 8
