@@ -373,6 +373,50 @@ def test_loss_scaler_skips_overflowing_steps_and_recovers():
     flat.release()
 
 
+def test_cfg2_128_fp16_storage_against_reference_golden(golden_dir):
+    """BASELINE config 2's model at 128^3 through train.SegmentationStep in fp16 storage with the device-side loss scaler -- the
+    same kernels as the benchmarked bf16 mode, instantiated for the other 16-bit type -- against the reference's golden vectors.
+    fp16 carries 3 more mantissa bits than bf16: this mode is held to the north-star 1e-3 on logits and gradient norms at the
+    16-bit modes' speed (bench.py reports its rate as `fp16_mode`); the random projections (which see the whole per-tensor
+    error vector) are held to twice what was measured."""
+    from mednet_hip.train import SegmentationStep
+    rec = np.load(os.path.join(golden_dir, "res_cfg2_128.npz"))
+    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64, 128, 256])
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(1, 1, (128, 128, 128), 4, 0, seed=int(rec["meta.seed"])).items()}
+    with mednet_hip.precision("fp16"):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+        step = SegmentationStep(net, loss_weight=[0.05, 1.0, 1.0, 1.0], lr=1e-3)
+        with torch.no_grad():
+            lg = net(batch["data"].float())
+        scale = step.scaler.snapshot()[0]
+        (loss,) = step._fwd_bwd(batch)
+        torch.cuda.synchronize()
+    s = int(rec["meta.stride"])
+    rl = assert_close(lg[..., ::s, ::s, ::s], torch.from_numpy(rec["logits.strided"]), 1e-3, "strided logits (fp16)")
+    dl = abs(float(loss) - float(rec["loss"]))
+    assert dl <= 1e-4, dl
+    assert bool(torch.isfinite(step.flat.grad).all())
+    step.flat.grad.div_(scale)  # (the gradients carry the loss scale)
+    step.flat.grads_as_attr()
+    # measured on an MI355X (round 5): strided logits 8.7e-4, loss diff 3e-7, gradient norms 4.2e-4, projections 3.6e-3, leading
+    # elements: median tensor 8.9e-4, worst (decoders.1 conv2 weight) 1.55e-2
+    wn, wp = _check_grads_against_golden_summaries(net, rec, 1e-3, 8e-3, "cfg2 128^3 fp16")
+    heads = []
+    for name, p in net.named_parameters():
+        g = p.grad.detach().double().cpu().numpy().reshape(-1)
+        head = rec[f"grad.{name}.head"]
+        norm = float(rec[f"grad.{name}.norm"])
+        heads.append((np.linalg.norm(g[: head.size] - head) / max(np.linalg.norm(head), 1e-3 * norm / np.sqrt(g.size) * 8), name))
+    heads.sort(reverse=True)
+    wh = heads[0][0]
+    print("[cfg2 128^3 fp16] leading-elements rel-L2, worst five:", ", ".join(f"{k} {v:.2e}" for v, k in heads[:5]),
+          " median", f"{heads[len(heads) // 2][0]:.2e}")
+    assert wh <= 4e-2, heads[0]  # (element-wise error of the 16-bit stored gradients; the bf16 mode is not held to this at all)
+    step.flat.release()
+    print(f"[cfg2 128^3 fp16 storage vs reference] strided logits {rl:.2e} (tol 1e-3)  loss diff {dl:.1e}  worst gradient-norm diff "
+          f"{wn:.2e} (tol 1e-3)  worst projection diff {wp:.2e} (tol 8e-3)  worst leading-elements rel-L2 {wh:.2e}")
+
+
 # cfg5 at full size against the reference (tests/golden/res_cfg5_full.npz: the reference's ResidualUNet3D
 # [64 .. 1024] on one 160 x 160 x 96 patch, fp32 on the CPU, bit-equal to the oracle; tools/make_golden.py).
 # fp32 storage: the north-star 1e-3.  16-bit storage: the bounds of the 128^3 tests of the same modes.
