@@ -337,6 +337,33 @@ int mednet_head_dice_bwd(const float* logits, const void* labels, int label_dtyp
                          const float* weight, const float* saved, const float* dloss, void* dz, const void* gn_y, const void* z,
                          int gn_act, float* gn_partial, float* dw, float* dbias, int n, size_t spatial, int cin, int cout,
                          float eps, int sigmoid, int ignore_index, int z_dtype, void* ws, size_t ws_bytes, mednet_stream stream);
+
+/* The landmark head (LandmarkNet, landmarks.py:66-83: final_conv 32 -> nh heat maps + ncls classes) fused with BOTH terms of its
+ * loss (landmarks.py:125-134: sum_c w_c mean f(out_c - heatmap_c), f = square | abs, plus DiceLoss of the class channels,
+ * loss.py:114-130) on the matrix cores, 16-bit storage only.  z: N x spatial x cin (NDHWC); heatmaps: uint8, N x nh x spatial,
+ * sample stride heatmap_stride_n; labels: uint8, N x spatial, sample stride label_stride_n (both 4-byte aligned per sample);
+ * `packed` = the head's mednet_conv3d_pack image (its fp32 [co][ci] block is used, split hi + lo for the MFMAs).
+ * _fwd writes class_loss, reg_loss and saved[ncls][2] (the Dice sums the backward needs); the logits only if `logits` != NULL
+ * (N x (nh + ncls) x spatial fp32).  _bwd rebuilds the logits with the same instructions, forms their gradient in registers and
+ * writes dz (N x spatial x cin), dw [nh + ncls][cin], dbias (nullable) and -- gn_y != NULL -- gn_partial[n][rows][cin][2] =
+ * {sum du, sum du * gn_y}, du = dz * act'(z), rows = mednet_head_landmark_gn_rows(spatial), for mednet_gn_act_bwd_fused_res.
+ * _supported: cin == 32, 1 <= nh <= 16, 1 <= ncls <= 4, spatial % 4 == 0.  Results equal the unfused launches
+ * (mednet_conv3d_fwd k=1, mednet_heatmap_loss_*, mednet_dice_*, mednet_head_dgrad_gn, mednet_conv3d_wgrad k=1) up to fp32
+ * summation order. */
+int mednet_head_landmark_supported(int cin, int nh, int ncls, int dtype, size_t spatial);
+size_t mednet_head_landmark_ws_bytes(int n, size_t spatial, int nh, int ncls);
+int mednet_head_landmark_gn_rows(size_t spatial);
+int mednet_head_landmark_fwd(const void* z, const void* packed, const float* bias, const void* heatmaps, int64_t heatmap_stride_n,
+                             const void* labels, int64_t label_stride_n, const float* class_weight, const float* reg_weight,
+                             float* logits, float* class_loss, float* reg_loss, float* saved, int n, size_t spatial, int cin, int nh,
+                             int ncls, int kind, float eps, int sigmoid, int ignore_index, int z_dtype, void* ws, size_t ws_bytes,
+                             mednet_stream stream);
+int mednet_head_landmark_bwd(const void* z, const void* packed, const float* bias, const void* heatmaps, int64_t heatmap_stride_n,
+                             const void* labels, int64_t label_stride_n, const float* class_weight, const float* reg_weight,
+                             const float* saved, const float* dclass_loss, const float* dreg_loss, void* dz, const void* gn_y,
+                             int gn_act, float* gn_partial, float* dw, float* dbias, int n, size_t spatial, int cin, int nh, int ncls,
+                             int kind, float eps, int sigmoid, int ignore_index, int z_dtype, void* ws, size_t ws_bytes,
+                             mednet_stream stream);
 /* nn.CrossEntropyLoss(weight)  segmentation.py:49: sum w_y * -log softmax_y / sum w_y.  saved[0] = sum w_y. */
 int mednet_ce_fwd(const float* logits, const int64_t* labels, const float* weight, float* loss, float* saved,
                   int n, int c, size_t spatial, int64_t stride_n, int64_t stride_c, int ignore_index, void* ws,

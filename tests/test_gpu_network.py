@@ -1048,6 +1048,50 @@ def test_landmark_step_matches_oracle():
         assert rel(a, b) <= 2e-3, k
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape,nh,ncls,kind,sigmoid,n", [((32, 32, 32), 16, 2, "L2", False, 2), ((12, 10, 6), 5, 3, "L1", False, 3),
+                                                         ((8, 8, 20), 16, 2, "L2", True, 1), ((64, 48, 32), 16, 2, "L2", False, 1),
+                                                         ((4, 4, 4), 1, 1, "L2", True, 2)])
+def test_landmark_head_on_the_matrix_cores_against_the_unfused_launches(mode, shape, nh, ncls, kind, sigmoid, n):
+    """LandmarkNet.training_step + .loss (landmarks.py:66-83, 125-134) in the 16-bit storage modes: head and both loss terms as one
+    matrix-core node (ops.head_landmark: logits^T = W z^T, dz^T = W^T dl^T, dW = dl^T z with hi + lo split operands, loss terms
+    and logit gradient in registers) against the stock launches (1x1x1 head, heat-map and Dice kernels, head data / weight
+    gradient) on the same network and batch: same losses and gradients up to fp32 summation order.  Shapes cover whole and
+    partial 128-voxel runs, several samples, fewer than 16 heat maps, 1 .. 3 classes, L1 / L2, softmax / sigmoid Dice."""
+    from mednet_hip import ops as hops
+    from mednet_hip.train import LandmarkStep
+    ctor = dict(in_channels=1, out_channels=nh + ncls, final_sigmoid=sigmoid, f_maps=[32, 64])
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(n, 1, shape, ncls, nh, seed=99).items()}
+    regw = [0.015 + 0.003 * i for i in range(nh)]
+    res = {}
+    for fused in (True, False):
+        old = hops.FUSE_HEAD_LOSS
+        hops.FUSE_HEAD_LOSS = fused
+        try:
+            with mednet_hip.precision(mode):
+                net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+                step = LandmarkStep(net, class_weight=[0.05, 1.0, 0.7][:ncls], regression_weight=regw, regression=kind, lr=1e-3)
+                step.loss_class.sigmoid_normalization = sigmoid
+                scale = step.scaler.snapshot()[0] if step.scaler is not None else 1.0
+                tot, cl, rg = step._fwd_bwd(batch)
+                torch.cuda.synchronize()
+                res[fused] = (float(tot), float(cl), float(rg), (step.flat.grad / scale).clone())
+                with torch.no_grad():
+                    took = hops.head_landmark_supported(net.forward_features(batch["data"].float()), 32, nh, ncls,
+                                                        batch["label"][:, :-1], batch["label"][:, -1])
+                step.flat.release()
+        finally:
+            hops.FUSE_HEAD_LOSS = old
+        assert took == fused
+    (t1, c1, r1, g1), (t0, c0, r0, g0) = res[True], res[False]
+    assert abs(c1 - c0) <= 2e-6 * max(1.0, abs(c0)), (c1, c0)
+    assert abs(r1 - r0) <= 2e-6 * max(1.0, abs(r0)), (r1, r0)
+    assert torch.isfinite(g1).all()
+    e = float((g1 - g0).norm() / g0.norm())
+    print(f"[landmark head fused vs stock, {mode} {shape} nh={nh} ncls={ncls}] losses {c1:.7f}/{c0:.7f} {r1:.5f}/{r0:.5f}  all gradients rel-L2 {e:.2e}")
+    assert e <= 3e-3, e
+
+
 def test_cfg5_shape_smoke_bf16():
     """BASELINE config 5's topology (5 levels, 64 base channels -> 1024 at the bottom) at a reduced patch, bf16 storage:
     exercises the >256-channel paths (GroupNorm columns, wide bias sums, 32x32 channel-block pairs up to 1024x1024)

@@ -404,6 +404,57 @@ extern "C" int mednet_head_dgrad_gn(const void* dy, const void* packed, void* dx
                               (size_t)d * h * w, cout, cin, dtype, (hipStream_t)stream);
 }
 
+// ---- the landmark head fused with its two losses (head_mfma.hip) ---------------------------------------------------------
+extern "C" int mednet_head_landmark_supported(int cin, int nh, int ncls, int dtype, size_t spatial) {
+  return is16(dtype) && ELT_CALL(dtype, head_lm_supported, cin, nh, ncls, dtype, spatial) ? 1 : 0;
+}
+extern "C" size_t mednet_head_landmark_ws_bytes(int n, size_t spatial, int nh, int ncls) {
+  return head_lm_ws_bytes(n, spatial, nh, ncls);
+}
+extern "C" int mednet_head_landmark_gn_rows(size_t spatial) { return head_lm_chunks(spatial); }
+extern "C" int mednet_head_landmark_fwd(const void* z, const void* packed, const float* bias, const void* heatmaps,
+                                        int64_t heatmap_stride_n, const void* labels, int64_t label_stride_n,
+                                        const float* class_weight, const float* reg_weight, float* logits, float* class_loss,
+                                        float* reg_loss, float* saved, int n, size_t spatial, int cin, int nh, int ncls, int kind,
+                                        float eps, int sigmoid, int ignore_index, int z_dtype, void* ws, size_t ws_bytes,
+                                        mednet_stream stream) {
+  MEDNET_REQUIRE(n > 0 && spatial > 0 && z && packed && heatmaps && labels && class_loss && reg_loss && saved && ws, MEDNET_E_SHAPE,
+                 "head_landmark_fwd: bad arguments");
+  MEDNET_REQUIRE(mednet_head_landmark_supported(cin, nh, ncls, z_dtype, spatial), MEDNET_E_UNSUPPORTED,
+                 "head_landmark_fwd: %d -> %d heat maps + %d classes, dtype %d, %zu voxels", cin, nh, ncls, z_dtype, spatial);
+  MEDNET_REQUIRE(kind == MEDNET_REG_L2 || kind == MEDNET_REG_L1, MEDNET_E_UNSUPPORTED, "head_landmark_fwd: regression kind %d", kind);
+  MEDNET_REQUIRE(ws_bytes >= head_lm_ws_bytes(n, spatial, nh, ncls), MEDNET_E_WORKSPACE, "head_landmark_fwd: workspace too small");
+  const PackLayout L = pack_layout(cin, nh + ncls, 1);
+  const float* W = (const float*)((const char*)packed + L.f32_bwd);  // [co][ci]
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = head_lm_chunks(spatial);
+  float* hm_partial = (float*)ws;
+  float* dice_partial = hm_partial + (size_t)n * nh * chunks;
+  int rc = ELT_CALL(z_dtype, launch_head_lm_fwd, z, W, bias, heatmaps, heatmap_stride_n, labels, label_stride_n, logits, hm_partial,
+                    dice_partial, n, spatial, nh, ncls, kind, sigmoid, ignore_index, s);
+  if (rc) return rc;
+  rc = launch_hm_finalize(hm_partial, reg_weight, reg_loss, n, nh, chunks, spatial, s);
+  if (rc) return rc;
+  return launch_dice_finalize(dice_partial, class_weight, class_loss, saved, ncls, n * chunks, eps, s);
+}
+extern "C" int mednet_head_landmark_bwd(const void* z, const void* packed, const float* bias, const void* heatmaps,
+                                        int64_t heatmap_stride_n, const void* labels, int64_t label_stride_n,
+                                        const float* class_weight, const float* reg_weight, const float* saved,
+                                        const float* dclass_loss, const float* dreg_loss, void* dz, const void* gn_y, int gn_act,
+                                        float* gn_partial, float* dw, float* dbias, int n, size_t spatial, int cin, int nh, int ncls,
+                                        int kind, float eps, int sigmoid, int ignore_index, int z_dtype, void* ws, size_t ws_bytes,
+                                        mednet_stream stream) {
+  MEDNET_REQUIRE(n > 0 && spatial > 0 && z && packed && heatmaps && labels && saved && dclass_loss && dreg_loss && dz && dw && ws,
+                 MEDNET_E_SHAPE, "head_landmark_bwd: bad arguments");
+  MEDNET_REQUIRE(mednet_head_landmark_supported(cin, nh, ncls, z_dtype, spatial), MEDNET_E_UNSUPPORTED,
+                 "head_landmark_bwd: %d -> %d heat maps + %d classes, dtype %d, %zu voxels", cin, nh, ncls, z_dtype, spatial);
+  const PackLayout L = pack_layout(cin, nh + ncls, 1);
+  const float* W = (const float*)((const char*)packed + L.f32_bwd);
+  return ELT_CALL(z_dtype, launch_head_lm_bwd, z, W, bias, heatmaps, heatmap_stride_n, labels, label_stride_n, saved, class_weight,
+                  reg_weight, dclass_loss, dreg_loss, eps, dz, gn_y, gn_act, gn_partial, dw, dbias, n, spatial, nh, ncls, kind,
+                  sigmoid, ignore_index, ws, ws_bytes, (hipStream_t)stream);
+}
+
 extern "C" int mednet_conv3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int algo) {
   if (!tuning_option("conv_fuse_gnb", 1) || !mednet_conv3d_act_supported(n, d, h, w, cout, cin, algo)) return 0;
   return conv_mfma_stats_chunks(n, d, h, w, cout, cin, true);  // (the kernel reads the layer's Cout channels, writes its Cin)

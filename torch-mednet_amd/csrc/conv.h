@@ -54,6 +54,12 @@ int launch_wgrad_c1(const void* x, const void* dy, float* dw, int n, int d, int 
                     int dy_dtype, void* ws, size_t ws_bytes, hipStream_t s, bool split_bf16 = false);
 int launch_pack_f32(const float* w, float* Pf, float* Pb, int cin, int cout, int T, int transposed_src, hipStream_t s);
 
+// loss.hip: the single-workgroup fp64 combines of the per-workgroup loss partials
+int launch_hm_finalize(const float* partial, const float* cweight, float* loss, int n, int c, int nblocks, size_t spatial,
+                       hipStream_t s);
+int launch_dice_finalize(const float* partial, const float* weight, float* loss, float* saved, int c, int nblocks, float eps,
+                         hipStream_t s);
+
 // 16-bit matrix-core kernels, conv_mfma.hip (namespace mednet: bf16; api.hip declares the same set in namespace mednet_f16
 // for the fp16 build of that file)
 #include "conv_mfma_decl.inc"

@@ -21,43 +21,9 @@
 #include <type_traits>
 #include "conv.h"
 
-// The 16-bit element type of this translation unit.  The file is compiled twice: as it stands for bf16 storage, and with
-// -DMEDNET_ELT_F16 -Dmednet=mednet_f16 for fp16 storage (BASELINE config 5): every kernel and launcher below then lives in
-// namespace mednet_f16 with the same names (declared by conv_mfma_decl.inc), and api.hip picks the namespace by dtype.
-namespace mednet {
-#ifdef MEDNET_ELT_F16
-typedef f16 elt;
-typedef f16x8 eltx8;
-typedef f16x4 eltx4;
-constexpr int ELT_DTYPE = MEDNET_F16;
-#define MEDNET_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
-#define MEDNET_FDOT2(a, b, c, clamp) __builtin_amdgcn_fdot2(a, b, c, clamp)
-typedef __fp16 tr_v4 __attribute__((__vector_size__(8)));  // (the fp16 builtin is declared on __fp16 vectors)
-#define MEDNET_DS_READ_TR16(p) __builtin_bit_cast(eltx4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_v4*)(p)))
-#else
-typedef bf16 elt;
-typedef bf16x8 eltx8;
-typedef bf16x4 eltx4;
-constexpr int ELT_DTYPE = MEDNET_BF16;
-#define MEDNET_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
-#define MEDNET_FDOT2(a, b, c, clamp) __builtin_amdgcn_fdot2_f32_bf16(a, b, c, clamp)
-#define MEDNET_DS_READ_TR16(p) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) eltx4*)(p))
-#endif
-}  // namespace mednet
+#include "elt16.inc"
 
 namespace mednet {
-
-typedef __attribute__((address_space(3))) eltx4 lds_eltx4;
-
-// One MFMA operand (8 k-values) from two transposing LDS reads.  Each lane passes the address of 4 consecutive channels
-// of ONE voxel row; the hardware hands lane i of every 16-lane group channel i of 4 voxel rows (measured mapping:
-// tools/probes/tr_probe.hip).  The whole-vector form matters: extracting the four 16-bit results one by one made
-// hipcc (ROCm 7.2) broadcast element 0.
-__device__ __forceinline__ eltx8 tr_operand(const char* base, int second_read_byte_offset) {
-  const eltx4 lo = MEDNET_DS_READ_TR16(base);
-  const eltx4 hi = MEDNET_DS_READ_TR16(base + second_read_byte_offset);
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
 
 // ================================================================================================== geometry
 // Brick KINDS of the forward / data-gradient kernel (the template parameter of conv_mfma_kernel and launch_fwd):

@@ -336,6 +336,18 @@ __global__ __launch_bounds__(256) void hm_bwd_kernel(const float* __restrict__ o
   }
 }
 
+// (for head_mfma.hip's fused landmark head, whose partial sums have hm_fwd_kernel's / dice_fwd_kernel's layouts)
+int launch_hm_finalize(const float* partial, const float* cweight, float* loss, int n, int c, int nblocks, size_t spatial,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(hm_finalize_kernel, dim3(1), dim3(1024), 0, s, partial, cweight, loss, n, c, nblocks, (double)n * (double)spatial);
+  return check_launch("heatmap_loss_finalize");
+}
+int launch_dice_finalize(const float* partial, const float* weight, float* loss, float* saved, int c, int nblocks, float eps,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, s, partial, weight, loss, saved, (float*)nullptr, c, nblocks, eps);
+  return check_launch("dice_finalize");
+}
+
 }  // namespace mednet
 
 using namespace mednet;

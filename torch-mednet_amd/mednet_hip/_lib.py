@@ -90,6 +90,13 @@ SIGNATURES = {
     "mednet_loss_ws_bytes": (_sz, [_i, _i, _sz]),
     "mednet_dice_fwd": (_i, [_vp] * 6 + [_i, _i, _sz, _i64, _i64, _f, _i, _i, _vp, _sz, _vp]),
     "mednet_dice_bwd": (_i, [_vp] * 6 + [_i, _i, _sz, _i64, _i64, _f, _i, _i, _vp]),
+    "mednet_head_landmark_supported": (_i, [_i, _i, _i, _i, _sz]),
+    "mednet_head_landmark_ws_bytes": (_sz, [_i, _sz, _i, _i]),
+    "mednet_head_landmark_gn_rows": (_i, [_sz]),
+    "mednet_head_landmark_fwd": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _i64] + [_vp] * 6 + [_i, _sz, _i, _i, _i, _i, _f, _i, _i, _i,
+                                      _vp, _sz, _vp]),
+    "mednet_head_landmark_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _i64] + [_vp] * 7 + [_i, _vp, _vp, _vp, _i, _sz, _i, _i, _i,
+                                      _i, _f, _i, _i, _i, _vp, _sz, _vp]),
     "mednet_head_dice_supported": (_i, [_i] * 4),
     "mednet_head_dice_ws_bytes": (_sz, [_i, _sz, _i, _i]),
     "mednet_head_dice_gn_rows": (_i, [_i, _sz, _i]),

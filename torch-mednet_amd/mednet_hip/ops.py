@@ -1113,6 +1113,110 @@ def head_dice(x, weight, bias, packed, labels, loss_weight=None, eps=1e-5, sigmo
     return HeadDiceFn.apply(x, weight, bias, packed, labels, loss_weight, eps, sigmoid, ignore_index)
 
 
+def _heatmap_view(heatmaps: torch.Tensor, n: int, nh: int, spatial_shape):
+    """uint8 heat-map targets as the fused landmark head takes them: N x nh x spatial, channels dense, any stride between samples
+    (the first channels of a uint8 label volume are consumed where they lie, landmarks.py:69)."""
+    if tuple(heatmaps.shape) != (n, nh) + tuple(spatial_shape):
+        raise RuntimeError(f"heatmap_loss: target shape {tuple(heatmaps.shape)} != output {(n, nh) + tuple(spatial_shape)}")
+    dense, acc = [], 1
+    for sdim in reversed((nh,) + tuple(spatial_shape)):
+        dense.insert(0, acc)
+        acc *= sdim
+    if tuple(heatmaps.stride()[1:]) != tuple(dense) or (n > 1 and heatmaps.stride(0) < acc):
+        heatmaps = heatmaps.contiguous()
+    return heatmaps, (heatmaps.stride(0) if n > 1 else acc)
+
+
+def head_landmark_supported(x: torch.Tensor, cin: int, nh: int, ncls: int, heatmaps: torch.Tensor, labels: torch.Tensor) -> bool:
+    if not (FUSE_HEAD_LOSS and x.is_cuda and x.dim() == 5 and labels.is_cuda and heatmaps.is_cuda):
+        return False
+    if x.dtype != config.act_dtype() or x.dtype == torch.float32 or not x.is_contiguous(memory_format=CL):
+        return False
+    if heatmaps.dtype != torch.uint8 or labels.dtype != torch.uint8:
+        return False
+    # (a network whose last block ends in conv -> activation hands the head an activation mask to fold in: the stock path does that)
+    if getattr(x, "_mednet_actmask", None) is not None and _gn3_hook_of(x, x.dtype) is None:
+        return False
+    return bool(L.lib().mednet_head_landmark_supported(cin, nh, ncls, L.dt(x), x[0, 0].numel()))
+
+
+class HeadLandmarkFn(Function):
+    """LandmarkNet's head and loss (landmarks.py:66-83, 125-134) as ONE autograd node in the 16-bit storage modes:
+    outputs = final_conv(x) (model.py:207), class_loss = DiceLoss(outputs[:, nh:], labels), regression_loss = sum_c w_c *
+    mean f(outputs[:, c] - heatmaps[:, c]).  Forward: one matrix-core pass over the features that writes nothing but loss partials
+    (mednet_head_landmark_fwd); backward: one pass that rebuilds the logits the same way and produces the feature gradient, the
+    head's weight / bias gradients and the first pass of the producing block's GroupNorm-3 backward
+    (mednet_head_landmark_bwd).  No logit or logit-gradient tensor exists.  Returns (class_loss, regression_loss)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, packed, heatmaps, labels, class_weight, reg_weight, kind, eps, sigmoid, ignore_index):
+        L.require_gpu(x, "head_landmark")
+        n, cin, d, h, w = x.shape
+        nh = heatmaps.shape[1]
+        ncls = weight.shape[0] - nh
+        spatial = d * h * w
+        hm, hm_sn = _heatmap_view(heatmaps, n, nh, (d, h, w))
+        lab, lab_sn, _ = _label_view(labels, n, (d, h, w))
+        cw = None if class_weight is None else class_weight.to(device=x.device, dtype=torch.float32).contiguous()
+        rw = None if reg_weight is None else torch.as_tensor(reg_weight, dtype=torch.float32, device=x.device).contiguous()
+        closs = torch.empty((), dtype=torch.float32, device=x.device)
+        rloss = torch.empty((), dtype=torch.float32, device=x.device)
+        saved = torch.empty((ncls, 2), dtype=torch.float32, device=x.device)
+        lib = L.lib()
+        ws = L.workspace(lib.mednet_head_landmark_ws_bytes(n, spatial, nh, ncls), x.device)
+        ii = L.NO_IGNORE if ignore_index is None else int(ignore_index)
+        L.check(lib.mednet_head_landmark_fwd(x.data_ptr(), packed.data_ptr(), L.ptr(bias), hm.data_ptr(), hm_sn, lab.data_ptr(), lab_sn,
+                                             L.ptr(cw), L.ptr(rw), None, closs.data_ptr(), rloss.data_ptr(), saved.data_ptr(), n,
+                                             spatial, cin, nh, ncls, kind, eps, int(sigmoid), ii, L.dt(x), ws.data_ptr(), ws.numel(),
+                                             L.stream()), "head_landmark_fwd")
+        ctx.save_for_backward(x, packed, hm, lab, cw, rw, saved)
+        ctx.meta = (kind, eps, int(sigmoid), ii, hm_sn, lab_sn, cin, nh, ncls)
+        ctx.params = (weight, bias)
+        ctx.gn3 = _gn3_hook_of(x, x.dtype)
+        if debug.TRACE is not None:
+            debug.trace("head_landmark.fwd", closs, rloss, saved)
+        return closs, rloss
+
+    @staticmethod
+    def backward(ctx, dclass, dreg):
+        x, packed, hm, lab, cw, rw, saved = ctx.saved_tensors
+        kind, eps, sigmoid, ii, hm_sn, lab_sn, cin, nh, ncls = ctx.meta
+        weight, bias = ctx.params
+        n, _, d, h, w = x.shape
+        spatial = d * h * w
+        lib = L.lib()
+        zero = None
+        if dclass is None or dreg is None:
+            zero = torch.zeros((), dtype=torch.float32, device=x.device)
+        dc = zero if dclass is None else dclass.to(torch.float32).contiguous()
+        dr = zero if dreg is None else dreg.to(torch.float32).contiguous()
+        dx = torch.empty_like(x, memory_format=CL)
+        dw, direct_w = _grad_target(weight, (nh + ncls, cin, 1, 1, 1))
+        db, direct_b = (None, True) if bias is None else _grad_target(bias, (nh + ncls,))
+        hook = ctx.gn3
+        partial = None
+        if hook is not None:
+            partial = torch.empty((n, lib.mednet_head_landmark_gn_rows(spatial), cin, 2), dtype=torch.float32, device=x.device)
+        ws = L.workspace(lib.mednet_head_landmark_ws_bytes(n, spatial, nh, ncls), x.device)
+        L.check(lib.mednet_head_landmark_bwd(x.data_ptr(), packed.data_ptr(), L.ptr(bias), hm.data_ptr(), hm_sn, lab.data_ptr(), lab_sn,
+                                             L.ptr(cw), L.ptr(rw), saved.data_ptr(), dc.data_ptr(), dr.data_ptr(), dx.data_ptr(),
+                                             None if hook is None else hook.gn_in.data_ptr(), hook.act if hook is not None else 0,
+                                             L.ptr(partial), dw.data_ptr(), L.ptr(db), n, spatial, cin, nh, ncls, kind, eps, sigmoid,
+                                             ii, L.dt(x), ws.data_ptr(), ws.numel(), L.stream()), "head_landmark_bwd")
+        if hook is not None:
+            hook.offer(dx, partial)
+        if debug.TRACE is not None:
+            debug.trace("head_landmark.bwd", dx, partial, dw, db)
+        return (dx, (None if direct_w else dw), (None if (bias is None or direct_b) else db)) + (None,) * 9
+
+
+def head_landmark(x, weight, bias, packed, heatmaps, labels, class_weight=None, reg_weight=None, kind="L2", eps=1e-5, sigmoid=False,
+                  ignore_index=None):
+    """-> (class_loss, regression_loss) of LandmarkNet.loss on final_conv(x)."""
+    return HeadLandmarkFn.apply(x, weight, bias, packed, heatmaps, labels, class_weight, reg_weight,
+                                L.REG_L2 if kind == "L2" else L.REG_L1, eps, sigmoid, ignore_index)
+
+
 def per_channel_dice(logits, labels, weight=None, eps=1e-5, sigmoid=False, ignore_index=None):
     """dice_metric  -- loss.py:51-55 (no gradient)."""
     L.require_gpu(logits, "dice_metric")

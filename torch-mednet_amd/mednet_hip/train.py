@@ -465,6 +465,25 @@ class LandmarkStep(_GraphedStep):
         self._init_graph(graph)
         self._exchange = BucketedExchange(model, self.flat, world_size)
 
+    def _head_losses(self, inputs, heatmaps, labels, nh):
+        """`outputs = self(inputs)` and the two terms of LandmarkNet.loss (landmarks.py:71-75, 125-134).  In the 16-bit storage
+        modes, with this package's U-Net, a 32-feature 1x1x1 head and uint8 targets, head and losses run as one fused node on the
+        matrix cores (ops.head_landmark: no logit tensor); anything else takes the calls as they stand."""
+        from .unet.model import _UNetCore
+        m, fc = self.model, getattr(self.model, "final_conv", None)
+        if (isinstance(m, _UNetCore) and not m.testing and fc is not None and getattr(fc, "planar_output", False)
+                and fc.kernel_size[0] == 1 and inputs.is_cuda and not self.loss_class.skip_last_target and self.loss_reg.kind in ("L1", "L2")):
+            feats = m.forward_features(inputs)
+            if ops.head_landmark_supported(feats, fc.in_channels, nh, fc.out_channels - nh, heatmaps, labels):
+                return ops.head_landmark(feats, fc.weight, fc.bias, fc._packed(), heatmaps, labels, self.loss_class.weight,
+                                         self.loss_reg.channel_weights, self.loss_reg.kind, self.loss_class.epsilon,
+                                         self.loss_class.sigmoid_normalization, self.loss_class.ignore_index)
+            outputs = fc(feats)
+        else:
+            outputs = m(inputs)
+        out_hm, out_cls = ops.split_channels(outputs, nh)  # (= outputs[:, :nh], outputs[:, nh:]; one gradient join)
+        return self.loss_class(out_cls, labels), self.loss_reg(out_hm, heatmaps)
+
     def _fwd_bwd(self, batch):
         inputs = batch["data"].float()
         heatmaps = batch["label"][:, :-1, ...]  # uint8 is consumed directly by the fused regression kernel
@@ -472,10 +491,7 @@ class LandmarkStep(_GraphedStep):
         labels = batch["label"][:, -1, ...]  # uint8, consumed where it lies (ops.dice_loss takes uint8 or int64 labels)
         if not labels.is_cuda:
             labels = labels.long()
-        outputs = self.model(inputs)
-        out_hm, out_cls = ops.split_channels(outputs, nh)  # (= outputs[:, :nh], outputs[:, nh:]; one gradient join)
-        class_loss = self.loss_class(out_cls, labels)
-        regression_loss = self.loss_reg(out_hm, heatmaps)
+        class_loss, regression_loss = self._head_losses(inputs, heatmaps, labels, nh)
         loss = regression_loss + class_loss
         (loss if self.scaler is None else self.scaler.scale_loss(loss)).backward()
         finish_backward()
