@@ -63,6 +63,7 @@ template <bool BWD>
 __global__ __launch_bounds__(256, 2) void head_lm_kernel(HlmArgs a) {
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   __shared__ __attribute__((aligned(16))) char smem[256 * HLM_SCR * 4];
+  __shared__ float cst[2][32];
   __shared__ u32x4 wops[8][64];  // the 8 weight operands (below), one 16-byte fragment per lane: the same in every wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,38 +112,34 @@ __global__ __launch_bounds__(256, 2) void head_lm_kernel(HlmArgs a) {
       wops[6 + b][lane] = __builtin_bit_cast(u32x4, wd_lo[b]);
     }
   }
+  // ---- constants of a lane half, in LDS (they would hold 36 registers for the whole kernel): per h the biases of its 8 heat maps
+  // [0..7] and of the classes [8..11], the heat maps' gradient scales [12..19] and the Dice gradient terms gI [20..23], gD [24..27]
+  if (wv == 2) {
+    const int hh = lane >> 5, i = lane & 31;
+    float v = 0.f;
+    if (i < 8) v = (a.bias && 8 * hh + i < a.nh) ? a.bias[8 * hh + i] : 0.f;
+    else if (i < 12) v = (a.bias && i - 8 < a.ncls) ? a.bias[a.nh + i - 8] : 0.f;
+    else if (BWD && i < 20) {
+      const int c = 8 * hh + i - 12;
+      v = c < a.nh ? *a.dreg * (a.reg_weight ? a.reg_weight[c] : 1.f) * a.inv_count : 0.f;
+    } else if (BWD && i < 28) {  // loss.hip dice_bwd_kernel
+      const int k = (i - 20) & 3;
+      if (k < a.ncls) {
+        const float gc = *a.dcls, w = a.cls_weight ? a.cls_weight[k] : 1.f;
+        const float I = a.saved[2 * k], D = a.saved[2 * k + 1];
+        const float Dc = fmaxf(D, a.eps);
+        v = i < 24 ? -2.f * w / ((float)a.ncls * Dc) * gc + ((I != I || D != D) ? __builtin_nanf("") : 0.f)
+                   : (D >= a.eps ? 2.f * w * I / ((float)a.ncls * Dc * Dc) : 0.f) * gc;
+      }
+    }
+    cst[hh][i] = v;
+  }
   __syncthreads();
   // 0,1: logits hi; 2,3: lo; 4,5: dz hi; 6,7: lo.  `wbase` is made opaque once per sub-tile: left alone, the compiler hoists the
   // eight loop-invariant fragments back into 32 registers for the whole kernel
   const u32x4* wbase = &wops[0][lane];
+  const float* cbase = &cst[h][0];
   auto wop = [&](int i) { return __builtin_bit_cast(eltx8, wbase[i * 64]); };
-  float bh[8], bc[HLM_MAXC];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bh[e] = (a.bias && 8 * h + e < a.nh) ? a.bias[8 * h + e] : 0.f;
-#pragma unroll
-  for (int k = 0; k < HLM_MAXC; ++k) bc[k] = (a.bias && k < a.ncls) ? a.bias[a.nh + k] : 0.f;
-
-  // ---- per-lane constants of the loss gradients -------------------------------------------------------------------
-  float hscale[8], gI[HLM_MAXC], gD[HLM_MAXC];
-  if constexpr (BWD) {
-    const float go = *a.dreg;
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      hscale[e] = 8 * h + e < a.nh ? go * (a.reg_weight ? a.reg_weight[8 * h + e] : 1.f) * a.inv_count : 0.f;
-    const float gc = *a.dcls;
-#pragma unroll
-    for (int k = 0; k < HLM_MAXC; ++k) {
-      gI[k] = gD[k] = 0.f;
-      if (k < a.ncls) {  // loss.hip dice_bwd_kernel
-        const float w = a.cls_weight ? a.cls_weight[k] : 1.f;
-        const float I = a.saved[2 * k], D = a.saved[2 * k + 1];
-        const float Dc = fmaxf(D, a.eps);
-        gI[k] = -2.f * w / ((float)a.ncls * Dc) * gc + ((I != I || D != D) ? __builtin_nanf("") : 0.f);
-        gD[k] = (D >= a.eps ? 2.f * w * I / ((float)a.ncls * Dc * Dc) : 0.f) * gc;
-      }
-    }
-  }
-
   // ---- accumulators ---------------------------------------------------------------------------------------------------
   float hm_acc[8], dI[HLM_MAXC], dD[HLM_MAXC];  // forward
   float ss[16], sq[16], dbh[8], dbc[HLM_MAXC];  // backward
@@ -177,6 +174,8 @@ __global__ __launch_bounds__(256, 2) void head_lm_kernel(HlmArgs a) {
   const uint8_t* lb8 = a.lab + (size_t)n * a.lab_sn;
   const int run_end = min(a.runs, (chunk + 1) * a.chunk_runs);
 
+  // (Measured, profiles/r05_ab.md: requesting zp[j] of the NEXT run as soon as sub-tile j has used it -- a register-neutral software
+  //  pipeline -- made both kernels slower, 0.47 -> 0.52 ms and 0.17 -> 0.22 ms at config 4: the loads stay at the top of a run.)
   for (int run = chunk * a.chunk_runs + wv; run < run_end; run += 4) {
     const size_t vb = (size_t)run * HLM_RUN + 4 * g;  // this lane's first voxel
     const bool live = vb < a.spatial;                 // (spatial % 4 == 0: all four voxels or none)
@@ -201,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void head_lm_kernel(HlmArgs a) {
 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      asm volatile("" : "+v"(wbase));
+      asm volatile("" : "+v"(wbase), "+v"(cbase));
       if constexpr (BWD) {
         if (j < 3) fetch_y(j + 1);
       }
@@ -217,9 +216,9 @@ __global__ __launch_bounds__(256, 2) void head_lm_kernel(HlmArgs a) {
       }
       float lh[8], lc[HLM_MAXC], p[HLM_MAXC];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) lh[e] = lg[e] + bh[e];
+      for (int e = 0; e < 8; ++e) lh[e] = lg[e] + cbase[e];
 #pragma unroll
-      for (int k = 0; k < HLM_MAXC; ++k) lc[k] = lg[8 + k] + bc[k];
+      for (int k = 0; k < HLM_MAXC; ++k) lc[k] = lg[8 + k] + cbase[8 + k];
       if (!BWD && a.logits && live) {
         float* lo = a.logits + (size_t)n * m * a.spatial + vb + j;
 #pragma unroll
@@ -279,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void head_lm_kernel(HlmArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float d = lh[e] - (float)((tb[e] >> (8 * j)) & 0xFFu);
-          const float sc = live ? hscale[e] : 0.f;  // (0 for heat maps >= nh)
+          const float sc = live ? cbase[12 + e] : 0.f;  // (0 for heat maps >= nh)
           dh[e] = a.kind == MEDNET_REG_L2 ? 2.f * d * sc : (d > 0.f ? sc : (d < 0.f ? -sc : 0.f));
           dbh[e] += dh[e];
         }
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void head_lm_kernel(HlmArgs a) {
           for (int k = 0; k < HLM_MAXC; ++k) {
             const float t = (k == yl) ? 1.f : 0.f;
             const float mk = (a.ignore != MEDNET_NO_IGNORE && t == (float)a.ignore) ? 0.f : 1.f;
-            gg[k] = k < a.ncls ? mk * (gI[k] * t * mk + gD[k]) : 0.f;
+            gg[k] = k < a.ncls ? mk * (cbase[20 + k] * t * mk + cbase[24 + k]) : 0.f;
             dot = fmaf(p[k], gg[k], dot);
           }
 #pragma unroll
@@ -447,31 +446,37 @@ __global__ __launch_bounds__(256, 2) void head_lm_kernel(HlmArgs a) {
   }
 }
 
-// dw[co][ci] = sum over workgroups of wpart[.][k'(co)][ci], db[co] likewise; fixed order (deterministic)
+// dw[co][ci] = sum over workgroups of wpart[.][k'(co)][ci], db[co] likewise; fixed order (deterministic).  A workgroup = 16 outputs x
+// 16 row slices (a thread: every 16th row, 8 loads in flight), then the slices in order.
 __global__ __launch_bounds__(256) void head_lm_wfinal_kernel(const float* __restrict__ wpart, int rows, int nh, int ncls,
                                                             float* __restrict__ dw, float* __restrict__ db) {
-  __shared__ double sh[4][64];
-  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  __shared__ double sh[16][17];
+  const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int m = nh + ncls, total = m * 33;
-  const int o = blockIdx.x * 64 + e;
-  double s0 = 0.0, s1 = 0.0;
-  int src = 0;
+  const int o = blockIdx.x * 16 + e;
+  double acc = 0.0;
   if (o < total) {
     const int co = o < m * 32 ? o / 32 : o - m * 32, kp = co < nh ? co : 16 + (co - nh);
-    src = o < m * 32 ? kp * 32 + o % 32 : 1024 + kp;
+    const int src = o < m * 32 ? kp * 32 + o % 32 : 1024 + kp;
+    const float* p = wpart + src;
     int r = q;
-    for (; r + 4 < rows; r += 8) {
-      s0 += (double)wpart[(size_t)r * HLM_WIDTH + src];
-      s1 += (double)wpart[(size_t)(r + 4) * HLM_WIDTH + src];
+    for (; r + 7 * 16 < rows; r += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(r + 16 * u) * HLM_WIDTH];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)v[u];
     }
-    for (; r < rows; r += 4) s0 += (double)wpart[(size_t)r * HLM_WIDTH + src];
+    for (; r < rows; r += 16) acc += (double)p[(size_t)r * HLM_WIDTH];
   }
-  sh[q][e] = s0 + s1;
+  sh[q][e] = acc;
   __syncthreads();
   if (q == 0 && o < total) {
-    const float v = (float)((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]));
-    if (o < m * 32) dw[o] = v;
-    else if (db) db[o - m * 32] = v;
+    double t = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t += sh[u][e];
+    if (o < m * 32) dw[o] = (float)t;
+    else if (db) db[o - m * 32] = (float)t;
   }
 }
 
@@ -534,7 +539,7 @@ int launch_head_lm_bwd(const void* z, const float* W, const float* bias, const v
   int rc = check_launch("head_lm_bwd");
   if (rc) return rc;
   const int total = (nh + ncls) * 33;
-  hipLaunchKernelGGL(head_lm_wfinal_kernel, dim3((total + 63) / 64), dim3(256), 0, s, a.wpart, n * a.chunks, nh, ncls, dw, db);
+  hipLaunchKernelGGL(head_lm_wfinal_kernel, dim3((total + 15) / 16), dim3(256), 0, s, a.wpart, n * a.chunks, nh, ncls, dw, db);
   return check_launch("head_lm_wfinal");
 }
 
