@@ -340,3 +340,32 @@ def test_algo_mfma_is_satisfied_by_the_fp32_mode_matrix_core_kernels():
     rc = lib.mednet_conv3d_wgrad(None, None, None, None, 1, 8, 8, 16, 32, 32, 3, L.BF16, L.NDHWC, L.BF16, L.NDHWC, L.ALGO_AUTO, -1, None, 0, None)
     assert rc == -1 and "workgroups" in lib.mednet_last_error().decode()
     assert lib.mednet_get_option(b"wgrad_wgs", -7) == -7 and lib.mednet_abi_version() == 2
+
+
+def test_fused_landmark_head_and_first_layer_entry_points_answer_without_a_device():
+    """The round-5 entry points' host side: which shapes the matrix-core landmark head (head_mfma.hip) and the first layer's fused
+    GroupNorm-backward + weight gradient take, their workspace / row counts, and argument errors that come before any launch."""
+    from mednet_hip import _lib as L
+    lib = L.lib()
+    sp = 128 ** 3
+    # landmarks.py:71-75: 16 heat maps + 2 classes on 32 features, either 16-bit type; not fp32 storage, not other widths
+    assert lib.mednet_head_landmark_supported(32, 16, 2, L.BF16, sp) == 1 and lib.mednet_head_landmark_supported(32, 16, 2, L.F16, sp) == 1
+    assert lib.mednet_head_landmark_supported(32, 16, 2, L.F32, sp) == 0
+    assert lib.mednet_head_landmark_supported(64, 16, 2, L.BF16, sp) == 0
+    assert lib.mednet_head_landmark_supported(32, 17, 2, L.BF16, sp) == 0 and lib.mednet_head_landmark_supported(32, 16, 5, L.BF16, sp) == 0
+    assert lib.mednet_head_landmark_supported(32, 1, 1, L.BF16, 64) == 1 and lib.mednet_head_landmark_supported(32, 1, 1, L.BF16, 66) == 0
+    rows = lib.mednet_head_landmark_gn_rows(sp)
+    assert rows == (sp // 128 + 63) // 64 == 256 and lib.mednet_head_landmark_gn_rows(4) == 1
+    assert lib.mednet_head_landmark_ws_bytes(4, sp, 16, 2) >= 4 * rows * 32 * 33 * 4
+    rc = lib.mednet_head_landmark_fwd(None, None, None, None, 0, None, 0, None, None, None, None, None, None, 4, sp, 32, 16, 2, 0, 1e-5, 0,
+                                      L.NO_IGNORE, L.BF16, None, 0, None)
+    assert rc == -1 and "head_landmark_fwd" in lib.mednet_last_error().decode()
+    # first layer (Cin = 1): 16 / 32 / 64 output channels, 16-bit gradients, patch fp32 or the same 16-bit type
+    for dt in (L.BF16, L.F16):
+        assert all(lib.mednet_conv3d_wgrad_c1_gn_supported(c, L.F32, dt) == 1 for c in (16, 32, 64))
+        assert lib.mednet_conv3d_wgrad_c1_gn_supported(32, dt, dt) == 1 and lib.mednet_conv3d_wgrad_c1_gn_supported(48, L.F32, dt) == 0
+    assert lib.mednet_conv3d_wgrad_c1_gn_supported(32, L.F32, L.F32) == 0 and lib.mednet_conv3d_wgrad_c1_gn_supported(32, L.BF16, L.F16) == 0
+    rc = lib.mednet_conv3d_wgrad_c1_gn(None, None, None, None, None, None, 1, 8, 8, 16, 32, 0, L.F32, L.BF16, None, 0, None)
+    assert rc == -1 and "conv3d_wgrad_c1_gn" in lib.mednet_last_error().decode()
+    rc = lib.mednet_gn_bwd_coefficients(None, None, None, 0, None, None, None, 1, 64, 32, 8, None, 0, None)
+    assert rc == -1 and "gn_bwd_coefficients" in lib.mednet_last_error().decode()
