@@ -57,3 +57,10 @@ def test_size_queries_work_without_gpu():
     assert lib.mednet_gn_ws_bytes(4, 32, 128 ** 3) > 0
     assert lib.mednet_loss_ws_bytes(4, 4, 128 ** 3) > 0
     assert lib.mednet_conv3d_wgrad_ws_bytes(1, 16, 16, 16, 32, 32, 3, 0) > 0
+
+
+def test_the_driver_build_hook_runs_clean():
+    """__graft_entry__.build() is what the driver calls every round: it must compile (a no-op when the library is current),
+    import the package and agree with the library about the ABI version (it still asserted version 1 after round 5 moved to 2)."""
+    import __graft_entry__ as entry
+    entry.build()
