@@ -1092,6 +1092,37 @@ def test_landmark_head_on_the_matrix_cores_against_the_unfused_launches(mode, sh
     assert e <= 3e-3, e
 
 
+def test_landmark_head_node_without_the_groupnorm_hook():
+    """ops.head_landmark when the producing block offers no GroupNorm-3 hook (MEDNET_FUSE_GN3 off: the block runs its own first
+    pass): the kernel's gn_y == NULL path -- no sums taken, dz stored as before -- against the stock launches."""
+    from mednet_hip import ops as hops
+    from mednet_hip.train import LandmarkStep
+    ctor = dict(in_channels=1, out_channels=18, final_sigmoid=False, f_maps=[32, 64])
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(2, 1, (16, 24, 20), 2, 16, seed=5).items()}
+    res = {}
+    old_gn3 = hops.FUSE_GN3
+    hops.FUSE_GN3 = False
+    try:
+        for fused in (True, False):
+            old = hops.FUSE_HEAD_LOSS
+            hops.FUSE_HEAD_LOSS = fused
+            try:
+                with mednet_hip.precision("bf16"):
+                    net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+                    step = LandmarkStep(net, [0.05, 1.0], [0.015] * 16, "L2")
+                    tot, cl, rg = step._fwd_bwd(batch)
+                    torch.cuda.synchronize()
+                    res[fused] = (float(cl), float(rg), step.flat.grad.clone())
+                    step.flat.release()
+            finally:
+                hops.FUSE_HEAD_LOSS = old
+    finally:
+        hops.FUSE_GN3 = old_gn3
+    (c1, r1, g1), (c0, r0, g0) = res[True], res[False]
+    assert abs(c1 - c0) <= 2e-6 * max(1.0, abs(c0)) and abs(r1 - r0) <= 2e-6 * max(1.0, abs(r0))
+    assert torch.isfinite(g1).all() and float((g1 - g0).norm() / g0.norm()) <= 3e-3
+
+
 def test_cfg5_shape_smoke_bf16():
     """BASELINE config 5's topology (5 levels, 64 base channels -> 1024 at the bottom) at a reduced patch, bf16 storage:
     exercises the >256-channel paths (GroupNorm columns, wide bias sums, 32x32 channel-block pairs up to 1024x1024)
