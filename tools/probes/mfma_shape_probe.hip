@@ -48,6 +48,66 @@ __global__ __launch_bounds__(256, 1) void probe(const u32x4* src, float* out, in
 #pragma unroll
       for (int i = 0; i < 16; ++i) r += acc[t][i];
     out[blockIdx.x * 256 + tid] = r;
+  } else if constexpr (SHAPE == 2) {
+    // 32x32x16 with NO LDS traffic in the loop: the four B fragments are read once and reused (what the matrix pipe alone sustains)
+    f32x16 acc[4] = {};
+    bf16x8 b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = __builtin_bit_cast(bf16x8, p[t * 64]);
+    for (int s = 0; s < steps; s += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[(u * 4 + t) & 7], b[t], acc[t], 0, 0, 0);
+      }
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r += acc[t][i];
+    out[blockIdx.x * 256 + tid] = r;
+  } else if constexpr (SHAPE == 3 || SHAPE == 4) {
+    // 32x32x16, ONE ds_read_b128 per THREE MFMAs: the x-shifted taps of a 3x3x3 convolution read the same voxel rows moved by one
+    // lane, so two of three B operands can be made from the first with 4 DPP row shifts each instead of a 1 KB LDS read
+    // (the boundary lane's value is not patched here: timing only)
+    f32x16 acc[4] = {};
+    bf16x8 b[2][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[0][t] = __builtin_bit_cast(bf16x8, p[t * 64]);
+    // lanes without a source inside their 16-lane row keep `edge` (bound_ctrl off): the halo voxel needs no merge instruction
+    auto shift = [](bf16x8 v, bf16x8 edge, bool right) {
+      u32x4 q = __builtin_bit_cast(u32x4, v), e = __builtin_bit_cast(u32x4, edge), r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        r[i] = right ? (unsigned)__builtin_amdgcn_update_dpp((int)e[i], (int)q[i], 0x111, 0xF, 0xF, false)   // row_shr:1
+                     : (unsigned)__builtin_amdgcn_update_dpp((int)e[i], (int)q[i], 0x101, 0xF, 0xF, false);  // row_shl:1
+      return __builtin_bit_cast(bf16x8, r);
+    };
+    for (int s = 0; s < steps; s += 6) {  // 6 steps of 4 MFMAs = 2 groups of 3 steps sharing one set of reads
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          b[u ^ 1][t] = __builtin_bit_cast(bf16x8, p[((s + u + 1) & 3) * 256 + t * 64]);
+          bf16x8 hl = b[u][t], hr = b[u][t];
+          if constexpr (SHAPE == 4) {  // the voxel beyond either end of a 16-voxel row: lanes 0 / 15 of every row read it (8 of 64 lanes)
+            if ((lane & 15) == 0) hl = __builtin_bit_cast(bf16x8, p[((s + u + 2) & 3) * 256 + t * 64 + 1]);
+            if ((lane & 15) == 15) hr = __builtin_bit_cast(bf16x8, p[((s + u + 3) & 3) * 256 + t * 64 - 1]);
+          }
+          const bf16x8 bl = shift(b[u][t], hr, false), br = shift(b[u][t], hl, true);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[(u * 4 + t) & 7], bl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[(u * 4 + t + 1) & 7], b[u][t], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[(u * 4 + t + 2) & 7], br, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r += acc[t][i];
+    out[blockIdx.x * 256 + tid] = r;
   } else {
     f32x4 acc[16] = {};
     bf16x8 b[2][8];
@@ -88,24 +148,33 @@ int main() {
   hipMemcpy(d, h.data(), n * 16, hipMemcpyHostToDevice);
   hipFuncSetAttribute((const void*)probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipFuncSetAttribute((const void*)probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute((const void*)probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute((const void*)probe<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute((const void*)probe<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  const int steps0 = 40000;  // shape 0 steps; shape 1 runs half as many of twice the FLOPs
+  const int steps0 = 39996;  // shape 0 steps (a multiple of 6 for shape 3); shape 1 runs half as many of twice the FLOPs
+  const char* names[5] = {"32x32x16, 1 ds_read_b128 per MFMA", "16x16x32, 1 ds_read_b128 per 2 MFMAs", "32x32x16, no LDS reads in the loop",
+                          "32x32x16, 1 ds_read_b128 + 8 DPP shifts per 3 MFMAs",
+                          "... + the two halo columns by 4-lane ds_read_b128"};
   for (int rep = 0; rep < 3; ++rep)
-    for (int shape = 0; shape < 2; ++shape) {
+    for (int shape = 0; shape < 5; ++shape) {
       for (int warm = 0; warm < 2; ++warm) {
         hipEventRecord(e0);
         if (shape == 0) hipLaunchKernelGGL(probe<0>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
-        else hipLaunchKernelGGL(probe<1>, dim3(256), dim3(256), 131072, 0, d, o, steps0 / 2);
+        else if (shape == 1) hipLaunchKernelGGL(probe<1>, dim3(256), dim3(256), 131072, 0, d, o, steps0 / 2);
+        else if (shape == 2) hipLaunchKernelGGL(probe<2>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
+        else if (shape == 3) hipLaunchKernelGGL(probe<3>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
+        else hipLaunchKernelGGL(probe<4>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
       }
       float ms;
       hipEventElapsedTime(&ms, e0, e1);
-      const double flop = 256.0 * 4 * steps0 * 4 * 2.0 * 32 * 32 * 16;  // the same for both shapes
-      printf("shape %s: %8.3f ms  %7.1f TFLOP/s  (%.1f cycles per 32768 FLOP per SIMD at 2.4 GHz; 32 = nominal peak)\n",
-             shape == 0 ? "32x32x16" : "16x16x32", ms, flop / ms / 1e9, ms * 1e-3 * 2.4e9 / (steps0 * 4.0));
+      const double flop = 256.0 * 4 * steps0 * 4 * 2.0 * 32 * 32 * 16;  // the same for every shape
+      printf("%-52s %8.3f ms  %7.1f TFLOP/s  (%.1f cycles per 32768 FLOP per SIMD at 2.4 GHz; 32 = nominal peak)\n",
+             names[shape], ms, flop / ms / 1e9, ms * 1e-3 * 2.4e9 / (steps0 * 4.0));
     }
   return 0;
 }
