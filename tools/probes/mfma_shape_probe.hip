@@ -67,6 +67,57 @@ __global__ __launch_bounds__(256, 1) void probe(const u32x4* src, float* out, in
 #pragma unroll
       for (int i = 0; i < 16; ++i) r += acc[t][i];
     out[blockIdx.x * 256 + tid] = r;
+  } else if constexpr (SHAPE == 5) {
+    // the general convolution kernel's tiling: per tap step 4 N-tiles x 1 channel block = 4 B reads + 1 A read per 4 MFMAs
+    f32x16 acc[4] = {};
+    bf16x8 b[2][4], a[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[0][t] = __builtin_bit_cast(bf16x8, p[t * 64]);
+    a[0] = __builtin_bit_cast(bf16x8, p[4096]);
+    for (int s = 0; s < steps; s += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        a[u ^ 1] = __builtin_bit_cast(bf16x8, p[4096 + ((s + u + 1) & 7) * 64]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          b[u ^ 1][t] = __builtin_bit_cast(bf16x8, p[((s + u + 1) & 3) * 256 + t * 64]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[u][t], acc[t], 0, 0, 0);
+        }
+      }
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r += acc[t][i];
+    out[blockIdx.x * 256 + tid] = r;
+  } else if constexpr (SHAPE == 6) {
+    // two channel blocks per wave: 4 N-tiles x 2 blocks = 4 B reads + 2 A reads per 8 MFMAs (128 accumulator registers)
+    f32x16 acc[8] = {};
+    bf16x8 b[2][4], a[2][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[0][t] = __builtin_bit_cast(bf16x8, p[t * 64]);
+    a[0][0] = __builtin_bit_cast(bf16x8, p[4096]);
+    a[0][1] = __builtin_bit_cast(bf16x8, p[4160]);
+    for (int s = 0; s < steps; s += 4) {  // a step of this shape = 8 MFMAs = two steps of the others
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        a[u ^ 1][0] = __builtin_bit_cast(bf16x8, p[4096 + ((s + u + 1) & 7) * 128]);
+        a[u ^ 1][1] = __builtin_bit_cast(bf16x8, p[4096 + ((s + u + 1) & 7) * 128 + 64]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          b[u ^ 1][t] = __builtin_bit_cast(bf16x8, p[((s / 2 + u + 1) & 3) * 256 + t * 64]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], b[u][t], acc[t], 0, 0, 0);
+          acc[4 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][1], b[u][t], acc[4 + t], 0, 0, 0);
+        }
+      }
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r += acc[t][i];
+    out[blockIdx.x * 256 + tid] = r;
   } else if constexpr (SHAPE == 3 || SHAPE == 4) {
     // 32x32x16, ONE ds_read_b128 per THREE MFMAs: the x-shifted taps of a 3x3x3 convolution read the same voxel rows moved by one
     // lane, so two of three B operands can be made from the first with 4 DPP row shifts each instead of a 1 KB LDS read
@@ -151,22 +202,27 @@ int main() {
   hipFuncSetAttribute((const void*)probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipFuncSetAttribute((const void*)probe<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipFuncSetAttribute((const void*)probe<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute((const void*)probe<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute((const void*)probe<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const int steps0 = 39996;  // shape 0 steps (a multiple of 6 for shape 3); shape 1 runs half as many of twice the FLOPs
-  const char* names[5] = {"32x32x16, 1 ds_read_b128 per MFMA", "16x16x32, 1 ds_read_b128 per 2 MFMAs", "32x32x16, no LDS reads in the loop",
+  const char* names[7] = {"32x32x16, 1 ds_read_b128 per MFMA", "16x16x32, 1 ds_read_b128 per 2 MFMAs", "32x32x16, no LDS reads in the loop",
                           "32x32x16, 1 ds_read_b128 + 8 DPP shifts per 3 MFMAs",
-                          "... + the two halo columns by 4-lane ds_read_b128"};
+                          "... + the two halo columns by 4-lane ds_read_b128",
+                          "4 N-tiles x 1 block: 4 B + 1 A reads per 4 MFMAs", "4 N-tiles x 2 blocks: 4 B + 2 A reads per 8 MFMAs"};
   for (int rep = 0; rep < 3; ++rep)
-    for (int shape = 0; shape < 5; ++shape) {
+    for (int shape = 0; shape < 7; ++shape) {
       for (int warm = 0; warm < 2; ++warm) {
         hipEventRecord(e0);
         if (shape == 0) hipLaunchKernelGGL(probe<0>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
         else if (shape == 1) hipLaunchKernelGGL(probe<1>, dim3(256), dim3(256), 131072, 0, d, o, steps0 / 2);
         else if (shape == 2) hipLaunchKernelGGL(probe<2>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
         else if (shape == 3) hipLaunchKernelGGL(probe<3>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
-        else hipLaunchKernelGGL(probe<4>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
+        else if (shape == 4) hipLaunchKernelGGL(probe<4>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
+        else if (shape == 5) hipLaunchKernelGGL(probe<5>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
+        else hipLaunchKernelGGL(probe<6>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
       }
