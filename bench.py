@@ -344,6 +344,12 @@ def main():
                           "pid": os.getpid()}), flush=True)
         return
     assert torch.cuda.is_available(), (f"bench.py rank {rank}/{world} needs an MI355X (no CPU fallback for the product path)")
+    # Rehearsal of an N > 1 run on a ONE-GPU box (never a measurement): MEDNET_REHEARSE_ONE_GPU=1 puts every rank on cuda:0 and
+    # exchanges over gloo (RCCL refuses two ranks on one device); launcher, barriers, bucketed exchange, MAX-over-ranks and the
+    # JSON line are the real ones.  The line is marked `rehearsal`.
+    rehearse = os.environ.get("MEDNET_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("MEDNET_FORCE_DIST") == "1"  # the latter: 1-rank RCCL rehearsal
@@ -352,7 +358,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     import mednet_hip
     from mednet_hip import _lib, ops
@@ -417,6 +426,8 @@ def main():
                                        "wgrad_workgroups": ops.SIDE["wgrad_wgs"] or "one per CU"}},
             "host_enqueue_ms_per_step": round(1e3 * t_issue / n_issue, 3),
         }
+        if rehearse:
+            out["rehearsal"] = f"{world} ranks on ONE GPU over gloo: exercises the multi-rank code path, not a throughput"
         if P == 128 and a.precision == "bf16":
             out["model_flops_utilization"] = round(patches / dt * FLOP_PER_PATCH / (world * MFMA_PEAK_TFLOPS["bf16"] * 1e12), 4)
         if not a.no_roofline and ops.PROFILE["events"]:
