@@ -1305,13 +1305,14 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
       wa[ks][j] = (elt)(tap < 27 && cb * 32 + r < a.cout ? a.w[(size_t)tap * a.cout + cb * 32 + r] : 0.f);  // (a 16-channel layer fills half a block)
     }
   // LDS offsets of this lane's 8 taps per k-step
-  int toff[2][8];
+  int toff[2][8];  // (both k-halves' offsets are compile-time constants: one select per entry instead of the divisions by 9 and 3)
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int tap = ks * 16 + 8 * h + j;
-      toff[ks][j] = tap < 27 ? ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3 : 0;
+      const int t0 = ks * 16 + j, t1 = ks * 16 + 8 + j;
+      const int o0 = t0 < 27 ? ((t0 / 9) * HY + (t0 / 3) % 3) * HX + t0 % 3 : 0, o1 = t1 < 27 ? ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3 : 0;
+      toff[ks][j] = h ? o1 : o0;
     }
   for (int i = tid; i < NV; i += 256) {
     const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
@@ -1386,13 +1387,20 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
     }
   }
   if (a.gn_partial) {  // one row per wave: sum over the 32 voxel lanes of each k-half, lanes r == 0 write their 16 channels
+    // (DPP / v_permlane16_swap steps: plain VALU.  As __shfl_xor -- ds_bpermute_b32, 320 LDS-queue instructions per wave -- this
+    //  reduction was a quarter of the kernel's time)
+    auto half_sum = [](float v) {  // sum over the 32 lanes that share lane / 32, in every lane
+      v += dpp_f32<0xB1>(v);
+      v += dpp_f32<0x4E>(v);
+      v += dpp_f32<0x124>(v);
+      v += dpp_f32<0x128>(v);
+      return xor16_sum(v);
+    };
 #pragma unroll
-    for (int m = 1; m < 32; m <<= 1)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        ssum[i] += __shfl_xor(ssum[i], m, 64);
-        ssq[i] += __shfl_xor(ssq[i], m, 64);
-      }
+    for (int i = 0; i < 16; ++i) {
+      ssum[i] = half_sum(ssum[i]);
+      ssq[i] = half_sum(ssq[i]);
+    }
     if (r == 0) {
       const int tps = a.tiles_x * a.tiles_y * a.tiles_z;
       float* dst = a.gn_partial + ((((size_t)n * tps + tile % tps) * 4 + wv) * a.cout + cb * 32) * 2;
