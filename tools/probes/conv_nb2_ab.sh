@@ -1,5 +1,6 @@
 #!/bin/bash
-# Two channel blocks per work item in the general convolution kernel (option conv_nb2): bit-identity tests, layer timings, step A/B.
+# Two channel blocks per work item in the general convolution kernel: bit-identity tests, layer timings, step A/B.  Needs the library
+# built from the patched sources (git apply tools/probes/conv_nb2.patch; make): the option conv_nb2 exists only there.
 set -o pipefail
 mkdir -p gpurun_out
 export PYTHONPATH="$PWD:$PWD/torch-mednet_amd:$PYTHONPATH"
