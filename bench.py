@@ -189,7 +189,7 @@ def wgrad_alone_ms(dev, batch: int, patch: int, precision: str) -> float:
     lib = L.lib()
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(precision)
     if dt is None:
-        return float("nan")
+        return float("nan"), 0
     code = L.BF16 if dt == torch.bfloat16 else L.F16
     c = F_MAPS[0]
     g = torch.Generator(device=dev).manual_seed(7)
@@ -203,16 +203,17 @@ def wgrad_alone_ms(dev, batch: int, patch: int, precision: str) -> float:
     for _ in range(20):  # (the chip idled while the host assembled the record: bring the clocks back before timing)
         run()
     torch.cuda.synchronize()
-    rounds = []
+    rounds, per_round = [], 20
     for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20):
+        for _ in range(per_round):
             run()
         e1.record()
         torch.cuda.synchronize()
-        rounds.append(e0.elapsed_time(e1) / 20)
-    return sorted(rounds)[1]  # median of three rounds of 20 launches (each launch = the kernel + its fixed-order reduce)
+        rounds.append(e0.elapsed_time(e1) / per_round)
+    # median of three rounds of 20 launches (each launch = the kernel + its fixed-order reduce), and how many launches were timed
+    return sorted(rounds)[1], len(rounds) * per_round
 
 
 def fp32_parity_mode(dev, batch: int, patch: int, steps: int):
@@ -278,9 +279,10 @@ def fp16_storage_mode(dev, batch: int, patch: int, steps: int):
            "dtype": "fp16", "loss": round(float(loss), 6), "loss_scale": float(scale), "optimizer_steps_taken": int(taken),
            "arithmetic": "fp16 storage of activations and gradients, fp16 matrix-core operands (v_mfma_f32_32x32x16_f16), fp32 "
                          "accumulation, fp32 master parameters, GroupNorm statistics and losses; dynamic loss scaling on the device",
-           "tolerance_met": "1e-3 on strided logits (rel-L2, measured 8.7e-4) and on every gradient tensor's norm (4.2e-4) vs "
-                            "the reference, projections 3.6e-3 (the fp32 mode's bound is 4e-3); element-wise gradient error of "
-                            "the worst tensor is above 1e-3 (test_cfg2_128_fp16_storage_against_reference_golden prints it)"}
+           "tolerance_met": "not measured by this run; the bounds are the tests': test_cfg2_128_fp16_storage_against_reference_golden "
+                            "holds strided logits and every gradient tensor's norm to 1e-3 vs the reference (N=1), "
+                            "test_cfg2_timed_workload_against_the_live_oracle[fp16] holds the full tensors at this batch to the "
+                            "16-bit bounds written there (full-tensor gradient rel-L2 of the worst tensors is ABOVE 1e-3)"}
     if patch == 128:
         rec["frac_of_fp16_mfma_peak"] = round(pps * FLOP_PER_PATCH / (MFMA_PEAK_TFLOPS["fp16"] * 1e12), 4)
     del model, step
@@ -391,8 +393,11 @@ def main():
     if not a.no_roofline:
         # dominant kernel: the 3x3x3 conv at full resolution with f0 -> f0 channels (forward launches; the data
         # gradient runs the same kernel).  HIP events on the launch stream (= torch's current stream).
-        ops.PROFILE.update(enabled=True, events=[], wgrad_events=[],
+        ops.PROFILE.update(enabled=True, events=[], wgrad_events=[], dgrad_events=[],
                            match=lambda k, ci, co, d, h, w: k == 3 and ci == F_MAPS[0] and co == F_MAPS[0] and d == P)
+    if use_dist:
+        from mednet_hip.train import BucketedExchange
+        BucketedExchange.TIMING = []
     t0 = time.perf_counter()
     t_issue, n_issue = 0.0, min(a.steps, 5)
     for i in range(a.steps):
@@ -426,6 +431,25 @@ def main():
                                        "wgrad_workgroups": ops.SIDE["wgrad_wgs"] or "one per CU"}},
             "host_enqueue_ms_per_step": round(1e3 * t_issue / n_issue, 3),
         }
+        if use_dist:
+            from mednet_hip.train import BucketedExchange
+            ev = BucketedExchange.TIMING or []
+            xms = [e0.elapsed_time(e1) for e0, e1 in ev]
+            nbytes = step.flat.total * 4
+            x_avg = sum(xms) / len(xms) if xms else None
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as exc:  # (gloo rehearsal builds, or a torch without the binding)
+                ver = f"unavailable ({type(exc).__name__})"
+            out["rccl"] = {"world": dist.get_world_size(), "backend": dist.get_backend(), "nccl_version": ver,
+                           "exchange_form": step._exchange.describe() if step._exchange is not None else "none",
+                           "bytes": nbytes, "exchanges_timed": len(xms),
+                           "allreduce_ms_per_step": None if x_avg is None else round(x_avg, 4),
+                           # all-reduce bus bandwidth (the figure rccl-tests prints): bytes x 2 (n - 1) / n / time; 0 at one rank
+                           "alg_GBps": None if not x_avg else round(nbytes / (x_avg * 1e-3) / 1e9, 2),
+                           "bus_GBps": None if not x_avg else round(nbytes * 2 * (world - 1) / world / (x_avg * 1e-3) / 1e9, 2),
+                           "timed_with": "HIP events on the compute stream around BucketedExchange.finish() of every timed step "
+                                         "(what the step waits for; the early bucket of the two-bucket form runs inside backward)"}
         if rehearse:
             out["rehearsal"] = f"{world} ranks on ONE GPU over gloo: exercises the multi-rank code path, not a throughput"
         if P == 128 and a.precision == "bf16":
@@ -442,6 +466,32 @@ def main():
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "traffic_source": traffic_source, "launches": len(ms),
                                "avg_ms": round(avg, 4), "flop_per_launch": flops}
+            dev_ = ops.PROFILE.get("dgrad_events") or []
+            if dev_:
+                # the data gradients of the same layers run the OTHER epilogue variants of the same kernel (<1>: GroupNorm-backward
+                # sums, <3>: + the summed residual gradient): slower than <4>.  `roofline_dgrad` reports them per variant and
+                # `roofline.family` the FLOP-weighted fraction over every launch of the kernel family in the timed steps, so that
+                # the forward variant's fraction does not stand in for the family.
+                by = {}
+                for e0, e1, fl, var in dev_:
+                    by.setdefault(var, []).append(e0.elapsed_time(e1))
+                names = {"gn": "conv32_mfma_kernel<1> (data gradient + GroupNorm-backward sums)",
+                         "add+gn": "conv32_mfma_kernel<3> (data gradient + summed residual gradient + GroupNorm-backward sums)",
+                         "add": "conv32_mfma_kernel<2> (data gradient + summed residual gradient)",
+                         "plain": "conv32_mfma_kernel<0> (plain data gradient)"}
+                var = {}
+                for k, v in sorted(by.items()):
+                    a_ms = sum(v) / len(v)
+                    a_tf = flops / (a_ms * 1e-3) / 1e12
+                    var[k] = {"kernel": names.get(k, k), "avg_ms": round(a_ms, 4), "launches": len(v),
+                              "achieved": round(a_tf, 2), "frac": round(a_tf / peak, 4)}
+                tot_ms = sum(ms) + sum(sum(v) for v in by.values())
+                tot_n = len(ms) + sum(len(v) for v in by.values())
+                fam = flops * tot_n / (tot_ms * 1e-3) / 1e12
+                out["roofline"]["family"] = {"what": "all conv32_mfma_kernel launches of the timed steps (forward + data gradients), "
+                                                     "FLOP-weighted", "launches": tot_n, "avg_ms": round(tot_ms / tot_n, 4),
+                                             "achieved": round(fam, 2), "frac": round(fam / peak, 4)}
+                out["roofline_dgrad"] = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s", "flop_per_launch": flops, "variants": var}
         if not a.no_roofline and ops.PROFILE.get("wgrad_events"):
             # the kernel with the largest share of the step's kernel time: the weight gradient of the same layers.  In the step it
             # runs on the second stream, on all CUs, BESIDE the main stream's bandwidth-bound GroupNorm-backward passes (which is
@@ -452,13 +502,14 @@ def main():
             flops = ev[0][2]
             avg = sum(ms) / len(ms)
             peak = MFMA_PEAK_TFLOPS[a.precision]
-            alone = wgrad_alone_ms(dev, a.batch, P, a.precision)
-            out["roofline_wgrad"] = {"kernel": "wgrad_mfma4_kernel: weight gradient of conv3d 3x3x3 32->32 @128^3", "bound": "mfma",
-                                     "achieved": round(flops / (alone * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
-                                     "frac": round(flops / (alone * 1e-3) / 1e12 / peak, 4), "avg_ms": round(alone, 4),
-                                     "launches": 60, "flop_per_launch": flops,
-                                     "in_step_beside_the_main_stream": {"avg_ms": round(avg, 4), "launches": len(ms),
-                                                                        "achieved": round(flops / (avg * 1e-3) / 1e12, 2)}}
+            alone, alone_launches = wgrad_alone_ms(dev, a.batch, P, a.precision)
+            if alone == alone:  # (NaN in the fp32 storage mode: another kernel runs there and this record does not describe it)
+                out["roofline_wgrad"] = {"kernel": "wgrad_mfma4_kernel: weight gradient of conv3d 3x3x3 32->32 @128^3", "bound": "mfma",
+                                         "achieved": round(flops / (alone * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                                         "frac": round(flops / (alone * 1e-3) / 1e12 / peak, 4), "avg_ms": round(alone, 4),
+                                         "launches": alone_launches, "flop_per_launch": flops,
+                                         "in_step_beside_the_main_stream": {"avg_ms": round(avg, 4), "launches": len(ms),
+                                                                            "achieved": round(flops / (avg * 1e-3) / 1e12, 2)}}
         if a.fp32_steps > 0 and world == 1 and a.precision == "bf16":
             del step, model
             torch.cuda.empty_cache()

@@ -163,17 +163,18 @@ def test_cfg2_128_against_reference_golden(golden_dir):
         dn = abs(np.sqrt((g * g).sum()) - norm) / norm
         assert dn <= 1e-3, name
         pv = np.random.Generator(np.random.PCG64(zlib.crc32(("proj:" + name).encode()))).standard_normal(g.size)
-        # |<g - g_ref, r>| <= ||g - g_ref|| * ||r||-ish: a 1e-3 relative error moves the projection by <= ~4e-3*norm
+        # <g - g_ref, r> with r ~ N(0, I) has standard deviation ||g - g_ref||: a 1e-3 relative error moves the projection by
+        # ~1e-3 * norm (one sigma).  Measured 2.9e-4 (round 3 .. 6): held to the north star's 1e-3, as the leading elements are.
         dp = abs(g @ pv - float(rec[f"grad.{name}.proj"])) / norm
-        assert dp <= 4e-3, name
+        assert dp <= 1e-3, name
         head = rec[f"grad.{name}.head"]
         dh = np.linalg.norm(g[: head.size] - head) / max(np.linalg.norm(head), 1e-3 * norm / np.sqrt(g.size) * 8)
-        assert dh <= 2e-3, name
+        assert dh <= 1e-3, name
         wn, wp, wh = max(wn, dn), max(wp, dp), max(wh, dh)
     # (measured on an MI355X in the split-bf16 fp32 mode, round 3: strided logits 1.05e-5, loss diff 0, worst gradient-norm diff
     #  2.6e-4, worst projection diff 2.9e-4, worst leading-elements rel-L2 3.1e-4; cfg4: 9.4e-6 / 2.5e-4 / 7.7e-5)
     print(f"[cfg2 128^3 fp32 mode vs reference] strided logits {rl:.2e} (tol 1e-3)  loss diff {abs(float(loss) - float(rec['loss'])):.1e}"
-          f"  worst gradient-norm diff {wn:.2e} (tol 1e-3)  worst projection diff {wp:.2e} (tol 4e-3)  worst leading-elements rel-L2 {wh:.2e}")
+          f"  worst gradient-norm diff {wn:.2e} (tol 1e-3)  worst projection diff {wp:.2e} (tol 1e-3)  worst leading-elements rel-L2 {wh:.2e} (tol 1e-3)")
 
 
 def test_cfg4_128_landmark_against_reference_golden(golden_dir):
@@ -202,11 +203,11 @@ def test_cfg4_128_landmark_against_reference_golden(golden_dir):
         assert dn <= 1e-3, name
         pv = np.random.Generator(np.random.PCG64(zlib.crc32(("proj:" + name).encode()))).standard_normal(g.size)
         dp = abs(g @ pv - float(rec[f"grad.{name}.proj"])) / norm
-        assert dp <= 4e-3, name
+        assert dp <= 1e-3, name  # (measured 7.7e-5)
         wn, wp = max(wn, dn), max(wp, dp)
     step.flat.release()
     print(f"[cfg4 128^3 fp32 mode vs reference] strided logits {rl:.2e} (tol 1e-3)  worst gradient-norm diff {wn:.2e} (tol 1e-3)"
-          f"  worst projection diff {wp:.2e} (tol 4e-3)")
+          f"  worst projection diff {wp:.2e} (tol 1e-3)")
 
 
 # ---- the BENCHMARKED path (bf16 storage: persistent matrix-core kernels with statistics accumulated over a workgroup's

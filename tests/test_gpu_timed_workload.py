@@ -1,0 +1,161 @@
+"""Parity AT THE WORKLOAD bench.py TIMES: BASELINE config 2 exactly as the benchmark runs it -- batch 4 of 128^3 patches through
+train.SegmentationStep, Dice over the 4-sample batch (loss.py:38-47 via :114-130), per-sample GroupNorm statistic flushes, the N = 4
+z-slab walk of conv32_mfma_kernel, weight gradients on the side stream, the flat gradient buffer -- against the oracle RUN LIVE on
+the box's host cores on the same seeded batch (segmentation.py:58-65): loss, the FULL logit tensor and the full-tensor rel-L2 of EVERY
+gradient.  The N = 1 goldens of test_gpu_network.py cannot see the multi-sample reductions; this file can.  The same for config 4
+(LandmarkNet, landmarks.py:66-83,125-134) through train.LandmarkStep.
+
+The oracle pass costs ~30-60 s of CPU and ~30 GB of host memory per configuration; it runs once per configuration (module-scoped
+fixture) and every storage mode is compared with it.
+
+Tolerances (||a - b||2 / ||b||2, written next to what was measured on an MI355X, round 6):
+  fp32 storage mode  -- the north star's 1e-3 on the logits and on every gradient tensor, element-wise (full-tensor rel-L2);
+  fp16 / bf16 storage -- the 16-bit modes' own bounds (2x measured), NOT 1e-3: see DESIGN.md section 2 / 14.
+"""
+import gc
+import os
+import time
+
+import pytest
+import torch
+
+import mednet_hip
+from mednet_hip.unet import model as HM
+from oracle import ref_cpu as O
+
+from gpu_util import DEV, rel
+
+pytestmark = pytest.mark.gpu
+
+F_MAPS = [32, 64, 128, 256]
+N, P = 4, 128
+SEG_W = [0.05, 1.0, 1.0, 1.0]
+
+# mode -> (full logits, |loss - oracle|, worst full-tensor gradient rel-L2, concatenated-gradient rel-L2)
+# measured (round 6, printed by the tests): see profiles/r06_timed_workload_parity.log
+SEG_TOL = {"fp32": (1e-3, 1e-5, 1e-3, 1e-3), "fp16": (2e-3, 1e-4, 4e-2, 1e-2), "bf16": (1.5e-2, 1e-3, 2.5e-1, 6e-2)}
+LDMK_TOL = {"fp32": (1e-3, 1e-4, 1e-3, 1e-3), "fp16": (2e-3, 1e-3, 4e-2, 1e-2), "bf16": (1.5e-2, 1e-2, 2.5e-1, 6e-2)}
+
+
+def _host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def _oracle_pass(ctor, batch, loss_of):
+    """-> dict(logits, losses (tuple of floats), grads {name: tensor}, seconds)."""
+    torch.set_num_threads(_host_threads())
+    t0 = time.perf_counter()
+    ora = O.keyed_init_(O.ResidualUNet3D(**ctor))
+    logits = ora(batch["data"].float())
+    losses = loss_of(logits)
+    losses[0].backward()
+    out = {"logits": logits.detach(), "losses": tuple(float(v.detach()) for v in losses),
+           "grads": {k: p.grad.detach().clone() for k, p in ora.named_parameters()}, "seconds": time.perf_counter() - t0}
+    del ora, logits, losses
+    gc.collect()
+    return out
+
+
+@pytest.fixture(scope="module")
+def seg_oracle():
+    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=F_MAPS)
+    batch = O.synthetic_batch(N, 1, (P, P, P), 4, 0, seed=1234)  # (bench.py's batch: same generator, same seed)
+    crit = O.DiceLoss(weight=torch.tensor(SEG_W))
+    ref = _oracle_pass(ctor, batch, lambda lg: (crit(lg, batch["label"][:, -1].long()),))
+    return ctor, batch, ref
+
+
+@pytest.fixture(scope="module")
+def ldmk_oracle():
+    ctor = dict(in_channels=1, out_channels=18, final_sigmoid=False, f_maps=F_MAPS)
+    batch = O.synthetic_batch(N, 1, (P, P, P), 2, 16, seed=1234)
+    crit = O.DiceLoss(weight=torch.tensor([0.05, 1.0]))
+    reg = torch.nn.MSELoss()
+
+    def loss_of(lg):
+        return O.landmark_loss(lg[:, 16:], lg[:, :16], batch["label"][:, -1].long(), batch["label"][:, :-1].float(), crit, reg, [0.015] * 16)
+
+    ref = _oracle_pass(ctor, batch, loss_of)
+    return ctor, batch, ref
+
+
+def _compare(tag, mode, net, lg, losses, ref, tol):
+    tl, tloss, tg, tcat = tol
+    rl = rel(lg, ref["logits"])
+    dl = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(losses, ref["losses"]))
+    worst, worst_name, num, den = 0.0, "", 0.0, 0.0
+    per = []
+    for name, p in net.named_parameters():
+        g = p.grad.detach().double().cpu()
+        assert torch.isfinite(g).all(), name
+        go = ref["grads"][name].double()
+        d2 = float((g - go).pow(2).sum())
+        n2 = float(go.pow(2).sum())
+        r = (d2 / n2) ** 0.5
+        per.append((r, name))
+        num += d2
+        den += n2
+        if r > worst:
+            worst, worst_name = r, name
+    cat = (num / den) ** 0.5
+    per.sort(reverse=True)
+    print(f"[timed workload] {tag} N={N} {P}^3 {mode}: logits (full tensor) {rl:.2e} (tol {tl:.0e})  loss diff {dl:.1e} (tol {tloss:.0e})  "
+          f"worst gradient tensor {worst:.2e} ({worst_name}; tol {tg:.0e})  concatenated gradient {cat:.2e} (tol {tcat:.0e})  "
+          f"oracle pass {ref['seconds']:.0f} s on {_host_threads()} host threads")
+    print("[timed workload]   five worst gradient tensors: " + ", ".join(f"{n} {r:.2e}" for r, n in per[:5]))
+    assert rl <= tl, f"{tag} {mode}: logits rel-L2 {rl:.3e} > {tl:.1e}"
+    assert dl <= tloss, f"{tag} {mode}: loss differs by {dl:.3e} > {tloss:.1e}"
+    assert worst <= tg, f"{tag} {mode}: gradient {worst_name} rel-L2 {worst:.3e} > {tg:.1e}"
+    assert cat <= tcat, f"{tag} {mode}: concatenated gradient rel-L2 {cat:.3e} > {tcat:.1e}"
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16", "bf16"])
+def test_cfg2_timed_workload_against_the_live_oracle(seg_oracle, mode):
+    """bench.py's step (SegmentationStep, N = 4, 128^3) against segmentation.py:58-65 run on the CPU, every gradient in full."""
+    from mednet_hip.train import SegmentationStep
+    ctor, batch, ref = seg_oracle
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    with mednet_hip.precision(mode):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+        step = SegmentationStep(net, loss_weight=SEG_W, lr=1e-3)
+        with torch.no_grad():
+            lg = net(b["data"].float())
+        (loss,) = step._fwd_bwd(b)
+        torch.cuda.synchronize()
+        if step.scaler is not None:  # fp16: the gradients carry the loss scale until Adam divides it out
+            step.flat.grad.div_(step.scaler.snapshot()[0])
+        step.flat.grads_as_attr()
+        try:
+            _compare("cfg2", mode, net, lg, (float(loss),), ref, SEG_TOL[mode])
+        finally:
+            step.flat.release()
+    del net, step, lg
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16", "bf16"])
+def test_cfg4_timed_workload_against_the_live_oracle(ldmk_oracle, mode):
+    """Config 4 at the batch it is timed at (LandmarkStep, N = 4, 128^3, 16 heat maps + 2 classes) against landmarks.py:66-83 on the CPU."""
+    from mednet_hip.train import LandmarkStep
+    ctor, batch, ref = ldmk_oracle
+    b = {k: v.to(DEV) for k, v in batch.items()}
+    with mednet_hip.precision(mode):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+        step = LandmarkStep(net, [0.05, 1.0], [0.015] * 16, "L2")
+        with torch.no_grad():
+            lg = net(b["data"].float())
+        tot, cl, rg = step._fwd_bwd(b)
+        torch.cuda.synchronize()
+        if step.scaler is not None:
+            step.flat.grad.div_(step.scaler.snapshot()[0])
+        step.flat.grads_as_attr()
+        try:
+            _compare("cfg4", mode, net, lg, (float(tot), float(cl), float(rg)), ref, LDMK_TOL[mode])
+        finally:
+            step.flat.release()
+    del net, step, lg
+    torch.cuda.empty_cache()

@@ -369,3 +369,41 @@ def test_fused_landmark_head_and_first_layer_entry_points_answer_without_a_devic
     assert rc == -1 and "conv3d_wgrad_c1_gn" in lib.mednet_last_error().decode()
     rc = lib.mednet_gn_bwd_coefficients(None, None, None, 0, None, None, None, 1, 64, 32, 8, None, 0, None)
     assert rc == -1 and "gn_bwd_coefficients" in lib.mednet_last_error().decode()
+
+
+def test_fused_head_nodes_step_aside_for_hooks_on_the_bypassed_calls():
+    """The fused head + loss nodes (train.SegmentationStep._head_loss, LandmarkStep._head_losses) call forward_features() and never
+    final_conv: a forward hook / pre-hook on the model or on final_conv would not fire, so the steps take the stock model(inputs)
+    path then.  Hooks on encoder / decoder children fire either way and do not switch the fusion off."""
+    from mednet_hip.train import _call_is_hooked
+    m = HM.ResidualUNet3D(1, 4, False, f_maps=[16, 32])
+    fc = m.final_conv
+    assert not _call_is_hooked(m, fc)
+    h = m.encoders[0].register_forward_hook(lambda *a: None)  # a child the fused form still calls through __call__
+    assert not _call_is_hooked(m, fc)
+    h.remove()
+    for mod, reg in ((fc, "register_forward_hook"), (fc, "register_forward_pre_hook"), (m, "register_forward_hook"),
+                     (m, "register_forward_pre_hook")):
+        h = getattr(mod, reg)(lambda *a: None)
+        assert _call_is_hooked(m, fc), reg
+        h.remove()
+        assert not _call_is_hooked(m, fc)
+    g = torch.nn.modules.module.register_module_forward_hook(lambda *a: None)
+    try:
+        assert _call_is_hooked(m, fc)
+    finally:
+        g.remove()
+    assert not _call_is_hooked(m, fc)
+
+
+def test_loss_module_keeps_product_and_restated_reference_code_apart():
+    """mednet_hip/unet/loss.py defines the fused HIP losses; the reference's unused loss zoo lives in loss_compat.py and is only
+    re-exported (VERDICT r5 housekeeping), and every public name of the reference's module still resolves through the alias."""
+    import midasmednet.unet.loss as ML
+    from mednet_hip.unet import loss_compat as HCOMP
+    for name in ("DiceLoss", "dice_metric", "CrossEntropyLoss", "HeatmapRegressionLoss", "LandmarkLoss"):
+        assert getattr(HL, name).__module__ == "mednet_hip.unet.loss", name
+    for name in ("flatten", "expand_as_one_hot", "compute_per_channel_dice", "CELoss", "WeightedCrossEntropyLoss", "BCELossWrapper",
+                 "PixelWiseCrossEntropyLoss"):
+        assert getattr(HL, name) is getattr(HCOMP, name) and getattr(ML, name) is getattr(HCOMP, name), name
+        assert getattr(HCOMP, name).__module__ == "mednet_hip.unet.loss_compat", name

@@ -25,6 +25,6 @@ cd $W
 /opt/rocm/bin/hipcc $F ${C32Z_DEFS:-} -DMEDNET_ELT_F16 -Dmednet=mednet_f16 -c conv_mfma.hip -o conv_mfma_f16.o &
 wait
 O=$R/torch-mednet_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/api.o $O/conv_direct.o conv_mfma.o conv_mfma_f16.o $O/conv_f32_mfma.o $O/conv_x3_mfma.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/api.o $O/head_mfma.o $O/head_mfma_f16.o $O/conv_direct.o conv_mfma.o conv_mfma_f16.o $O/conv_f32_mfma.o $O/conv_x3_mfma.o \
   $O/norm_act.o $O/loss.o $O/head_loss.o $O/predict.o $O/augment.o -o $R/torch-mednet_amd/mednet_hip/libmednet_hip_conv32z.so
 echo built $R/torch-mednet_amd/mednet_hip/libmednet_hip_conv32z.so

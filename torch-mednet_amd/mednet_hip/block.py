@@ -170,19 +170,21 @@ def _conv_bwd(x, dy, packed, weight_p, need_dx, add=None, gnb=None):
             if gnb is not None and FUSE_GNB and dx.dtype == dy.dtype and (add is None or add.dtype == dy.dtype):
                 # (16-bit storage: the bf16 / fp16 matrix-core kernel; fp32 storage: the split-bf16 kernel)
                 rows = lib.mednet_conv3d_dgrad_gn_rows_dt(n, d, h, w, cin, cout, config.conv_algo(), L.dt(dy))
-            if rows > 0:
-                y_prev, coef_prev, act_prev = gnb
-                partial = torch.empty((n, rows, cin, 2), dtype=torch.float32, device=dy.device)
-                L.check(lib.mednet_conv3d_dgrad_gn(dy.data_ptr(), packed.data_ptr(), L.ptr(add), dx.data_ptr(), y_prev.data_ptr(),
-                                                   coef_prev.data_ptr(), act_prev, partial.data_ptr(), n, d, h, w, cin, cout,
-                                                   config.conv_algo(), L.dt(dy), L.stream()), "conv3d_dgrad_gn")
-            elif add is not None:
-                L.check(lib.mednet_conv3d_dgrad_add(dy.data_ptr(), packed.data_ptr(), add.data_ptr(), dx.data_ptr(), n, d, h, w,
-                                                    cin, cout, config.conv_algo(), L.dt(dy), L.stream()), "conv3d_dgrad_add")
-            else:
-                L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin, 3,
-                                              L.dt(dy), L.NDHWC, L.dt(dx), L.NDHWC, 1, config.conv_algo(), None, L.stream()),
-                        "conv3d_dgrad")
+            variant = ("add+gn" if add is not None else "gn") if rows > 0 else ("add" if add is not None else "plain")
+            with ops.profiled_dgrad(variant, 3, cout, cin, n, d, h, w):
+                if rows > 0:
+                    y_prev, coef_prev, act_prev = gnb
+                    partial = torch.empty((n, rows, cin, 2), dtype=torch.float32, device=dy.device)
+                    L.check(lib.mednet_conv3d_dgrad_gn(dy.data_ptr(), packed.data_ptr(), L.ptr(add), dx.data_ptr(), y_prev.data_ptr(),
+                                                       coef_prev.data_ptr(), act_prev, partial.data_ptr(), n, d, h, w, cin, cout,
+                                                       config.conv_algo(), L.dt(dy), L.stream()), "conv3d_dgrad_gn")
+                elif add is not None:
+                    L.check(lib.mednet_conv3d_dgrad_add(dy.data_ptr(), packed.data_ptr(), add.data_ptr(), dx.data_ptr(), n, d, h, w,
+                                                        cin, cout, config.conv_algo(), L.dt(dy), L.stream()), "conv3d_dgrad_add")
+                else:
+                    L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), packed.data_ptr(), None, dx.data_ptr(), n, d, h, w, cout, cin, 3,
+                                                  L.dt(dy), L.NDHWC, L.dt(dx), L.NDHWC, 1, config.conv_algo(), None, L.stream()),
+                            "conv3d_dgrad")
 
     if not WGRAD_FIRST:
         dgrad()

@@ -167,6 +167,22 @@ class profiled_wgrad(profiled_conv):
         return False
 
 
+class profiled_dgrad(profiled_conv):
+    """The same for the DATA gradient of matching layers (bench.py's `roofline_dgrad` / `roofline.family`): `variant` names the
+    epilogue the launch carries ("gn": GroupNorm-backward sums, "add+gn": summed residual gradient + sums, "plain")."""
+
+    def __init__(self, variant, ksize, cin, cout, n, d, h, w):
+        super().__init__(ksize, cin, cout, n, d, h, w)
+        self.on = self.on and PROFILE.get("dgrad_events") is not None
+        self.variant = variant
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            PROFILE["dgrad_events"].append((self.e0, self.e1, self.flops, self.variant))
+        return False
+
+
 def _with_algo(backward):
     """backward of a conv-family Function: replays the algorithm choice (config.conv_algo()) captured at forward."""
     def wrapped(ctx, *grads):
@@ -1157,6 +1173,14 @@ class HeadLandmarkFn(Function):
         spatial = d * h * w
         hm, hm_sn = _heatmap_view(heatmaps, n, nh, (d, h, w))
         lab, lab_sn, _ = _label_view(labels, n, (d, h, w))
+        # launch_head_lm_* reads targets and labels four voxels at a time: base pointers and sample strides must be multiples of 4
+        # bytes.  A view with an odd storage offset / stride (e.g. a label volume sliced at an odd channel offset) is copied once.
+        if hm.data_ptr() % 4 or (n > 1 and hm_sn % 4):
+            hm = hm.contiguous().clone() if hm.is_contiguous() else hm.contiguous()
+            hm_sn = nh * spatial
+        if lab.data_ptr() % 4 or (n > 1 and lab_sn % 4):
+            lab = lab.contiguous().clone() if lab.is_contiguous() else lab.contiguous()
+            lab_sn = spatial
         cw = None if class_weight is None else class_weight.to(device=x.device, dtype=torch.float32).contiguous()
         rw = None if reg_weight is None else torch.as_tensor(reg_weight, dtype=torch.float32, device=x.device).contiguous()
         closs = torch.empty((), dtype=torch.float32, device=x.device)

@@ -307,8 +307,24 @@ class BucketedExchange:
                 self.work = dist.all_reduce(early, op=dist.ReduceOp.SUM, async_op=True)
         return None
 
+    # bench.py's `rccl` record: a list to which finish() appends (start, end) HIP events around the exchange on the compute
+    # stream (the early bucket of the two-bucket form runs inside backward and is not in them: the record says which form ran)
+    TIMING = None
+
     def finish(self):
         """After backward (and the side-stream join): exchange what is left, wait for the early bucket; -> 1/world."""
+        timed = (BucketedExchange.TIMING is not None and (self.world > 1 or self.force) and self.flat.grad.is_cuda
+                 and not torch.cuda.is_current_stream_capturing())
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        scale = self._finish()
+        if timed:
+            e1.record()
+            BucketedExchange.TIMING.append((e0, e1))
+        return scale
+
+    def _finish(self):
         if self.work is not None:
             dist.all_reduce(self.flat.grad[:self.split], op=dist.ReduceOp.SUM)
             self.work.wait()
@@ -359,6 +375,18 @@ def use_side_stream():
     ops.SIDE["enabled"] = os.environ.get("MEDNET_SIDE_STREAM", "1") == "1"
 
 
+def _call_is_hooked(model, final_conv) -> bool:
+    """The fused head + loss nodes call model.forward_features() and never final_conv: they bypass `model.__call__` and
+    `final_conv.__call__`, and in the landmark form no `outputs` tensor exists at all.  Any forward hook / pre-hook registered on
+    those two modules, or a global module hook, would silently not fire -- the steps then take the stock `model(inputs)` path.
+    (Hooks on encoder / decoder children still fire in the fused form: forward_features calls them through __call__.)"""
+    import torch.nn.modules.module as M
+    for name in ("_global_forward_hooks", "_global_forward_pre_hooks", "_global_forward_hooks_always_called"):
+        if getattr(M, name, None):
+            return True
+    return any(bool(getattr(mod, attr, None)) for mod in (model, final_conv) for attr in ("_forward_hooks", "_forward_pre_hooks"))
+
+
 class SegmentationStep(_GraphedStep):
     """One data-parallel training step of SegmentationNet (segmentation.py:58-65) on the MI355X path."""
 
@@ -384,7 +412,8 @@ class SegmentationStep(_GraphedStep):
         from .unet.model import _UNetCore
         m, fc = self.model, getattr(self.model, "final_conv", None)
         if (isinstance(m, _UNetCore) and not m.testing and isinstance(self.loss, HL.DiceLoss) and not self.loss.skip_last_target
-                and fc is not None and getattr(fc, "planar_output", False) and fc.kernel_size[0] == 1 and inputs.is_cuda):
+                and fc is not None and getattr(fc, "planar_output", False) and fc.kernel_size[0] == 1 and inputs.is_cuda
+                and not _call_is_hooked(m, fc)):
             feats = m.forward_features(inputs)
             if ops.head_dice_supported(feats, fc.in_channels, fc.out_channels, label_u8):
                 return ops.head_dice(feats, fc.weight, fc.bias, fc._packed(), label_u8, self.loss.weight, self.loss.epsilon,
@@ -471,8 +500,11 @@ class LandmarkStep(_GraphedStep):
         matrix cores (ops.head_landmark: no logit tensor); anything else takes the calls as they stand."""
         from .unet.model import _UNetCore
         m, fc = self.model, getattr(self.model, "final_conv", None)
+        # (the fused branch bypasses model.__call__ and final_conv.__call__ and never forms `outputs`: with a forward (pre-)hook on
+        #  the model, on one of its children or a global module hook, the stock m(inputs) path runs so that the hook sees its tensor)
         if (isinstance(m, _UNetCore) and not m.testing and fc is not None and getattr(fc, "planar_output", False)
-                and fc.kernel_size[0] == 1 and inputs.is_cuda and not self.loss_class.skip_last_target and self.loss_reg.kind in ("L1", "L2")):
+                and fc.kernel_size[0] == 1 and inputs.is_cuda and not self.loss_class.skip_last_target and self.loss_reg.kind in ("L1", "L2")
+                and not _call_is_hooked(m, fc)):
             feats = m.forward_features(inputs)
             if ops.head_landmark_supported(feats, fc.in_channels, nh, fc.out_channels - nh, heatmaps, labels):
                 return ops.head_landmark(feats, fc.weight, fc.bias, fc._packed(), heatmaps, labels, self.loss_class.weight,
