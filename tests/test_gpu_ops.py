@@ -1,6 +1,8 @@
 """Per-op parity of every libmednet_hip entry point against the CPU oracle's ATen ops (fp32 storage: <= 1e-4,
 bf16 storage: <= 2.5e-2 rel-L2), including the edge cases the U-Net hits: Cin=1, odd channel counts, odd spatial
 sizes, GroupNorm's single-group fallback, pooling tails and ties, strided logits slices."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -991,6 +993,95 @@ def test_conv32_epilogue_variants_match_the_general_kernel(mode, n, shape):
             assert ta.shape == tb.shape
             scale = tb.abs().amax(dim=(1,), keepdim=True) + 1e-3
             assert torch.all((ta - tb).abs() <= 5e-5 * scale + 2e-5 * tb.abs() + 1e-3 * nv ** 0.5 * 1e-2), f"{k}: partial sums differ"
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("n,cin,cout,shape", [
+    (1, 64, 64, (32, 64, 64)),    # 256 bricks x 1 block pair: one item per workgroup, accumulate mode
+    (1, 64, 64, (30, 60, 50)),    # the same grid, ragged in z, y and x
+    (2, 32, 128, (24, 40, 48)),   # 184 brick slots (180 real: padding items) x 2 pairs, two rounds, the sample changes
+    (1, 128, 128, (36, 40, 48)),  # 135 bricks (not a multiple of 8): one statistics row per wave and brick; 8 K chunks
+    (3, 48, 64, (32, 32, 64)),    # 3 K chunks, 384 bricks over three samples: 1.5 rounds, sample changes inside a workgroup's list
+    (1, 16, 64, (32, 64, 64)),    # ONE K chunk: every chunk is first and last
+])
+def test_two_block_kernel_is_bit_identical_to_the_general_kernel(mode, n, cin, cout, shape):
+    """Layers with >= 64 output channels run conv2b_mfma_kernel (round 6: two channel blocks per wave, one wave per SIMD, inputs and a
+    ring of weight slots by LDS-DMA).  It accumulates in the general kernel's order (K chunk outer, tap inner), so every tensor it
+    writes -- forward with / without activation and statistics, plain data gradient, data gradient with the summed second gradient
+    and / or the first pass of a GroupNorm backward -- must equal conv_mfma_kernel<1>'s (option conv2b=0) BIT FOR BIT through the
+    same C-ABI entry points; the fused partial sums agree up to fp32 summation order (their row layout differs)."""
+    lib = L.lib()
+    dt = torch.bfloat16 if mode == "bf16" else torch.float16
+    dcode = L.dt(torch.empty(0, dtype=dt))
+    CL = torch.channels_last_3d
+    g = torch.Generator(device=DEV).manual_seed(23)
+
+    def rand(c, scale=1.0):
+        return (torch.randn(n, c, *shape, device=DEV, generator=g) * scale).to(dt).contiguous(memory_format=CL)
+    x, dy, add, gy = rand(cin), rand(cout), rand(cin), rand(cin)
+    w = torch.randn(cout, cin, 3, 3, 3, device=DEV, generator=g) * 0.05
+    coef = torch.randn(n, cin, 2, device=DEV, generator=g).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    ALGO_MFMA = 2
+    with mednet_hip.precision(mode):
+        pk = ops.pack_conv_weight(w, 3, False)
+    d, h, wd = shape
+    plan = (ctypes.c_int * 13)()
+
+    def run(two_block):
+        assert lib.mednet_set_option(b"conv2b", two_block) == 0
+        out = {}
+        if two_block:
+            assert lib.mednet_conv3d_stats_plan(n, d, h, wd, cin, cout, dcode, 0, 1, plan) == 0 and plan[0] in (5, 6), list(plan)
+        for act in (0, 3):   # none, ELU; with and without the statistics
+            for stats in (False, True):
+                y = torch.empty(n, cout, *shape, device=DEV, dtype=dt).contiguous(memory_format=CL)
+                rows = lib.mednet_conv3d_fused_stats_chunks(n, d, h, wd, cin, cout, 3, dcode, dcode, ALGO_MFMA)
+                assert rows > 0
+                part = torch.full((n, rows, cout, 2), float("nan"), device=DEV) if stats else None
+                L.check(lib.mednet_conv3d_act_fwd(x.data_ptr(), pk.data_ptr(), y.data_ptr(), n, d, h, wd, cin, cout, act, ALGO_MFMA,
+                                                  part.data_ptr() if stats else None, dcode, st), "act_fwd")
+                out[f"act{act}{stats}"] = (y, part.double().sum(1) if stats else None)
+        if cin % 64 == 0:  # data gradients write `cin` channels: the two-block kernel takes them when those come in pairs of blocks
+            # (dy has cout channels; the packed image's second section is the transposed + mirrored one)
+            dx = torch.empty_like(x)
+            L.check(lib.mednet_conv3d_fwd(dy.data_ptr(), pk.data_ptr(), None, dx.data_ptr(), n, d, h, wd, cout, cin, 3, dcode, L.NDHWC,
+                                          dcode, L.NDHWC, 1, ALGO_MFMA, None, st), "dgrad")
+            out["dgrad"] = (dx, None)
+            dx = torch.empty_like(x)
+            L.check(lib.mednet_conv3d_dgrad_add(dy.data_ptr(), pk.data_ptr(), add.data_ptr(), dx.data_ptr(), n, d, h, wd, cin, cout,
+                                                ALGO_MFMA, dcode, st), "dgrad_add")
+            out["dgrad_add"] = (dx, None)
+            rows = lib.mednet_conv3d_dgrad_gn_rows_dt(n, d, h, wd, cin, cout, ALGO_MFMA, dcode)
+            assert rows > 0
+            for gact in (0, 1, 2, 3):
+                for with_add in (False, True):
+                    dx = torch.empty_like(x)
+                    part = torch.full((n, rows, cin, 2), float("nan"), device=DEV)
+                    L.check(lib.mednet_conv3d_dgrad_gn(dy.data_ptr(), pk.data_ptr(), add.data_ptr() if with_add else None, dx.data_ptr(),
+                                                       gy.data_ptr(), coef.data_ptr(), gact, part.data_ptr(), n, d, h, wd, cin, cout,
+                                                       ALGO_MFMA, dcode, st), "dgrad_gn")
+                    out[f"gn{gact}{with_add}"] = (dx, part.double().sum(1))
+        torch.cuda.synchronize()
+        return out
+
+    assert lib.mednet_set_option(b"conv2b_min_fill", 0) == 0 and lib.mednet_set_option(b"conv2b_min_cin", 16) == 0
+    try:
+        a, b = run(1), run(0)
+    finally:
+        lib.mednet_set_option(b"conv2b", 1)
+        lib.mednet_set_option(b"conv2b_min_fill", 80)
+        lib.mednet_set_option(b"conv2b_min_cin", 64)
+    nv = float(np.prod(shape))
+    for k in a:
+        assert torch.equal(a[k][0], b[k][0]), f"{k}: tensor differs from the general kernel ({(a[k][0] != b[k][0]).float().mean().item():.3%} of the elements)"
+        if a[k][1] is not None:
+            ta, tb = a[k][1], b[k][1]
+            assert ta.shape == tb.shape and bool(torch.isfinite(ta).all()), f"{k}: a row of the partial buffer was not written"
+            scale = tb.abs().amax(dim=(1,), keepdim=True) + 1e-3
+            assert torch.all((ta - tb).abs() <= 5e-5 * scale + 2e-5 * tb.abs() + 1e-3 * nv ** 0.5 * 1e-2), f"{k}: partial sums differ"
+    yr = F.conv3d(x.float().cpu(), w.to(dt).float().cpu(), None, padding=1)
+    assert_close(a["act0False"][0], yr, 6e-3 if mode == "bf16" else 1e-3, "y vs ATen")
 
 
 def test_conv3d_mfma_batch_larger_than_4GB():

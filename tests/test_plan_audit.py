@@ -45,8 +45,12 @@ def audit(n, p):
     def put(table, key):
         table[key] = table.get(key, 0) + 1
 
-    if p["kind"] in (2, 3):
+    if p["kind"] in (2, 3, 5, 6):
+        # 2 / 3: conv_mfma_kernel (two workgroups per CU); 5 / 6: conv2b_mfma_kernel (round 6: one workgroup per CU, `ncb` counts PAIRS
+        # of channel blocks -- a wave writes the sums of its pair's 64 channels into its row) -- the same item numbering and row rules
         grid, ncb = p["grid"], p["ncb"]
+        if p["kind"] in (5, 6):
+            assert grid == 256 and p["nitems"] >= 256, p
         for b in range(grid):
             items = []
             i = b
@@ -58,7 +62,7 @@ def audit(n, p):
                 i += grid
             for tile, cb in items:
                 put(computed, (tile, cb))
-            if p["kind"] == 2:
+            if p["kind"] in (2, 5):
                 for tile, cb in items:
                     for wv in range(4):
                         put(written, (tile // p["tps"], (tile % p["tps"]) * 4 + wv, cb))
@@ -137,6 +141,11 @@ CFG = {"cfg5": ([64, 128, 256, 512, 1024], (160, 160, 96), 2), "cfg2": ([32, 64,
        "cfg2_n1": ([32, 64, 128, 256], (128, 128, 128), 1), "odd": ([32, 64, 96], (36, 44, 20), 3)}
 
 
+# which kernels the layers of the two benchmarked configurations go to: conv_mfma_kernel per-brick rows (2) / accumulate mode (3), the
+# 32 -> 32 specialisation (4), the two-block kernel per-brick rows (5) / accumulate mode (6)
+EXPECTED_KINDS = {"cfg5": {2, 3, 5, 6}, "cfg2": {2, 3, 4, 6}}
+
+
 @pytest.mark.parametrize("dtype", [BF16, F16])
 @pytest.mark.parametrize("cfg", sorted(CFG))
 def test_every_partial_row_is_written_exactly_once(cfg, dtype):
@@ -149,9 +158,9 @@ def test_every_partial_row_is_written_exactly_once(cfg, dtype):
     for (nn, d, h, w, cin, cout) in convts:
         kinds.add(check(nn, d, h, w, cin, cout, dtype, True, 2)["kind"])  # ConvTranspose data gradient + GroupNorm-3 sums
     if cfg == "cfg5":
-        assert kinds == {2, 3}, kinds  # per-brick rows (levels 3, 4) and accumulate mode (levels 0 - 2)
+        assert kinds == EXPECTED_KINDS["cfg5"], kinds
     if cfg == "cfg2":
-        assert kinds == {2, 3, 4}, kinds  # + the 32 -> 32 specialisation
+        assert kinds == EXPECTED_KINDS["cfg2"], kinds
 
 
 @pytest.mark.parametrize("shape", [(9, 11, 21), (4, 8, 16), (130, 70, 34), (64, 64, 64), (5, 300, 17)])

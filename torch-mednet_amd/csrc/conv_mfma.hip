@@ -1050,6 +1050,8 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
   }
 }
 
+#include "conv2b_mfma.inc"
+
 // ================================================================================================== ConvTranspose3d forward
 // out[2j + p] = bias + skip + sum_{taps k of parity class p} W[k] * x[j + delta_k]   (per dim: k=1 -> p=0,d=0; k=0 -> p=1,d=1;
 // k=2 -> p=1,d=0).  A workgroup owns a 2x4x16 brick of INPUT voxels (4x8x32 outputs); a wave owns one N-tile of 32 input
@@ -1625,6 +1627,18 @@ static bool conv32_applies(int ntiles, int cin, int cout) {
 static bool conv32_takes(int ntiles, int cin, int cout, bool gnb) {
   return conv32_applies(ntiles, cin, cout) && (!gnb || tuning_option("conv32_gnb", 1));
 }
+// The two-block kernel (conv2b_mfma_kernel, round 6): layers whose output channels come in pairs of 32-channel blocks, on 16-wide
+// bricks, with enough (brick, block pair) items to give each of the 256 one-per-CU workgroups work in nearly full rounds (the
+// last round of a persistent grid runs with whatever is left: 288 items would keep 7/8 of the chip idle for half of the launch).
+static bool conv2b_takes(int ntiles, int cin, int cout) {
+  // (from 4 K chunks on: with two -- 32 input channels -- an item is too short for its fixed costs, measured 0.95-0.99 of the general kernel)
+  if (!(cout % 64 == 0 && cin % 16 == 0 && cin >= tuning_option("conv2b_min_cin", 64) && ::mednet_internal_cu_count() == 256 &&
+        tuning_option("conv2b", 1)))
+    return false;
+  const int nitems = ((ntiles + 7) / 8) * 8 * (cout / 64);
+  const int rounds = (nitems + 255) / 256;
+  return nitems >= 256 && nitems * 100 >= tuning_option("conv2b_min_fill", 80) * rounds * 256;
+}
 // Brick kind of a stride-1 launch: 3 (8-wide bricks) where that covers the volume with fewer voxel slots, unless the 32 -> 32
 // specialisation (16-wide bricks only) takes the call
 static int conv_fwd_kind(int n, int d, int h, int w, int cin, int cout, bool gnb) {
@@ -1642,6 +1656,15 @@ static void conv_stats_plan(int n, int d, int h, int w, int cin, int cout, int& 
     rows = 256 * 4;
     return;
   }
+  if (tx == G::TX && conv2b_takes(ntiles, cin, cout)) {
+    // 256 workgroups stepping by 256 items: a workgroup keeps its block pair when the pair count divides 32, and without padding
+    // items every workgroup starts on a valid brick: one row per wave of the workgroups that share a pair, else a row per wave
+    // and brick
+    const int ncbp = cout / 64;
+    accum = tuning_option("conv_stats_accum", 1) && ntiles % 8 == 0 && 32 % ncbp == 0;
+    rows = accum ? (32 / ncbp) * 8 * 4 : 4 * tps;
+    return;
+  }
   const int nitems = ((ntiles + 7) / 8) * 8 * ncb;
   accum = tuning_option("conv_persist", 1) && tuning_option("conv_stats_accum", 1) && nitems >= 1024 && ntiles % 8 == 0 &&
           64 % ncb == 0;
@@ -1651,7 +1674,8 @@ static void conv_stats_plan(int n, int d, int h, int w, int cin, int cout, int& 
 // What a launch of the forward / data-gradient family is made of, for audits without a device (mednet_conv3d_stats_plan,
 // tests/test_plan_audit.py): the launcher fills it from the SAME code path that launches and returns before the launch.
 struct FwdPlanProbe {
-  int kind;  // 2: general kernel, one statistics row per wave and brick; 3: general kernel, accumulate mode; 4: conv32_mfma_kernel
+  int kind;  // 2: general kernel, one statistics row per wave and brick; 3: general kernel, accumulate mode; 4: conv32_mfma_kernel;
+             // 5 / 6: conv2b_mfma_kernel (`ncb` = PAIRS of channel blocks), row per wave and brick / accumulate mode
   int grid, nitems, ncb, ntiles, tiles_per_sample, accum, rows, xcd_chunk, zslab, tiles_x, tiles_y, tiles_z;
 };
 
@@ -1752,6 +1776,45 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
       }
       if (rc32) return rc32;
       return check_launch("conv32_mfma");
+    }
+    if (conv2b_takes(a.ntiles, cin, cout)) {
+      FwdArgs b2 = a;
+      b2.ncb = cout / 64;  // PAIRS of channel blocks
+      b2.rcp_ncb = rcp(b2.ncb);
+      b2.nitems = ((a.ntiles + 7) / 8) * 8 * b2.ncb;
+      const int variant = use_gnb ? (C32_GNB | (add ? C32_ADD : 0))
+                                  : ((add ? C32_ADD : 0) | (gn_partial ? C32_STATS : 0) | (act != MEDNET_ACT_NONE ? C32_ACT : 0));
+      MEDNET_REQUIRE(!use_gnb || act == MEDNET_ACT_NONE, MEDNET_E_UNSUPPORTED, "conv2b_mfma: no activation in the data-gradient form");
+      if (probe) {
+        *probe = FwdPlanProbe{b2.stats_accum ? 6 : 5, 256, b2.nitems, b2.ncb, a.ntiles, a.tiles_z * a.tiles_y * a.tiles_x, b2.stats_accum,
+                              b2.stats_rows, 0, 0, a.tiles_x, a.tiles_y, a.tiles_z};
+        return MEDNET_OK;
+      }
+      static bool attr2b[16] = {};
+      auto go2 = [&](auto kernel) -> int {
+        if (!attr2b[variant]) {
+          if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2B_LDS) != hipSuccess)
+            return fail(MEDNET_E_HIP, "conv2b_mfma: cannot raise dynamic LDS to %zu", C2B_LDS);
+          attr2b[variant] = true;
+        }
+        hipLaunchKernelGGL(kernel, dim3(256), dim3(256), C2B_LDS, s, b2);
+        return MEDNET_OK;
+      };
+      int rc2 = MEDNET_OK;
+      switch (variant) {
+        case 0: rc2 = go2(conv2b_mfma_kernel<0>); break;
+        case C32_ADD: rc2 = go2(conv2b_mfma_kernel<C32_ADD>); break;
+        case C32_STATS: rc2 = go2(conv2b_mfma_kernel<C32_STATS>); break;
+        case C32_STATS | C32_ADD: rc2 = go2(conv2b_mfma_kernel<C32_STATS | C32_ADD>); break;
+        case C32_ACT: rc2 = go2(conv2b_mfma_kernel<C32_ACT>); break;
+        case C32_ACT | C32_ADD: rc2 = go2(conv2b_mfma_kernel<C32_ACT | C32_ADD>); break;
+        case C32_ACT | C32_STATS: rc2 = go2(conv2b_mfma_kernel<C32_ACT | C32_STATS>); break;
+        case C32_ACT | C32_STATS | C32_ADD: rc2 = go2(conv2b_mfma_kernel<C32_ACT | C32_STATS | C32_ADD>); break;
+        case C32_GNB: rc2 = go2(conv2b_mfma_kernel<C32_GNB>); break;
+        default: rc2 = go2(conv2b_mfma_kernel<C32_GNB | C32_ADD>); break;
+      }
+      if (rc2) return rc2;
+      return check_launch("conv2b_mfma");
     }
   }
   if (probe) {
