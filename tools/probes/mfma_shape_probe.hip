@@ -118,6 +118,81 @@ __global__ __launch_bounds__(256, 1) void probe(const u32x4* src, float* out, in
 #pragma unroll
       for (int i = 0; i < 16; ++i) r += acc[t][i];
     out[blockIdx.x * 256 + tid] = r;
+  } else if constexpr (SHAPE == 7) {
+    // round 6: y-reuse by REGISTER RENAMING.  An N-tile = the two x-rows (t, t + 4) of the wave's z-plane (not (2t, 2t + 1)): the tap
+    // shifted by ky then needs rows (t + ky, t + ky + 4) -- the fragment of tile t + ky.  Six fragments (row pairs (a, a + 4), a = 0..5;
+    // the last two reach into the halo) serve the three ky taps of all four tiles: 6 ds_read_b128 per 12 MFMAs, no shuffle at all.
+    f32x16 acc[4] = {};
+    bf16x8 f[2][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) f[0][a] = __builtin_bit_cast(bf16x8, p[a * 64]);
+    for (int s = 0; s < steps; s += 6) {  // 6 steps of 4 MFMAs = 2 groups of 12 MFMAs, each with 6 reads for the next group
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int m = ky * 4 + t;
+            if (m % 2 == 0) f[u ^ 1][m / 2] = __builtin_bit_cast(bf16x8, p[((s / 3 + u + 1) & 3) * 384 + (m / 2) * 64]);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[(ky * 4 + t + u) & 7], f[u][t + ky], acc[t], 0, 0, 0);
+          }
+      }
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r += acc[t][i];
+    out[blockIdx.x * 256 + tid] = r;
+  } else if constexpr (SHAPE == 8) {
+    // ... + x-reuse: the kx = 1 fragments made from the kx = 0 and kx = 2 ones (row_shl:1 of the first; the row's last lanes from
+    // row_shr:1 of the second, bank 3 only): 12 reads + 48 DPP moves per 36 MFMAs (0.33 reads per MFMA)
+    f32x16 acc[4] = {};
+    bf16x8 f0[2][6], f2[2][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      f0[0][a] = __builtin_bit_cast(bf16x8, p[a * 64]);
+      f2[0][a] = __builtin_bit_cast(bf16x8, p[384 + a * 64]);
+    }
+    for (int s = 0; s < steps; s += 18) {  // 18 steps of 4 MFMAs = 2 groups of 36 MFMAs
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bf16x8 f1[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const u32x4 q0 = __builtin_bit_cast(u32x4, f0[u][a]), q2 = __builtin_bit_cast(u32x4, f2[u][a]);
+          u32x4 r1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int sh = __builtin_amdgcn_update_dpp(0, (int)q0[i], 0x101, 0xF, 0xF, false);       // row_shl:1: lane x <- x + 1
+            r1[i] = (unsigned)__builtin_amdgcn_update_dpp(sh, (int)q2[i], 0x111, 0xF, 0x8, false);  // row_shr:1, lanes 12..15 only
+          }
+          f1[a] = __builtin_bit_cast(bf16x8, r1);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int m = (kx * 3 + ky) * 4 + t;  // 0..35: one read every third MFMA
+              if (m % 3 == 0) {
+                const int k = m / 3;  // 0..11
+                if (k < 6) f0[u ^ 1][k] = __builtin_bit_cast(bf16x8, p[((s / 9 + u + 1) & 3) * 768 + k * 64]);
+                else f2[u ^ 1][k - 6] = __builtin_bit_cast(bf16x8, p[((s / 9 + u + 1) & 3) * 768 + k * 64]);
+              }
+              const bf16x8 b = kx == 0 ? f0[u][t + ky] : (kx == 1 ? f1[t + ky] : f2[u][t + ky]);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[(m + u) & 7], b, acc[t], 0, 0, 0);
+            }
+      }
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r += acc[t][i];
+    out[blockIdx.x * 256 + tid] = r;
   } else if constexpr (SHAPE == 3 || SHAPE == 4) {
     // 32x32x16, ONE ds_read_b128 per THREE MFMAs: the x-shifted taps of a 3x3x3 convolution read the same voxel rows moved by one
     // lane, so two of three B operands can be made from the first with 4 DPP row shifts each instead of a 1 KB LDS read
@@ -204,16 +279,19 @@ int main() {
   hipFuncSetAttribute((const void*)probe<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipFuncSetAttribute((const void*)probe<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipFuncSetAttribute((const void*)probe<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute((const void*)probe<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute((const void*)probe<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  const int steps0 = 39996;  // shape 0 steps (a multiple of 6 for shape 3); shape 1 runs half as many of twice the FLOPs
-  const char* names[7] = {"32x32x16, 1 ds_read_b128 per MFMA", "16x16x32, 1 ds_read_b128 per 2 MFMAs", "32x32x16, no LDS reads in the loop",
+  const int steps0 = 39996;  // shape 0 steps (a multiple of 6 for shapes 3 and 7 and of 18 for shape 8); shape 1 runs half as many of twice the FLOPs
+  const char* names[9] = {"32x32x16, 1 ds_read_b128 per MFMA", "16x16x32, 1 ds_read_b128 per 2 MFMAs", "32x32x16, no LDS reads in the loop",
                           "32x32x16, 1 ds_read_b128 + 8 DPP shifts per 3 MFMAs",
                           "... + the two halo columns by 4-lane ds_read_b128",
-                          "4 N-tiles x 1 block: 4 B + 1 A reads per 4 MFMAs", "4 N-tiles x 2 blocks: 4 B + 2 A reads per 8 MFMAs"};
+                          "4 N-tiles x 1 block: 4 B + 1 A reads per 4 MFMAs", "4 N-tiles x 2 blocks: 4 B + 2 A reads per 8 MFMAs",
+                          "row pairs (t, t+4): 6 reads per 12 MFMAs, no shuffles", "... + kx = 1 by DPP: 12 reads + 48 DPP per 36 MFMAs"};
   for (int rep = 0; rep < 3; ++rep)
-    for (int shape = 0; shape < 7; ++shape) {
+    for (int shape = 0; shape < 9; ++shape) {
       for (int warm = 0; warm < 2; ++warm) {
         hipEventRecord(e0);
         if (shape == 0) hipLaunchKernelGGL(probe<0>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
@@ -222,7 +300,9 @@ int main() {
         else if (shape == 3) hipLaunchKernelGGL(probe<3>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
         else if (shape == 4) hipLaunchKernelGGL(probe<4>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
         else if (shape == 5) hipLaunchKernelGGL(probe<5>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
-        else hipLaunchKernelGGL(probe<6>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
+        else if (shape == 6) hipLaunchKernelGGL(probe<6>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
+        else if (shape == 7) hipLaunchKernelGGL(probe<7>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
+        else hipLaunchKernelGGL(probe<8>, dim3(256), dim3(256), 131072, 0, d, o, steps0);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
       }

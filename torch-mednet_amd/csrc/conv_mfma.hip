@@ -52,6 +52,12 @@ static bool narrow_bricks(int w) {
   return mode != 0 && (w <= 8 || (mode == 2 && (w + 7) / 8 < 2 * ((w + 15) / 16)));
 }
 
+// Order in which the forward / data-gradient kernels of this file visit the 27 taps of a K chunk: position s = (kz, kx, ky) with ky
+// FASTEST, i.e. tap index tap_at(s) = kz * 9 + ky * 3 + kx.  Round 6: conv32_mfma_kernel serves the three ky taps of a (kz, kx)
+// from the same six operand fragments (its N-tiles are row pairs (t, t + 4), so a shift in y is a register renaming), which
+// needs them adjacent; every kernel accumulates in this one order so that their outputs stay bit-identical to each other.
+__host__ __device__ constexpr int tap_at(int s) { return (s / 9) * 9 + (s % 3) * 3 + (s / 3) % 3; }
+
 // x / d for launch constants d: the host passes ceil(2^32 / d); exact while x * d < 2^32 (checked by the launcher).
 // d == 1 has no 32-bit reciprocal and is passed through.
 __device__ __forceinline__ int fastdiv(int x, int d, unsigned rcp) { return d == 1 ? x : (int)__umulhi((unsigned)x, rcp); }
@@ -347,10 +353,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       eltx8 wa[PD + 1], xb[PD + 1][NTW];
       auto tap_off = [&](int t1) { return ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3; };
 #pragma unroll
-      for (int p = 0; p < PD; ++p) {
-        wa[p] = __builtin_bit_cast(eltx8, w_lds[(p * 2 + h) * 32 + r]);
+      for (int p = 0; p < PD; ++p) {  // (loop positions are visited in the order tap_at(): see there)
+        wa[p] = __builtin_bit_cast(eltx8, w_lds[(tap_at(p) * 2 + h) * 32 + r]);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) xb[p][t] = __builtin_bit_cast(eltx8, in_lds[lbase[t] + tap_off(p)]);
+        for (int t = 0; t < NTW; ++t) xb[p][t] = __builtin_bit_cast(eltx8, in_lds[lbase[t] + tap_off(tap_at(p))]);
       }
       static_assert(IN_ROUNDS + W_ROUNDS <= 27, "one staging load per tap");
       // The wave in its MFMA loop outranks its SIMD partner (the other workgroup's wave, which is then staging, in its
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       for (int tap = 0; tap < 27; ++tap) {
         const int cur = tap % (PD + 1), nxt = (tap + PD) % (PD + 1);
         if (tap + PD < 27) {
-          const int t1 = tap + PD;
+          const int t1 = tap_at(tap + PD);
           const int toff = tap_off(t1);
           wa[nxt] = __builtin_bit_cast(eltx8, w_lds[(t1 * 2 + h) * 32 + r]);
 #pragma unroll
@@ -587,6 +593,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 // Variant bits of the specialisation: what the epilogue does is known at compile time (one wave per SIMD: a runtime
 // branch per row or value costs its full latency, nobody else is there to hide it)
 enum : int { C32_GNB = 1, C32_ADD = 2, C32_STATS = 4, C32_ACT = 8 };
+// The MFMA of conv32_mfma_kernel's tap loop, with its A operand (a weight fragment) read from the ACCUMULATION registers where it
+// lives: the kernel keeps 54 fragments = 216 registers for its lifetime, more than half of them in AGPRs, and through the builtin
+// hipcc copies each one to VGPRs in front of its MFMA (4 v_accvgpr_read + wait states per step: 154 copies per brick in the tap
+// loop of a kernel with one wave per SIMD, where every issue slot between two MFMAs is spoken for).  gfx90a+ MFMAs take A / B from
+// either file; the constraint "a" pins the fragments there and the copies disappear.  (The accumulators go to VGPRs instead.)
+#ifdef MEDNET_ELT_F16
+#define MEDNET_MFMA_ASM_OP "v_mfma_f32_32x32x16_f16"
+#else
+#define MEDNET_MFMA_ASM_OP "v_mfma_f32_32x32x16_bf16"
+#endif
+__device__ __forceinline__ void mfma_a_acc(f32x16& acc, const eltx8& w_in_agpr, const eltx8& b) {
+  asm volatile(MEDNET_MFMA_ASM_OP " %0, %1, %2, %0" : "+v"(acc) : "a"(w_in_agpr), "v"(b));
+}
+__device__ __forceinline__ void mfma_a_zero(f32x16& acc, const eltx8& w_in_agpr, const eltx8& b) {
+  asm volatile(MEDNET_MFMA_ASM_OP " %0, %1, %2, 0" : "=v"(acc) : "a"(w_in_agpr), "v"(b));
+}
 template <int V>
 __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
   constexpr bool GNB = (V & C32_GNB) != 0, ADD = (V & C32_ADD) != 0, STATS = (V & C32_STATS) != 0, ACT = (V & C32_ACT) != 0;
@@ -704,8 +726,8 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
   eltx8 wreg[54];
   const u32x4* wp = reinterpret_cast<const u32x4*>(a.wpk) + h * 32 + r;
 #pragma unroll
-  for (int i = 0; i < 54; ++i)
-    if (i < TW0 || i >= TW1) wreg[i] = __builtin_bit_cast(eltx8, wp[i * 64]);
+  for (int i = 0; i < 54; ++i)  // wreg[] is in the order of USE: step i = (K chunk, kz, kx, ky) multiplies tap tap_at(i % 27)
+    if (i < TW0 || i >= TW1) wreg[i] = __builtin_bit_cast(eltx8, wp[((i / 27) * 27 + tap_at(i % 27)) * 64]);
 
   // ---- staging plan of a brick (halo 6 x 10 x 18 voxels = 60 x-rows of 72 16-byte pieces).  One wave per SIMD means
   //      that whatever runs outside the tap loop is exposed in full and that vector work inside it must stay small, so the
@@ -782,12 +804,15 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
       in_lds[sl >= 0 ? b * BUF_PIECES + sl : spare_slot] = in_reg[it];
     }
   };
-  int lbase[NTW];  // LDS piece index of tap (0,0,0) for this lane in plane 0 (row-rotated: conflict-free ds_read_b128)
-#pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    const int ly = 2 * t + (r >> 4), lx = ((r & 15) - (r >> 4) * HX) & 15;
-    lbase[t] = (wv * HY + ly) * HX + lx;
-  }
+  // Operand fragments (round 6).  N-tile t of the wave's z-plane = the x-rows t (lanes 0..15 of a k-half) and t + 4 (lanes 16..31),
+  // not 2t and 2t + 1: the tap shifted by ky then needs the rows (t + ky, t + ky + 4) -- the fragment of "tile" t + ky.  SIX fragments
+  // a = 0..5 (rows (a, a + 4); a = 4, 5 reach into the halo) therefore serve the three ky taps of all four tiles of a (K chunk, kz,
+  // kx): 6 ds_read_b128 per 12 MFMAs instead of 12, without a single shuffle.  A bare loop of this shape runs at 1.63 PFLOP/s against
+  // 1.11-1.34 with one read per MFMA (tools/probes/mfma_shape_probe.hip, profiles/r06_mfma_feed_probe.log).  Row t + 4 lies 72
+  // voxels = 8 mod 16 behind row t: its lanes are rotated by 8 so that every hardware lane group of a ds_read_b128 ({0-3, 12-15,
+  // 20-27}, {4-11, 16-19, 28-31}) hits 16 distinct 16-byte slots.
+  const int lx6 = ((r & 15) + 8 * (r >> 4)) & 15;
+  const int lbase6 = (wv * HY + 4 * (r >> 4)) * HX + lx6;  // fragment a, tap (kz, ., kx): + (kz * HY + a) * HX + kx
   [[maybe_unused]] const eltx2 ones = {(elt)1.0f, (elt)1.0f};
   const size_t ovol = (size_t)a.od * a.oh * a.ow;
 
@@ -872,38 +897,33 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
     //      requested into them.
     f32x16 acc[NTW];
     const u32x4* img = in_lds + (size_t)buf * BUF_PIECES;
-    auto b_operand = [&](int s1, int t) {
-      const int kc1 = s1 / 27, t1 = s1 % 27;
-      return __builtin_bit_cast(eltx8, img[(2 * kc1 + h) * NVP + lbase[t] + ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3]);
+    // group gq = (K chunk, kz, kx) = steps 3 gq .. 3 gq + 2 (ky = 0, 1, 2): fragment a of the group
+    auto b_fragment = [&](int gq, int a6) {
+      const int kc1 = gq / 9, kz1 = (gq / 3) % 3, kx1 = gq % 3;
+      return __builtin_bit_cast(eltx8, img[(2 * kc1 + h) * NVP + lbase6 + (kz1 * HY + a6) * HX + kx1]);
     };
-    eltx8 xb[3][NTW];
+    eltx8 xf[2][6];  // two sets: the six reads of group g + 1 are dealt out over the twelve MFMAs of group g
 #pragma unroll
-    for (int s1 = 0; s1 < 2; ++s1) {
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) xb[s1][t] = b_operand(s1, t);
-    }
+    for (int a6 = 0; a6 < 6; ++a6) xf[0][a6] = b_fragment(0, a6);
     // issue order written out and fenced (sched_barrier): one MFMA, then the few other instructions of its gap -- a gap
     // hides ~5 issue slots; the scheduler left to itself packs a step's reads and scalar work into one gap and the
     // matrix pipe idles for the rest
 #pragma unroll
     for (int s54 = 0; s54 < 54; ++s54) {
-      const int cur = s54 % 3, pre = (s54 + 2) % 3;
+      const int gq = s54 / 3, ky = s54 % 3, cur = gq & 1;
       const int round = s54 / 3;
       const bool staging = s54 % 3 == 0 && round < IN_ROUNDS;
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
         __builtin_amdgcn_sched_barrier(0);
-        if (s54 == 0) {
-          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[t] = MEDNET_MFMA_32x32x16(wreg[0], xb[cur][t], zero, 0, 0, 0);
-        } else {
-          acc[t] = MEDNET_MFMA_32x32x16(wreg[s54], xb[cur][t], acc[t], 0, 0, 0);
-        }
+        if (s54 == 0) mfma_a_zero(acc[t], wreg[0], xf[cur][t]);
+        else mfma_a_acc(acc[t], wreg[s54], xf[cur][t + ky]);
         __builtin_amdgcn_sched_barrier(0);
-        if (s54 + 2 < 54) xb[pre][t] = b_operand(s54 + 2, t);
+        if (gq + 1 < 18 && (t & 1) == 0) xf[cur ^ 1][(ky * 4 + t) >> 1] = b_fragment(gq + 1, (ky * 4 + t) >> 1);
         if (s54 == 0 && t == 1) plan_main(tx2);
         if (t == 3 && s54 >= 24 && s54 < 32) plan_row(s54 - 24);
-        if (t == 2 && s54 < WT) wreg[TW0 + s54] = __builtin_bit_cast(eltx8, __builtin_nontemporal_load(wp + (TW0 + s54) * 64));
+        if (t == 2 && s54 < WT)
+          wreg[TW0 + s54] = __builtin_bit_cast(eltx8, __builtin_nontemporal_load(wp + (((TW0 + s54) / 27) * 27 + tap_at((TW0 + s54) % 27)) * 64));
         if (t == 2 && s54 >= SEC0) {  // second operands of row s54 - SEC0
           const int j = s54 - SEC0;
           if constexpr (ADD) adr[j] = __builtin_bit_cast(eltx8, __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(a.add, j), vb, row_soff(j), 0));
@@ -936,7 +956,7 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
 #pragma unroll
       for (int t = 0; t < NTW; ++t) act_apply_v16(acc[t], a.act);
     }
-    const int e_lx = ((r & 15) - (r >> 4) * HX) & 15;
+    const int e_lx = lx6;
     const int e_sw = (e_lx >> 1) & 7;
     eltx8 rows[8];
     // LDS operations of a wave execute in order, so the hardware needs no barrier between a half's writes, the other lanes'
@@ -946,16 +966,18 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       wave_lds_fence();  // (half 1: the reads of half 0 stay above these writes)
+      // rows 4 half .. 4 half + 3 of the plane = the lanes (r >> 4) == half of ALL four tiles (tile t holds rows t and t + 4)
+      if ((r >> 4) == half) {
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int t = 2 * half + tt;
-        const int vl = (2 * tt + (r >> 4)) * 16 + e_lx;  // voxel of the half: row (0..3) * 16 + x
+        for (int t = 0; t < NTW; ++t) {
+          const int vl = t * 16 + e_lx;  // voxel of the half: row (0..3) * 16 + x
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          eltx4 o;
+          for (int q = 0; q < 4; ++q) {
+            eltx4 o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (elt)acc[t][q * 4 + j];  // co = 8q + 4h + j
-          *reinterpret_cast<eltx4*>(wlds + vl * 32 + ((2 * q + h) ^ e_sw) * 4) = o;
+            for (int j = 0; j < 4; ++j) o[j] = (elt)acc[t][q * 4 + j];  // co = 8q + 4h + j
+            *reinterpret_cast<eltx4*>(wlds + vl * 32 + ((2 * q + h) ^ e_sw) * 4) = o;
+          }
         }
       }
       wave_lds_fence();  // the rows below were written by OTHER lanes of this wave
