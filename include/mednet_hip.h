@@ -43,7 +43,17 @@ enum { MEDNET_POOL_MAX = 0, MEDNET_POOL_AVG = 1 };
 enum { MEDNET_ALGO_AUTO = 0, MEDNET_ALGO_DIRECT = 1, MEDNET_ALGO_MFMA = 2, MEDNET_ALGO_EXACT = 3,
        /* the same request OR-ed onto a base choice: MEDNET_ALGO_MFMA | MEDNET_ALGO_EXACT_BIT = matrix-core path required AND
         * exact fp32 products (ALGO_MFMA alone takes the split-bf16 contraction in the fp32 storage mode) */
-       MEDNET_ALGO_EXACT_BIT = 4 };
+       MEDNET_ALGO_EXACT_BIT = 4,
+       /* (ABI 3, round 6) SPLIT WEIGHTS, OR-ed onto any base choice; 16-bit storage modes only (ignored for fp32 storage).  The
+        * matrix cores read 16-bit weight images: in fp16 storage that 11-bit rounding of the WEIGHTS -- not the 16-bit storage of
+        * activations and gradients -- is what keeps the gradients of the reference's fp32 step outside 1e-3 (tools/attrib16.py,
+        * profiles/r06_ab.md section 2).  With this bit every 3x3x3 forward / data-gradient convolution, ConvTranspose3d forward /
+        * data gradient and the first layer also multiply the LOW image elt(w - elt(w)) of the layer's weights (two MFMAs per
+        * product; the weight gradients have no weight operand and are unchanged).  The pack must hold the low images: pack with
+        * elt_dtype | MEDNET_PACK_LOW (every bf16 pack holds them anyway). */
+       MEDNET_ALGO_SPLITW_BIT = 8 };
+/* flag of the elt_dtype argument of mednet_conv3d_pack_elt / mednet_conv3d_pack_many: an fp16 pack with the low images as well */
+enum { MEDNET_PACK_LOW = 0x100 };
 enum { MEDNET_REG_L2 = 0, MEDNET_REG_L1 = 1 };
 enum {
   MEDNET_OK = 0, MEDNET_E_SHAPE = -1, MEDNET_E_DTYPE = -2, MEDNET_E_WORKSPACE = -3, MEDNET_E_HIP = -4,

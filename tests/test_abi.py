@@ -34,7 +34,7 @@ def test_ctypes_table_matches_header():
     from mednet_hip import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     lib = _lib.lib()
-    assert lib.mednet_abi_version() == 2
+    assert lib.mednet_abi_version() == 3
     assert lib.mednet_device_ok() in (0, 1)
 
 

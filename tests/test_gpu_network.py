@@ -374,6 +374,35 @@ def test_loss_scaler_skips_overflowing_steps_and_recovers():
     flat.release()
 
 
+def test_cfg2_128_fp16_split_weights_against_reference_golden(golden_dir):
+    """fp16x2 (round 6: fp16 storage + split weights, MEDNET_ALGO_SPLITW_BIT) against the REFERENCE's golden vectors of BASELINE config
+    2 at 128^3 (N = 1): the 16-bit-storage mode that is held to the north star's 1e-3 -- strided logits, loss, every gradient
+    tensor's norm, and the random projections at the fp32 mode's former bound.  (Full tensors at the timed batch:
+    tests/test_gpu_timed_workload.py[fp16x2].)"""
+    from mednet_hip.train import SegmentationStep
+    rec = np.load(os.path.join(golden_dir, "res_cfg2_128.npz"))
+    ctor = dict(in_channels=1, out_channels=4, final_sigmoid=False, f_maps=[32, 64, 128, 256])
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(1, 1, (128, 128, 128), 4, 0, seed=int(rec["meta.seed"])).items()}
+    with mednet_hip.precision("fp16x2"):
+        net = O.keyed_init_(HM.ResidualUNet3D(**ctor)).to(DEV)
+        step = SegmentationStep(net, loss_weight=[0.05, 1.0, 1.0, 1.0], lr=1e-3)
+        with torch.no_grad():
+            lg = net(batch["data"].float())
+        scale = step.scaler.snapshot()[0]
+        (loss,) = step._fwd_bwd(batch)
+        torch.cuda.synchronize()
+    s = int(rec["meta.stride"])
+    rl = assert_close(lg[..., ::s, ::s, ::s], torch.from_numpy(rec["logits.strided"]), 1e-3, "strided logits (fp16x2)")
+    dl = abs(float(loss) - float(rec["loss"]))
+    assert dl <= 1e-4, dl
+    step.flat.grad.div_(scale)
+    step.flat.grads_as_attr()
+    wn, wp = _check_grads_against_golden_summaries(net, rec, 1e-3, 4e-3, "cfg2 128^3 fp16x2")
+    step.flat.release()
+    print(f"[cfg2 128^3 fp16x2 vs reference] strided logits {rl:.2e} (tol 1e-3)  loss diff {dl:.1e}  worst gradient-norm diff {wn:.2e} "
+          f"(tol 1e-3)  worst projection diff {wp:.2e} (tol 4e-3)")
+
+
 def test_cfg2_128_fp16_storage_against_reference_golden(golden_dir):
     """BASELINE config 2's model at 128^3 through train.SegmentationStep in fp16 storage with the device-side loss scaler -- the
     same kernels as the benchmarked bf16 mode, instantiated for the other 16-bit type -- against the reference's golden vectors.

@@ -16,7 +16,7 @@ from mednet_hip import ops
 from mednet_hip.unet import loss as HL
 from oracle import ref_cpu as O
 
-from gpu_util import DEV, TOL, assert_close, bf16_round, half_round, rnd
+from gpu_util import DEV, TOL, assert_close, bf16_round, half_round, rnd, rel
 
 pytestmark = pytest.mark.gpu
 MODES = ["fp32", "bf16", "fp16"]
@@ -1082,6 +1082,57 @@ def test_two_block_kernel_is_bit_identical_to_the_general_kernel(mode, n, cin, c
             assert torch.all((ta - tb).abs() <= 5e-5 * scale + 2e-5 * tb.abs() + 1e-3 * nv ** 0.5 * 1e-2), f"{k}: partial sums differ"
     yr = F.conv3d(x.float().cpu(), w.to(dt).float().cpu(), None, padding=1)
     assert_close(a["act0False"][0], yr, 6e-3 if mode == "bf16" else 1e-3, "y vs ATen")
+
+
+@pytest.mark.parametrize("kind,n,cin,cout,shape", [
+    ("conv", 1, 32, 32, (32, 64, 64)),     # conv2b's (high, low) form in place of the 32 -> 32 specialisation, 256 bricks
+    ("conv", 2, 64, 128, (16, 24, 48)),    # four channel blocks, 36 bricks per sample: fewer items than CUs, padding items
+    ("conv", 1, 32, 64, (8, 8, 8)),        # narrow volume: conv_mfma_kernel<3> with the low image as extra K chunks
+    ("convt", 2, 64, 32, (8, 16, 16)),     # ConvTranspose3d forward (extra chunks) and data gradient (conv_mfma_kernel<2>, extra chunks)
+    ("first", 2, 1, 32, (24, 32, 32)),     # first layer: the weights' low parts as a third MFMA
+])
+def test_split_weights_remove_the_weight_rounding(kind, n, cin, cout, shape):
+    """fp16x2 (round 6, MEDNET_ALGO_SPLITW_BIT): fp16 storage, every matrix-core convolution multiplies fp16(w) AND fp16(w - fp16(w)).
+    Against the exact (fp64) convolution of the SAME fp16-representable activations with the fp32 weights, plain fp16 mode carries
+    the weights' 2^-12 rounding (~3e-4 rel-L2 of the output); the split mode must be at the level of the output's own fp16 rounding
+    -- forward and data gradient, through conv2b's (high, low) form, the general kernel's extra K chunks, the ConvTranspose3d
+    kernels and the first layer."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, cin, *shape, generator=g).half().float()
+    res = {}
+    for mode in ("fp16", "fp16x2"):
+        with mednet_hip.precision(mode):
+            if kind == "convt":
+                mod = hnn.ConvTranspose3d(cin, cout).to(DEV)
+            else:
+                mod = hnn.Conv3d(cin, cout, 3, bias=False).to(DEV)
+            gw = torch.Generator().manual_seed(7)
+            w = (torch.rand(mod.weight.shape, generator=gw) * 2 - 1) * (1.0 / (27 * cin) ** 0.5)
+            with torch.no_grad():
+                mod.weight.copy_(w)
+                if kind == "convt":
+                    mod.bias.zero_()
+            xg = x.to(DEV).requires_grad_(kind != "first")
+            y = mod(xg if kind == "first" else xg.half())
+            cot = torch.randn(y.shape, generator=torch.Generator().manual_seed(9)).half()
+            if kind != "first":
+                y.backward(cot.to(DEV))
+            res[mode] = (y.detach().float().cpu(), None if kind == "first" else xg.grad.float().cpu())
+    xd, wd = x.double(), w.double()
+    xd.requires_grad_(True)
+    yr = F.conv_transpose3d(xd, wd, None, stride=2, padding=1, output_padding=1) if kind == "convt" else F.conv3d(xd, wd, None, padding=1)
+    yr.backward(cot.double())
+    for what, i, ref in (("forward", 0, yr.detach()), ("data gradient", 1, xd.grad)):
+        if res["fp16"][i] is None:
+            continue
+        # the outputs themselves are stored in fp16 (~2e-4 rel-L2 of rounding): compared with the exact result ROUNDED THE SAME WAY,
+        # the split result differs only where the fp32 accumulation tips a rounding; the single-image result carries the weights'
+        # rounding (~2e-4) in full
+        ref16 = ref.float().half().float()
+        e1, e2 = rel(res["fp16"][i], ref16), rel(res["fp16x2"][i], ref16)
+        print(f"[split weights] {kind} {cin}->{cout} {what}: against the fp16-rounded exact result: fp16 {e1:.2e}  fp16x2 {e2:.2e}")
+        assert e2 <= 8e-5, f"{kind} {what}: split-weight error {e2:.3e}"
+        assert e2 <= 0.4 * e1, f"{kind} {what}: the low image did not help ({e1:.3e} -> {e2:.3e})"
 
 
 def test_conv3d_mfma_batch_larger_than_4GB():

@@ -10,6 +10,7 @@ fixture) and every storage mode is compared with it.
 
 Tolerances (||a - b||2 / ||b||2, written next to what was measured on an MI355X, round 6):
   fp32 storage mode  -- the north star's 1e-3 on the logits and on every gradient tensor, element-wise (full-tensor rel-L2);
+  fp16x2 (fp16 storage + split weights, round 6) -- the same 1e-3 on everything, at 16-bit storage;
   fp16 / bf16 storage -- the 16-bit modes' own bounds (2x measured), NOT 1e-3: see DESIGN.md section 2 / 14.
 """
 import gc
@@ -33,8 +34,12 @@ SEG_W = [0.05, 1.0, 1.0, 1.0]
 
 # mode -> (full logits, |loss - oracle|, worst full-tensor gradient rel-L2, concatenated-gradient rel-L2)
 # measured (round 6, printed by the tests): see profiles/r06_timed_workload_parity.log
-SEG_TOL = {"fp32": (1e-3, 1e-5, 1e-3, 1e-3), "fp16": (2e-3, 1e-4, 4e-2, 1e-2), "bf16": (1.5e-2, 1e-3, 2.5e-1, 6e-2)}
-LDMK_TOL = {"fp32": (1e-3, 1e-4, 1e-3, 1e-3), "fp16": (2e-3, 1e-3, 4e-2, 1e-2), "bf16": (1.5e-2, 1e-2, 2.5e-1, 6e-2)}
+# measured on an MI355X, round 6 (cfg2 / cfg4): fp32 logits 1.0e-5 / 9.0e-6, worst gradient tensor 3.2e-4 / 2.6e-4 (final_conv.bias);
+# fp16 logits 8.7e-4 / 7.6e-4, worst gradient 1.27e-3 / 1.53e-3, concatenated 2.8e-4 / 2.9e-4; bf16 logits 6.9e-3 / 6.1e-3, worst
+# gradient 1.37e-2 / 1.08e-2, concatenated 2.3e-3 / 2.4e-3.  The 16-bit bounds are those times two; "fp16x2" (fp16 storage + split
+# weights) is held to the north star's 1e-3 like the fp32 mode.
+SEG_TOL = {"fp32": (1e-3, 1e-5, 1e-3, 1e-3), "fp16x2": (1e-3, 1e-5, 1e-3, 1e-3), "fp16": (2e-3, 1e-4, 3e-3, 6e-4), "bf16": (1.5e-2, 1e-3, 3e-2, 5e-3)}
+LDMK_TOL = {"fp32": (1e-3, 1e-4, 1e-3, 1e-3), "fp16x2": (1e-3, 1e-4, 1e-3, 1e-3), "fp16": (2e-3, 1e-3, 3e-3, 6e-4), "bf16": (1.5e-2, 1e-2, 3e-2, 5e-3)}
 
 
 def _host_threads():
@@ -113,7 +118,7 @@ def _compare(tag, mode, net, lg, losses, ref, tol):
     assert cat <= tcat, f"{tag} {mode}: concatenated gradient rel-L2 {cat:.3e} > {tcat:.1e}"
 
 
-@pytest.mark.parametrize("mode", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "fp16x2", "fp16", "bf16"])
 def test_cfg2_timed_workload_against_the_live_oracle(seg_oracle, mode):
     """bench.py's step (SegmentationStep, N = 4, 128^3) against segmentation.py:58-65 run on the CPU, every gradient in full."""
     from mednet_hip.train import SegmentationStep
@@ -137,7 +142,7 @@ def test_cfg2_timed_workload_against_the_live_oracle(seg_oracle, mode):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("mode", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "fp16x2", "fp16", "bf16"])
 def test_cfg4_timed_workload_against_the_live_oracle(ldmk_oracle, mode):
     """Config 4 at the batch it is timed at (LandmarkStep, N = 4, 128^3, 16 heat maps + 2 classes) against landmarks.py:66-83 on the CPU."""
     from mednet_hip.train import LandmarkStep

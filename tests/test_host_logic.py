@@ -339,7 +339,7 @@ def test_algo_mfma_is_satisfied_by_the_fp32_mode_matrix_core_kernels():
     # and the weight-gradient plan is an argument: a negative workgroup count is a shape error before anything else happens
     rc = lib.mednet_conv3d_wgrad(None, None, None, None, 1, 8, 8, 16, 32, 32, 3, L.BF16, L.NDHWC, L.BF16, L.NDHWC, L.ALGO_AUTO, -1, None, 0, None)
     assert rc == -1 and "workgroups" in lib.mednet_last_error().decode()
-    assert lib.mednet_get_option(b"wgrad_wgs", -7) == -7 and lib.mednet_abi_version() == 2
+    assert lib.mednet_get_option(b"wgrad_wgs", -7) == -7 and lib.mednet_abi_version() == 3
 
 
 def test_fused_landmark_head_and_first_layer_entry_points_answer_without_a_device():

@@ -101,7 +101,8 @@ def _patch_weight(m, name):
 
 def instrument(model):
     for name, m in model.named_modules():
-        if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)) and not name.endswith("final_conv") and m.kernel_size[0] == 3 and m.in_channels > 1:
+        if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)) and not name.endswith("final_conv") and m.kernel_size[0] == 3 and (
+                m.in_channels > 1 or os.environ.get("ATTRIB_FIRST_LAYER") == "1"):
             _patch_weight(m, name)  # (the first layer keeps ~16 mantissa bits of its input and the head runs in fp32: DESIGN section 4)
         if isinstance(m, (nn.ELU, nn.ReLU, nn.LeakyReLU)):
             m.inplace = False

@@ -58,6 +58,10 @@ static inline bool is16(int dt) { return dt == MEDNET_BF16 || dt == MEDNET_F16; 
 // is required AND its products must be exact": the fp32 matrix instruction, never the split-bf16 contraction.
 static inline bool algo_exact(int a) { return a == MEDNET_ALGO_EXACT || (a > MEDNET_ALGO_EXACT && (a & MEDNET_ALGO_EXACT_BIT)); }
 static inline int algo_base(int a) { return (a & 3) == MEDNET_ALGO_EXACT ? MEDNET_ALGO_AUTO : (a & 3); }
+// split weights (MEDNET_ALGO_SPLITW_BIT): the 16-bit matrix-core forward / data-gradient convolutions multiply the pack's LOW
+// weight images too; the pack must hold them (MEDNET_PACK_LOW for fp16 packs, every bf16 pack).  -> distance of the low image
+static inline size_t algo_lo_delta(int a, int dtype, const PackLayout& L) { return (a & MEDNET_ALGO_SPLITW_BIT) && is16(dtype) ? L.lo_delta : 0; }
+static inline bool algo_split(int a, int dtype) { return (a & MEDNET_ALGO_SPLITW_BIT) && is16(dtype); }
 
 extern "C" int mednet_set_option(const char* name, int value) {
   for (int i = 0; i < g_noptions; ++i)
@@ -73,7 +77,7 @@ extern "C" int mednet_set_option(const char* name, int value) {
 
 extern "C" int mednet_get_option(const char* name, int default_value) { return mednet_internal_tuning_option(name, default_value); }
 
-extern "C" int mednet_abi_version(void) { return 2; }  // 2: `workgroups` argument of the weight-gradient calls (round 5)
+extern "C" int mednet_abi_version(void) { return 3; }  // 2: `workgroups` argument of the weight-gradient calls (round 5); 3: MEDNET_ALGO_SPLITW_BIT, MEDNET_PACK_LOW (round 6)
 extern "C" const char* mednet_last_error(void) { return g_err; }
 extern "C" int mednet_device_ok(void) {
   int count = 0;
@@ -102,8 +106,12 @@ extern "C" int mednet_conv3d_pack_elt(const float* w, void* packed, int cin, int
   // region unwritten (round 3 wrote it for MEDNET_F32 only; a caller who packed with mednet_conv3d_pack, as the header of
   // round 2 said, then ran an fp32 conv got uninitialised memory).  MEDNET_F32 = MEDNET_BF16 here.  An fp16 pack has fp16
   // images in the high slots and no room for bf16 ones: it serves fp16-storage calls only (include/mednet_hip.h).
+  // (round 6) elt_dtype | MEDNET_PACK_LOW: an fp16 pack with the low images too -- elt(w - elt(w)), the same arithmetic in fp16 --
+  // for the split-weight mode of the fp16 kernels (MEDNET_ALGO_SPLITW_BIT)
+  const bool want_low = (elt_dtype & MEDNET_PACK_LOW) != 0;
+  elt_dtype &= ~MEDNET_PACK_LOW;
   if (elt_dtype == MEDNET_F32) elt_dtype = MEDNET_BF16;
-  const bool with_low = elt_dtype == MEDNET_BF16;
+  const bool with_low = elt_dtype == MEDNET_BF16 || want_low;
   MEDNET_REQUIRE(is16(elt_dtype), MEDNET_E_DTYPE, "conv3d_pack: the matrix-core images are bf16 or fp16 (got dtype %d)", elt_dtype);
   MEDNET_REQUIRE(ksize == 3 || ksize == 1, MEDNET_E_UNSUPPORTED, "conv3d_pack: kernel size %d (supported: 1, 3)", ksize);
   MEDNET_REQUIRE(cin > 0 && cout > 0, MEDNET_E_SHAPE, "conv3d_pack: bad channels %d -> %d", cin, cout);
@@ -151,8 +159,10 @@ extern "C" int mednet_conv3d_pack_table(const mednet_pack_job* jobs, int njobs, 
 }
 extern "C" int mednet_conv3d_pack_many(const void* table_device, int njobs, unsigned max_blocks, int elt_dtype,
                                        mednet_stream stream) {
+  const bool want_low = (elt_dtype & MEDNET_PACK_LOW) != 0;
+  elt_dtype &= ~MEDNET_PACK_LOW;
   if (elt_dtype == MEDNET_F32) elt_dtype = MEDNET_BF16;
-  const bool with_low = elt_dtype == MEDNET_BF16;  // bf16 high + low images always (see mednet_conv3d_pack_elt)
+  const bool with_low = elt_dtype == MEDNET_BF16 || want_low;  // bf16 high + low images always (see mednet_conv3d_pack_elt)
   MEDNET_REQUIRE(is16(elt_dtype), MEDNET_E_DTYPE, "conv3d_pack_many: the matrix-core images are bf16 or fp16 (got dtype %d)", elt_dtype);
   MEDNET_REQUIRE(table_device && njobs > 0 && njobs <= 65535 && max_blocks > 0, MEDNET_E_SHAPE, "conv3d_pack_many: bad arguments");
   return ELT_CALL(elt_dtype, launch_pack_mfma_many, table_device, njobs, max_blocks, (hipStream_t)stream, with_low ? 1 : 0);
@@ -176,7 +186,7 @@ extern "C" int mednet_conv3d_fused_stats_chunks(int n, int d, int h, int w, int 
   }
   if (ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, false)) return conv_c1_stats_chunks(d, h, w);
   if (!ELT_CALL(y_dtype, conv_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, MEDNET_NDHWC, false)) return 0;
-  return conv_mfma_stats_chunks(n, d, h, w, cin, cout);
+  return conv_mfma_stats_chunks(n, d, h, w, cin, cout, false, algo_split(algo, y_dtype));
 }
 
 // Launch plan of the producer of a 3x3x3 layer's fused partial rows, computed by the launcher's own planning code (no device
@@ -187,7 +197,7 @@ extern "C" int mednet_conv3d_stats_plan(int n, int d, int h, int w, int cin, int
   MEDNET_REQUIRE(out13 && n > 0 && d > 0 && h > 0 && w > 0 && (stride == 1 || stride == 2), MEDNET_E_SHAPE, "conv3d_stats_plan: bad arguments");
   MEDNET_REQUIRE(is16(dtype) && cin % 16 == 0 && cout % 16 == 0, MEDNET_E_UNSUPPORTED,
                  "conv3d_stats_plan: the 16-bit matrix-core kernels only (dtype %d, %d -> %d)", dtype, cin, cout);
-  return ELT_CALL(dtype, conv_mfma_plan, n, d, h, w, cin, cout, gnb != 0, stride, out13);
+  return ELT_CALL(dtype, conv_mfma_plan, n, d, h, w, cin, cout, (gnb & 1) != 0, stride, out13, (gnb & 2) != 0);  // (gnb bit 1: split weights)
 }
 
 extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float* bias, void* y, int n, int d, int h,
@@ -211,11 +221,12 @@ extern "C" int mednet_conv3d_fwd(const void* x, const void* packed, const float*
                 ksize, x_dtype, y_dtype);
   if (mfma_ok && algo_base(algo) != MEDNET_ALGO_DIRECT)
     return ELT_CALL(y_dtype, launch_conv_mfma, x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), y, n, d, h, w, cin, cout, x_dtype,
-                    y_dtype, gn_partial, s, MEDNET_ACT_NONE, nullptr);
+                    y_dtype, gn_partial, s, MEDNET_ACT_NONE, nullptr, algo_lo_delta(algo, y_dtype, L));
   // first layer (one input channel): contraction over the 27 taps on the matrix cores
   if (!dgrad && algo_base(algo) != MEDNET_ALGO_DIRECT && x_layout == MEDNET_NDHWC &&
       ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, y_layout, bias != nullptr))
-    return ELT_CALL(y_dtype, launch_conv_c1_mfma, x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, gn_partial, s, x_dtype);
+    return ELT_CALL(y_dtype, launch_conv_c1_mfma, x, (const float*)(base + L.f32_fwd), y, n, d, h, w, cout, gn_partial, s, x_dtype,
+                    algo_split(algo, y_dtype) ? 1 : 0);
   // fp32 storage: the split-bf16 contraction ...
   if (f32_mode && (!algo_exact(algo) && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin))
     return launch_conv_x3(x, base + (dgrad ? L.mfma_bwd : L.mfma_fwd), L.lo_delta, bias, y, n, d, h, w, cin, cout, gn_partial, s);
@@ -349,7 +360,7 @@ extern "C" int mednet_conv3d_act_fwd(const void* x, const void* packed, void* y,
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_act_fwd: only the bf16 matrix-core path fuses the activation (cin=%d cout=%d)", cin, cout);
   const PackLayout L = pack_layout(cin, cout, 3);
   return ELT_CALL(dtype, launch_conv_mfma, x, (const char*)packed + L.mfma_fwd, y, n, d, h, w, cin, cout, dtype, dtype,
-                  gn_partial, (hipStream_t)stream, act, nullptr);
+                  gn_partial, (hipStream_t)stream, act, nullptr, algo_lo_delta(algo, dtype, L));
 }
 
 // data gradient of a 3x3x3 conv with a second gradient of the same tensor summed in the epilogue (matrix-core path only)
@@ -383,7 +394,7 @@ extern "C" int mednet_conv3d_dgrad_add(const void* dy, const void* packed, const
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_dgrad_add: only the bf16 matrix-core path fuses the add (cin=%d cout=%d)", cin, cout);
   const PackLayout L = pack_layout(cin, cout, 3);
   return ELT_CALL(dtype, launch_conv_mfma, dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cout, cin, dtype, dtype, nullptr,
-                  (hipStream_t)stream, MEDNET_ACT_NONE, add);
+                  (hipStream_t)stream, MEDNET_ACT_NONE, add, algo_lo_delta(algo, dtype, L));
 }
 
 // data gradient of the 1x1x1 head + the first pass of the GroupNorm-3 backward of the ExtResNetBlock whose output it is
@@ -457,7 +468,8 @@ extern "C" int mednet_head_landmark_bwd(const void* z, const void* packed, const
 
 extern "C" int mednet_conv3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int algo) {
   if (!tuning_option("conv_fuse_gnb", 1) || !mednet_conv3d_act_supported(n, d, h, w, cout, cin, algo)) return 0;
-  return conv_mfma_stats_chunks(n, d, h, w, cout, cin, true);  // (the kernel reads the layer's Cout channels, writes its Cin)
+  // (the kernel reads the layer's Cout channels, writes its Cin; 16-bit storage only, so the split-weight request counts as given)
+  return conv_mfma_stats_chunks(n, d, h, w, cout, cin, true, (algo & MEDNET_ALGO_SPLITW_BIT) != 0);
 }
 extern "C" int mednet_conv3d_dgrad_gn_rows_dt(int n, int d, int h, int w, int cin, int cout, int algo, int dtype) {
   if (dtype == MEDNET_F32)  // (the kernel writes the layer's Cin channels: they are its "output" channel blocks)
@@ -487,7 +499,7 @@ extern "C" int mednet_conv3d_dgrad_gn(const void* dy, const void* packed, const 
     return fail(MEDNET_E_UNSUPPORTED, "conv3d_dgrad_gn: only the bf16 matrix-core path fuses the GroupNorm sums (cin=%d cout=%d)", cin, cout);
   const PackLayout L = pack_layout(cin, cout, 3);
   return ELT_CALL(dtype, launch_conv_mfma_gnb, dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cout, cin, add, gn_y,
-                  gn_coef, gn_act, gn_partial, (hipStream_t)stream);
+                  gn_coef, gn_act, gn_partial, (hipStream_t)stream, algo_lo_delta(algo, dtype, L));
 }
 
 // ---- ConvTranspose3d(k3,s2,p1,op1) ------------------------------------------------------------------------------------
@@ -503,7 +515,7 @@ extern "C" int mednet_convt3d_fwd(const void* x, const void* packed, const float
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_fwd: MFMA path does not take cin=%d cout=%d", cin, cout);
   if (mfma_ok && algo_base(algo) != MEDNET_ALGO_DIRECT)
     return ELT_CALL(x_dtype, launch_convt_fwd_mfma, x, (const char*)packed + L.mfma_fwd, bias, skip, y, n, d, h, w, cin, cout,
-                    (hipStream_t)stream);
+                    (hipStream_t)stream, algo_lo_delta(algo, x_dtype, L));
   if (algo_base(algo) != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && x_dtype == MEDNET_F32 && y_dtype == MEDNET_F32) {
     if ((!algo_exact(algo) && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, 3))
       return launch_convt_fwd_x3(x, (const char*)packed + L.mfma_fwd, L.lo_delta, bias, skip, y, n, d, h, w, cin, cout,
@@ -530,7 +542,7 @@ extern "C" int mednet_convt3d_dgrad(const void* dy, const void* packed, void* dx
     return fail(MEDNET_E_UNSUPPORTED, "convt3d_dgrad: MFMA path does not take cin=%d cout=%d", cin, cout);
   if (mfma_ok && algo_base(algo) != MEDNET_ALGO_DIRECT)
     return ELT_CALL(dy_dtype, launch_convt_dgrad_mfma, dy, (const char*)packed + L.mfma_bwd, dx, n, d, h, w, cin, cout,
-                    (hipStream_t)stream);
+                    (hipStream_t)stream, algo_lo_delta(algo, dy_dtype, L));
   if (algo_base(algo) != MEDNET_ALGO_DIRECT && conv_f32_mfma_enabled() && dy_dtype == MEDNET_F32 && dx_dtype == MEDNET_F32) {
     if ((!algo_exact(algo) && conv_x3_enabled()) && L.mfma_bytes && conv_x3_supported(cin, cout, 3) && conv_x3_fits(2 * d, 2 * h, 2 * w, cout))
       return launch_convt_dgrad_x3(dy, (const char*)packed + L.mfma_bwd, L.lo_delta, dx, n, d, h, w, cin, cout, (hipStream_t)stream);
@@ -562,7 +574,7 @@ extern "C" int mednet_convt3d_dgrad_gn(const void* dy, const void* packed, void*
                  "convt3d_dgrad_gn: cin=%d cout=%d dtype=%d not on the matrix-core path", cin, cout, dtype);
   const PackLayout L = pack_layout(cin, cout, 3);
   return ELT_CALL(dtype, launch_convt_dgrad_gn_mfma, dy, (const char*)packed + L.mfma_bwd, dx, gn_y, gn_z, gn_act, gn_partial, n, d,
-                  h, w, cin, cout, (hipStream_t)stream);
+                  h, w, cin, cout, (hipStream_t)stream, algo_lo_delta(algo, dtype, L));
 }
 
 extern "C" size_t mednet_convt3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int workgroups) {

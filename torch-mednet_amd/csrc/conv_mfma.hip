@@ -98,6 +98,13 @@ struct FwdArgs {
                           // CONTIGUOUS part of the volume, so neighbouring bricks' halos meet in its L2), else 0
   int zslab;              // conv32_mfma_kernel: z-layers of bricks per XCD (> 0: the x-z-y walk of origin(); implies xcd_chunk)
   unsigned rcp_zslab;
+  // Split weights (round 6, MEDNET_ALGO_SPLITW_BIT): the layer's LOW image -- elt(w - elt(w)), what 16-bit rounding takes from a
+  // weight -- lies lo_delta bytes behind the high one and is multiplied too, into the same fp32 accumulators (fp16 MFMAs honour
+  // subnormal inputs: tools/probes/f16_denorm_probe.py).  conv_mfma_kernel runs the low image as nkc_in more K chunks (nkc = 2
+  // nkc_in loop chunks over the same nkc_in input chunks); conv2b_mfma_kernel<V | C32_SPLIT> takes (high, low) of ONE channel
+  // block as its two "blocks".  0 = off.
+  unsigned lo_delta;
+  int nkc_in;  // input K chunks (cin / 16)
 };
 
 template <int KIND, bool GNB = false>
@@ -179,13 +186,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
   };
 
   u32x4 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
+  // loop chunk kc: input chunk kc mod nkc_in; weight slice of the high image, or (kc >= nkc_in: split weights) of the low one
+  auto w_slice = [&](int cb, int kc) {
+    const bool low = kc >= a.nkc_in;
+    return reinterpret_cast<const char*>(a.wpk) + (low ? (size_t)a.lo_delta : 0) + ((size_t)cb * a.nkc_in + (low ? kc - a.nkc_in : kc)) * (W_CHUNKS * 16);
+  };
+  auto in_chunk = [&](int kc) { return kc >= a.nkc_in ? kc - a.nkc_in : kc; };
   auto prefetch = [&](int cb, int kc) {  // 15 loads issued back to back, nothing waits on them until commit()
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)pn * a.id * a.ih * a.iw * a.cin), 0, a.bytes_x, 0x00020000);
 #pragma unroll
-    for (int it = 0; it < IN_ROUNDS; ++it) in_reg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, goff[it], kc * 32, 0);
+    for (int it = 0; it < IN_ROUNDS; ++it) in_reg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, goff[it], in_chunk(kc) * 32, 0);
     // the weight slice of (cb, kc) is one linear 27 KB run: thread t takes pieces t, t+256, ...; the last round is cut
     // off by the resource's size (the round is part of voffset: the hardware range check does not see soffset)
-    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + ((size_t)cb * a.nkc + kc) * (W_CHUNKS * 8)), 0, W_CHUNKS * 16, 0x00020000);
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_slice(cb, kc), 0, W_CHUNKS * 16, 0x00020000);
 #pragma unroll
     for (int it = 0; it < W_ROUNDS; ++it) w_reg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, tid * 16 + it * 4096, 0, 0);
   };
@@ -345,7 +358,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
       }
       const unsigned kill = do_pf ? 0u : OOB;
       const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)pn * a.id * a.ih * a.iw * a.cin), 0, a.bytes_x, 0x00020000);
-      const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + ((size_t)pf_cb * a.nkc + pf_kc) * (W_CHUNKS * 8)), 0, W_CHUNKS * 16, 0x00020000);
+      const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_slice(pf_cb, pf_kc), 0, W_CHUNKS * 16, 0x00020000);
+      const int pf_in = in_chunk(pf_kc) * 32;
       // Software-pipelined over the 27 taps: the fragments of tap t+1 (1 weight + NTW input ds_read_b128) are in flight
       // while tap t is on the matrix cores; sched_group_barrier pins that interleave (hipcc otherwise sinks each read to
       // just in front of its MFMA and exposes the LDS latency 108 times per chunk).
@@ -374,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
           for (int t = 0; t < NTW; ++t) xb[nxt][t] = __builtin_bit_cast(eltx8, in_lds[lbase[t] + toff]);
         }
         if (tap < IN_ROUNDS)
-          in_reg[tap] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, goff[tap] | kill, pf_kc * 32, 0);
+          in_reg[tap] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, goff[tap] | kill, pf_in, 0);
         else if (tap < IN_ROUNDS + W_ROUNDS)
           w_reg[tap - IN_ROUNDS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(tid * 16 + (tap - IN_ROUNDS) * 4096) | kill, 0, 0);
 #pragma unroll
@@ -592,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(FwdArgs a) {
 // B operand reads are the only LDS traffic of the tap loop: 1 KB per MFMA instead of 1.25 KB.
 // Variant bits of the specialisation: what the epilogue does is known at compile time (one wave per SIMD: a runtime
 // branch per row or value costs its full latency, nobody else is there to hide it)
-enum : int { C32_GNB = 1, C32_ADD = 2, C32_STATS = 4, C32_ACT = 8 };
+enum : int { C32_GNB = 1, C32_ADD = 2, C32_STATS = 4, C32_ACT = 8, C32_SPLIT = 16 /* conv2b only: (high, low) weight images as the two blocks */ };
 // The MFMA of conv32_mfma_kernel's tap loop, with its A operand (a weight fragment) read from the ACCUMULATION registers where it
 // lives: the kernel keeps 54 fragments = 216 registers for its lifetime, more than half of them in AGPRs, and through the builtin
 // hipcc copies each one to VGPRs in front of its MFMA (4 v_accvgpr_read + wait states per step: 154 copies per brick in the tap
@@ -1090,6 +1104,8 @@ struct CtArgs {
   int cin, cout;
   int tiles_z, tiles_y, tiles_x, ntiles;
   int nkc, ncb;
+  int nkc_in;         // input K chunks; nkc = 2 nkc_in with split weights (the low image as nkc_in more chunks, FwdArgs::lo_delta)
+  unsigned lo_delta;
 };
 
 __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
@@ -1133,15 +1149,17 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
     }
     goff[it] = off;
   }
-  const elt* wsrc = a.wpk + (size_t)cb * a.nkc * (W_CHUNKS * 8);
+  const elt* wsrc = a.wpk + (size_t)cb * a.nkc_in * (W_CHUNKS * 8);
   eltx8 in_reg[IN_ROUNDS], w_reg[W_ROUNDS];
   // Branch-free: every lane always loads (padding / out-of-image lanes read a valid dummy address); what is invalid
   // is replaced by zeros when the registers are committed to LDS, so the 16 loads issue back to back with no waits.
   auto prefetch = [&](int kc) {
+    const bool low = kc >= a.nkc_in;  // (split weights: the low image's chunks over the same input chunks)
+    const int kci = low ? kc - a.nkc_in : kc;
 #pragma unroll
     for (int it = 0; it < IN_ROUNDS; ++it)
-      in_reg[it] = *reinterpret_cast<const eltx8*>(a.x + (goff[it] >= 0 ? goff[it] : 0) + kc * 16);
-    const elt* ws = wsrc + (size_t)kc * (W_CHUNKS * 8);
+      in_reg[it] = *reinterpret_cast<const eltx8*>(a.x + (goff[it] >= 0 ? goff[it] : 0) + kci * 16);
+    const elt* ws = reinterpret_cast<const elt*>(reinterpret_cast<const char*>(wsrc) + (low ? (size_t)a.lo_delta : 0)) + (size_t)kci * (W_CHUNKS * 8);
 #pragma unroll
     for (int it = 0; it < W_ROUNDS; ++it) {
       const int c = it * 256 + tid;
@@ -1263,7 +1281,7 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_mfma_kernel(CtArgs a) {
 }
 
 int launch_convt_fwd_mfma(const void* x, const void* sec, const float* bias, const void* skip, void* y, int n, int d,
-                          int h, int w, int cin, int cout, hipStream_t s) {
+                          int h, int w, int cin, int cout, hipStream_t s, size_t lo_delta) {
   constexpr size_t lds = 512 * 32 * 4;  // the epilogue's fp32 half-block (64 KB) > staging images (36 KB); 2 workgroups per CU
   static_assert(lds >= ((size_t)2 * 3 * 5 * 17 + 27 * 2 * 32) * 16 && lds <= 80 * 1024, "LDS plan of convt_fwd");
   CtArgs a;
@@ -1277,7 +1295,9 @@ int launch_convt_fwd_mfma(const void* x, const void* sec, const float* bias, con
   a.tiles_y = (h + 3) / 4;
   a.tiles_x = (w + 15) / 16;
   a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
-  a.nkc = cin / 16;
+  a.nkc_in = cin / 16;
+  a.nkc = lo_delta ? 2 * a.nkc_in : a.nkc_in;
+  a.lo_delta = (unsigned)lo_delta;
   a.ncb = cout / 32;
   const unsigned grid = (unsigned)((a.ntiles + 7) / 8) * 8 * a.ncb;
   static bool attr_set = false;
@@ -1304,6 +1324,7 @@ struct C1Args {
   int n, d, h, w_, cout;
   int tiles_z, tiles_y, tiles_x, ntiles, ncb;
   int x16;  // 1: x holds elt values (the 1-channel output of a GroupNorm in the 'gcr' orders), else fp32 (the network input)
+  int split;  // split weights (MEDNET_ALGO_SPLITW_BIT): the weights' low parts elt(w - elt(w)) are multiplied too
 };
 
 __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
@@ -1320,13 +1341,15 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
   const int tz0 = (tt % a.tiles_z) * TZ;
   const int n = tt / a.tiles_z;
   // weights: A operand, lane (co = r, h) holds taps 8h..8h+7 (k-step 0) and 16+8h..16+8h+7 (k-step 1); taps >= 27 are 0
-  eltx8 wa[2];
+  eltx8 wa[2], wl[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int tap = ks * 16 + 8 * h + j;
-      wa[ks][j] = (elt)(tap < 27 && cb * 32 + r < a.cout ? a.w[(size_t)tap * a.cout + cb * 32 + r] : 0.f);  // (a 16-channel layer fills half a block)
+      const float wf = tap < 27 && cb * 32 + r < a.cout ? a.w[(size_t)tap * a.cout + cb * 32 + r] : 0.f;  // (a 16-channel layer fills half a block)
+      wa[ks][j] = (elt)wf;
+      wl[ks][j] = (elt)(wf - (float)wa[ks][j]);
     }
   // LDS offsets of this lane's 8 taps per k-step
   int toff[2][8];  // (both k-halves' offsets are compile-time constants: one select per entry instead of the divisions by 9 and 3)
@@ -1371,6 +1394,7 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
       }
       acc = MEDNET_MFMA_32x32x16(wa[ks], hi, acc, 0, 0, 0);
       acc = MEDNET_MFMA_32x32x16(wa[ks], lo, acc, 0, 0, 0);
+      if (a.split) acc = MEDNET_MFMA_32x32x16(wl[ks], hi, acc, 0, 0, 0);  // (workgroup-uniform)
     }
     // The accumulator layout gives a lane four 8-byte pieces (channels 8q + 4h ..) of ITS voxel's 64-byte row: stored as they
     // stand, one instruction touches 64 rows with 8 bytes each, and this kernel does little else than store (264 us for 537 MB).
@@ -1446,8 +1470,9 @@ bool conv_c1_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dty
 }
 int conv_c1_stats_chunks(int d, int h, int w) { return 4 * ((d + 3) / 4) * ((h + 7) / 8) * ((w + 15) / 16); }
 int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d, int h, int w, int cout, float* gn_partial,
-                        hipStream_t s, int x_dtype) {
+                        hipStream_t s, int x_dtype, int split) {
   C1Args a;
+  a.split = split;
   a.gn_partial = gn_partial;
   a.x = (const float*)x;
   a.x16 = x_dtype != MEDNET_F32;
@@ -1646,13 +1671,16 @@ static bool conv32_applies(int ntiles, int cin, int cout) {
 }
 // (A/B knob conv32_gnb=0: the data-gradient launches that also take a GroupNorm backward's first pass go to the general kernel,
 //  whose second workgroup per CU hides that epilogue; the specialisation's single wave per SIMD cannot)
-static bool conv32_takes(int ntiles, int cin, int cout, bool gnb) {
-  return conv32_applies(ntiles, cin, cout) && (!gnb || tuning_option("conv32_gnb", 1));
+// (split weights: the specialisation keeps ONE image of the layer's weights in registers -- conv2b's split form takes those calls)
+static bool conv32_takes(int ntiles, int cin, int cout, bool gnb, bool split = false) {
+  return !split && conv32_applies(ntiles, cin, cout) && (!gnb || tuning_option("conv32_gnb", 1));
 }
 // The two-block kernel (conv2b_mfma_kernel, round 6): layers whose output channels come in pairs of 32-channel blocks, on 16-wide
 // bricks, with enough (brick, block pair) items to give each of the 256 one-per-CU workgroups work in nearly full rounds (the
 // last round of a persistent grid runs with whatever is left: 288 items would keep 7/8 of the chip idle for half of the launch).
-static bool conv2b_takes(int ntiles, int cin, int cout) {
+// Split weights: its (high, low) form takes every layer whose output channels come in whole 32-channel blocks, whatever the item count.
+static bool conv2b_takes(int ntiles, int cin, int cout, bool split = false) {
+  if (split) return cout % 32 == 0 && cin % 16 == 0 && ::mednet_internal_cu_count() == 256 && tuning_option("conv2b_split", 1);
   // (from 4 K chunks on: with two -- 32 input channels -- an item is too short for its fixed costs, measured 0.95-0.99 of the general kernel)
   if (!(cout % 64 == 0 && cin % 16 == 0 && cin >= tuning_option("conv2b_min_cin", 64) && ::mednet_internal_cu_count() == 256 &&
         tuning_option("conv2b", 1)))
@@ -1663,28 +1691,31 @@ static bool conv2b_takes(int ntiles, int cin, int cout) {
 }
 // Brick kind of a stride-1 launch: 3 (8-wide bricks) where that covers the volume with fewer voxel slots, unless the 32 -> 32
 // specialisation (16-wide bricks only) takes the call
-static int conv_fwd_kind(int n, int d, int h, int w, int cin, int cout, bool gnb) {
+static int conv_fwd_kind(int n, int d, int h, int w, int cin, int cout, bool gnb, bool split = false) {
   using G = FwdTile<1>;
   const int ntiles16 = n * ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
-  return narrow_bricks(w) && !conv32_takes(ntiles16, cin, cout, gnb) ? 3 : 1;
+  return narrow_bricks(w) && !conv32_takes(ntiles16, cin, cout, gnb, split) ? 3 : 1;
 }
-static void conv_stats_plan(int n, int d, int h, int w, int cin, int cout, int& rows, int& accum, bool gnb = false) {
-  const int tx = conv_fwd_kind(n, d, h, w, cin, cout, gnb) == 3 ? FwdTile<3>::TX : FwdTile<1>::TX;
+// workgroups of a conv2b launch: one per CU, fewer (a multiple of 8) when the launch has fewer items
+static int conv2b_grid(int nitems) { return nitems < 256 ? nitems : 256; }
+static void conv_stats_plan(int n, int d, int h, int w, int cin, int cout, int& rows, int& accum, bool gnb = false, bool split = false) {
+  const int tx = conv_fwd_kind(n, d, h, w, cin, cout, gnb, split) == 3 ? FwdTile<3>::TX : FwdTile<1>::TX;
   using G = FwdTile<1>;
   const int tps = ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + tx - 1) / tx);
   const int ncb = (cout + 31) / 32, ntiles = n * tps;
-  if (tx == G::TX && conv32_takes(ntiles, cin, cout, gnb)) {  // always accumulating: one row per wave of the 256 workgroups
+  if (tx == G::TX && conv32_takes(ntiles, cin, cout, gnb, split)) {  // always accumulating: one row per wave of the 256 workgroups
     accum = 1;
     rows = 256 * 4;
     return;
   }
-  if (tx == G::TX && conv2b_takes(ntiles, cin, cout)) {
-    // 256 workgroups stepping by 256 items: a workgroup keeps its block pair when the pair count divides 32, and without padding
-    // items every workgroup starts on a valid brick: one row per wave of the workgroups that share a pair, else a row per wave
-    // and brick
-    const int ncbp = cout / 64;
-    accum = tuning_option("conv_stats_accum", 1) && ntiles % 8 == 0 && 32 % ncbp == 0;
-    rows = accum ? (32 / ncbp) * 8 * 4 : 4 * tps;
+  if (tx == G::TX && conv2b_takes(ntiles, cin, cout, split)) {
+    // 256 workgroups stepping by 256 items: a workgroup keeps its block pair (split weights: its block) when the pair count
+    // divides 32, and without padding items every workgroup starts on a valid brick: one row per wave of the workgroups that
+    // share a pair, else a row per wave and brick
+    const int ncbp = split ? cout / 32 : cout / 64;
+    const int grid = conv2b_grid(((ntiles + 7) / 8) * 8 * ncbp);
+    accum = tuning_option("conv_stats_accum", 1) && ntiles % 8 == 0 && (grid / 8) % ncbp == 0;
+    rows = accum ? (grid / 8 / ncbp) * 8 * 4 : 4 * tps;
     return;
   }
   const int nitems = ((ntiles + 7) / 8) * 8 * ncb;
@@ -1711,7 +1742,7 @@ struct GnbSpec {  // fused first pass of a GroupNorm backward (see FwdArgs::gnb_
 template <int KIND>
 static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, int oh, int ow, int id, int ih, int iw,
                       int cin, int cout, float* gn_partial, hipStream_t s, int act = MEDNET_ACT_NONE,
-                      const void* add = nullptr, GnbSpec gnb = GnbSpec(), FwdPlanProbe* probe = nullptr) {
+                      const void* add = nullptr, GnbSpec gnb = GnbSpec(), FwdPlanProbe* probe = nullptr, size_t lo_delta = 0) {
   using G = FwdTile<KIND>;
   constexpr int STRIDE = G::STRIDE;
   constexpr int HZ = STRIDE * (G::TZ - 1) + 3, HY = STRIDE * (G::TY - 1) + 3, HX = STRIDE * (G::TX - 1) + 3;
@@ -1738,7 +1769,11 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   a.tiles_y = (oh + G::TY - 1) / G::TY;
   a.tiles_x = (ow + G::TX - 1) / G::TX;
   a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
-  a.nkc = cin / 16;
+  const bool split = lo_delta != 0;  // split weights: the low image lies lo_delta bytes behind `sec` (FwdArgs::lo_delta)
+  MEDNET_REQUIRE(lo_delta < 0xFFFFFFFFull, MEDNET_E_UNSUPPORTED, "conv_mfma: weight images too large for split weights");
+  a.lo_delta = (unsigned)lo_delta;
+  a.nkc_in = cin / 16;
+  a.nkc = split ? 2 * a.nkc_in : a.nkc_in;  // (the general kernel: the low image as nkc_in more chunks)
   a.ncb = (cout + 31) / 32;
   auto rcp = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
   a.rcp_tiles_x = rcp(a.tiles_x); a.rcp_tiles_y = rcp(a.tiles_y); a.rcp_tiles_z = rcp(a.tiles_z); a.rcp_ncb = rcp(a.ncb);
@@ -1752,10 +1787,10 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   if (tuning_option("conv_persist", 1) && grid > 512u) grid = 512u;
   a.stats_accum = 0;
   a.stats_rows = 4 * a.tiles_z * a.tiles_y * a.tiles_x;
-  if (gn_partial && STRIDE == 1) conv_stats_plan(n, od, oh, ow, cin, cout, a.stats_rows, a.stats_accum, use_gnb);
+  if (gn_partial && STRIDE == 1) conv_stats_plan(n, od, oh, ow, cin, cout, a.stats_rows, a.stats_accum, use_gnb, split);
   a.xcd_chunk = 0;
   if constexpr (KIND == 1) {
-    if (conv32_takes(a.ntiles, cin, cout, use_gnb)) {
+    if (conv32_takes(a.ntiles, cin, cout, use_gnb, split)) {
       constexpr size_t lds32 = (size_t)2 * 4 * (HZ * HY * HX + 4) * 16 + 4 * 4096 + 256 * 16;
       static_assert(lds32 <= 160 * 1024, "two bricks of whole rows + the waves' epilogue areas + spare slots");
       a.xcd_chunk = a.ntiles % 8 == 0 ? a.ntiles / 8 : 0;
@@ -1799,31 +1834,44 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
       if (rc32) return rc32;
       return check_launch("conv32_mfma");
     }
-    if (conv2b_takes(a.ntiles, cin, cout)) {
+    if (conv2b_takes(a.ntiles, cin, cout, split)) {
       FwdArgs b2 = a;
-      b2.ncb = cout / 64;  // PAIRS of channel blocks
+      b2.ncb = split ? cout / 32 : cout / 64;  // PAIRS of channel blocks; split weights: blocks (the pair is (high, low))
       b2.rcp_ncb = rcp(b2.ncb);
       b2.nitems = ((a.ntiles + 7) / 8) * 8 * b2.ncb;
-      const int variant = use_gnb ? (C32_GNB | (add ? C32_ADD : 0))
-                                  : ((add ? C32_ADD : 0) | (gn_partial ? C32_STATS : 0) | (act != MEDNET_ACT_NONE ? C32_ACT : 0));
+      b2.nkc = a.nkc_in;
+      const int grid2 = conv2b_grid(b2.nitems);
+      const int variant = (use_gnb ? (C32_GNB | (add ? C32_ADD : 0))
+                                   : ((add ? C32_ADD : 0) | (gn_partial ? C32_STATS : 0) | (act != MEDNET_ACT_NONE ? C32_ACT : 0))) |
+                          (split ? C32_SPLIT : 0);
       MEDNET_REQUIRE(!use_gnb || act == MEDNET_ACT_NONE, MEDNET_E_UNSUPPORTED, "conv2b_mfma: no activation in the data-gradient form");
       if (probe) {
-        *probe = FwdPlanProbe{b2.stats_accum ? 6 : 5, 256, b2.nitems, b2.ncb, a.ntiles, a.tiles_z * a.tiles_y * a.tiles_x, b2.stats_accum,
+        *probe = FwdPlanProbe{b2.stats_accum ? 6 : 5, grid2, b2.nitems, b2.ncb, a.ntiles, a.tiles_z * a.tiles_y * a.tiles_x, b2.stats_accum,
                               b2.stats_rows, 0, 0, a.tiles_x, a.tiles_y, a.tiles_z};
         return MEDNET_OK;
       }
-      static bool attr2b[16] = {};
+      static bool attr2b[32] = {};
       auto go2 = [&](auto kernel) -> int {
         if (!attr2b[variant]) {
           if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C2B_LDS) != hipSuccess)
             return fail(MEDNET_E_HIP, "conv2b_mfma: cannot raise dynamic LDS to %zu", C2B_LDS);
           attr2b[variant] = true;
         }
-        hipLaunchKernelGGL(kernel, dim3(256), dim3(256), C2B_LDS, s, b2);
+        hipLaunchKernelGGL(kernel, dim3(grid2), dim3(256), C2B_LDS, s, b2);
         return MEDNET_OK;
       };
       int rc2 = MEDNET_OK;
       switch (variant) {
+        case C32_SPLIT: rc2 = go2(conv2b_mfma_kernel<C32_SPLIT>); break;
+        case C32_SPLIT | C32_ADD: rc2 = go2(conv2b_mfma_kernel<C32_SPLIT | C32_ADD>); break;
+        case C32_SPLIT | C32_STATS: rc2 = go2(conv2b_mfma_kernel<C32_SPLIT | C32_STATS>); break;
+        case C32_SPLIT | C32_STATS | C32_ADD: rc2 = go2(conv2b_mfma_kernel<C32_SPLIT | C32_STATS | C32_ADD>); break;
+        case C32_SPLIT | C32_ACT: rc2 = go2(conv2b_mfma_kernel<C32_SPLIT | C32_ACT>); break;
+        case C32_SPLIT | C32_ACT | C32_ADD: rc2 = go2(conv2b_mfma_kernel<C32_SPLIT | C32_ACT | C32_ADD>); break;
+        case C32_SPLIT | C32_ACT | C32_STATS: rc2 = go2(conv2b_mfma_kernel<C32_SPLIT | C32_ACT | C32_STATS>); break;
+        case C32_SPLIT | C32_ACT | C32_STATS | C32_ADD: rc2 = go2(conv2b_mfma_kernel<C32_SPLIT | C32_ACT | C32_STATS | C32_ADD>); break;
+        case C32_SPLIT | C32_GNB: rc2 = go2(conv2b_mfma_kernel<C32_SPLIT | C32_GNB>); break;
+        case C32_SPLIT | C32_GNB | C32_ADD: rc2 = go2(conv2b_mfma_kernel<C32_SPLIT | C32_GNB | C32_ADD>); break;
         case 0: rc2 = go2(conv2b_mfma_kernel<0>); break;
         case C32_ADD: rc2 = go2(conv2b_mfma_kernel<C32_ADD>); break;
         case C32_STATS: rc2 = go2(conv2b_mfma_kernel<C32_STATS>); break;
@@ -1881,43 +1929,45 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
 }
 
 int launch_conv_mfma(const void* x, const void* packed_section, void* y, int n, int d, int h, int w, int cin, int cout,
-                     int x_dtype, int y_dtype, float* gn_partial, hipStream_t s, int act, const void* add) {
+                     int x_dtype, int y_dtype, float* gn_partial, hipStream_t s, int act, const void* add, size_t lo_delta) {
   (void)x_dtype;
   (void)y_dtype;
-  if (conv_fwd_kind(n, d, h, w, cin, cout, false) == 3)
-    return launch_fwd<3>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, gn_partial, s, act, add);
-  return launch_fwd<1>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, gn_partial, s, act, add);
+  if (conv_fwd_kind(n, d, h, w, cin, cout, false, lo_delta != 0) == 3)
+    return launch_fwd<3>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, gn_partial, s, act, add, GnbSpec(), nullptr, lo_delta);
+  return launch_fwd<1>(x, packed_section, y, n, d, h, w, d, h, w, cin, cout, gn_partial, s, act, add, GnbSpec(), nullptr, lo_delta);
 }
 // data gradient + the first pass of the GroupNorm backward its output feeds (gn_partial: per-channel {sum du, sum du*y})
 int launch_conv_mfma_gnb(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin, int cout,
-                         const void* add, const void* gn_y, const float* gn_coef, int gn_act, float* gn_partial, hipStream_t s) {
+                         const void* add, const void* gn_y, const float* gn_coef, int gn_act, float* gn_partial, hipStream_t s,
+                         size_t lo_delta) {
   GnbSpec g;
   g.y = gn_y;
   g.coef = gn_coef;
   g.act = gn_act;
-  if (conv_fwd_kind(n, d, h, w, cin, cout, true) == 3)
-    return launch_fwd<3>(dy, packed_section, dx, n, d, h, w, d, h, w, cin, cout, gn_partial, s, MEDNET_ACT_NONE, add, g);
-  return launch_fwd<1>(dy, packed_section, dx, n, d, h, w, d, h, w, cin, cout, gn_partial, s, MEDNET_ACT_NONE, add, g);
+  if (conv_fwd_kind(n, d, h, w, cin, cout, true, lo_delta != 0) == 3)
+    return launch_fwd<3>(dy, packed_section, dx, n, d, h, w, d, h, w, cin, cout, gn_partial, s, MEDNET_ACT_NONE, add, g, nullptr, lo_delta);
+  return launch_fwd<1>(dy, packed_section, dx, n, d, h, w, d, h, w, cin, cout, gn_partial, s, MEDNET_ACT_NONE, add, g, nullptr, lo_delta);
 }
 // plan of launch_conv_mfma / launch_conv_mfma_gnb (stride 1) or launch_convt_dgrad_gn_mfma (stride 2; d, h, w = the LOW-resolution
 // grid the data gradient writes), with fused sums: out[13] = the fields of FwdPlanProbe in order
-int conv_mfma_plan(int n, int d, int h, int w, int cin, int cout, bool gnb, int stride, int* out) {
+int conv_mfma_plan(int n, int d, int h, int w, int cin, int cout, bool gnb, int stride, int* out, bool split) {
   FwdPlanProbe p{};
+  const size_t lo = split ? 256 : 0;  // (any non-zero distance: the probe returns before the launch)
   float dummy_partial;  // (never dereferenced: the probe returns before the launch)
   GnbSpec g;
   int rc;
   if (stride == 2) {
     g.y = g.z = &dummy_partial;
     rc = launch_fwd<2>(nullptr, nullptr, nullptr, n, d, h, w, 2 * d, 2 * h, 2 * w, cout, cin, &dummy_partial, nullptr, MEDNET_ACT_NONE,
-                       nullptr, g, &p);
+                       nullptr, g, &p, lo);
   } else {
     if (gnb) {
       g.y = &dummy_partial;
       g.coef = &dummy_partial;
     }
-    rc = conv_fwd_kind(n, d, h, w, cin, cout, gnb) == 3
-             ? launch_fwd<3>(nullptr, nullptr, nullptr, n, d, h, w, d, h, w, cin, cout, &dummy_partial, nullptr, MEDNET_ACT_NONE, nullptr, g, &p)
-             : launch_fwd<1>(nullptr, nullptr, nullptr, n, d, h, w, d, h, w, cin, cout, &dummy_partial, nullptr, MEDNET_ACT_NONE, nullptr, g, &p);
+    rc = conv_fwd_kind(n, d, h, w, cin, cout, gnb, split) == 3
+             ? launch_fwd<3>(nullptr, nullptr, nullptr, n, d, h, w, d, h, w, cin, cout, &dummy_partial, nullptr, MEDNET_ACT_NONE, nullptr, g, &p, lo)
+             : launch_fwd<1>(nullptr, nullptr, nullptr, n, d, h, w, d, h, w, cin, cout, &dummy_partial, nullptr, MEDNET_ACT_NONE, nullptr, g, &p, lo);
   }
   if (rc) return rc;
   const int v[13] = {p.kind, p.grid, p.nitems, p.ncb, p.ntiles, p.tiles_per_sample, p.accum, p.rows, p.xcd_chunk, p.zslab,
@@ -1925,23 +1975,24 @@ int conv_mfma_plan(int n, int d, int h, int w, int cin, int cout, bool gnb, int 
   for (int i = 0; i < 13; ++i) out[i] = v[i];
   return MEDNET_OK;
 }
-int conv_mfma_stats_chunks(int n, int d, int h, int w, int cin, int cout, bool gnb) {
+int conv_mfma_stats_chunks(int n, int d, int h, int w, int cin, int cout, bool gnb, bool split) {
   int rows, accum;
-  conv_stats_plan(n, d, h, w, cin, cout, rows, accum, gnb);
+  conv_stats_plan(n, d, h, w, cin, cout, rows, accum, gnb, split);
   // (A/B knob conv_fuse_gnb_general=0: only the 32 -> 32 specialisation takes the GroupNorm-backward sums in its epilogue; the
   //  general kernel's data gradients leave them to the stand-alone pass)
   if (gnb && !tuning_option("conv_fuse_gnb_general", 1)) {
     using G = FwdTile<1>;
     const int ntiles16 = n * ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
-    if (!conv32_takes(ntiles16, cin, cout, true)) return 0;
+    if (!conv32_takes(ntiles16, cin, cout, true, split)) return 0;
   }
   return rows;
 }
 
 int launch_convt_dgrad_mfma(const void* dy, const void* packed_section, void* dx, int n, int d, int h, int w, int cin,
-                            int cout, hipStream_t s) {
+                            int cout, hipStream_t s, size_t lo_delta) {
   // dx (d,h,w; Cin channels) <- dy (2d,2h,2w; Cout channels)
-  return launch_fwd<2>(dy, packed_section, dx, n, d, h, w, 2 * d, 2 * h, 2 * w, cout, cin, nullptr, s);
+  return launch_fwd<2>(dy, packed_section, dx, n, d, h, w, 2 * d, 2 * h, 2 * w, cout, cin, nullptr, s, MEDNET_ACT_NONE, nullptr, GnbSpec(),
+                       nullptr, lo_delta);
 }
 // ... + the first pass of the GroupNorm-3 backward of the ExtResNetBlock whose output the ConvTranspose3d upsamples
 // (model.py:202-207): one partial row per wave and brick, gn_partial[n][rows][Cin][2]
@@ -1950,12 +2001,13 @@ int convt_dgrad_gn_rows(int d, int h, int w) {
   return 4 * ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
 }
 int launch_convt_dgrad_gn_mfma(const void* dy, const void* packed_section, void* dx, const void* gn_y, const void* gn_z, int gn_act,
-                               float* gn_partial, int n, int d, int h, int w, int cin, int cout, hipStream_t s) {
+                               float* gn_partial, int n, int d, int h, int w, int cin, int cout, hipStream_t s, size_t lo_delta) {
   GnbSpec g;
   g.y = gn_y;
   g.z = gn_z;
   g.act = gn_act;
-  return launch_fwd<2>(dy, packed_section, dx, n, d, h, w, 2 * d, 2 * h, 2 * w, cout, cin, gn_partial, s, MEDNET_ACT_NONE, nullptr, g);
+  return launch_fwd<2>(dy, packed_section, dx, n, d, h, w, 2 * d, 2 * h, 2 * w, cout, cin, gn_partial, s, MEDNET_ACT_NONE, nullptr, g,
+                       nullptr, lo_delta);
 }
 
 // ================================================================================================== weight gradient

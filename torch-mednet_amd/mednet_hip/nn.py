@@ -20,7 +20,7 @@ class _PackedWeightMixin:
 
     def _packed(self):
         w = self.weight
-        key = (w.data_ptr(), w._version, getattr(w, "_mednet_step", 0), str(w.device), config.act_dtype())
+        key = (w.data_ptr(), w._version, getattr(w, "_mednet_step", 0), str(w.device), config.act_dtype(), config.pack_elt())
         if getattr(self, "_pack_key", None) != key:
             self._pack_buf = ops.pack_conv_weight(w, self.kernel_size[0], self._transposed)
             self._pack_key = key

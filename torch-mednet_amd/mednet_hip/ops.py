@@ -232,8 +232,8 @@ def pack_conv_weight(weight: torch.Tensor, ksize: int, transposed: bool) -> torc
     cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
     nbytes = L.lib().mednet_conv3d_pack_bytes(cin, cout, ksize)
     buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    # element type of the matrix-core fragment images; fp32 storage: bf16 high + low images (split-bf16 contraction)
-    elt = {torch.float16: L.F16, torch.bfloat16: L.BF16}.get(config.act_dtype(), L.F32)
+    # element type of the matrix-core fragment images; fp32 storage: bf16 high + low images (split-bf16 contraction); fp16x2: fp16 + low
+    elt = config.pack_elt()
     L.check(L.lib().mednet_conv3d_pack_elt(w.data_ptr(), buf.data_ptr(), cin, cout, ksize, int(transposed), elt, L.stream()),
             "conv3d_pack")
     return buf

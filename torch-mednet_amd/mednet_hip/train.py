@@ -141,7 +141,7 @@ class BatchedRepack:
 
     def _signature(self):
         from . import config
-        return tuple((m.weight.data_ptr(), m._pack_buf.data_ptr()) for m in self.mods) + (config.act_dtype(),)
+        return tuple((m.weight.data_ptr(), m._pack_buf.data_ptr()) for m in self.mods) + (config.act_dtype(), config.split_weights())
 
     def run(self):
         """Call right after the parameters changed (same stream).  No-op until every layer has been packed once."""
@@ -165,11 +165,11 @@ class BatchedRepack:
             L.check(lib.mednet_conv3d_pack_table(C.addressof(jobs), len(self.mods), host.data_ptr(), C.addressof(mb)), "pack_table")
             self.table = host.to(self.mods[0].weight.device)
             self.max_blocks, self.sig = mb.value, sig
-        elt = {torch.float16: L.F16, torch.bfloat16: L.BF16}.get(config.act_dtype(), L.F32)  # (F32: + the low images)
+        elt = config.pack_elt()  # (fp32 storage: bf16 + the low images; fp16x2: fp16 + the low images)
         L.check(lib.mednet_conv3d_pack_many(self.table.data_ptr(), len(self.mods), self.max_blocks, elt, L.stream()), "pack_many")
         for m in self.mods:  # what _PackedWeightMixin._packed() will compute at the next forward
             w = m.weight
-            m._pack_key = (w.data_ptr(), w._version, getattr(w, "_mednet_step", 0), str(w.device), config.act_dtype())
+            m._pack_key = (w.data_ptr(), w._version, getattr(w, "_mednet_step", 0), str(w.device), config.act_dtype(), config.pack_elt())
 
 
 class LossScaler:
