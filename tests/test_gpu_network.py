@@ -449,8 +449,8 @@ def test_cfg2_128_fp16_storage_against_reference_golden(golden_dir):
 
 # cfg5 at full size against the reference (tests/golden/res_cfg5_full.npz: the reference's ResidualUNet3D
 # [64 .. 1024] on one 160 x 160 x 96 patch, fp32 on the CPU, bit-equal to the oracle; tools/make_golden.py).
-# fp32 storage: the north-star 1e-3.  16-bit storage: the bounds of the 128^3 tests of the same modes.
-@pytest.mark.parametrize("mode", ["fp32", "fp16", "bf16"])
+# fp32 storage and fp16x2 (fp16 storage + split weights): the north-star 1e-3.  16-bit storage: the bounds of the 128^3 tests of the same modes.
+@pytest.mark.parametrize("mode", ["fp32", "fp16x2", "fp16", "bf16"])
 def test_cfg5_full_size_against_reference_golden(mode, golden_dir):
     from mednet_hip.train import SegmentationStep
     rec = np.load(os.path.join(golden_dir, "res_cfg5_full.npz"))
@@ -459,6 +459,7 @@ def test_cfg5_full_size_against_reference_golden(mode, golden_dir):
     assert shape == (160, 160, 96) and int(rec["meta.n"]) == 1
     batch = {k: v.to(DEV) for k, v in O.synthetic_batch(1, 1, shape, 4, 0, seed=int(rec["meta.seed"])).items()}
     logit_tol, loss_tol, norm_tol, proj_tol = {"fp32": (1e-3, 1e-4, 1e-3, 4e-3),
+                                               "fp16x2": (1e-3, 1e-4, 1e-3, 4e-3),  # (fp16 storage + split weights: the fp32 mode's bounds)
                                                "fp16": (FP16_LOGITS, 1e-3, FP16_GRAD_NORM, FP16_GRAD_PROJ),
                                                "bf16": (BF16_128_LOGITS, BF16_128_LOSS, BF16_128_GRAD_NORM, BF16_128_GRAD_PROJ)}[mode]
     with mednet_hip.precision(mode):
