@@ -55,7 +55,9 @@ def audit(n, p):
             items = []
             i = b
             while i < p["nitems"]:
-                tile, cb = (i >> 3) // ncb * 8 + (i & 7), (i >> 3) % ncb
+                lq, cb = (i >> 3) // ncb, (i >> 3) % ncb
+                # (conv2b with a brick count that is a multiple of 8: XCD i & 7 owns a contiguous run of xcd_chunk bricks)
+                tile = (i & 7) * p["xcd_chunk"] + lq if (p["kind"] in (5, 6) and p["xcd_chunk"]) else lq * 8 + (i & 7)
                 if tile >= p["ntiles"]:
                     break  # padding item: the kernel returns (first item) or stops (later ones)
                 items.append((tile, cb))

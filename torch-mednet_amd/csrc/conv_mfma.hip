@@ -1840,6 +1840,7 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
       b2.rcp_ncb = rcp(b2.ncb);
       b2.nitems = ((a.ntiles + 7) / 8) * 8 * b2.ncb;
       b2.nkc = a.nkc_in;
+      b2.xcd_chunk = (a.ntiles % 8 == 0 && tuning_option("conv2b_xcd_walk", 1)) ? a.ntiles / 8 : 0;
       const int grid2 = conv2b_grid(b2.nitems);
       const int variant = (use_gnb ? (C32_GNB | (add ? C32_ADD : 0))
                                    : ((add ? C32_ADD : 0) | (gn_partial ? C32_STATS : 0) | (act != MEDNET_ACT_NONE ? C32_ACT : 0))) |
@@ -1847,7 +1848,7 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
       MEDNET_REQUIRE(!use_gnb || act == MEDNET_ACT_NONE, MEDNET_E_UNSUPPORTED, "conv2b_mfma: no activation in the data-gradient form");
       if (probe) {
         *probe = FwdPlanProbe{b2.stats_accum ? 6 : 5, grid2, b2.nitems, b2.ncb, a.ntiles, a.tiles_z * a.tiles_y * a.tiles_x, b2.stats_accum,
-                              b2.stats_rows, 0, 0, a.tiles_x, a.tiles_y, a.tiles_z};
+                              b2.stats_rows, b2.xcd_chunk, 0, a.tiles_x, a.tiles_y, a.tiles_z};
         return MEDNET_OK;
       }
       static bool attr2b[32] = {};
