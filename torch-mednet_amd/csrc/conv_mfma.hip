@@ -1329,7 +1329,10 @@ struct C1Args {
 
 __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
   constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, NV = HZ * HY * HX, NTW = 4;
-  __shared__ float xs[NV];
+  // the halo brick of the input, ALREADY split into its elt high and low parts (x = hi + lo to ~2^-17): every halo value feeds up to 27
+  // taps, and split where it is gathered (round 1-5) the two conversions and the subtraction ran once per tap, tile and k-step --
+  // 64 of the ~150 vector instructions of a tile in a kernel that is instruction-bound (round 6)
+  __shared__ elt xs_hi[NV], xs_lo[NV];
   __shared__ __attribute__((aligned(16))) elt epi[4 * 1024];  // per wave: one tile of 32 voxels x 32 channels on its way out
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
   const int tile = blockIdx.x / a.ncb, cb = blockIdx.x % a.ncb;
@@ -1365,9 +1368,12 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
     const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
     const int gz = tz0 - 1 + hz, gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
     const size_t gi = (((size_t)n * a.d + gz) * a.h + gy) * a.w_ + gx;
-    xs[i] = (gz >= 0 && gz < a.d && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_)
-                ? (a.x16 ? (float)reinterpret_cast<const elt*>(a.x)[gi] : a.x[gi])
-                : 0.f;
+    const float xv = (gz >= 0 && gz < a.d && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_)
+                         ? (a.x16 ? (float)reinterpret_cast<const elt*>(a.x)[gi] : a.x[gi])
+                         : 0.f;
+    const elt xh = (elt)xv;
+    xs_hi[i] = xh;
+    xs_lo[i] = (elt)(xv - (float)xh);
   }
   __syncthreads();
   const size_t vol = (size_t)a.d * a.h * a.w_;
@@ -1388,9 +1394,8 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
       eltx8 hi, lo;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float v = xs[base + toff[ks][j]];
-        hi[j] = (elt)v;
-        lo[j] = (elt)(v - (float)hi[j]);
+        hi[j] = xs_hi[base + toff[ks][j]];
+        lo[j] = xs_lo[base + toff[ks][j]];
       }
       acc = MEDNET_MFMA_32x32x16(wa[ks], hi, acc, 0, 0, 0);
       acc = MEDNET_MFMA_32x32x16(wa[ks], lo, acc, 0, 0, 0);
