@@ -1084,6 +1084,78 @@ def test_two_block_kernel_is_bit_identical_to_the_general_kernel(mode, n, cin, c
     assert_close(a["act0False"][0], yr, 6e-3 if mode == "bf16" else 1e-3, "y vs ATen")
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("n,shape", [
+    (1, (32, 32, 64)),    # 1024 bricks of 2 x 4 x 16: four per workgroup, a contiguous run per XCD
+    (2, (16, 32, 32)),    # 512 bricks over two samples: the sample changes between XCDs
+    (3, (14, 30, 40)),    # ragged in z, y and x (7 x 8 x 3 = 168 brick slots per sample, 504 in all: interleaved walk, the sample
+                          # changes inside a workgroup's list, bricks that hang over every face)
+    (1, (10, 12, 100)),   # 105 brick slots: fewer than CUs -> the general kernel keeps the call (plan kind 2)
+])
+def test_convt_dgrad32_is_bit_identical_to_the_general_kernel(mode, n, shape):
+    """The data gradient of the decoder's last ConvTranspose3d (64 -> 32; components.py:259-264) runs convt_dgrad32_mfma_kernel
+    (round 6: one wave per SIMD, the wave's 54 weight fragments in registers, whole 64-byte gradient rows staged once for both
+    channel blocks).  Same accumulation order as conv_mfma_kernel<2> (option convt_dgrad32=0): dx must be equal BIT FOR BIT, with
+    and without the fused first pass of the GroupNorm-3 backward, whose partial sums agree up to fp32 summation order."""
+    lib = L.lib()
+    dt = torch.bfloat16 if mode == "bf16" else torch.float16
+    dcode = L.dt(torch.empty(0, dtype=dt))
+    CL = torch.channels_last_3d
+    g = torch.Generator(device=DEV).manual_seed(29)
+    cin, cout = 64, 32
+    d, h, wd = shape
+
+    def rand(c, shp):
+        return torch.randn(n, c, *shp, device=DEV, generator=g).to(dt).contiguous(memory_format=CL)
+    dy = rand(cout, (2 * d, 2 * h, 2 * wd))
+    gy, gz = rand(cin, shape), rand(cin, shape)
+    w = torch.randn(cin, cout, 3, 3, 3, device=DEV, generator=g) * 0.05
+    st = torch.cuda.current_stream().cuda_stream
+    ALGO_MFMA = 2
+    with mednet_hip.precision(mode):
+        pk = ops.pack_conv_weight(w, 3, True)
+    plan = (ctypes.c_int * 13)()
+    tiles = n * ((d + 1) // 2) * ((h + 3) // 4) * ((wd + 15) // 16)
+
+    def run(special):
+        assert lib.mednet_set_option(b"convt_dgrad32", special) == 0
+        assert lib.mednet_conv3d_stats_plan(n, d, h, wd, cin, cout, dcode, 1, 2, plan) == 0
+        assert plan[0] == (7 if special and tiles >= 256 else 2), list(plan)
+        out = {}
+        dx = torch.full((n, cin, *shape), float("nan"), device=DEV).to(dt).contiguous(memory_format=CL)
+        L.check(lib.mednet_convt3d_dgrad(dy.data_ptr(), pk.data_ptr(), dx.data_ptr(), n, d, h, wd, cin, cout, dcode, dcode, ALGO_MFMA, st),
+                "convt3d_dgrad")
+        out["plain"] = (dx, None)
+        rows = lib.mednet_convt3d_dgrad_gn_rows(n, d, h, wd, cin, cout, dcode, ALGO_MFMA)
+        assert rows == plan[7] > 0, (rows, list(plan))
+        for gact in (1, 2, 3):
+            dx = torch.full((n, cin, *shape), float("nan"), device=DEV).to(dt).contiguous(memory_format=CL)
+            part = torch.full((n, rows, cin, 2), float("nan"), device=DEV)
+            L.check(lib.mednet_convt3d_dgrad_gn(dy.data_ptr(), pk.data_ptr(), dx.data_ptr(), gy.data_ptr(), gz.data_ptr(), gact,
+                                                part.data_ptr(), n, d, h, wd, cin, cout, dcode, ALGO_MFMA, st), "convt3d_dgrad_gn")
+            out[f"gn{gact}"] = (dx, part.double().sum(1))
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        a, b = run(1), run(0)
+    finally:
+        lib.mednet_set_option(b"convt_dgrad32", 1)
+    nv = float(np.prod(shape))
+    for k in a:
+        assert bool(torch.isfinite(a[k][0].float()).all()), f"{k}: part of dx was not written"
+        assert torch.equal(a[k][0], b[k][0]), f"{k}: dx differs from the general kernel ({(a[k][0] != b[k][0]).float().mean().item():.3%} of the elements)"
+        if a[k][1] is not None:
+            ta, tb = a[k][1], b[k][1]
+            assert ta.shape == tb.shape and bool(torch.isfinite(ta).all()), f"{k}: a row of the partial buffer was not written"
+            scale = tb.abs().amax(dim=(1,), keepdim=True) + 1e-3
+            assert torch.all((ta - tb).abs() <= 5e-5 * scale + 2e-5 * tb.abs() + 1e-3 * nv ** 0.5 * 1e-2), f"{k}: partial sums differ"
+    # ... and against ATen: dx = conv3d(dy, W^T, stride 2, padding 1) -- the adjoint of conv_transpose3d
+    xr = torch.zeros(n, cin, *shape, dtype=torch.float64, requires_grad=True)
+    F.conv_transpose3d(xr, w.to(dt).double().cpu(), None, stride=2, padding=1, output_padding=1).backward(dy.double().cpu())
+    assert_close(a["plain"][0], xr.grad.float(), 6e-3 if mode == "bf16" else 1e-3, "dx vs ATen")
+
+
 @pytest.mark.parametrize("kind,n,cin,cout,shape", [
     ("conv", 1, 32, 32, (32, 64, 64)),     # conv2b's (high, low) form in place of the 32 -> 32 specialisation, 256 bricks
     ("conv", 2, 64, 128, (16, 24, 48)),    # four channel blocks, 36 bricks per sample: fewer items than CUs, padding items

@@ -102,6 +102,25 @@ def audit(n, p):
             for nn in range(n):  # (workgroups without bricks still owe their zero rows)
                 for wv in range(4):
                     put(written, (nn, b * 4 + wv, 0))
+    elif p["kind"] == 7:
+        # convt_dgrad32_mfma_kernel (round 6): one workgroup per CU, wave = (channel block, z-plane of the 2 x 4 x 16 brick); a wave keeps
+        # its sums over the workgroup's bricks of a sample: row 2 * workgroup + z-plane, the two waves of a plane write its two halves
+        grid = p["grid"]
+        assert grid == 256 and p["ncb"] == 2 and p["rows"] == 2 * grid and p["ntiles"] >= grid
+        for b in range(grid):
+            seq, step, end = (b >> 3, grid >> 3, p["xcd_chunk"]) if p["xcd_chunk"] else (b, grid, p["ntiles"])
+            samples = []
+            for q in range(seq, end, step):
+                tile = (b & 7) * p["xcd_chunk"] + q if p["xcd_chunk"] else q
+                assert 0 <= tile < p["ntiles"]
+                for cb in range(2):
+                    put(computed, (tile, cb))
+                samples.append(tile // p["tps"])
+            assert samples == sorted(samples), f"workgroup {b} re-opens a sample"
+            for nn in range(n):
+                for nt in range(2):
+                    for cb in range(2):
+                        put(written, (nn, 2 * b + nt, cb))
     else:
         raise AssertionError(f"unknown plan kind {p['kind']}")
     return written, computed
@@ -144,8 +163,8 @@ CFG = {"cfg5": ([64, 128, 256, 512, 1024], (160, 160, 96), 2), "cfg2": ([32, 64,
 
 
 # which kernels the layers of the two benchmarked configurations go to: conv_mfma_kernel per-brick rows (2) / accumulate mode (3), the
-# 32 -> 32 specialisation (4), the two-block kernel per-brick rows (5) / accumulate mode (6)
-EXPECTED_KINDS = {"cfg5": {2, 3, 5, 6}, "cfg2": {2, 3, 4, 6}}
+# 32 -> 32 specialisation (4), the two-block kernel per-brick rows (5) / accumulate mode (6), the ConvTranspose3d 64 -> 32 data gradient (7)
+EXPECTED_KINDS = {"cfg5": {2, 3, 5, 6}, "cfg2": {2, 3, 4, 6, 7}}
 
 
 @pytest.mark.parametrize("dtype", [BF16, F16])

@@ -562,7 +562,7 @@ static bool convt_dgrad_mfma_ok(int n, int d, int h, int w, int cin, int cout, i
 }
 extern "C" int mednet_convt3d_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, int dtype, int algo) {
   if (algo_base(algo) == MEDNET_ALGO_DIRECT || !tuning_option("gn3_fuse", 1) || !convt_dgrad_mfma_ok(n, d, h, w, cin, cout, dtype)) return 0;
-  return ELT_CALL(dtype, convt_dgrad_gn_rows, d, h, w);
+  return ELT_CALL(dtype, convt_dgrad_gn_rows, n, d, h, w, cin, cout, algo_split(algo, dtype));
 }
 extern "C" int mednet_convt3d_dgrad_gn(const void* dy, const void* packed, void* dx, const void* gn_y, const void* gn_z, int gn_act,
                                        float* gn_partial, int n, int d, int h, int w, int cin, int cout, int dtype, int algo,

@@ -1087,6 +1087,7 @@ __global__ __launch_bounds__(256, 1) void conv32_mfma_kernel(FwdArgs a) {
 }
 
 #include "conv2b_mfma.inc"
+#include "convt_dgrad32_mfma.inc"
 
 // ================================================================================================== ConvTranspose3d forward
 // out[2j + p] = bias + skip + sum_{taps k of parity class p} W[k] * x[j + delta_k]   (per dim: k=1 -> p=0,d=0; k=0 -> p=1,d=1;
@@ -1703,6 +1704,11 @@ static int conv_fwd_kind(int n, int d, int h, int w, int cin, int cout, bool gnb
 }
 // workgroups of a conv2b launch: one per CU, fewer (a multiple of 8) when the launch has fewer items
 static int conv2b_grid(int nitems) { return nitems < 256 ? nitems : 256; }
+// The ConvTranspose3d data-gradient specialisation (convt_dgrad32_mfma_kernel, round 6): 32 gradient channels in, 64 out, one
+// workgroup per CU with at least one 2 x 4 x 16 brick each; split weights stay with the general kernel (one image in registers)
+static bool convt_dgrad32_takes(int ntiles, int k_dy, int m_dx, bool split) {
+  return k_dy == 32 && m_dx == 64 && !split && ntiles >= 256 && ::mednet_internal_cu_count() == 256 && tuning_option("convt_dgrad32", 1);
+}
 static void conv_stats_plan(int n, int d, int h, int w, int cin, int cout, int& rows, int& accum, bool gnb = false, bool split = false) {
   const int tx = conv_fwd_kind(n, d, h, w, cin, cout, gnb, split) == 3 ? FwdTile<3>::TX : FwdTile<1>::TX;
   using G = FwdTile<1>;
@@ -1794,6 +1800,36 @@ static int launch_fwd(const void* x, const void* sec, void* y, int n, int od, in
   a.stats_rows = 4 * a.tiles_z * a.tiles_y * a.tiles_x;
   if (gn_partial && STRIDE == 1) conv_stats_plan(n, od, oh, ow, cin, cout, a.stats_rows, a.stats_accum, use_gnb, split);
   a.xcd_chunk = 0;
+  if constexpr (KIND == 2) {
+    if (convt_dgrad32_takes(a.ntiles, cin, cout, split) && !add && act == MEDNET_ACT_NONE) {
+      Ct32Args c;
+      c.dy = a.x; c.wpk = a.wpk; c.dx = a.y;
+      c.gn_y = a.gnb_y; c.gn_z = a.gnb_z; c.gn_partial = a.gn_partial; c.gn_act = a.gnb_act;
+      c.n = n; c.d = od; c.h = oh; c.w = ow;
+      c.tiles_z = a.tiles_z; c.tiles_y = a.tiles_y; c.tiles_x = a.tiles_x; c.ntiles = a.ntiles;
+      c.rcp_tiles_x = a.rcp_tiles_x; c.rcp_tiles_y = a.rcp_tiles_y; c.rcp_tiles_z = a.rcp_tiles_z;
+      c.bytes_dy = a.bytes_x; c.bytes_dx = a.bytes_y;
+      const int rows32 = 2 * 256;  // one row per (workgroup, z-plane of its bricks) and sample: see convt_dgrad_gn_rows
+      if (probe) {
+        *probe = FwdPlanProbe{7, 256, a.ntiles, 2, a.ntiles, a.tiles_z * a.tiles_y * a.tiles_x, 1, rows32,
+                              a.ntiles % 8 == 0 ? a.ntiles / 8 : 0, 0, a.tiles_x, a.tiles_y, a.tiles_z};
+        return MEDNET_OK;
+      }
+      static bool attr_ct32[2] = {false, false};
+      auto go = [&](auto kernel) -> int {
+        if (!attr_ct32[use_gnb]) {
+          if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CT32_LDS) != hipSuccess)
+            return fail(MEDNET_E_HIP, "convt_dgrad32_mfma: cannot raise dynamic LDS to %zu", CT32_LDS);
+          attr_ct32[use_gnb] = true;
+        }
+        hipLaunchKernelGGL(kernel, dim3(256), dim3(256), CT32_LDS, s, c);
+        return MEDNET_OK;
+      };
+      const int rc = use_gnb ? go(convt_dgrad32_mfma_kernel<true>) : go(convt_dgrad32_mfma_kernel<false>);
+      if (rc) return rc;
+      return check_launch("convt_dgrad32_mfma");
+    }
+  }
   if constexpr (KIND == 1) {
     if (conv32_takes(a.ntiles, cin, cout, use_gnb, split)) {
       constexpr size_t lds32 = (size_t)2 * 4 * (HZ * HY * HX + 4) * 16 + 4 * 4096 + 256 * 16;
@@ -2002,9 +2038,12 @@ int launch_convt_dgrad_mfma(const void* dy, const void* packed_section, void* dx
 }
 // ... + the first pass of the GroupNorm-3 backward of the ExtResNetBlock whose output the ConvTranspose3d upsamples
 // (model.py:202-207): one partial row per wave and brick, gn_partial[n][rows][Cin][2]
-int convt_dgrad_gn_rows(int d, int h, int w) {
+int convt_dgrad_gn_rows(int n, int d, int h, int w, int cin, int cout, bool split) {
   using G = FwdTile<2>;
-  return 4 * ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
+  const int tps = ((d + G::TZ - 1) / G::TZ) * ((h + G::TY - 1) / G::TY) * ((w + G::TX - 1) / G::TX);
+  // (cin, cout are the ConvTranspose3d's: its data gradient reads cout channels and writes cin)
+  if (convt_dgrad32_takes(n * tps, cout, cin, split)) return 2 * 256;  // convt_dgrad32_mfma_kernel: 2 rows per workgroup and sample
+  return 4 * tps;
 }
 int launch_convt_dgrad_gn_mfma(const void* dy, const void* packed_section, void* dx, const void* gn_y, const void* gn_z, int gn_act,
                                float* gn_partial, int n, int d, int h, int w, int cin, int cout, hipStream_t s, size_t lo_delta) {
