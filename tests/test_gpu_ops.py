@@ -1262,6 +1262,58 @@ def test_first_layer_mfma_keeps_fp32_input_precision(n, cout, shape):
     assert_close(y, bf16_round(yr), 4e-4, "y vs correctly rounded reference")
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "fp16x2"])
+@pytest.mark.parametrize("n,cout,shape", [
+    (3, 32, (40, 72, 80)),    # 3 x 450 bricks > 1024 workgroups: the persistent walk, the sample changes inside a workgroup's list
+    (2, 64, (36, 60, 70)),    # two channel blocks: 2 x 360 x 2 items, ragged in x, y and z
+    (2, 48, (30, 64, 64)),    # three halves-of-blocks: ncb = 2 with the second block half filled
+    (1, 32, (9, 11, 21)),     # fewer items than workgroups: one brick per workgroup
+])
+def test_first_layer_persistent_walk_and_fused_statistics(mode, n, cout, shape):
+    """conv_c1_mfma_kernel (model.py:171-174's first convolution, one input channel) as a persistent kernel (round 6): at most four
+    workgroups per CU walk the (brick, channel block) items and a wave keeps its GroupNorm sums over its bricks of a sample.  The
+    output must be BIT-identical to the one-workgroup-per-item launch (option conv_c1_persist=0), every partial row must be written
+    (NaN-filled buffer), and the rows must add up to the sums of the STORED output per channel pair."""
+    lib = L.lib()
+    x = rnd(f"c1p{n}{cout}{shape}x", n, 1, *shape)
+    w = rnd(f"c1p{n}{cout}{shape}w", cout, 1, 3, 3, 3, scale=0.2)
+    res = {}
+    try:
+        for persist in (1, 0):
+            lib.mednet_set_option(b"conv_c1_persist", persist)
+            with mednet_hip.precision(mode):
+                conv = hnn.Conv3d(1, cout, 3, bias=False).to(DEV)
+                with torch.no_grad():
+                    conv.weight.copy_(w)
+                # (the partial buffer comes from torch.empty: fill the allocator's block with NaNs first so that an unwritten row shows)
+                rows = lib.mednet_conv3d_fused_stats_chunks(n, *shape, 1, cout, 3, L.F32, L.dt(torch.empty(0, dtype=mednet_hip.config.act_dtype())), mednet_hip.config.conv_algo())
+                assert rows > 0
+                poison = torch.full((n, rows, cout, 2), float("nan"), device=DEV)
+                del poison
+                y, partial = conv.forward_with_stats(x.to(DEV))
+                torch.cuda.synchronize()
+                assert partial is not None and tuple(partial.shape) == (n, rows, cout, 2)
+                res[persist] = (y.detach().clone(), partial.detach().double().sum(1).cpu(), rows)
+    finally:
+        lib.mednet_set_option(b"conv_c1_persist", 1)
+    nitems = n * ((shape[0] + 3) // 4) * ((shape[1] + 7) // 8) * ((shape[2] + 15) // 16) * ((cout + 31) // 32)
+    assert res[0][2] == 4 * nitems // ((cout + 31) // 32)
+    assert res[1][2] <= min(res[0][2], 4 * 1024 // ((cout + 31) // 32)), (res[1][2], res[0][2])  # at most 4 workgroups per CU
+    assert torch.equal(res[1][0], res[0][0]), "persistent walk changed the output"
+    ys = res[1][0].double().cpu()
+    s_ref = ys.sum(dim=(2, 3, 4)).reshape(n, cout // 2, 2).sum(-1)
+    q_ref = (ys ** 2).sum(dim=(2, 3, 4)).reshape(n, cout // 2, 2).sum(-1)
+    nv = float(np.prod(shape))
+    for persist in (1, 0):
+        tot = res[persist][1]
+        assert bool(torch.isfinite(tot).all()), f"persist={persist}: a partial row was not written"
+        assert bool((tot[:, 1::2] == 0).all()), "odd entries of the pair format must be zero"
+        assert torch.all((tot[:, 0::2, 0] - s_ref).abs() <= 2e-5 * (q_ref * nv).sqrt() + 1e-3), f"persist={persist}: sum y"
+        assert torch.all((tot[:, 0::2, 1] - q_ref).abs() <= 2e-5 * q_ref + 1e-6), f"persist={persist}: sum y^2"
+    yr = F.conv3d(x, w, None, padding=1)
+    assert_close(res[1][0], yr, 6e-3 if mode == "bf16" else 1e-3, "y vs ATen")
+
+
 @pytest.mark.parametrize("n,cout,shape", [(1, 32, (4, 8, 16)), (2, 32, (9, 11, 21)), (2, 64, (5, 6, 7)), (1, 32, (20, 24, 40)),
                                           (2, 16, (9, 11, 21))])  # 16: UNet3D's first DoubleConv (components.py:119-121)
 def test_first_layer_weight_gradient_on_matrix_cores(n, cout, shape):

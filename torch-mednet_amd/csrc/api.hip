@@ -184,7 +184,7 @@ extern "C" int mednet_conv3d_fused_stats_chunks(int n, int d, int h, int w, int 
     if (conv_c1_x3_supported(cin, cout, ksize)) return tuning_option("x3_stats", 1) ? conv_c1_x3_stats_rows(d, h, w) : 0;
     return conv_x3_supported(cin, cout, ksize) && conv_x3_fits(d, h, w, cin) ? conv_x3_stats_rows(n, d, h, w, cout) : 0;
   }
-  if (ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, false)) return conv_c1_stats_chunks(d, h, w);
+  if (ELT_CALL(y_dtype, conv_c1_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, false)) return ELT_CALL(y_dtype, conv_c1_stats_chunks, n, d, h, w, cout);
   if (!ELT_CALL(y_dtype, conv_mfma_supported, cin, cout, ksize, x_dtype, y_dtype, MEDNET_NDHWC, MEDNET_NDHWC, false)) return 0;
   return conv_mfma_stats_chunks(n, d, h, w, cin, cout, false, algo_split(algo, y_dtype));
 }

@@ -1317,35 +1317,44 @@ int launch_convt_fwd_mfma(const void* x, const void* sec, const float* bias, con
 // scalar LDS reads per fragment -- and split into elt hi + lo parts (x = hi + lo to ~2^-17), so the network input keeps
 // fp32-level precision at 4 MFMAs per 32 voxels; the weights (32 x 32 elt) live in registers for the kernel's lifetime.
 // The kernel is bound by writing its output (32 channels per input voxel); the VALU formulation it replaces was 4x slower.
+// Round 6: PERSISTENT.  With one short-lived workgroup per brick, 63 % of the instruction stream was per-brick fixed cost -- the
+// weight fragments and tap offsets (21 %) and the reduction of the 32 statistics sums over the wave (42 %) -- in a kernel that
+// is instruction-bound (252 us for 537 MB of output).  Now at most 4 workgroups per CU walk the (brick, channel block) items:
+// weights and offsets are made once, the next brick's halo values are in flight (registers) while the current brick is on the
+// matrix cores, and a wave keeps its sums over all its bricks of a sample: one partial row per wave, workgroup and sample.
+// The output is bit-identical to the one-brick-per-workgroup form (same MFMA sequence per voxel); option conv_c1_persist=0
+// launches a workgroup per item.
 struct C1Args {
   const float* x;    // N x D x H x W (one channel)
   const float* w;    // packed forward image Pf[tap][co] (fp32)
   elt* y;           // NDHWC
-  float* gn_partial; // nullable: [n][4 * bricks per sample][cout][2] per-wave {sum y, sum y^2} of the stored values
+  float* gn_partial; // nullable: [n][4 * gridDim.x / ncb][cout][2] per-wave {sum y, sum y^2} of the stored values
   int n, d, h, w_, cout;
   int tiles_z, tiles_y, tiles_x, ntiles, ncb;
+  unsigned rcp_tiles_x, rcp_tiles_y, rcp_tiles_z, rcp_ncb;
   int x16;  // 1: x holds elt values (the 1-channel output of a GroupNorm in the 'gcr' orders), else fp32 (the network input)
   int split;  // split weights (MEDNET_ALGO_SPLITW_BIT): the weights' low parts elt(w - elt(w)) are multiplied too
+  unsigned bytes_x;  // one sample of x
 };
 
-__global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
+// SPLIT: the weights' low parts as a third MFMA per k-step (split weights); compiled apart so that the default form keeps no
+// registers for them (128 per lane at four workgroups per CU)
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 4) void conv_c1_mfma_kernel(C1Args a) {
   constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, NV = HZ * HY * HX, NTW = 4;
+  static_assert(NTW == TY / 2 && TZ == 4, "a wave owns one z-plane of the brick");
+  constexpr int IN_ROUNDS = (NV + 255) / 256;
+  constexpr unsigned OOB = 0xFFFFFF00u;
   // the halo brick of the input, ALREADY split into its elt high and low parts (x = hi + lo to ~2^-17): every halo value feeds up to 27
-  // taps, and split where it is gathered (round 1-5) the two conversions and the subtraction ran once per tap, tile and k-step --
-  // 64 of the ~150 vector instructions of a tile in a kernel that is instruction-bound (round 6)
+  // taps, and split where it is gathered (round 1-5) the two conversions and the subtraction ran once per tap, tile and k-step
   __shared__ elt xs_hi[NV], xs_lo[NV];
   __shared__ __attribute__((aligned(16))) elt epi[4 * 1024];  // per wave: one tile of 32 voxels x 32 channels on its way out
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int tile = blockIdx.x / a.ncb, cb = blockIdx.x % a.ncb;
-  int tt = tile;
-  const int tx0 = (tt % a.tiles_x) * TX;
-  tt /= a.tiles_x;
-  const int ty0 = (tt % a.tiles_y) * TY;
-  tt /= a.tiles_y;
-  const int tz0 = (tt % a.tiles_z) * TZ;
-  const int n = tt / a.tiles_z;
+  // items (brick, channel block) = item / ncb, item % ncb; gridDim.x is a multiple of ncb: a workgroup keeps its channel block
+  const int cb = (int)(blockIdx.x % a.ncb);
+  const int nitems = a.ntiles * a.ncb;
   // weights: A operand, lane (co = r, h) holds taps 8h..8h+7 (k-step 0) and 16+8h..16+8h+7 (k-step 1); taps >= 27 are 0
-  eltx8 wa[2], wl[2];
+  eltx8 wa[2], wl[SPLIT ? 2 : 1];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1353,7 +1362,7 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
       const int tap = ks * 16 + 8 * h + j;
       const float wf = tap < 27 && cb * 32 + r < a.cout ? a.w[(size_t)tap * a.cout + cb * 32 + r] : 0.f;  // (a 16-channel layer fills half a block)
       wa[ks][j] = (elt)wf;
-      wl[ks][j] = (elt)(wf - (float)wa[ks][j]);
+      if constexpr (SPLIT) wl[ks][j] = (elt)(wf - (float)wa[ks][j]);
     }
   // LDS offsets of this lane's 8 taps per k-step
   int toff[2][8];  // (both k-halves' offsets are compile-time constants: one select per entry instead of the divisions by 9 and 3)
@@ -1365,107 +1374,177 @@ __global__ __launch_bounds__(256) void conv_c1_mfma_kernel(C1Args a) {
       const int o0 = t0 < 27 ? ((t0 / 9) * HY + (t0 / 3) % 3) * HX + t0 % 3 : 0, o1 = t1 < 27 ? ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3 : 0;
       toff[ks][j] = h ? o1 : o0;
     }
-  for (int i = tid; i < NV; i += 256) {
-    const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
-    const int gz = tz0 - 1 + hz, gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-    const size_t gi = (((size_t)n * a.d + gz) * a.h + gy) * a.w_ + gx;
-    const float xv = (gz >= 0 && gz < a.d && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_)
-                         ? (a.x16 ? (float)reinterpret_cast<const elt*>(a.x)[gi] : a.x[gi])
-                         : 0.f;
-    const elt xh = (elt)xv;
-    xs_hi[i] = xh;
-    xs_lo[i] = (elt)(xv - (float)xh);
+  // this thread's halo positions (the same for every brick): hz << 16 | hy << 8 | hx; slots past the halo fail every range check
+  int hpos[IN_ROUNDS];
+#pragma unroll
+  for (int k = 0; k < IN_ROUNDS; ++k) {
+    const int i = tid + 256 * k;
+    hpos[k] = i < NV ? ((i / (HX * HY)) << 16) | (((i / HX) % HY) << 8) | (i % HX) : 0x7FFF0000;
   }
-  __syncthreads();
+  auto origin = [&](int item, int& n, int& tz0, int& ty0, int& tx0) {
+    int tt = fastdiv(item, a.ncb, a.rcp_ncb);
+    int qd = fastdiv(tt, a.tiles_x, a.rcp_tiles_x);
+    tx0 = (tt - qd * a.tiles_x) * TX;
+    tt = qd;
+    qd = fastdiv(tt, a.tiles_y, a.rcp_tiles_y);
+    ty0 = (tt - qd * a.tiles_y) * TY;
+    tt = qd;
+    qd = fastdiv(tt, a.tiles_z, a.rcp_tiles_z);
+    tz0 = (tt - qd * a.tiles_z) * TZ;
+    n = qd;
+  };
+  // halo values of a brick: buffer loads through a per-sample resource, positions outside the volume get an out-of-range offset
+  // and come back as zeros
+  float xin[IN_ROUNDS];
+  auto fetch = [&](int item, bool valid) {
+    int n, tz0, ty0, tx0;
+    origin(item, n, tz0, ty0, tx0);
+    const unsigned esz = a.x16 ? 2u : 4u;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(a.x) + (size_t)n * a.bytes_x), 0,
+                                                        a.bytes_x & (0u - (unsigned)valid), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < IN_ROUNDS; ++k) {
+      const int gz = tz0 - 1 + (hpos[k] >> 16), gy = ty0 - 1 + ((hpos[k] >> 8) & 255), gx = tx0 - 1 + (hpos[k] & 255);
+      const bool in_vol = ((unsigned)gz < (unsigned)a.d) & ((unsigned)gy < (unsigned)a.h) & ((unsigned)gx < (unsigned)a.w_);
+      const unsigned off = in_vol ? (unsigned)((gz * a.h + gy) * a.w_ + gx) * esz : OOB;
+      if (a.x16) {  // (workgroup-uniform)
+        const unsigned short u = __builtin_amdgcn_raw_buffer_load_b16(rsrc, off, 0, 0);
+        xin[k] = (float)__builtin_bit_cast(elt, u);
+      } else {
+        xin[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < IN_ROUNDS; ++k) {
+      const int i = tid + 256 * k;
+      if (i < NV) {
+        const elt xh = (elt)xin[k];
+        xs_hi[i] = xh;
+        xs_lo[i] = (elt)(xin[k] - (float)xh);
+      }
+    }
+  };
   const size_t vol = (size_t)a.d * a.h * a.w_;
-  float ssum[16], ssq[16];  // fused GroupNorm statistics of this lane's 16 channels over the wave's 4 N-tiles
+  // fused GroupNorm statistics, as in conv_mfma_kernel: per channel PAIR (v_dot2c_f32: two exact products + fp32 add per
+  // instruction), taken from the stored 64-byte rows -- lane = (voxel, 16-byte piece lane & 3) -- over the wave's tiles of a sample;
+  // entry 2j of the partial row gets the sums of channels 2j and 2j + 1, entry 2j + 1 is zero (GroupNorm only adds the channels of a
+  // group; the host asks for fused partials only when the channels per group are even).  Until round 6: 32 per-channel sums per
+  // lane from the accumulators, reduced over the wave once per BRICK -- 42 % of the kernel's instructions.
+  typedef __attribute__((ext_vector_type(2))) elt eltx2;
+  const eltx2 ones = {(elt)1.0f, (elt)1.0f};
+  float gs[4], gq[4];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) ssum[i] = ssq[i] = 0.f;
+  for (int k = 0; k < 4; ++k) gs[k] = gq[k] = 0.f;
+  int acc_n = 0;
+  auto flush = [&](int nn) {  // one row per wave: sum over the 16 lanes that share a piece (DPP / v_permlane steps: plain VALU)
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    const int g = wv * NTW + t;
-    const int lz = g / (TY / 2), ly = (g % (TY / 2)) * 2 + (r >> 4), lx = r & 15;
-    const int oz_t = tz0 + lz;
-    const int base = (lz * HY + ly) * HX + lx;
-    f32x16 acc;
+    for (int k = 0; k < 4; ++k) {
+      gs[k] = lane_class_sum<4>(gs[k]);
+      gq[k] = lane_class_sum<4>(gq[k]);
+    }
+    const int pjl = lane & 3;
+    if (lane < 4 && cb * 32 + pjl * 8 < a.cout) {
+      const int rows = 4 * (int)(gridDim.x / a.ncb);
+      float* dst = a.gn_partial + (((size_t)nn * rows + (blockIdx.x / a.ncb) * 4 + wv) * a.cout + cb * 32 + pjl * 8) * 2;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      eltx8 hi, lo;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        hi[j] = xs_hi[base + toff[ks][j]];
-        lo[j] = xs_lo[base + toff[ks][j]];
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 o = {gs[k], gq[k], 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(dst + k * 4) = o;
       }
-      acc = MEDNET_MFMA_32x32x16(wa[ks], hi, acc, 0, 0, 0);
-      acc = MEDNET_MFMA_32x32x16(wa[ks], lo, acc, 0, 0, 0);
-      if (a.split) acc = MEDNET_MFMA_32x32x16(wl[ks], hi, acc, 0, 0, 0);  // (workgroup-uniform)
     }
-    // The accumulator layout gives a lane four 8-byte pieces (channels 8q + 4h ..) of ITS voxel's 64-byte row: stored as they
-    // stand, one instruction touches 64 rows with 8 bytes each, and this kernel does little else than store (264 us for 537 MB).
-    // The tile goes through 2 KB of LDS private to the wave (8-byte pieces XOR-swizzled by voxel: conflict-free both ways, no
-    // barrier -- a wave's LDS operations execute in order, the fence keeps the compiler from reordering them) and leaves as whole
-    // rows: 4 lanes per voxel, 16 voxels = one x-row of the brick = 1 KB contiguous per instruction when Cout = 32.
-    const int oz = tz0 + lz, oy = ty0 + ly, ox = tx0 + lx;
-    const bool in_vol = oz < a.d && oy < a.h && ox < a.w_;
-    elt* tile_lds = epi + wv * 1024;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      eltx4 o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o[j] = (elt)acc[q * 4 + j];
-        const float f = in_vol ? (float)o[j] : 0.f;  // statistics of what is stored
-        ssum[q * 4 + j] += f;
-        ssq[q * 4 + j] = fmaf(f, f, ssq[q * 4 + j]);
+    for (int k = 0; k < 4; ++k) gs[k] = gq[k] = 0.f;
+  };
+
+  int item = blockIdx.x;  // (the launcher never starts more workgroups than items)
+  fetch(item, true);
+  while (true) {
+    int n, tz0, ty0, tx0;
+    origin(item, n, tz0, ty0, tx0);
+    const int nitem = item + (int)gridDim.x;
+    const bool has_next = nitem < nitems;
+    if (a.gn_partial) {
+      while (acc_n < n) {  // (workgroup-uniform) a new sample: the finished one's row goes out, zero rows for skipped samples
+        flush(acc_n);
+        ++acc_n;
       }
-      *reinterpret_cast<eltx4*>(tile_lds + r * 32 + (((2 * q + h) ^ ((r >> 2) & 7)) * 4)) = o;
     }
-    wave_lds_fence();
-    eltx8 rows2[2];
+    __syncthreads();  // every wave is done gathering from the previous brick
+    commit();
+    __syncthreads();
+    fetch(has_next ? nitem : item, has_next);  // in flight while this brick is on the matrix cores
+    // (a rolled loop: unrolled inside the item loop, the compiler hoists the 4 x 16 gather addresses, which are the same for every
+    //  brick, out of it and spills 181 registers at the 128 that four workgroups per CU leave)
+#pragma unroll 1
+    for (int t = 0; t < NTW; ++t) {
+      const int g = wv * NTW + t;
+      const int lz = wv, ly = t * 2 + (r >> 4), lx = r & 15;  // (N-tile g = wv * 4 + t: z-plane g / 4, rows 2 (g % 4), + 1)
+      const int oz_t = tz0 + lz;
+      const int base = (lz * HY + ly) * HX + lx;
+      f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int v = i * 16 + (lane >> 2), sw = (v >> 2) & 7;
-      eltx8 rv = *reinterpret_cast<const eltx8*>(tile_lds + v * 32 + (((lane & 3) ^ (sw >> 1)) * 8));
-      if (sw & 1) rv = __builtin_shufflevector(rv, rv, 4, 5, 6, 7, 0, 1, 2, 3);
-      rows2[i] = rv;
-    }
-    wave_lds_fence();
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int v = i * 16 + (lane >> 2);
-      const int sy = ty0 + (g % (TY / 2)) * 2 + (v >> 4), sx = tx0 + (v & 15);
-      if (oz_t < a.d && sy < a.h && sx < a.w_ && cb * 32 + (lane & 3) * 8 < a.cout)
-        __builtin_nontemporal_store(rows2[i], reinterpret_cast<eltx8*>(a.y + ((size_t)n * vol + ((size_t)oz_t * a.h + sy) * a.w_ + sx) * a.cout + cb * 32 + (lane & 3) * 8));
-    }
-  }
-  if (a.gn_partial) {  // one row per wave: sum over the 32 voxel lanes of each k-half, lanes r == 0 write their 16 channels
-    // (DPP / v_permlane16_swap steps: plain VALU.  As __shfl_xor -- ds_bpermute_b32, 320 LDS-queue instructions per wave -- this
-    //  reduction was a quarter of the kernel's time)
-    auto half_sum = [](float v) {  // sum over the 32 lanes that share lane / 32, in every lane
-      v += dpp_f32<0xB1>(v);
-      v += dpp_f32<0x4E>(v);
-      v += dpp_f32<0x124>(v);
-      v += dpp_f32<0x128>(v);
-      return xor16_sum(v);
-    };
+      for (int ks = 0; ks < 2; ++ks) {
+        eltx8 hi, lo;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      ssum[i] = half_sum(ssum[i]);
-      ssq[i] = half_sum(ssq[i]);
-    }
-    if (r == 0) {
-      const int tps = a.tiles_x * a.tiles_y * a.tiles_z;
-      float* dst = a.gn_partial + ((((size_t)n * tps + tile % tps) * 4 + wv) * a.cout + cb * 32) * 2;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (cb * 32 + 8 * q + 4 * h + j >= a.cout) continue;
-          dst[(8 * q + 4 * h + j) * 2] = ssum[q * 4 + j];
-          dst[(8 * q + 4 * h + j) * 2 + 1] = ssq[q * 4 + j];
+        for (int j = 0; j < 8; ++j) {
+          hi[j] = xs_hi[base + toff[ks][j]];
+          lo[j] = xs_lo[base + toff[ks][j]];
         }
+        acc = MEDNET_MFMA_32x32x16(wa[ks], hi, acc, 0, 0, 0);
+        acc = MEDNET_MFMA_32x32x16(wa[ks], lo, acc, 0, 0, 0);
+        if constexpr (SPLIT) acc = MEDNET_MFMA_32x32x16(wl[ks], hi, acc, 0, 0, 0);
+      }
+      // The accumulator layout gives a lane four 8-byte pieces (channels 8q + 4h ..) of ITS voxel's 64-byte row: stored as they
+      // stand, one instruction touches 64 rows with 8 bytes each, and this kernel does little else than store.
+      // The tile goes through 2 KB of LDS private to the wave (8-byte pieces XOR-swizzled by voxel: conflict-free both ways, no
+      // barrier -- a wave's LDS operations execute in order, the fence keeps the compiler from reordering them) and leaves as whole
+      // rows: 4 lanes per voxel, 16 voxels = one x-row of the brick = 1 KB contiguous per instruction when Cout = 32.
+      elt* tile_lds = epi + wv * 1024;
+      wave_lds_fence();  // (the previous tile's row reads stay above these writes)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        eltx4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (elt)acc[q * 4 + j];
+        *reinterpret_cast<eltx4*>(tile_lds + r * 32 + (((2 * q + h) ^ ((r >> 2) & 7)) * 4)) = o;
+      }
+      wave_lds_fence();
+      eltx8 rows2[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int v = i * 16 + (lane >> 2), sw = (v >> 2) & 7;
+        eltx8 rv = *reinterpret_cast<const eltx8*>(tile_lds + v * 32 + (((lane & 3) ^ (sw >> 1)) * 8));
+        if (sw & 1) rv = __builtin_shufflevector(rv, rv, 4, 5, 6, 7, 0, 1, 2, 3);
+        rows2[i] = rv;
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int v = i * 16 + (lane >> 2);
+        const int sy = ty0 + (g % (TY / 2)) * 2 + (v >> 4), sx = tx0 + (v & 15);
+        const bool ok = oz_t < a.d && sy < a.h && sx < a.w_ && cb * 32 + (lane & 3) * 8 < a.cout;
+        if (ok)
+          __builtin_nontemporal_store(rows2[i], reinterpret_cast<eltx8*>(a.y + ((size_t)n * vol + ((size_t)oz_t * a.h + sy) * a.w_ + sx) * a.cout + cb * 32 + (lane & 3) * 8));
+        const eltx8 vz = ok ? rows2[i] : eltx8{};  // statistics of what is stored
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const eltx2 pr = {vz[2 * k], vz[2 * k + 1]};
+          gs[k] = MEDNET_FDOT2(pr, ones, gs[k], false);
+          gq[k] = MEDNET_FDOT2(pr, pr, gq[k], false);
+        }
+      }
+    }
+    if (!has_next) break;
+    item = nitem;
+  }
+  if (a.gn_partial) {
+    while (acc_n < a.n) {  // the last sample of this workgroup, then zero rows for the samples after it
+      flush(acc_n);
+      ++acc_n;
     }
   }
 }
@@ -1474,7 +1553,29 @@ bool conv_c1_mfma_supported(int cin, int cout, int ksize, int x_dtype, int y_dty
   return cin == 1 && ksize == 3 && cout % 16 == 0 && (x_dtype == MEDNET_F32 || x_dtype == ELT_DTYPE) && y_dtype == ELT_DTYPE &&
          y_layout == MEDNET_NDHWC && !bias;
 }
-int conv_c1_stats_chunks(int d, int h, int w) { return 4 * ((d + 3) / 4) * ((h + 7) / 8) * ((w + 15) / 16); }
+// workgroups of a launch: 4, 3 or 2 per CU -- whichever leaves the last round of the walk fullest (the item count of config 5's
+// first layer, 14 400, is 14.06 rounds of 1024 workgroups: 15 rounds with the last one 6 % full, measured 6 % slower than 18.75
+// rounds of 768) -- rounded down to a multiple of the channel-block count so that a workgroup keeps its block; one per (brick,
+// channel block) item when there are no more items than that, or with option conv_c1_persist=0
+static int conv_c1_grid(int n, int d, int h, int w, int cout) {
+  const int ncb = (cout + 31) / 32;
+  const int nitems = n * ((d + 3) / 4) * ((h + 7) / 8) * ((w + 15) / 16) * ncb;
+  const int cus = ::mednet_internal_cu_count() > 0 ? ::mednet_internal_cu_count() : 256;
+  if (!tuning_option("conv_c1_persist", 1) || nitems <= 4 * cus) return nitems;
+  int best = 0;
+  double best_fill = 0.0;
+  for (int per_cu = 4; per_cu >= 2; --per_cu) {
+    const int g = per_cu * cus / ncb * ncb;
+    if (g <= 0) continue;
+    const double fill = (double)nitems / ((double)((nitems + g - 1) / g) * g);
+    if (fill > best_fill + 0.01) {  // (more workgroups per CU hide more latency: fewer only for a clearly fuller last round)
+      best = g;
+      best_fill = fill;
+    }
+  }
+  return best > 0 ? best : nitems;
+}
+int conv_c1_stats_chunks(int n, int d, int h, int w, int cout) { return 4 * (conv_c1_grid(n, d, h, w, cout) / ((cout + 31) / 32)); }
 int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d, int h, int w, int cout, float* gn_partial,
                         hipStream_t s, int x_dtype, int split) {
   C1Args a;
@@ -1490,7 +1591,14 @@ int launch_conv_c1_mfma(const void* x, const float* w_pf, void* y, int n, int d,
   a.tiles_x = (w + 15) / 16;
   a.ntiles = n * a.tiles_z * a.tiles_y * a.tiles_x;
   a.ncb = (cout + 31) / 32;
-  hipLaunchKernelGGL(conv_c1_mfma_kernel, dim3((unsigned)a.ntiles * a.ncb), dim3(256), 0, s, a);
+  auto rcp = [](int dd) { return dd == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)dd - 1) / (unsigned)dd); };
+  a.rcp_tiles_x = rcp(a.tiles_x); a.rcp_tiles_y = rcp(a.tiles_y); a.rcp_tiles_z = rcp(a.tiles_z); a.rcp_ncb = rcp(a.ncb);
+  MEDNET_REQUIRE((double)a.ntiles * a.ncb * 1024.0 < 4294967296.0, MEDNET_E_UNSUPPORTED, "conv_c1_mfma: grid too large");
+  MEDNET_REQUIRE((double)d * h * w * 4.0 < 4294960000.0, MEDNET_E_UNSUPPORTED, "conv_c1_mfma: one input sample must stay below 4 GB");
+  a.bytes_x = (unsigned)((size_t)d * h * w * (a.x16 ? 2 : 4));
+  const dim3 grid((unsigned)conv_c1_grid(n, d, h, w, cout));
+  if (split) hipLaunchKernelGGL(conv_c1_mfma_kernel<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(conv_c1_mfma_kernel<false>, grid, dim3(256), 0, s, a);
   return check_launch("conv_c1_mfma");
 }
 
