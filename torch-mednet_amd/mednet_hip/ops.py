@@ -70,8 +70,9 @@ def side_stream(device):
         main = torch.cuda.current_stream(device)
         probe = os.environ.get("MEDNET_SIDE_PROBE", "1") == "1" and not torch.cuda.is_current_stream_capturing()
         cands, chosen = [], None
+        prio = int(os.environ.get("MEDNET_SIDE_PRIORITY", "0"))  # (A/B knob: HIP stream priority of the weight-gradient stream)
         for _ in range(8 if probe else 1):
-            c = torch.cuda.Stream(device=device)
+            c = torch.cuda.Stream(device=device, priority=prio) if prio else torch.cuda.Stream(device=device)
             cands.append(c)  # (kept alive until the choice is made: a released stream's slot would be handed out again)
             if not probe or _runs_beside(main, c, device):
                 chosen = c
