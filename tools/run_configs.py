@@ -18,7 +18,7 @@ mednet_hip.set_precision("bf16")
 PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp16x2": 2500.0 / 2, "fp32": 2500.0 / 3}
 
 
-def run(name, make_step, batch, steps=5, warmup=2, precision="bf16", dominant=None):
+def run(name, make_step, batch, steps=10, warmup=3, precision="bf16", dominant=None):
     """`dominant` = (cin, cout, depth) of the config's dominant 3x3x3 convolution: its launches are timed live with HIP events
     on the launch stream (ops.PROFILE, as bench.py does) -> `roofline` of that kernel for this config."""
     from mednet_hip import ops
