@@ -1090,6 +1090,9 @@ def test_two_block_kernel_is_bit_identical_to_the_general_kernel(mode, n, cin, c
     (2, (16, 32, 32)),    # 512 bricks over two samples: the sample changes between XCDs
     (3, (14, 30, 40)),    # ragged in z, y and x (7 x 8 x 3 = 168 brick slots per sample, 504 in all: interleaved walk, the sample
                           # changes inside a workgroup's list, bricks that hang over every face)
+    (2, (15, 34, 24)),    # odd depth: the last brick layer holds one z-plane; 2 x 8 x 9 x 2 = 288 brick slots, not a multiple of 8 per XCD run... (288 = 8 x 36: contiguous runs)
+    (1, (17, 22, 50)),    # 9 x 6 x 4 = 216 slots < 256: general kernel; with n = 1 only -- see the next case
+    (3, (17, 22, 50)),    # 648 slots = 8 x 81, odd depth, ragged y and x, three samples inside one XCD run
     (1, (10, 12, 100)),   # 105 brick slots: fewer than CUs -> the general kernel keeps the call (plan kind 2)
 ])
 def test_convt_dgrad32_is_bit_identical_to_the_general_kernel(mode, n, shape):
