@@ -111,7 +111,9 @@ int mednet_conv3d_pack_many(const void* table_device, int njobs, unsigned blocks
  * Cout, i.e. the layer's Cout / Cin); stride 2: the ConvTranspose3d data gradient with GroupNorm-3 sums (d, h, w = the
  * low-resolution grid).  out13 = {kind (2: one row per wave and brick, row = 4 * brick-in-sample + wave; 3: accumulate mode,
  * a wave keeps its sums over its workgroup's items and writes row ((wg >> 3) / ncb * 8 + (wg & 7)) * 4 + wave for EVERY
- * sample; 4: the 32 -> 32 specialisation, row = 4 * wg + wave for every sample), grid, work items, channel blocks, bricks,
+ * sample; 4: the 32 -> 32 specialisation, row = 4 * wg + wave for every sample; 5 / 6: the two-block kernel with the rows of
+ * 2 / 3 and "channel blocks" counting PAIRS of 32-channel blocks; 7: the ConvTranspose3d 64 -> 32 data gradient, row = 2 * wg +
+ * z-plane of its bricks for every sample, both channel blocks), grid, work items, channel blocks, bricks,
  * bricks per sample, accumulate flag, rows per sample, and for kind 4 bricks per XCD, z-slab height, brick counts in x, y, z}.
  * Work item i of the general kernel = (brick (i >> 3) / ncb * 8 + (i & 7), channel block (i >> 3) % ncb); workgroup b takes
  * items b, b + grid, ... and stops at the first brick >= bricks (padding items). */
