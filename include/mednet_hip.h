@@ -53,7 +53,14 @@ enum { MEDNET_ALGO_AUTO = 0, MEDNET_ALGO_DIRECT = 1, MEDNET_ALGO_MFMA = 2, MEDNE
         * elt_dtype | MEDNET_PACK_LOW (every bf16 pack holds them anyway). */
        MEDNET_ALGO_SPLITW_BIT = 8 };
 /* flag of the elt_dtype argument of mednet_conv3d_pack_elt / mednet_conv3d_pack_many: an fp16 pack with the low images as well */
-enum { MEDNET_PACK_LOW = 0x100 };
+enum { MEDNET_PACK_LOW = 0x100,
+       /* (round 6) mednet_conv3d_pack_many only: rewrite ONLY what the 16-bit matrix-core kernels of the training step read -- the
+        * high 16-bit images (and the low ones iff MEDNET_PACK_LOW is set) -- and leave the fp32 images of the direct / fp32-matrix
+        * kernels and the unrequested low images as they are, i.e. STALE after an optimizer step (2.8 GB per step for a 141 M
+        * parameter network against 1.1 GB).  The caller then owns the bookkeeping: before a call that takes another path with such a
+        * pack (fp32 tensors, MEDNET_ALGO_DIRECT / exact products, a sample of 4 GB and more, a ConvTranspose3d whose channels are not
+        * multiples of 32) it must re-pack that layer in full (mednet_conv3d_pack_elt).  mednet_hip.nn does (`_packed(x)`). */
+       MEDNET_PACK_HIGH_ONLY = 0x200 };
 enum { MEDNET_REG_L2 = 0, MEDNET_REG_L1 = 1 };
 enum {
   MEDNET_OK = 0, MEDNET_E_SHAPE = -1, MEDNET_E_DTYPE = -2, MEDNET_E_WORKSPACE = -3, MEDNET_E_HIP = -4,

@@ -160,12 +160,14 @@ extern "C" int mednet_conv3d_pack_table(const mednet_pack_job* jobs, int njobs, 
 extern "C" int mednet_conv3d_pack_many(const void* table_device, int njobs, unsigned max_blocks, int elt_dtype,
                                        mednet_stream stream) {
   const bool want_low = (elt_dtype & MEDNET_PACK_LOW) != 0;
-  elt_dtype &= ~MEDNET_PACK_LOW;
+  const bool high_only = (elt_dtype & MEDNET_PACK_HIGH_ONLY) != 0;  // (the caller keeps track of what its packs hold: mednet_hip.h)
+  elt_dtype &= ~(MEDNET_PACK_LOW | MEDNET_PACK_HIGH_ONLY);
+  MEDNET_REQUIRE(!(high_only && elt_dtype == MEDNET_F32), MEDNET_E_UNSUPPORTED, "conv3d_pack_many: MEDNET_PACK_HIGH_ONLY is for the 16-bit storage modes");
   if (elt_dtype == MEDNET_F32) elt_dtype = MEDNET_BF16;
-  const bool with_low = elt_dtype == MEDNET_BF16 || want_low;  // bf16 high + low images always (see mednet_conv3d_pack_elt)
+  const bool with_low = (elt_dtype == MEDNET_BF16 && !high_only) || want_low;  // bf16 high + low images always (see mednet_conv3d_pack_elt)
   MEDNET_REQUIRE(is16(elt_dtype), MEDNET_E_DTYPE, "conv3d_pack_many: the matrix-core images are bf16 or fp16 (got dtype %d)", elt_dtype);
   MEDNET_REQUIRE(table_device && njobs > 0 && njobs <= 65535 && max_blocks > 0, MEDNET_E_SHAPE, "conv3d_pack_many: bad arguments");
-  return ELT_CALL(elt_dtype, launch_pack_mfma_many, table_device, njobs, max_blocks, (hipStream_t)stream, with_low ? 1 : 0);
+  return ELT_CALL(elt_dtype, launch_pack_mfma_many, table_device, njobs, max_blocks, (hipStream_t)stream, (with_low ? 1 : 0) | (high_only ? 2 : 0));
 }
 
 static int conv_common_checks(const char* who, int n, int d, int h, int w, int cin, int cout, int ksize, int dt1, int dt2) {

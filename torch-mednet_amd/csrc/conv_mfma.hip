@@ -1726,8 +1726,9 @@ __global__ __launch_bounds__(256) void pack_mfma_many_kernel(const PackJobDev* _
   const PackJobDev j = jobs[lo];
   const unsigned blk = blockIdx.x - j.first_block;
   if (blk >= j.nblocks) return;
-  pack_mfma_body(j.w, (elt*)j.sec_fwd, (elt*)j.sec_bwd, j.cout, j.cin, j.transposed ? 2 : 0, j.transposed ? 3 : 1, j.Pf, j.Pb,
-                 j.transposed, with_low ? (size_t)j.lo_delta : 0, blk, tile);
+  // with_low bit 0: the low 16-bit images too; bit 1 (MEDNET_PACK_HIGH_ONLY): no fp32 images
+  pack_mfma_body(j.w, (elt*)j.sec_fwd, (elt*)j.sec_bwd, j.cout, j.cin, j.transposed ? 2 : 0, j.transposed ? 3 : 1,
+                 (with_low & 2) ? nullptr : j.Pf, j.Pb, j.transposed, (with_low & 1) ? (size_t)j.lo_delta : 0, blk, tile);
 }
 
 PackLayout pack_layout(int cin, int cout, int ksize) {

@@ -22,6 +22,7 @@ ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_EXACT = 0, 1, 2, 3
 ALGO_EXACT_BIT = 4  # OR-ed onto ALGO_MFMA: matrix-core path required AND exact fp32 products
 ALGO_SPLITW_BIT = 8  # OR-ed onto any choice: 16-bit modes multiply the LOW weight images too (include/mednet_hip.h, round 6)
 PACK_LOW = 0x100     # OR-ed onto the element type of a pack call: an fp16 pack with the low images
+PACK_HIGH_ONLY = 0x200  # mednet_conv3d_pack_many: only the images the 16-bit matrix-core kernels read (see mednet_hip.h)
 REG_L2, REG_L1 = 0, 1
 PAD_CONSTANT, PAD_SYMMETRIC = 0, 1
 F16, U8, I64 = 2, 3, 4  # F16: fp16 storage / resident volumes; U8, I64: label types

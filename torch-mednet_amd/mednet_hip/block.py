@@ -282,7 +282,8 @@ def res_block(x, convs, norms, groups, eps, act, pool_mode=None):
     hook = ops.GN3Hook() if (ops.FUSE_GN3 and torch.is_grad_enabled()) else None  # (training only)
     stash = PoolStash(pool_mode) if (pool_mode is not None and FUSE_POOL) else None
     out = ResBlockFn.apply(x, k1.weight, n1.weight, n1.bias, k2.weight, n2.weight, n2.bias, k3.weight, n3.weight, n3.bias,
-                           k1._packed(), k2._packed(), k3._packed(), groups, eps, act, hook, stash)
+                           k1._packed(x, converts=True), k2._packed(x, converts=True), k3._packed(x, converts=True), groups, eps, act,
+                           hook, stash)  # (the node casts x to the storage type; its inner tensors have x's extent)
     if hook is not None:
         out._mednet_gn3 = hook  # see ops.GN3Hook: the consumer of `out` may take GroupNorm-3's first backward pass
     if stash is not None and stash.pooled is not None:

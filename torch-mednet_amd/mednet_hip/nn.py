@@ -18,13 +18,39 @@ class _PackedWeightMixin:
 
     _transposed = False
 
-    def _packed(self):
+    def _packed(self, x=None, converts=False):
+        """`x`: the tensor the op is about to read (None: one the op made itself, in the mode's storage type); `converts`: the op
+        casts its input to the storage type first.  Needed for packs the trainer rewrote with MEDNET_PACK_HIGH_ONLY (train.
+        BatchedRepack): their fp32 and unrequested low images are stale, so a call that would take another path than the 16-bit
+        matrix-core kernels gets the layer packed in full first."""
         w = self.weight
         key = (w.data_ptr(), w._version, getattr(w, "_mednet_step", 0), str(w.device), config.act_dtype(), config.pack_elt())
         if getattr(self, "_pack_key", None) != key:
             self._pack_buf = ops.pack_conv_weight(w, self.kernel_size[0], self._transposed)
             self._pack_key = key
-        return self._pack_buf
+        buf = self._pack_buf
+        if getattr(buf, "_mednet_lean", False) and not self._lean_call_ok(x, converts):
+            ops.pack_conv_weight(w, self.kernel_size[0], self._transposed, out=buf)
+            buf._mednet_lean = False
+        return buf
+
+    def _lean_layer_ok(self) -> bool:
+        """Structurally: does this layer ALWAYS run on the 16-bit matrix-core kernels when it is given 16-bit tensors?"""
+        return False
+
+    def _lean_call_ok(self, x, converts) -> bool:
+        from . import _lib
+        if not (config.is_half_mode() and self._lean_layer_ok()):
+            return False
+        if config._decompose(config.conv_algo())[0] == _lib.ALGO_DIRECT:
+            return False
+        if x is not None:
+            if x.dim() != 5 or (x.dtype != config.act_dtype() and not converts):
+                return False
+            vox = x.shape[2] * x.shape[3] * x.shape[4] * (8 if self._transposed else 1)
+            if vox * max(self.in_channels, self.out_channels) * 2 >= 4294960000:  # (conv_mfma_fits: one sample below 4 GB)
+                return False
+        return True
 
 
 class Conv3d(nn.Module, _PackedWeightMixin):
@@ -52,13 +78,17 @@ class Conv3d(nn.Module, _PackedWeightMixin):
             bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
             nn.init.uniform_(self.bias, -bound, bound)
 
+    def _lean_layer_ok(self) -> bool:  # (conv_mfma_supported: 3x3x3, channels in 16s, no bias, channels-last 16-bit output)
+        return (self.kernel_size[0] == 3 and self.bias is None and not self.planar_output and self.in_channels % 16 == 0
+                and self.out_channels % 16 == 0)
+
     def forward(self, x):
         out_dtype = torch.float32 if self.planar_output else config.act_dtype()
-        return ops.conv3d(x, self.weight, self.bias, self._packed(), self.kernel_size[0], self.planar_output, out_dtype)
+        return ops.conv3d(x, self.weight, self.bias, self._packed(x), self.kernel_size[0], self.planar_output, out_dtype)
 
     def forward_with_stats(self, x):
         """(y, GroupNorm partial sums of y or None) -- used when a GroupNorm follows (SingleConv fuses the two)."""
-        return ops.conv3d_with_stats(x, self.weight, self.bias, self._packed(), self.kernel_size[0])
+        return ops.conv3d_with_stats(x, self.weight, self.bias, self._packed(x), self.kernel_size[0])
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, bias={self.bias is not None}"
@@ -87,8 +117,11 @@ class ConvTranspose3d(nn.Module, _PackedWeightMixin):
         bound = 1 / math.sqrt(fan_in)
         nn.init.uniform_(self.bias, -bound, bound)
 
+    def _lean_layer_ok(self) -> bool:  # (mednet_convt3d_fwd / _dgrad: matrix-core kernels for channels in 32s)
+        return self.in_channels % 32 == 0 and self.out_channels % 32 == 0
+
     def forward(self, x, skip=None):
-        return ops.conv_transpose3d(x, self.weight, self.bias, skip, self._packed())
+        return ops.conv_transpose3d(x, self.weight, self.bias, skip, self._packed(x, converts=True))
 
 
 class GroupNorm(nn.Module):

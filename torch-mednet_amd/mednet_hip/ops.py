@@ -224,15 +224,17 @@ def _as_act(x: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------- weights
-def pack_conv_weight(weight: torch.Tensor, ksize: int, transposed: bool) -> torch.Tensor:
-    """PyTorch-layout fp32 weight -> opaque packed buffer read by the forward / data-gradient kernels."""
+def pack_conv_weight(weight: torch.Tensor, ksize: int, transposed: bool, out: torch.Tensor = None) -> torch.Tensor:
+    """PyTorch-layout fp32 weight -> opaque packed buffer read by the forward / data-gradient kernels (`out`: rewrite that buffer)."""
     L.require_gpu(weight, "pack_conv_weight")
     w = weight.detach()
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
     cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
     nbytes = L.lib().mednet_conv3d_pack_bytes(cin, cout, ksize)
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    if out is not None and (out.numel() != nbytes or out.device != w.device):
+        raise RuntimeError("pack_conv_weight: `out` is not this layer's pack buffer")
+    buf = out if out is not None else torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     # element type of the matrix-core fragment images; fp32 storage: bf16 high + low images (split-bf16 contraction); fp16x2: fp16 + low
     elt = config.pack_elt()
     L.check(L.lib().mednet_conv3d_pack_elt(w.data_ptr(), buf.data_ptr(), cin, cout, ksize, int(transposed), elt, L.stream()),

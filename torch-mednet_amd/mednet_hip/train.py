@@ -130,6 +130,11 @@ class BatchedRepack:
     buffers are rewritten in place.  Layers without matrix-core images (first conv, 1x1x1 head) keep the per-layer path."""
 
     ENABLED = os.environ.get("MEDNET_BATCHED_PACK", "1") == "1"  # A/B knob
+    # 16-bit storage modes: rewrite only the images the step's matrix-core kernels read (MEDNET_PACK_HIGH_ONLY) -- not the fp32
+    # images of the direct / fp32-matrix kernels nor unrequested low images: 1.1 GB instead of 2.8 GB per step for config 5's 141 M
+    # parameters.  The buffers are marked (`_mednet_lean`) and nn._PackedWeightMixin._packed(x) re-packs a layer in full before a
+    # call that would read anything else.  Only when EVERY layer of the table always takes the matrix-core path on 16-bit tensors.
+    LEAN = os.environ.get("MEDNET_LEAN_PACK", "1") == "1"
 
     def __init__(self, model):
         from . import nn as hnn
@@ -166,10 +171,13 @@ class BatchedRepack:
             self.table = host.to(self.mods[0].weight.device)
             self.max_blocks, self.sig = mb.value, sig
         elt = config.pack_elt()  # (fp32 storage: bf16 + the low images; fp16x2: fp16 + the low images)
-        L.check(lib.mednet_conv3d_pack_many(self.table.data_ptr(), len(self.mods), self.max_blocks, elt, L.stream()), "pack_many")
+        lean = self.LEAN and config.is_half_mode() and all(m._lean_layer_ok() for m in self.mods)
+        L.check(lib.mednet_conv3d_pack_many(self.table.data_ptr(), len(self.mods), self.max_blocks, elt | (L.PACK_HIGH_ONLY if lean else 0),
+                                            L.stream()), "pack_many")
         for m in self.mods:  # what _PackedWeightMixin._packed() will compute at the next forward
             w = m.weight
             m._pack_key = (w.data_ptr(), w._version, getattr(w, "_mednet_step", 0), str(w.device), config.act_dtype(), config.pack_elt())
+            m._pack_buf._mednet_lean = lean
 
 
 class LossScaler:

@@ -109,7 +109,7 @@ class SingleConv(nn.Sequential):
                 last = i + 2 == len(mods)
                 want = last and stats_for is not None and stats_for.num_channels == m.out_channels \
                     and (m.out_channels // stats_for.num_groups) % 2 == 0
-                x, p = ops.conv3d_act(x, m.weight, m._packed(), nxt.code, want)
+                x, p = ops.conv3d_act(x, m.weight, m._packed(x), nxt.code, want)
                 if last:
                     out_partial = p
                 i += 2
