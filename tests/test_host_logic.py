@@ -407,3 +407,42 @@ def test_loss_module_keeps_product_and_restated_reference_code_apart():
                  "PixelWiseCrossEntropyLoss"):
         assert getattr(HL, name) is getattr(HCOMP, name) and getattr(ML, name) is getattr(HCOMP, name), name
         assert getattr(HCOMP, name).__module__ == "mednet_hip.unet.loss_compat", name
+
+
+def test_lean_pack_bookkeeping_decisions():
+    """MEDNET_PACK_HIGH_ONLY (train.BatchedRepack): which layers may run on packs whose fp32 / low images are stale, and which calls
+    must re-pack first -- the host-side rules of nn._PackedWeightMixin (mednet_hip.h: only the 16-bit matrix-core path reads nothing
+    else).  Decisions only; no device."""
+    import mednet_hip
+    from mednet_hip import nn as hnn
+    conv = hnn.Conv3d(32, 64, 3, bias=False)
+    assert conv._lean_layer_ok()
+    assert not hnn.Conv3d(32, 64, 3, bias=True)._lean_layer_ok()              # conv_mfma_supported: no bias
+    assert not hnn.Conv3d(1, 32, 3, bias=False)._lean_layer_ok()              # first layer: reads the fp32 image
+    assert not hnn.Conv3d(32, 4, 1, planar_output=True)._lean_layer_ok()      # 1x1x1 head
+    assert not hnn.Conv3d(24, 32, 3, bias=False)._lean_layer_ok()
+    assert hnn.ConvTranspose3d(64, 32)._lean_layer_ok()
+    assert not hnn.ConvTranspose3d(48, 16)._lean_layer_ok()                   # matrix-core ConvTranspose kernels: channels in 32s
+    x16 = torch.empty(1, 32, 8, 8, 8, dtype=torch.bfloat16, device="meta")
+    x32 = torch.empty(1, 32, 8, 8, 8, dtype=torch.float32, device="meta")
+    big = torch.empty(1, 32, 400, 400, 400, dtype=torch.bfloat16, device="meta")  # 4.1 GB per sample at 32 channels
+    with mednet_hip.precision("bf16"):
+        assert conv._lean_call_ok(x16, False) and conv._lean_call_ok(None, False)
+        assert not conv._lean_call_ok(x32, False)     # fp32 tensors in a 16-bit mode: split-bf16 kernels, low images
+        assert conv._lean_call_ok(x32, True)          # ... unless the op casts its input first (ResBlockFn, ConvTranspose3d)
+        assert not conv._lean_call_ok(big, False)     # conv_mfma_fits: direct kernels
+        assert not conv._lean_call_ok(x16.to(torch.float16), False)
+        mednet_hip.set_conv_algo("direct")
+        try:
+            assert not conv._lean_call_ok(x16, False)
+        finally:
+            mednet_hip.set_conv_algo("auto")
+        mednet_hip.set_conv_algo("mfma")
+        try:
+            assert conv._lean_call_ok(x16, False)
+        finally:
+            mednet_hip.set_conv_algo("auto")
+    with mednet_hip.precision("fp32"):
+        assert not conv._lean_call_ok(x32, False)     # fp32 storage: every image is read
+    with mednet_hip.precision("fp16x2"):
+        assert conv._lean_call_ok(x16.to(torch.float16), False)
